@@ -1,0 +1,785 @@
+"""CPU oracle for the NIF point-wise training-step hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement (fp64 by default, fp32 on request) of the arithmetic that
+pswpswpsw/nif v1.0.3 asks TensorFlow/Keras to do on the path named by BASELINE.json.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
+product (`nif_amd/`) never does.
+
+PARITY UNPINNED.  The reference has no tests, no golden vectors and cannot be imported here
+(`import nif` needs tensorflow==2.11.1, which is not installed and not vendored).  The oracle
+is therefore pinned only by (a) line-by-line restatement of the reference sources cited in
+every function below, (b) an independent torch-autograd fp64 restatement used as a cross-check
+in tests/test_oracle_autograd.py, (c) internal identities (3-stage factorisation, finite
+differences) and (d) the reference's bundled travelling-wave dataset + its NumPy-only
+normalisers, which *can* be executed here.
+
+All citations are `file:line` under /root/reference/.
+
+Deliberately reference-shaped: `pnet_output [B, po_dim]` is materialised and sliced exactly as
+`nif/model.py:253-300` / `:769-846` / `:883-933` do, and the ShapeNet uses
+`einsum('ai,aij->aj')` (`nif/layers/mlp.py:219`).  Use small B.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# activations (Keras names; `keras.activations.get`, nif/model.py:303, nif/layers/mlp.py:40-44)
+# ----------------------------------------------------------------------------------------------
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _erf(x):
+    try:
+        from scipy.special import erf  # noqa
+        return erf(x)
+    except Exception:  # pragma: no cover
+        return np.vectorize(math.erf)(x)
+
+
+def act_fn(name):
+    """Return (f, f') for a Keras activation name.  'sine' is the SIREN activation."""
+    if name in (None, "linear"):
+        return (lambda a: a), (lambda a: np.ones_like(a))
+    if name in ("swish", "silu"):
+        def f(a):
+            return a * _sigmoid(a)
+
+        def df(a):
+            s = _sigmoid(a)
+            return s * (1.0 + a * (1.0 - s))
+        return f, df
+    if name == "tanh":
+        return np.tanh, (lambda a: 1.0 - np.tanh(a) ** 2)
+    if name == "relu":
+        return (lambda a: np.maximum(a, 0.0)), (lambda a: (a > 0).astype(a.dtype))
+    if name == "sigmoid":
+        return _sigmoid, (lambda a: _sigmoid(a) * (1.0 - _sigmoid(a)))
+    if name == "elu":
+        return (lambda a: np.where(a > 0, a, np.expm1(np.minimum(a, 0.0)))), (
+            lambda a: np.where(a > 0, 1.0, np.exp(np.minimum(a, 0.0))))
+    if name == "softplus":
+        return (lambda a: np.logaddexp(a, 0.0)), _sigmoid
+    if name == "gelu":  # keras default approximate=False
+        def f(a):
+            return 0.5 * a * (1.0 + _erf(a / math.sqrt(2.0)))
+
+        def df(a):
+            return 0.5 * (1.0 + _erf(a / math.sqrt(2.0))) + a * np.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+        return f, df
+    if name == "sine":
+        return np.sin, np.cos
+    raise ValueError("unknown activation %r" % (name,))
+
+
+# ----------------------------------------------------------------------------------------------
+# model description (what nif/model.py's three constructors derive from the cfg dicts)
+# ----------------------------------------------------------------------------------------------
+
+KIND_NIF = "NIF"
+KIND_MS = "NIFMultiScale"
+KIND_LL = "NIFMultiScaleLastLayerParameterized"
+
+
+class Spec(object):
+    """Shape bookkeeping for one model.  Follows NIF.__init__ (model.py:73-128),
+    NIF._initialize_pnet po_dim (:169-173), NIFMultiScale._initialize_pnet (:569-587) and
+    NIFMultiScaleLastLayerParameterized.__init__/_initialize_snet (:1012-1042,:1147-1217)."""
+
+    def __init__(self, kind, cfg_shape_net, cfg_parameter_net):
+        self.kind = kind
+        cs, cp = cfg_shape_net, cfg_parameter_net
+        self.cs, self.cp = dict(cs), dict(cp)
+        self.si, self.so = cs["input_dim"], cs["output_dim"]
+        self.n, self.L = cs["units"], cs["nlayers"]
+        self.pi, self.r = cp["input_dim"], cp["latent_dim"]
+        self.nst, self.lst = cp["units"], cp["nlayers"]
+        self.p_act = cp["activation"]
+        if kind == KIND_NIF:
+            self.s_res = False
+            self.s_act = cs["activation"]
+            self.omega_s = 1.0
+            self.p_siren = False
+            self.p_res = False
+            self.omega_p = 1.0
+            self.po = self.L * self.n ** 2 + (self.si + self.so + 1 + self.L) * self.n + self.so
+        else:
+            assert "use_resblock" in cs, "`use_resblock` should be in cfg_shape_net"
+            self.s_res = bool(cs["use_resblock"])
+            self.s_act = "sine"
+            self.omega_s = float(cs["omega_0"])
+            self.p_siren = (cp["activation"] == "sine")
+            self.p_res = bool(cp.get("use_resblock", False))
+            self.omega_p = float(cp["omega_0"]) if self.p_siren else 1.0
+            if cs["connectivity"] == "full":
+                nh = 2 * self.L if self.s_res else self.L
+                self.po = nh * self.n ** 2 + (self.si + self.so + 1 + nh) * self.n + self.so
+            elif cs["connectivity"] == "last_layer":
+                self.po = self.r
+            else:
+                raise ValueError("cfg_shape_net missing correct `connectivity`")
+        if kind == KIND_LL:
+            assert cs["connectivity"] == "last_layer"
+        # number of hidden (n x n) hyper-matrices in the ShapeNet
+        self.n_hidden_mats = (2 * self.L if self.s_res else self.L)
+
+    # ---- pnet_output wire layout (model.py:253-300, :769-846, :883-933) -------------------
+    def slices(self):
+        """Offsets into pnet_output[:, po]: dict with 'w1','wh'(list),'wl','b1','bh'(list),'bl'."""
+        si, so, n = self.si, self.so, self.n
+        nh = self.n_hidden_mats
+        off = 0
+        out = {}
+        out["w1"] = (off, off + si * n); off += si * n
+        out["wh"] = []
+        for _ in range(nh):
+            out["wh"].append((off, off + n * n)); off += n * n
+        out["wl"] = (off, off + n * so); off += n * so
+        out["b1"] = (off, off + n); off += n
+        out["bh"] = []
+        for _ in range(nh):
+            out["bh"].append((off, off + n)); off += n
+        out["bl"] = (off, off + so); off += so
+        assert off == self.po
+        return out
+
+    # ---- Keras variable order (model.py:178-231,:591-734,:1162-1215) ---
+    def param_shapes(self):
+        sh = []
+        pi, nst, r, po = self.pi, self.nst, self.r, self.po
+        sh += [("pnet_first_w", (pi, nst)), ("pnet_first_b", (nst,))]
+        for i in range(self.lst):
+            sh += [("pnet_h%d_w" % i, (nst, nst)), ("pnet_h%d_b" % i, (nst,))]
+            if self.p_res:
+                sh += [("pnet_h%d_w2" % i, (nst, nst)), ("pnet_h%d_b2" % i, (nst,))]
+        sh += [("pnet_bottleneck_w", (nst, r)), ("pnet_bottleneck_b", (r,))]
+        sh += [("pnet_last_w", (r, po)), ("pnet_last_b", (po,))]
+        if self.kind == KIND_LL:
+            si, n, so = self.si, self.n, self.so
+            sh += [("snet_first_w", (si, n)), ("snet_first_b", (n,))]
+            for i in range(self.L):
+                sh += [("snet_h%d_w" % i, (n, n)), ("snet_h%d_b" % i, (n,))]
+                if self.s_res:
+                    sh += [("snet_h%d_w2" % i, (n, n)), ("snet_h%d_b2" % i, (n,))]
+            sh += [("snet_bottleneck_w", (n, self.po * so)), ("snet_bottleneck_b", (self.po * so,))]
+            sh += [("last_layer_bias", (so,))]
+        return sh
+
+    def n_params(self):
+        return int(sum(int(np.prod(s)) for _, s in self.param_shapes()))
+
+
+# ----------------------------------------------------------------------------------------------
+# initialisers (distribution parity only; model.py:181-182, siren.py:6-63,:178-204, mlp.py:245)
+# ----------------------------------------------------------------------------------------------
+
+
+def _trunc_normal(rng, shape, std=0.1):
+    """Keras TruncatedNormal(stddev): resample beyond 2 sigma."""
+    out = rng.standard_normal(shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return out * std
+
+
+def _uniform(rng, shape, lim):
+    return rng.uniform(-1.0, 1.0, size=shape) * lim
+
+
+def _siren_init(rng, nin, nout, pos, omega):
+    if pos == "first":  # siren.py:178-190
+        return _uniform(rng, (nin, nout), 1.0 / nin), _uniform(rng, (nout,), 1.0 / math.sqrt(nin))
+    # hidden / bottleneck, siren.py:192-204
+    return (_uniform(rng, (nin, nout), math.sqrt(6.0 / nin) / omega),
+            _uniform(rng, (nout,), 1.0 / math.sqrt(nin)))
+
+
+def _hyper_init(rng, spec):
+    """gen_hypernetwork_weights_bias_for_siren_shapenet (siren.py:6-63) as called from
+    HyperLinearForSIREN.__init__ (siren.py:479-501)."""
+    r, po = spec.r, spec.po
+    wf = spec.cs["weight_init_factor"]
+    w = _uniform(rng, (r, po), math.sqrt(6.0 / r) * wf)
+    if spec.cs["connectivity"] == "full":
+        nwf = spec.si * spec.n
+        nwh = spec.n_hidden_mats * spec.n ** 2
+        nwl = spec.so * spec.n
+    else:  # last_layer: siren.py:485-486
+        nwf, nwh, nwl = 0, 0, po
+    scale = np.ones((po,))
+    scale[:nwf] /= spec.si
+    scale[nwf:nwf + nwh] *= math.sqrt(6.0 / spec.n) / spec.omega_s
+    scale[nwf + nwh:nwf + nwh + nwl] *= math.sqrt(6.0 / (2 * spec.n))
+    scale[nwf + nwh + nwl:] /= spec.n
+    b = rng.uniform(-1.0, 1.0, size=(po,)) * scale
+    return w, b
+
+
+def init_weights(spec, rng, dtype=np.float64):
+    """Draw one set of weights in Keras variable order with the reference's distributions."""
+    ws = []
+    if spec.kind == KIND_NIF or not spec.p_siren:
+        # Dense layers, TruncatedNormal(0.1) for kernels AND biases (model.py:181-182,:671-672)
+        def dense(nin, nout):
+            return [_trunc_normal(rng, (nin, nout)), _trunc_normal(rng, (nout,))]
+        ws += dense(spec.pi, spec.nst)
+        for _ in range(spec.lst):
+            ws += dense(spec.nst, spec.nst)
+            if spec.p_res:
+                ws += dense(spec.nst, spec.nst)
+        ws += dense(spec.nst, spec.r)
+    else:
+        ws += list(_siren_init(rng, spec.pi, spec.nst, "first", spec.omega_p))
+        for _ in range(spec.lst):
+            w, b = _siren_init(rng, spec.nst, spec.nst, "hidden", spec.omega_p)
+            ws += [w, b]
+            if spec.p_res:  # w2,b2 start as copies (siren.py:370-379)
+                ws += [w.copy(), b.copy()]
+        ws += list(_siren_init(rng, spec.nst, spec.r, "bottleneck", spec.omega_p))
+    if spec.kind == KIND_NIF:
+        ws += [_trunc_normal(rng, (spec.r, spec.po)), _trunc_normal(rng, (spec.po,))]
+    else:
+        ws += list(_hyper_init(rng, spec))
+    if spec.kind == KIND_LL:
+        ws += list(_siren_init(rng, spec.si, spec.n, "first", spec.omega_s))
+        for _ in range(spec.L):
+            w, b = _siren_init(rng, spec.n, spec.n, "hidden", spec.omega_s)
+            ws += [w, b]
+            if spec.s_res:
+                ws += [w.copy(), b.copy()]
+        ws += list(_siren_init(rng, spec.n, spec.po * spec.so, "bottleneck", spec.omega_s))
+        ws += [_trunc_normal(rng, (spec.so,))]
+    shapes = spec.param_shapes()
+    assert len(ws) == len(shapes)
+    for w, (_, s) in zip(ws, shapes):
+        assert tuple(w.shape) == tuple(s), (w.shape, s)
+    return [np.asarray(w, dtype=dtype) for w in ws]
+
+
+# ----------------------------------------------------------------------------------------------
+# ParameterNet (model.py:326-343 driving the layers of model.py:178-231 / :591-734)
+# ----------------------------------------------------------------------------------------------
+
+
+def _pnet_split(spec, ws):
+    """-> (first, hidden[list], bottleneck, last, rest) with each entry a tuple of arrays."""
+    it = iter(ws)
+    first = (next(it), next(it))
+    hidden = []
+    for _ in range(spec.lst):
+        if spec.p_res:
+            hidden.append((next(it), next(it), next(it), next(it)))
+        else:
+            hidden.append((next(it), next(it)))
+    bott = (next(it), next(it))
+    last = (next(it), next(it))
+    rest = list(it)
+    return first, hidden, bott, last, rest
+
+
+def pnet_forward(spec, ws, p, keep=False):
+    """p [B,pi] -> (pnet_out [B,po], latent [B,r]); `keep` also returns the tape for backward.
+
+    Dense: act(x@K+b); MLP_SimpleShortCut: x + act(x@K+b) (mlp.py:148-160);
+    MLP_ResNet: act(x + L2(act(L1 x))) (mlp.py:62-79); SIREN first/hidden sin(w0*(x@w)+b),
+    bottleneck linear (siren.py:256-281); SIREN_ResNet 0.5*(x+sin(w0*(sin(w0*x@w+b))@w2+b2))
+    (siren.py:381-410); last layer linear (siren.py:514-522 / Keras Dense model.py:220-230)."""
+    first, hidden, bott, last, _ = _pnet_split(spec, ws)
+    tape = []
+    if spec.p_siren:
+        om = spec.omega_p
+        a = om * (p @ first[0]) + first[1]
+        h = np.sin(a)
+        tape.append(("first", p, a))
+        for lay in hidden:
+            if spec.p_res:
+                a1 = om * (h @ lay[0]) + lay[1]
+                t = np.sin(a1)
+                a2 = om * (t @ lay[2]) + lay[3]
+                hn = 0.5 * (h + np.sin(a2))
+                tape.append(("sres", h, a1, t, a2))
+            else:
+                a1 = om * (h @ lay[0]) + lay[1]
+                hn = np.sin(a1)
+                tape.append(("siren", h, a1))
+            h = hn
+    else:
+        f, _ = act_fn(spec.p_act)
+        a = p @ first[0] + first[1]
+        h = f(a)
+        tape.append(("first", p, a))
+        for lay in hidden:
+            if spec.p_res:
+                a1 = h @ lay[0] + lay[1]
+                t = f(a1)
+                a2 = h + (t @ lay[2] + lay[3])
+                hn = f(a2)
+                tape.append(("mres", h, a1, t, a2))
+            else:
+                a1 = h @ lay[0] + lay[1]
+                hn = h + f(a1)
+                tape.append(("short", h, a1))
+            h = hn
+    z = h @ bott[0] + bott[1]
+    out = z @ last[0] + last[1]
+    if keep:
+        return out, z, (tape, h)
+    return out, z
+
+
+def pnet_backward(spec, ws, tape_h, g_out, g_z_extra=None):
+    """Reverse sweep of pnet_forward.  g_out = dLoss/d pnet_out [B,po].  Returns list of grads
+    for the pnet variables (Keras order)."""
+    first, hidden, bott, last, _ = _pnet_split(spec, ws)
+    tape, h_last = tape_h
+    # last layer: out = z@Wl + bl
+    z = h_last @ bott[0] + bott[1]
+    g_last = [z.T @ g_out, g_out.sum(0)]
+    gz = g_out @ last[0].T
+    if g_z_extra is not None:
+        gz = gz + g_z_extra
+    g_bott = [h_last.T @ gz, gz.sum(0)]
+    gh = gz @ bott[0].T
+    g_hidden = []
+    om = spec.omega_p
+    f, df = act_fn(spec.p_act if not spec.p_siren else "sine")
+    for lay, rec in zip(reversed(hidden), reversed(tape[1:])):
+        kind = rec[0]
+        if kind == "sres":
+            _, hin, a1, t, a2 = rec
+            ga2 = 0.5 * gh * np.cos(a2)
+            gw2 = om * (t.T @ ga2); gb2 = ga2.sum(0)
+            gt = om * (ga2 @ lay[2].T)
+            ga1 = gt * np.cos(a1)
+            gw1 = om * (hin.T @ ga1); gb1 = ga1.sum(0)
+            gh = 0.5 * gh + om * (ga1 @ lay[0].T)
+            g_hidden.append([gw1, gb1, gw2, gb2])
+        elif kind == "siren":
+            _, hin, a1 = rec
+            ga1 = gh * np.cos(a1)
+            g_hidden.append([om * (hin.T @ ga1), ga1.sum(0)])
+            gh = om * (ga1 @ lay[0].T)
+        elif kind == "mres":
+            _, hin, a1, t, a2 = rec
+            ga2 = gh * df(a2)
+            gw2 = t.T @ ga2; gb2 = ga2.sum(0)
+            gt = ga2 @ lay[2].T
+            ga1 = gt * df(a1)
+            gw1 = hin.T @ ga1; gb1 = ga1.sum(0)
+            gh = ga2 + ga1 @ lay[0].T
+            g_hidden.append([gw1, gb1, gw2, gb2])
+        else:  # short
+            _, hin, a1 = rec
+            ga1 = gh * df(a1)
+            g_hidden.append([hin.T @ ga1, ga1.sum(0)])
+            gh = gh + ga1 @ lay[0].T
+    _, p, a = tape[0]
+    if spec.p_siren:
+        ga = gh * np.cos(a)
+        g_first = [om * (p.T @ ga), ga.sum(0)]
+    else:
+        ga = gh * df(a)
+        g_first = [p.T @ ga, ga.sum(0)]
+    grads = list(g_first)
+    for g in reversed(g_hidden):
+        grads += g
+    grads += g_bott + g_last
+    return grads
+
+
+# ----------------------------------------------------------------------------------------------
+# ShapeNet given per-sample weights (model.py:233-324 and :738-954) -- the einsum chain
+# ----------------------------------------------------------------------------------------------
+
+
+def _ein(u, w):
+    """EinsumLayer('ai,aij->aj') (mlp.py:209-219)."""
+    return np.einsum("ai,aij->aj", u, w)
+
+
+def shapenet_given_w(spec, x, w, keep=False):
+    """x [B,si], w = pnet_output [B,po] -> u [B,so].  NIF._call_shape_net (model.py:233-324)
+    for KIND_NIF, NIFMultiScale._call_shape_net_mres (model.py:738-954) otherwise."""
+    assert spec.kind in (KIND_NIF, KIND_MS)
+    B = x.shape[0]
+    si, so, n = spec.si, spec.so, spec.n
+    sl = spec.slices()
+    W1 = w[:, sl["w1"][0]:sl["w1"][1]].reshape(B, si, n)
+    Wh = [w[:, a:b].reshape(B, n, n) for (a, b) in sl["wh"]]
+    Wl = w[:, sl["wl"][0]:sl["wl"][1]].reshape(B, n, so)
+    b1 = w[:, sl["b1"][0]:sl["b1"][1]]
+    bh = [w[:, a:b] for (a, b) in sl["bh"]]
+    bl = w[:, sl["bl"][0]:sl["bl"][1]]
+    tape = {"W1": W1, "Wh": Wh, "Wl": Wl, "x": x}
+    if spec.kind == KIND_NIF:
+        f, _ = act_fn(spec.s_act)
+        a0 = _ein(x, W1) + b1
+        u = f(a0)
+        acts = [(None, a0)]
+        for i in range(spec.L):
+            a = _ein(u, Wh[i]) + bh[i]
+            acts.append((u, a))
+            u = f(a) + u
+    else:
+        om = spec.omega_s
+        a0 = om * _ein(x, W1) + b1
+        u = np.sin(a0)
+        acts = [(None, a0)]
+        if spec.s_res:
+            for i in range(spec.L):
+                a1 = om * _ein(u, Wh[2 * i]) + bh[2 * i]
+                t = np.sin(a1)
+                a2 = om * _ein(t, Wh[2 * i + 1]) + bh[2 * i + 1]
+                acts.append((u, a1, t, a2))
+                u = 0.5 * (u + np.sin(a2))
+        else:
+            for i in range(spec.L):
+                a = om * _ein(u, Wh[i]) + bh[i]
+                acts.append((u, a))
+                u = np.sin(a)
+    out = _ein(u, Wl) + bl
+    if keep:
+        tape["acts"] = acts
+        tape["hL"] = u
+        return out, tape
+    return out
+
+
+def shapenet_given_w_backward(spec, tape, g_u):
+    """Adjoint of shapenet_given_w w.r.t. w (returns g_w [B,po]) -- what GradientTape builds
+    through the slices/reshapes/einsums (SURVEY a-10)."""
+    B = g_u.shape[0]
+    si, so, n = spec.si, spec.so, spec.n
+    sl = spec.slices()
+    gw = np.zeros((B, spec.po), dtype=g_u.dtype)
+    hL = tape["hL"]
+    gw[:, sl["wl"][0]:sl["wl"][1]] = (hL[:, :, None] * g_u[:, None, :]).reshape(B, -1)
+    gw[:, sl["bl"][0]:sl["bl"][1]] = g_u
+    gh = np.einsum("aij,aj->ai", tape["Wl"], g_u)
+    acts = tape["acts"]
+    Wh = tape["Wh"]
+    if spec.kind == KIND_NIF:
+        _, df = act_fn(spec.s_act)
+        for i in reversed(range(spec.L)):
+            hin, a = acts[i + 1]
+            ga = gh * df(a)
+            gw[:, sl["wh"][i][0]:sl["wh"][i][1]] = (hin[:, :, None] * ga[:, None, :]).reshape(B, -1)
+            gw[:, sl["bh"][i][0]:sl["bh"][i][1]] = ga
+            gh = np.einsum("aij,aj->ai", Wh[i], ga) + gh
+        a0 = acts[0][1]
+        ga0 = gh * df(a0)
+        om = 1.0
+    else:
+        om = spec.omega_s
+        if spec.s_res:
+            for i in reversed(range(spec.L)):
+                hin, a1, t, a2 = acts[i + 1]
+                ga2 = 0.5 * gh * np.cos(a2)
+                s2 = sl["wh"][2 * i + 1]
+                gw[:, s2[0]:s2[1]] = (om * t[:, :, None] * ga2[:, None, :]).reshape(B, -1)
+                gw[:, sl["bh"][2 * i + 1][0]:sl["bh"][2 * i + 1][1]] = ga2
+                gt = om * np.einsum("aij,aj->ai", Wh[2 * i + 1], ga2)
+                ga1 = gt * np.cos(a1)
+                s1 = sl["wh"][2 * i]
+                gw[:, s1[0]:s1[1]] = (om * hin[:, :, None] * ga1[:, None, :]).reshape(B, -1)
+                gw[:, sl["bh"][2 * i][0]:sl["bh"][2 * i][1]] = ga1
+                gh = 0.5 * gh + om * np.einsum("aij,aj->ai", Wh[2 * i], ga1)
+        else:
+            for i in reversed(range(spec.L)):
+                hin, a = acts[i + 1]
+                ga = gh * np.cos(a)
+                gw[:, sl["wh"][i][0]:sl["wh"][i][1]] = (om * hin[:, :, None] * ga[:, None, :]).reshape(B, -1)
+                gw[:, sl["bh"][i][0]:sl["bh"][i][1]] = ga
+                gh = om * np.einsum("aij,aj->ai", Wh[i], ga)
+        a0 = acts[0][1]
+        ga0 = gh * np.cos(a0)
+    x = tape["x"]
+    gw[:, sl["w1"][0]:sl["w1"][1]] = (om * x[:, :, None] * ga0[:, None, :]).reshape(B, -1)
+    gw[:, sl["b1"][0]:sl["b1"][1]] = ga0
+    return gw
+
+
+# ----------------------------------------------------------------------------------------------
+# last-layer-parameterised ShapeNet (model.py:1219-1269)
+# ----------------------------------------------------------------------------------------------
+
+
+def _snet_split(spec, rest):
+    it = iter(rest)
+    first = (next(it), next(it))
+    hidden = []
+    for _ in range(spec.L):
+        if spec.s_res:
+            hidden.append((next(it), next(it), next(it), next(it)))
+        else:
+            hidden.append((next(it), next(it)))
+    bott = (next(it), next(it))
+    bias = next(it)
+    return first, hidden, bott, bias
+
+
+def snet_phi(spec, ws, x, keep=False):
+    """x [B,si] -> phi [B,so,r] (model.py:1219-1238; layers siren.py:256-281,:381-410)."""
+    *_, rest = _pnet_split(spec, ws)
+    first, hidden, bott, _ = _snet_split(spec, rest)
+    om = spec.omega_s
+    a = om * (x @ first[0]) + first[1]
+    h = np.sin(a)
+    tape = [("first", x, a)]
+    for lay in hidden:
+        if spec.s_res:
+            a1 = om * (h @ lay[0]) + lay[1]
+            t = np.sin(a1)
+            a2 = om * (t @ lay[2]) + lay[3]
+            tape.append(("sres", h, a1, t, a2))
+            h = 0.5 * (h + np.sin(a2))
+        else:
+            a1 = om * (h @ lay[0]) + lay[1]
+            tape.append(("siren", h, a1))
+            h = np.sin(a1)
+    phi = (h @ bott[0] + bott[1]).reshape(x.shape[0], spec.so, spec.r)
+    if keep:
+        return phi, (tape, h)
+    return phi
+
+
+def _snet_backward(spec, ws, tape_h, g_phi):
+    *_, rest = _pnet_split(spec, ws)
+    first, hidden, bott, _ = _snet_split(spec, rest)
+    tape, hL = tape_h
+    om = spec.omega_s
+    g = g_phi.reshape(g_phi.shape[0], -1)
+    g_bott = [hL.T @ g, g.sum(0)]
+    gh = g @ bott[0].T
+    g_hidden = []
+    for lay, rec in zip(reversed(hidden), reversed(tape[1:])):
+        if rec[0] == "sres":
+            _, hin, a1, t, a2 = rec
+            ga2 = 0.5 * gh * np.cos(a2)
+            gw2 = om * (t.T @ ga2); gb2 = ga2.sum(0)
+            gt = om * (ga2 @ lay[2].T)
+            ga1 = gt * np.cos(a1)
+            gw1 = om * (hin.T @ ga1); gb1 = ga1.sum(0)
+            gh = 0.5 * gh + om * (ga1 @ lay[0].T)
+            g_hidden.append([gw1, gb1, gw2, gb2])
+        else:
+            _, hin, a1 = rec
+            ga1 = gh * np.cos(a1)
+            g_hidden.append([om * (hin.T @ ga1), ga1.sum(0)])
+            gh = om * (ga1 @ lay[0].T)
+    _, x, a = tape[0]
+    ga = gh * np.cos(a)
+    grads = [om * (x.T @ ga), ga.sum(0)]
+    for g_ in reversed(g_hidden):
+        grads += g_
+    grads += g_bott
+    return grads
+
+
+# ----------------------------------------------------------------------------------------------
+# full model, loss, gradient, optimiser
+# ----------------------------------------------------------------------------------------------
+
+
+def forward(spec, ws, inputs):
+    """NIF.call (model.py:130-154) / NIFMultiScale.call (:510-539) /
+    NIFMultiScaleLastLayerParameterized.call (:1044-1068).  inputs [B, pi+si] -> u [B,so]."""
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    pout, _ = pnet_forward(spec, ws, p)
+    if spec.kind == KIND_LL:
+        phi = snet_phi(spec, ws, x)
+        # Dot(axes=(2,1)) + BiasAddLayer (model.py:1267-1268)
+        return np.einsum("bsj,bj->bs", phi, pout) + ws[-1]
+    return shapenet_given_w(spec, x, pout)
+
+
+def model_p_to_lr(spec, ws, p):
+    """model.py:406-420; for the last-layer class it is the pnet *output* (model.py:1070-1083)."""
+    out, z = pnet_forward(spec, ws, p)
+    return out if spec.kind == KIND_LL else z
+
+
+def model_lr_to_w(spec, ws, lr):
+    """model.py:422-433 -- only the last pnet layer.  Raises for the last-layer class
+    (model.py:1106-1115)."""
+    if spec.kind == KIND_LL:
+        raise ValueError("In this class: NIFMultiScaleLastLayerParameterization, `w` is the same as `lr`")
+    _, _, _, last, _ = _pnet_split(spec, ws)
+    return lr @ last[0] + last[1]
+
+
+def model_x_to_phi(spec, ws, x):
+    return snet_phi(spec, ws, x)
+
+
+def mse_loss(u, y, sample_weight=None):
+    """Keras 'mse' with SUM_OVER_BATCH_SIZE: mean_B( w_a * mean_so (u-y)^2 )."""
+    per = ((u - y) ** 2).mean(axis=1)
+    if sample_weight is not None:
+        per = per * sample_weight
+    return per.sum() / u.shape[0]
+
+
+def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None):
+    """MSE loss and gradient w.r.t. every variable (Keras order), hand-derived adjoint
+    (SURVEY a-10).  `batch_global` lets a shard compute its share of a larger batch's
+    mean (loss and grads are scaled by 1/batch_global instead of 1/B)."""
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    pout, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    if spec.kind == KIND_LL:
+        phi, stape = snet_phi(spec, ws, x, keep=True)
+        u = np.einsum("bsj,bj->bs", phi, pout) + ws[-1]
+    else:
+        u, tape = shapenet_given_w(spec, x, pout, keep=True)
+    e = u - y
+    per = (e ** 2).mean(axis=1)
+    w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
+    loss = (per * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
+    if spec.kind == KIND_LL:
+        g_pout = np.einsum("bsj,bs->bj", phi, g_u)
+        g_phi = g_u[:, :, None] * pout[:, None, :]
+        g_snet = _snet_backward(spec, ws, stape, g_phi)
+        g_bias = g_u.sum(0)
+        g_pnet = pnet_backward(spec, ws, ptape, g_pout)
+        return loss, g_pnet + g_snet + [g_bias]
+    g_pout = shapenet_given_w_backward(spec, tape, g_u)
+    return loss, pnet_backward(spec, ws, ptape, g_pout)
+
+
+def flatten(arrs):
+    return np.concatenate([np.asarray(a).ravel() for a in arrs])
+
+
+def unflatten(spec, flat):
+    out, off = [], 0
+    for _, s in spec.param_shapes():
+        k = int(np.prod(s))
+        out.append(np.asarray(flat[off:off + k]).reshape(s))
+        off += k
+    assert off == flat.shape[0]
+    return out
+
+
+def adam_step(theta, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+    """Keras-2.11 Adam (SURVEY a-11): t is the 1-based step index.  Returns (theta, m, v)."""
+    m = m + (g - m) * (1.0 - b1)
+    v = v + (g * g - v) * (1.0 - b2)
+    alpha = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    theta = theta - alpha * m / (np.sqrt(v) + eps)
+    return theta, m, v
+
+
+# ----------------------------------------------------------------------------------------------
+# JacobianLayer (gradient.py:36-49, :207-231): (y, dy_{y_index}/dx_{x_index}) w.r.t. the
+# model *input vector* (parameter columns first, then coordinates).
+# ----------------------------------------------------------------------------------------------
+
+
+def jacobian(spec, ws, inputs, y_index, x_index, h=1e-6):
+    """Central differences in fp64 -- the oracle for the analytic tangent kernels.  Returns
+    (y [B,so], dys_dxs [B,len(y_index),len(x_index)])."""
+    inputs = np.asarray(inputs, dtype=np.float64)
+    ws64 = [np.asarray(w, dtype=np.float64) for w in ws]
+    y = forward(spec, ws64, inputs)
+    B = inputs.shape[0]
+    J = np.zeros((B, len(y_index), len(x_index)))
+    for jj, j in enumerate(x_index):
+        d = np.zeros_like(inputs)
+        d[:, j] = h
+        yp = forward(spec, ws64, inputs + d)
+        ym = forward(spec, ws64, inputs - d)
+        J[:, :, jj] = ((yp - ym) / (2 * h))[:, list(y_index)]
+    return y, J
+
+
+def jacobian_analytic(spec, ws, inputs, y_index, x_index):
+    """Forward-mode tangent for coordinate columns (x_index >= pi) of the
+    hypernetwork classes; used to cross-check the central-difference oracle."""
+    assert spec.kind in (KIND_NIF, KIND_MS)
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    pout, _ = pnet_forward(spec, ws, p)
+    u, tape = shapenet_given_w(spec, x, pout, keep=True)
+    B = x.shape[0]
+    J = np.zeros((B, len(y_index), len(x_index)), dtype=u.dtype)
+    acts, Wh, W1, Wl = tape["acts"], tape["Wh"], tape["W1"], tape["Wl"]
+    for jj, j in enumerate(x_index):
+        assert j >= spec.pi, "analytic tangent only for coordinate columns"
+        d = j - spec.pi
+        if spec.kind == KIND_NIF:
+            _, df = act_fn(spec.s_act)
+            hd = df(acts[0][1]) * W1[:, d, :]
+            for i in range(spec.L):
+                _, a = acts[i + 1]
+                hd = df(a) * _ein(hd, Wh[i]) + hd
+        else:
+            om = spec.omega_s
+            hd = np.cos(acts[0][1]) * om * W1[:, d, :]
+            if spec.s_res:
+                for i in range(spec.L):
+                    _, a1, t, a2 = acts[i + 1]
+                    td = np.cos(a1) * om * _ein(hd, Wh[2 * i])
+                    hd = 0.5 * (hd + np.cos(a2) * om * _ein(td, Wh[2 * i + 1]))
+            else:
+                for i in range(spec.L):
+                    _, a = acts[i + 1]
+                    hd = np.cos(a) * om * _ein(hd, Wh[i])
+        ud = _ein(hd, Wl)
+        J[:, :, jj] = ud[:, list(y_index)]
+    return u, J
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic data = verified closed form of the bundled travelling-wave datasets
+# (nif/demo/dataset/*.npz) + the reference normalisers
+# (nif/data/point_wise_data.py:50-114)
+# ----------------------------------------------------------------------------------------------
+
+
+def traveling_wave(t, x, omega=4.0):
+    s = x - 0.2 - 0.006 * t
+    return np.exp(-1000.0 * s * s) * np.sin(omega * s)
+
+
+def standard_normalize(raw):
+    """point_wise_data.py:50-78 (area_weighted=False)."""
+    mean = raw.mean(axis=0)
+    std = raw.std(axis=0)
+    return (raw - mean) / std, mean, std
+
+
+def minmax_normalize(raw, n_para, n_x, n_target):
+    """point_wise_data.py:80-114 (area_weighted=False)."""
+    mean = raw.mean(axis=0)
+    std = raw.std(axis=0)
+    for i in range(n_para + n_x):
+        mean[i] = 0.5 * (np.min(raw[:, i]) + np.max(raw[:, i]))
+        std[i] = 0.5 * (-np.min(raw[:, i]) + np.max(raw[:, i]))
+    for j in range(n_para + n_x, n_para + n_x + n_target):
+        std[j] = np.max(np.abs(raw[:, j]))
+    return (raw - mean) / std, mean, std
+
+
+def synthetic_wave_batch(B, seed=0, omega=4.0, dtype=np.float32):
+    """(inputs [B,2] = (t,x) normalised, y [B,1]) per SURVEY 8(d): t~U[0,90], x~U[0,1)."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(0.0, 90.0, size=B)
+    x = rng.uniform(0.0, 1.0, size=B)
+    u = traveling_wave(t, x, omega)
+    raw = np.stack([t, x, u], axis=1)
+    if omega <= 10:
+        data, _, _ = standard_normalize(raw)
+    else:
+        data, _, _ = minmax_normalize(raw, 1, 1, 1)
+    return data[:, :2].astype(dtype), data[:, 2:3].astype(dtype)

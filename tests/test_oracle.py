@@ -1,0 +1,148 @@
+"""Pins the NumPy oracle: independent torch-autograd restatement, internal identities,
+finite differences, and the reference's bundled dataset / normalisers (via golden fixtures)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nif_oracle as O
+from tests.cfgs import ALL_SMALL
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _setup(name, B=9, seed=0, wscale=None):
+    kind, cs, cp = ALL_SMALL[name]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(seed)
+    ws = O.init_weights(spec, rng)
+    if kind != "NIF":
+        # weight_init_factor=0.01 makes z-dependence tiny; enlarge so the tests see it
+        names = [nm for nm, _ in spec.param_shapes()]
+        ws[names.index("pnet_last_w")] *= 20.0
+    inputs = rng.uniform(-1, 1, size=(B, spec.pi + spec.si))
+    y = rng.uniform(-1, 1, size=(B, spec.so))
+    sw = rng.uniform(0.5, 1.5, size=(B,))
+    return kind, cs, cp, spec, ws, inputs, y, sw
+
+
+@pytest.mark.parametrize("name", sorted(ALL_SMALL))
+def test_forward_and_grad_match_torch_autograd(name):
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name)
+    for sample_weight in (None, sw):
+        loss, grads = O.loss_and_grad(spec, ws, inputs, y, sample_weight)
+        tl, tg, tu = T.loss_and_grad(kind, cs, cp, ws, inputs, y, sample_weight)
+        u = O.forward(spec, ws, inputs)
+        assert np.allclose(u, tu, rtol=1e-12, atol=1e-12)
+        assert abs(loss - tl) <= 1e-12 * max(1.0, abs(tl))
+        assert len(grads) == len(tg)
+        for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
+            assert t is not None, nm
+            denom = max(np.abs(t).max(), 1e-30)
+            assert np.abs(g - t).max() / denom < 1e-9, nm
+
+
+@pytest.mark.parametrize("name", ["nif_swish", "ms_plain_r3_si2", "ms_res"])
+def test_three_stage_factorisation_identity(name):
+    # README.md:99-117: model_x_to_u_given_w(x, model_lr_to_w(model_p_to_lr(p))) == model([p,x])
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name)
+    p, x = inputs[:, :spec.pi], inputs[:, spec.pi:]
+    lr = O.model_p_to_lr(spec, ws, p)
+    w = O.model_lr_to_w(spec, ws, lr)
+    assert w.shape == (inputs.shape[0], spec.po)
+    u = O.shapenet_given_w(spec, x, w)
+    assert np.allclose(u, O.forward(spec, ws, inputs), rtol=1e-13, atol=1e-13)
+
+
+def test_last_layer_class_raises_for_lr_to_w():
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup("ll_plain")
+    with pytest.raises(ValueError):
+        O.model_lr_to_w(spec, ws, inputs[:, :1])
+
+
+@pytest.mark.parametrize("name", ["nif_swish", "ms_plain_r3_si2", "ms_res"])
+def test_grad_matches_finite_differences(name):
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=5)
+    loss, grads = O.loss_and_grad(spec, ws, inputs, y, sw)
+    flat = O.flatten(ws)
+    g = O.flatten(grads)
+    rng = np.random.default_rng(3)
+    for idx in rng.choice(flat.size, size=25, replace=False):
+        d = np.zeros_like(flat); d[idx] = 1e-6
+        lp = O.mse_loss(O.forward(spec, O.unflatten(spec, flat + d), inputs), y, sw)
+        lm = O.mse_loss(O.forward(spec, O.unflatten(spec, flat - d), inputs), y, sw)
+        fd = (lp - lm) / 2e-6
+        assert abs(fd - g[idx]) <= 2e-5 * max(1.0, abs(g[idx])) + 1e-8  # FD truncation (omega_0=30)
+
+
+@pytest.mark.parametrize("name", ["nif_tanh_r2_so2", "ms_plain_r3_si2", "ms_res"])
+def test_jacobian_fd_vs_analytic_vs_autograd(name):
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=6)
+    yi = list(range(spec.so))
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    y1, J1 = O.jacobian(spec, ws, inputs, yi, xi)
+    y2, J2 = O.jacobian_analytic(spec, ws, inputs, yi, xi)
+    tu, tJ = T.jacobian(kind, cs, cp, ws, inputs)
+    assert np.allclose(y1, y2) and np.allclose(y1, tu)
+    assert np.allclose(J2, tJ[:, :, xi], rtol=1e-10, atol=1e-12)
+    assert np.allclose(J1, tJ[:, :, xi], rtol=1e-5, atol=1e-7)
+    # parameter columns too (finite differences only)
+    _, Jp = O.jacobian(spec, ws, inputs, yi, list(range(spec.pi)))
+    assert np.allclose(Jp, tJ[:, :, :spec.pi], rtol=1e-5, atol=1e-7)
+
+
+def test_jacobian_shape_contract_notebook4():
+    # tutorial/4 cells 12-18: JacobianLayer output shapes (B, ny), (B, len(y_index), len(x_index))
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup("nif_tanh_r2_so2", B=10)
+    yv, J = O.jacobian(spec, ws, inputs, [0, 1], [1, 2])
+    assert yv.shape == (10, 2) and J.shape == (10, 2, 2)
+
+
+def test_po_dim_and_param_counts_match_survey_table():
+    # SURVEY section 8 size table (po_dim, trainable P)
+    def spec_of(kind, n, L, si=1, so=1, res=False):
+        if kind == "NIF":
+            cs = {"input_dim": si, "output_dim": so, "units": n, "nlayers": L, "activation": "swish"}
+            cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+        else:
+            cs = {"input_dim": si, "output_dim": so, "units": n, "nlayers": L, "use_resblock": res,
+                  "connectivity": "full", "omega_0": 30.0, "weight_init_factor": 0.01}
+            cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "sine",
+                  "use_resblock": False, "omega_0": 30.0}
+        return O.Spec(kind, cs, cp)
+    s = spec_of("NIF", 32, 2); assert (s.po, s.n_params()) == (2209, 6627)
+    s = spec_of("NIF", 64, 4); assert (s.po, s.n_params()) == (16833, 35875)
+    s = spec_of("NIFMultiScale", 64, 4); assert (s.po, s.n_params()) == (16833, 35875)
+    s = spec_of("NIFMultiScale", 128, 6, si=2); assert (s.po, s.n_params()) == (99585, 201379)
+    s = spec_of("NIFMultiScale", 128, 6, si=2, res=True); assert (s.po, s.n_params()) == (198657, 399523)
+    s = spec_of("NIFMultiScale", 64, 4, si=2); assert s.po == 16897
+
+
+def test_adam_matches_closed_form_first_step():
+    th = np.array([1.0, -2.0]); g = np.array([0.5, -0.25])
+    th1, m, v = O.adam_step(th, g, np.zeros(2), np.zeros(2), 1, lr=1e-3)
+    # first Adam step moves by ~lr*sign(g)
+    assert np.allclose(th1, th - 1e-3 * np.sign(g), atol=1e-8)
+
+
+def test_closed_form_matches_bundled_dataset():
+    # the reference's only real fixture: nif/demo/dataset/traveling_wave*.npz (copied as data)
+    for fn, om, tol in (("traveling_wave.npz", 4.0, 1e-6), ("traveling_wave_high_freq.npz", 400.0, 1e-4)):
+        d = np.load(os.path.join(GOLD, fn))["data"]
+        assert d.shape == (2000, 3)
+        u = O.traveling_wave(d[:, 0].astype(np.float64), d[:, 1].astype(np.float64), om)
+        assert np.abs(u - d[:, 2]).max() < tol
+
+
+def test_normalisers_match_reference_golden():
+    # golden produced by importing /root/reference/nif/data/point_wise_data.py (NumPy only)
+    g = np.load(os.path.join(GOLD, "normalisers.npz"))
+    raw = g["raw"]
+    d, m, s = O.standard_normalize(raw.copy())
+    assert np.array_equal(d, g["std_data"]) and np.array_equal(m, g["std_mean"]) and np.array_equal(s, g["std_std"])
+    d, m, s = O.minmax_normalize(raw.copy(), 1, 1, 1)
+    assert np.array_equal(d, g["mm_data"]) and np.array_equal(m, g["mm_mean"]) and np.array_equal(s, g["mm_std"])
