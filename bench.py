@@ -1,0 +1,198 @@
+"""bench.py -- train-step throughput of the NIF hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): 1D travelling wave, NIFMultiScale, ShapeNet 4x64 SIREN,
+ParameterNet 2x32, latent_dim 1, fp32, batch = 2^20 (t;x)->u points PER GPU (weak scaling),
+synthetic data from the closed form of the reference's bundled dataset, reference init.
+A step = loss+gradient of the local shard (HIP), ONE sum all-reduce of [grad|loss] over ranks
+(RCCL) when N > 1, Adam update.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG_SHAPE = {"input_dim": 1, "output_dim": 1, "units": 64, "nlayers": 4, "use_resblock": False,
+             "connectivity": "full", "omega_0": 30.0, "weight_init_factor": 0.01}
+CFG_PARAM = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish",
+             "use_resblock": False, "omega_0": 30.0}
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+HBM_PEAK_GBS = 8000.0        # spec; 6290 measured-achievable
+
+
+def cpu_baseline(sample_points=8192, micro=4096):
+    """The oracle (NumPy restatement of the reference formulation, materialising pnet_output
+    [b, po] and the per-sample einsum) timed on this box's host cores: one train step =
+    loss+grad+Adam on `sample_points` points in micro-batches of `micro` (fp32)."""
+    from oracle import nif_oracle as O
+    spec = O.Spec("NIFMultiScale", CFG_SHAPE, CFG_PARAM)
+    rng = np.random.default_rng(1)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    x, y = O.synthetic_wave_batch(sample_points, seed=0)
+    th = O.flatten(ws)
+    m = np.zeros_like(th); v = np.zeros_like(th)
+
+    def step(t):
+        nonlocal th, m, v
+        g = np.zeros_like(th)
+        wl = O.unflatten(spec, th)
+        for b0 in range(0, sample_points, micro):
+            _, gg = O.loss_and_grad(spec, wl, x[b0:b0 + micro], y[b0:b0 + micro], batch_global=sample_points)
+            g += O.flatten(gg)
+        th, m, v = O.adam_step(th, g, m, v, t)
+        th = th.astype(np.float32); m = m.astype(np.float32); v = v.astype(np.float32)
+
+    step(1)  # warm-up
+    t0 = time.perf_counter()
+    nrep, t = 0, 2
+    while True:
+        step(t); t += 1; nrep += 1
+        if time.perf_counter() - t0 > 12.0 or nrep >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": sample_points * nrep / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of %d points (micro-batches of %d), NumPy fp32 restatement of the reference "
+                      "formulation (materialised [b,po] + einsum), not TensorFlow" % (nrep, sample_points, micro)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1 << 20, help="points per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--given-w-points", type=int, default=1 << 17)
+    args = ap.parse_args()
+
+    import nif_amd
+    from nif_amd import distributed as dist
+    from nif_amd.engine import DeviceArray
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        rank, world = dist.init("nccl")
+    else:
+        rank = 0
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus (got WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+
+    nif_amd.set_seed(1)  # identical initial weights on every rank (mirrored variables)
+    m = nif_amd.NIFMultiScale(CFG_SHAPE, CFG_PARAM)
+    model = m.build()
+    e = m._engine
+    B = args.points
+    x, y = nif_amd.data.synthetic_wave_batch(B, seed=100 + rank)
+    d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
+    d_x.upload(x); d_y.upload(y)
+    adam = nif_amd.Adam(1e-3).as_struct()
+    Bg = B * world
+
+    def step():
+        e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
+        if world > 1:
+            dist.all_reduce_grad(e)
+        e.adam_step_dev(adam)
+
+    def fence():
+        e.sync()
+        if world > 1:
+            import torch
+            import torch.distributed as td
+            td.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        import torch.distributed as td
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = e.last_loss()
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations, live, with HIP events on the library's stream -------------
+        e.profile_enable(True)
+        nprof = max(3, min(args.steps, 10))
+        for _ in range(nprof):
+            e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
+            e.adam_step_dev(adam)
+        prof = e.profile_read(reset=True)
+        e.profile_enable(False)
+        kern_ms = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in prof.items()}
+        s = m._spec
+        n_w = s.si_dim * s.n_sx + s.n_hidden_mats * s.n_sx ** 2 + s.n_sx * s.so_dim
+        flops_snet = 4.0 * (s.pi_hidden + 1) * n_w * B          # fwd + data-adjoint GEMMs of the fused kernel
+        ach = flops_snet / (kern_ms["snet"] * 1e-3) / 1e12 if kern_ms["snet"] > 0 else 0.0
+        roofline = {"kernel": "k_snet<2,true> (ShapeNet fwd + MSE + adjoint, fp32 MFMA)", "bound": "mfma",
+                    "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                    "traffic": None, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w}
+        # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
+        Bw = args.given_w_points
+        rng = np.random.default_rng(7)
+        d_lr = DeviceArray(e, Bw * s.pi_hidden)
+        d_lr.upload(rng.standard_normal(Bw * s.pi_hidden).astype(np.float32))
+        d_w = DeviceArray(e, Bw * s.po_dim)
+        d_xs = DeviceArray(e, Bw * s.si_dim)
+        d_xs.upload(rng.uniform(-1, 1, Bw * s.si_dim).astype(np.float32))
+        d_u = DeviceArray(e, Bw * s.so_dim)
+        from nif_amd._lib import check
+        check(e.lib.nif_latent_to_w_dev(e.ctx, d_lr.at(0), Bw, d_w.at(0)))
+        for _ in range(2):
+            check(e.lib.nif_shapenet_given_w_dev(e.ctx, d_xs.at(0), d_w.at(0), Bw, d_u.at(0)))
+        e.sync()
+        e.profile_enable(True)
+        for _ in range(5):
+            check(e.lib.nif_shapenet_given_w_dev(e.ctx, d_xs.at(0), d_w.at(0), Bw, d_u.at(0)))
+            check(e.lib.nif_latent_to_w_dev(e.ctx, d_lr.at(0), Bw, d_w.at(0)))
+        prof2 = e.profile_read(reset=True)
+        e.profile_enable(False)
+        gw_ms = prof2["given_w"][0] / max(prof2["given_w"][1], 1)
+        l2w_ms = prof2["latent_to_w"][0] / max(prof2["latent_to_w"][1], 1)
+        bytes_gw = 4.0 * (s.si_dim + s.po_dim + s.so_dim) * Bw
+        gbs = bytes_gw / (gw_ms * 1e-3) / 1e9 if gw_ms > 0 else 0.0
+        roofline_given_w = {"kernel": "k_given_w<64> (model_x_to_u_given_w, per-sample batched matvec)", "bound": "hbm",
+                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "frac_of_measured_peak_6290": gbs / 6290.0, "traffic": None, "avg_ms": gw_ms,
+                            "points": Bw, "bytes_per_point": 4.0 * (s.si_dim + s.po_dim + s.so_dim),
+                            "latent_to_w_GBs": 4.0 * s.po_dim * Bw / (l2w_ms * 1e-3) / 1e9 if l2w_ms > 0 else 0.0}
+        out = {
+            "metric": "train-step points/sec (1D-wave, batch=1M per GPU)",
+            "value": Bg * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1D travelling wave, NIFMultiScale ShapeNet 4x64 SIREN (omega_0=30), "
+                                   "ParameterNet 2x32 swish, latent_dim 1, P=%d, %d points/GPU" % (e.n_params, B),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "final_loss": loss},
+            "roofline": roofline,
+            "roofline_given_w": roofline_given_w,
+            "kernel_ms": kern_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        fence()
+        dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/*
+ * nif_hip.h -- C-ABI of libnif_hip.so: the MI355X (gfx950) hot path of pswpswpsw/nif.
+ *
+ * The reference (pure Python on TensorFlow 2.11) exposes NO plugin / FFI interface; its boundary
+ * is the Python object surface of nif/model.py.  This header defines the C-ABI underneath the
+ * drop-in Python surface `nif_amd.NIF / NIFMultiScale / NIFMultiScaleLastLayerParameterized`.
+ * Every entry point names the reference interface it replaces (file:line under the reference
+ * tree).  Plain C types only: no torch / numpy / HIP types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative nif_status on failure; the message is
+ *     available (thread-local) from nif_last_error().
+ *   - "host" pointers are caller-owned, C-contiguous float32; "dev" pointers are device memory
+ *     obtained from nif_dev_alloc() (or any hipMalloc'ed pointer on ctx's device).
+ *   - inputs are rows [t, mu..., x...]: parameter columns first, then coordinates
+ *     (nif/model.py:142-143); targets are [B, so]; sample_weight is [B] or NULL.
+ *   - all device work is enqueued on the context's HIP stream; *_dev calls are asynchronous,
+ *     host-pointer calls synchronise before returning.
+ *   - there is NO CPU fallback: without a gfx950 device nif_create fails.
+ */
+#ifndef NIF_HIP_H
+#define NIF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIF_ABI_VERSION 1
+
+typedef enum {
+  NIF_OK = 0,
+  NIF_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  NIF_ERR_HIP = -2,       /* HIP runtime error (message has hipGetErrorString) */
+  NIF_ERR_NODEVICE = -3,  /* no gfx950 device */
+  NIF_ERR_STATE = -4      /* call order (e.g. train step before params are set) */
+} nif_status;
+
+/* model classes of nif/model.py */
+typedef enum {
+  NIF_KIND_NIF = 0,         /* class NIF                                   model.py:48   */
+  NIF_KIND_MULTISCALE = 1,  /* class NIFMultiScale                         model.py:483  */
+  NIF_KIND_LASTLAYER = 2    /* class NIFMultiScaleLastLayerParameterized   model.py:989  */
+} nif_kind;
+
+/* activations (`keras.activations.get(name)` model.py:303, mlp.py:40; 'sine' = SIREN) */
+typedef enum {
+  NIF_ACT_LINEAR = 0, NIF_ACT_SINE = 1, NIF_ACT_SWISH = 2, NIF_ACT_TANH = 3, NIF_ACT_RELU = 4,
+  NIF_ACT_SIGMOID = 5, NIF_ACT_ELU = 6, NIF_ACT_SOFTPLUS = 7, NIF_ACT_GELU = 8
+} nif_act;
+
+/* What NIF.__init__ (model.py:73-128) / NIFMultiScale._initialize_pnet (model.py:541-736)
+ * derive from cfg_shape_net / cfg_parameter_net. */
+typedef struct {
+  int32_t abi_version;   /* = NIF_ABI_VERSION */
+  int32_t kind;          /* nif_kind */
+  int32_t pi_dim;        /* cfg_parameter_net["input_dim"]   model.py:88 */
+  int32_t si_dim;        /* cfg_shape_net["input_dim"]       model.py:84 */
+  int32_t so_dim;        /* cfg_shape_net["output_dim"]      model.py:85 */
+  int32_t n_sx;          /* cfg_shape_net["units"]           model.py:86 */
+  int32_t l_sx;          /* cfg_shape_net["nlayers"]         model.py:87 */
+  int32_t n_st;          /* cfg_parameter_net["units"]       model.py:90 */
+  int32_t l_st;          /* cfg_parameter_net["nlayers"]     model.py:91 */
+  int32_t latent_dim;    /* cfg_parameter_net["latent_dim"]  model.py:89 */
+  int32_t s_act;         /* NIF: cfg_shape_net["activation"]; MultiScale: NIF_ACT_SINE */
+  int32_t s_resblock;    /* cfg_shape_net["use_resblock"]    model.py:532 */
+  float   s_omega0;      /* cfg_shape_net["omega_0"]         model.py:533 (1.0 for NIF) */
+  int32_t p_act;         /* cfg_parameter_net["activation"]; NIF_ACT_SINE => SIREN pnet (model.py:591) */
+  int32_t p_resblock;    /* cfg_parameter_net["use_resblock"] model.py:609,681 */
+  float   p_omega0;      /* cfg_parameter_net["omega_0"]     model.py:599 */
+  int32_t reserved[8];   /* must be zero */
+} nif_cfg;
+
+/* One trainable tensor in Keras variable order. */
+typedef struct {
+  char    name[48];
+  int64_t offset;        /* into the flat parameter vector */
+  int32_t rows, cols;    /* cols == 0 for vectors */
+} nif_tensor_desc;
+
+/* Keras-2.11 Adam hyper-parameters (README.md:33 `compile(optimizer, loss='mse')`). */
+typedef struct {
+  float lr, beta1, beta2, eps;
+} nif_adam;
+
+typedef struct nif_ctx nif_ctx;
+
+const char* nif_last_error(void);
+int nif_abi_version(void);
+/* number of visible HIP devices (0 if none / no driver) */
+int nif_device_count(void);
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* replaces: NIF(cfg_shape_net, cfg_parameter_net, mixed_policy) + .build()  model.py:73,345 */
+int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out);
+int nif_destroy(nif_ctx* ctx);
+
+/* ---- parameters (model.get_weights / set_weights / trainable_variables, README.md:179-195) */
+int nif_param_count(nif_ctx* ctx, int64_t* n_params);
+int nif_po_dim(nif_ctx* ctx, int64_t* po_dim);                 /* model.py:169-173,:569-587 */
+int nif_param_layout(nif_ctx* ctx, nif_tensor_desc* descs, int32_t* n_inout);
+int nif_set_params(nif_ctx* ctx, const float* host, int64_t n);
+int nif_get_params(nif_ctx* ctx, float* host, int64_t n);
+/* optimizer slots (Adam m, v, and step count) for checkpoint/resume */
+int nif_get_opt_state(nif_ctx* ctx, float* m_host, float* v_host, int64_t n, int64_t* step);
+int nif_set_opt_state(nif_ctx* ctx, const float* m_host, const float* v_host, int64_t n, int64_t step);
+
+/* ---- device memory / stream plumbing (no reference counterpart; TF owned these) -------- */
+int nif_dev_alloc(nif_ctx* ctx, int64_t bytes, void** dptr);
+int nif_dev_free(nif_ctx* ctx, void* dptr);
+int nif_h2d(nif_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int nif_d2h(nif_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+int nif_sync(nif_ctx* ctx);
+void* nif_stream(nif_ctx* ctx);          /* hipStream_t of the context */
+void* nif_grad_dev(nif_ctx* ctx);        /* device float[P+1]: flat gradient || loss  (the RCCL all-reduce buffer) */
+void* nif_params_dev(nif_ctx* ctx);      /* device float[P] */
+
+/* ---- inference ------------------------------------------------------------------------ */
+/* model.predict / model(x): NIF.call model.py:130-154, NIFMultiScale.call :510-539,
+ * NIFMultiScaleLastLayerParameterized.call :1044-1068.   xin [B, pi+si] -> u [B, so] */
+int nif_forward(nif_ctx* ctx, const float* xin_host, int64_t B, float* u_host);
+int nif_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, float* u_dev);
+/* model_p_to_lr().predict(p): model.py:406-420 (last-layer class: :1070-1083).  p [B,pi] -> [B,r] */
+int nif_pnet_latent(nif_ctx* ctx, const float* p_host, int64_t B, float* lr_host);
+/* model_lr_to_w().predict(lr): model.py:422-433 == last pnet layer (siren.py:514-522).
+ * lr [B,r] -> w [B,po].  NIF_ERR_INVALID for the last-layer class (model.py:1106-1115). */
+int nif_latent_to_w(nif_ctx* ctx, const float* lr_host, int64_t B, float* w_host);
+int nif_latent_to_w_dev(nif_ctx* ctx, const float* lr_dev, int64_t B, float* w_dev);
+/* model_x_to_u_given_w().predict([x, w]): model.py:435-464 / :956-986 -- the per-sample
+ * batched matvec  einsum('ai,aij->aj')  (mlp.py:209-219).  x [B,si], w [B,po] -> u [B,so] */
+int nif_shapenet_given_w(nif_ctx* ctx, const float* x_host, const float* w_host, int64_t B, float* u_host);
+int nif_shapenet_given_w_dev(nif_ctx* ctx, const float* x_dev, const float* w_dev, int64_t B, float* u_dev);
+
+/* ---- training ------------------------------------------------------------------------- */
+/* Keras train_step body without the update: loss = mse(y, model(x), sample_weight) and
+ * d loss / d theta (GradientTape).  Result stays on the device in nif_grad_dev():
+ * grad[0..P) and grad[P] = loss, both already scaled by 1/B_global so that a SUM all-reduce
+ * over shards gives the global-batch mean (tf.distribute.MirroredStrategy, README.md:39-49). */
+int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* sw_dev_or_null,
+                      int64_t B_local, int64_t B_global);
+/* optimizer.apply_gradients with Adam on the (already all-reduced) nif_grad_dev() buffer */
+int nif_adam_step_dev(nif_ctx* ctx, const nif_adam* opt);
+/* host-pointer conveniences */
+int nif_loss_and_grad(nif_ctx* ctx, const float* xin_host, const float* y_host, const float* sw_host_or_null,
+                      int64_t B, float* loss_out, float* grad_host);        /* lbfgs.py:66-74 */
+int nif_train_step(nif_ctx* ctx, const float* xin_host, const float* y_host, const float* sw_host_or_null,
+                   int64_t B, const nif_adam* opt, float* loss_out);        /* Model.fit's train_step */
+/* reads grad[P] (the loss of the last nif_loss_grad_dev) */
+int nif_last_loss(nif_ctx* ctx, float* loss_out);
+
+/* ---- measurement (HIP events on the context's stream; no reference counterpart) ------- */
+/* kernel groups timed when profiling is on */
+typedef enum {
+  NIF_PROF_PACK = 0,      /* theta -> MFMA operand order */
+  NIF_PROF_PNET_FWD = 1,  /* ParameterNet forward */
+  NIF_PROF_SNET = 2,      /* ShapeNet forward + MSE + adjoint (the dominant kernel) */
+  NIF_PROF_PNET_BWD = 3,  /* ParameterNet adjoint */
+  NIF_PROF_GW = 4,        /* all weight-gradient reductions */
+  NIF_PROF_REDUCE = 5,    /* partial rows -> flat gradient */
+  NIF_PROF_ADAM = 6,
+  NIF_PROF_GIVEN_W = 7,   /* model_x_to_u_given_w kernel */
+  NIF_PROF_LATENT_TO_W = 8,
+  NIF_PROF_SNET_FWD = 9,  /* ShapeNet forward only (predict) */
+  NIF_PROF_N = 10
+} nif_prof_id;
+int nif_profile_enable(nif_ctx* ctx, int on);
+/* synchronises, then adds the elapsed milliseconds / launch counts per group since the last reset */
+int nif_profile_read(nif_ctx* ctx, float* ms_out, int64_t* count_out, int n, int reset);
+/* a plain stopwatch on the stream */
+int nif_timer_start(nif_ctx* ctx);
+int nif_timer_stop(nif_ctx* ctx, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIF_HIP_H */

@@ -1,0 +1,270 @@
+// k_gw.hip -- weight-gradient reductions over the point batch (gfx950).
+//
+//   C[k][in][out] = scale * sum_p zt_k[p] * IN[p][in] * DA[p][out]        zt = (z_1..z_r, 1)
+//
+// is the gradient of every hypernetwork slice (k < r -> row k of the hyper kernel, k = r -> the
+// hyper bias) and, with r = 0, of every shared-weight dense layer.  The sum over points is the K
+// dimension of v_mfma_f32_32x32x2_f32; both operands come straight from the [tile][feature][32]
+// stashes with 16-byte loads (lane (i,hf) reads 16 consecutive points of feature i, so the K order
+// is "hf picks the half-tile" for A and B alike) -- no LDS transpose.  Each workgroup reduces a
+// strided subset of tiles and writes one row of the partial buffer; k_reduce sums the rows in a
+// fixed order (deterministic, no atomics).
+//
+// This replaces what GradientTape does for  tf.einsum('ai,aij->aj') / Dense / SIREN  weights
+// (nif/layers/mlp.py:219, nif/model.py:253-300 StridedSliceGrad + AddN; SURVEY a-10).
+#include "nif_internal.h"
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// sum a per-lane value over the 4 waves of the block (deterministic order), result valid on wave 0
+__device__ __forceinline__ float block_sum4(float v, float* red /*[3*64]*/, int wid, int lane) {
+  if (wid > 0) red[(wid - 1) * 64 + lane] = v;
+  __syncthreads();
+  if (wid == 0) v = ((v + red[lane]) + red[64 + lane]) + red[128 + lane];
+  __syncthreads();
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// n x n blocks on the matrix cores.  grid = (rows, ceil((r+1)/KC), NBO/OBC)
+// ------------------------------------------------------------------------------------------
+template <int NBI, int OBC, int KC>
+__global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
+  __shared__ float red[3 * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int k0 = blockIdx.y * KC;
+  const int ob0 = blockIdx.z * OBC;
+  const long nwaves = (long)gridDim.x * 4;
+  const long FI = (long)NBI * 32 * 32, FO = (long)NBO * 32 * 32;
+
+  f32x16 acc[KC][NBI][OBC];
+  float bacc[KC][OBC];
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int ob = 0; ob < OBC; ++ob)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[kk][ib][ob][e] = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = 0.f;
+  }
+
+  for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
+    f32x4 af[NBI][4], bf[OBC][4], zq[KC][4];
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[ib][q] = ld4(A.IN + t * FI + (long)(32 * ib + i) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+    for (int ob = 0; ob < OBC; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * (ob0 + ob) + i) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + kk;
+        if (k < A.r) zq[kk][q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+        else { zq[kk][q][0] = 1.f; zq[kk][q][1] = 1.f; zq[kk][q][2] = 1.f; zq[kk][q][3] = 1.f; }
+      }
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      if (k0 + kk > A.r) break;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float zt = zq[kk][q][c];
+#pragma unroll
+          for (int ib = 0; ib < NBI; ++ib) {
+            const float a = af[ib][q][c] * zt;
+#pragma unroll
+            for (int ob = 0; ob < OBC; ++ob)
+              acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[ob][q][c], acc[kk][ib][ob], 0, 0, 0);
+          }
+#pragma unroll
+          for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(zt, bf[ob][q][c], bacc[kk][ob]);
+        }
+    }
+  }
+
+  // block reduction (4 waves -> wave 0) and write of this block's partial row
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+    const int k = k0 + kk;
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int ob = 0; ob < OBC; ++ob)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = block_sum4(acc[kk][ib][ob][e], red, wid, lane);
+          const int in = 32 * ib + fmap(e, hf), out = 32 * (ob0 + ob) + i;
+          if (wid == 0 && k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v;
+        }
+#pragma unroll
+    for (int ob = 0; ob < OBC; ++ob) {
+      float v = bacc[kk][ob];
+      v += __shfl_xor(v, 32);
+      v = block_sum4(v, red, wid, lane);
+      const int out = 32 * (ob0 + ob) + i;
+      if (A.has_bias && wid == 0 && hf == 0 && k <= A.r && out < A.Bv.nout) prow[matref_index(A.Bv, k, 0, out)] = v;
+    }
+  }
+}
+
+void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st) {
+  dim3 block(256);
+  if (NBI == 1 && NBO == 1) {
+    dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
+    hipLaunchKernelGGL((k_gw_mfma<1, 1, 2>), grid, block, 0, st, a, NBO);
+  } else if (NBI == 2 && NBO == 2) {
+    dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
+    hipLaunchKernelGGL((k_gw_mfma<2, 2, 2>), grid, block, 0, st, a, NBO);
+  } else if (NBI == 4 && NBO == 4) {
+    dim3 grid(rows, a.r + 1, 2);
+    hipLaunchKernelGGL((k_gw_mfma<4, 2, 1>), grid, block, 0, st, a, NBO);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// first layers (K = pi or si input columns, tiny): VALU.  grid = (rows, r+1)
+//   gW[k][d][f] = scale * sum_p zt_k x_d da[p][f],  gb[k][f] = sum_p zt_k da[p][f]
+// ------------------------------------------------------------------------------------------
+template <int NBO>
+__global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
+  extern __shared__ float sm[];  // red[3*64] then per-wave acc[(nd+1)*NBO][64]
+  float* red = sm;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int k = blockIdx.y;
+  const long nwaves = (long)gridDim.x * 4;
+  const long FO = (long)NBO * 32 * 32;
+  const int nacc = (A.nd + 1) * NBO;
+  float* lacc = sm + 192 + (long)wid * nacc * 64;
+  for (int s = 0; s < nacc; ++s) lacc[s * 64 + lane] = 0.f;
+
+  for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
+    f32x4 bf[NBO][4], zq[4];
+#pragma unroll
+    for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * ob + i) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (k < A.r) zq[q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+      else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
+    }
+    for (int dd = 0; dd <= A.nd; ++dd) {  // dd == nd : the bias (x = 1)
+      float s[NBO];
+#pragma unroll
+      for (int ob = 0; ob < NBO; ++ob) s[ob] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          long pt = t * 32 + 16 * hf + 4 * q + c;
+          if (pt >= A.B) pt = A.B - 1;
+          const float xv = dd < A.nd ? A.xin[pt * A.ncol + A.col0 + dd] : 1.0f;
+          const float w = xv * zq[q][c];
+#pragma unroll
+          for (int ob = 0; ob < NBO; ++ob) s[ob] = fmaf(w, bf[ob][q][c], s[ob]);
+        }
+#pragma unroll
+      for (int ob = 0; ob < NBO; ++ob) lacc[(dd * NBO + ob) * 64 + lane] += s[ob];
+    }
+  }
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+  for (int dd = 0; dd <= A.nd; ++dd)
+    for (int ob = 0; ob < NBO; ++ob) {
+      float v = lacc[(dd * NBO + ob) * 64 + lane];
+      v += __shfl_xor(v, 32);
+      v = block_sum4(v, red, wid, lane);
+      const int f = 32 * ob + i;
+      if (wid == 0 && hf == 0) {
+        if (dd < A.nd) { if (f < A.W.nout) prow[matref_index(A.W, k, dd, f)] = A.scale * v; }
+        else if (A.has_bias && f < A.Bv.nout) prow[matref_index(A.Bv, k, 0, f)] = v;
+      }
+    }
+}
+
+void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st) {
+  dim3 grid(rows, a.r + 1), block(256);
+  const size_t shm = (size_t)(192 + 4 * (a.nd + 1) * NBO * 64) * sizeof(float);
+  if (NBO == 1) hipLaunchKernelGGL((k_gw_first<1>), grid, block, shm, st, a);
+  else if (NBO == 2) hipLaunchKernelGGL((k_gw_first<2>), grid, block, shm, st, a);
+  else hipLaunchKernelGGL((k_gw_first<4>), grid, block, shm, st, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// narrow output layers (n -> so, nst -> r): VALU.  grid = (rows, r+1)
+//   gW[k][f][c] = scale * sum_p zt_k h[p][f] dout[p][c],  gb[k][c] = sum_p zt_k dout[p][c]
+// ------------------------------------------------------------------------------------------
+template <int NBI>
+__global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
+  extern __shared__ float sm[];  // red[3*64] then per-wave acc[nc*(NBI+1)][64]
+  float* red = sm;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int k = blockIdx.y;
+  const long nwaves = (long)gridDim.x * 4;
+  const long FI = (long)NBI * 32 * 32;
+  const int nacc = A.nc * (NBI + 1);
+  float* lacc = sm + 192 + (long)wid * nacc * 64;
+  for (int s = 0; s < nacc; ++s) lacc[s * 64 + lane] = 0.f;
+
+  for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
+    f32x4 af[NBI][4], zq[4];
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[ib][q] = ld4(A.IN + t * FI + (long)(32 * ib + i) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (k < A.r) zq[q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+      else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
+    }
+    for (int c = 0; c < A.nc; ++c) {
+      float s[NBI + 1];
+#pragma unroll
+      for (int ib = 0; ib <= NBI; ++ib) s[ib] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 dq = ld4(A.SM + (t * A.nc + c) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float w = dq[e] * zq[q][e];
+#pragma unroll
+          for (int ib = 0; ib < NBI; ++ib) s[ib] = fmaf(w, af[ib][q][e], s[ib]);
+          s[NBI] += w;
+        }
+      }
+#pragma unroll
+      for (int ib = 0; ib <= NBI; ++ib) lacc[(c * (NBI + 1) + ib) * 64 + lane] += s[ib];
+    }
+  }
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+  for (int c = 0; c < A.nc; ++c)
+    for (int ib = 0; ib <= NBI; ++ib) {
+      float v = lacc[(c * (NBI + 1) + ib) * 64 + lane];
+      v += __shfl_xor(v, 32);
+      v = block_sum4(v, red, wid, lane);
+      if (wid == 0 && hf == 0) {
+        const int f = 32 * ib + i;
+        if (ib < NBI) { if (f < A.W.nin) prow[matref_index(A.W, k, f, c)] = A.scale * v; }
+        else if (A.has_bias && i == 0) prow[matref_index(A.Bv, k, 0, c)] = v;
+      }
+    }
+}
+
+void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st) {
+  dim3 grid(rows, a.r + 1), block(256);
+  const size_t shm = (size_t)(192 + 4 * a.nc * (NBI + 1) * 64) * sizeof(float);
+  if (NBI == 1) hipLaunchKernelGGL((k_gw_out<1>), grid, block, shm, st, a);
+  else if (NBI == 2) hipLaunchKernelGGL((k_gw_out<2>), grid, block, shm, st, a);
+  else hipLaunchKernelGGL((k_gw_out<4>), grid, block, shm, st, a);
+}

@@ -1,0 +1,286 @@
+// k_misc.hip -- the HBM-bound kernels of the path: per-sample-weight ShapeNet ("given w"), the
+// latent->weights map, gradient-row reduction, Adam, and row<->tile layout changes (gfx950).
+#include "nif_internal.h"
+
+// ============================================================================================
+// model_x_to_u_given_w: u = ShapeNet(x; w) with an arbitrary per-sample weight vector w[po]
+// (nif/model.py:435-464, :956-986; the einsum('ai,aij->aj') chain of mlp.py:209-219).
+//
+// HBM-bound by construction: 4*(si+po+so) bytes per point, 2 flop per weight.  One wavefront per
+// point.  Each n x n matrix is streamed with 16-byte loads, 1 KiB per wave-instruction (all loads of
+// a matrix are issued before the first use so a wave keeps up to 16 KiB in flight); the vec-mat
+// product is done as partial dot products per lane + wavefront shuffle reductions:
+//     lane = (g, cq):  g = row inside the 256-float chunk, cq = column quad; acc[c] += h[row]*w[row][4cq+c]
+// ============================================================================================
+template <int ACT>
+__device__ __forceinline__ void act4(float (&a)[4], float (&h)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { float d; act_eval<ACT>(a[c], &h[c], &d); }
+}
+__device__ __forceinline__ void act4_dyn(int act, float (&a)[4], float (&h)[4]) {
+  switch (act) {
+    case ACT_SINE: act4<ACT_SINE>(a, h); break;
+    case ACT_SWISH: act4<ACT_SWISH>(a, h); break;
+    case ACT_TANH: act4<ACT_TANH>(a, h); break;
+    case ACT_RELU: act4<ACT_RELU>(a, h); break;
+    case ACT_SIGMOID: act4<ACT_SIGMOID>(a, h); break;
+    case ACT_ELU: act4<ACT_ELU>(a, h); break;
+    case ACT_SOFTPLUS: act4<ACT_SOFTPLUS>(a, h); break;
+    case ACT_GELU: act4<ACT_GELU>(a, h); break;
+    default: act4<ACT_LINEAR>(a, h); break;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_given_w(const float* __restrict__ x, const float* __restrict__ w,
+                                                 float* __restrict__ u, long B, int si, int so, int nh, long po,
+                                                 int act, int res, int nif_skip, float omega) {
+  constexpr int LPR = N / 4;          // lanes per matrix row
+  constexpr int RPC = 64 / LPR;       // rows per 256-float chunk
+  constexpr int NCH = N * N / 256;    // chunks per matrix
+  constexpr int CB = NCH < 16 ? NCH : 16;  // chunks in flight per batch
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane / LPR, cq = lane % LPR;
+  const long nwaves = (long)gridDim.x * 4;
+  const long s_w1 = 0, s_wh = (long)si * N, s_wl = s_wh + (long)nh * N * N, s_b1 = s_wl + (long)N * so;
+  const long s_bh = s_b1 + N, s_bl = s_bh + (long)nh * N;
+
+  for (long pt = (long)blockIdx.x * 4 + wid; pt < B; pt += nwaves) {
+    const float* wp = w + pt * po;
+    float h4[4], a4[4], ub[4];
+    {  // first layer
+      const f32x4u b = *reinterpret_cast<const f32x4u*>(wp + s_b1 + 4 * cq);
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int d = 0; d < si; ++d) {
+        const float xv = x[pt * si + d];
+        const f32x4u wv = *reinterpret_cast<const f32x4u*>(wp + s_w1 + (long)d * N + 4 * cq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wv[c], acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a4[c] = fmaf(omega, acc[c], b[c]);
+      act4_dyn(act, a4, h4);
+    }
+    for (int j = 0; j < nh; ++j) {
+      const float* wm = wp + s_wh + (long)j * N * N;
+      const f32x4u b = *reinterpret_cast<const f32x4u*>(wp + s_bh + (long)j * N + 4 * cq);
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < NCH; cb += CB) {
+        f32x4u wv[CB];
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) wv[ch] = *reinterpret_cast<const f32x4u*>(wm + (long)(cb + ch) * 256 + lane * 4);
+#pragma unroll
+        for (int ch = 0; ch < CB; ++ch) {
+          // row = (cb+ch)*RPC + g ; it is component (row & 3) of the lane whose cq' = row >> 2
+          const int rbase = (cb + ch) * RPC;          // compile-time
+          const int comp0 = rbase & 3;                 // 0 (RPC>=4) or {0,2} (RPC=2)
+          const int compi = (comp0 + g) & 3;
+          const float hsel = compi == 0 ? h4[0] : compi == 1 ? h4[1] : compi == 2 ? h4[2] : h4[3];
+          const int src = g * LPR + ((rbase + g) >> 2);
+          const float hr = __shfl(hsel, src);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = fmaf(hr, wv[ch][c], acc[c]);
+        }
+      }
+      // sum the partial dot products of the RPC row groups
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a4[c] = fmaf(omega, acc[c], b[c]);
+      float hn[4];
+      act4_dyn(act, a4, hn);
+      const bool res_first = res && !(j & 1), res_second = res && (j & 1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (res_first) ub[c] = h4[c];
+        float v = hn[c];
+        if (nif_skip) v += h4[c];
+        if (res_second) v = 0.5f * (ub[c] + v);
+        h4[c] = v;
+      }
+    }
+    // last layer: u[o] = sum_f h[f] Wl[f][o] + bl[o]
+    for (int o = 0; o < so; ++o) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s = fmaf(h4[c], wp[s_wl + (long)(4 * cq + c) * so + o], s);
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off);
+      if (lane == 0) u[pt * so + o] = s + wp[s_bl + o];
+    }
+  }
+}
+
+// generic width (n <= 128, any n): lane owns columns lane and lane+64, dword loads
+__global__ __launch_bounds__(256) void k_given_w_generic(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ u, long B, int si, int so, int n, int nh,
+                                                         long po, int act, int res, int nif_skip, float omega) {
+  __shared__ float hs[4][128];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long nwaves = (long)gridDim.x * 4;
+  const long s_w1 = 0, s_wh = (long)si * n, s_wl = s_wh + (long)nh * n * n, s_b1 = s_wl + (long)n * so;
+  const long s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+  float* hsw = hs[wid];
+  for (long pt = (long)blockIdx.x * 4 + wid; pt < B; pt += nwaves) {
+    const float* wp = w + pt * po;
+    float hcur[2] = {0.f, 0.f}, ub[2] = {0.f, 0.f};
+    for (int q = 0; q < 2; ++q) {
+      const int f = lane + 64 * q;
+      if (f < n) {
+        float acc = 0.f;
+        for (int d = 0; d < si; ++d) acc = fmaf(x[pt * si + d], wp[s_w1 + (long)d * n + f], acc);
+        float a = fmaf(omega, acc, wp[s_b1 + f]), hv, dv;
+        float a1[4] = {a, 0, 0, 0}, h1[4];
+        act4_dyn(act, a1, h1);
+        hv = h1[0]; (void)dv;
+        hcur[q] = hv;
+      }
+    }
+    for (int j = 0; j < nh; ++j) {
+      hsw[lane] = hcur[0]; hsw[lane + 64] = hcur[1];
+      __builtin_amdgcn_wave_barrier();
+      const float* wm = wp + s_wh + (long)j * n * n;
+      float acc[2] = {0.f, 0.f};
+      for (int i = 0; i < n; ++i) {
+        const float hi = hsw[i];
+        if (lane < n) acc[0] = fmaf(hi, wm[(long)i * n + lane], acc[0]);
+        if (lane + 64 < n) acc[1] = fmaf(hi, wm[(long)i * n + lane + 64], acc[1]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const bool res_first = res && !(j & 1), res_second = res && (j & 1);
+      for (int q = 0; q < 2; ++q) {
+        const int f = lane + 64 * q;
+        float v = 0.f;
+        if (f < n) {
+          float a1[4] = {fmaf(omega, acc[q], wp[s_bh + (long)j * n + f]), 0, 0, 0}, h1[4];
+          act4_dyn(act, a1, h1);
+          v = h1[0];
+          if (res_first) ub[q] = hcur[q];
+          if (nif_skip) v += hcur[q];
+          if (res_second) v = 0.5f * (ub[q] + v);
+        }
+        hcur[q] = v;
+      }
+    }
+    for (int o = 0; o < so; ++o) {
+      float s = 0.f;
+      if (lane < n) s = fmaf(hcur[0], wp[s_wl + (long)lane * so + o], s);
+      if (lane + 64 < n) s = fmaf(hcur[1], wp[s_wl + (long)(lane + 64) * so + o], s);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) u[pt * so + o] = s + wp[s_bl + o];
+    }
+  }
+}
+
+void launch_given_w(const float* x, const float* w, float* u, long B, int si, int so, int n, int nh, long po, int act,
+                    int res, int nif_skip, float omega, hipStream_t st) {
+  long blocks = (B + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  dim3 grid((unsigned)blocks), block(256);
+  if (n == 32) hipLaunchKernelGGL((k_given_w<32>), grid, block, 0, st, x, w, u, B, si, so, nh, po, act, res, nif_skip, omega);
+  else if (n == 64) hipLaunchKernelGGL((k_given_w<64>), grid, block, 0, st, x, w, u, B, si, so, nh, po, act, res, nif_skip, omega);
+  else if (n == 128) hipLaunchKernelGGL((k_given_w<128>), grid, block, 0, st, x, w, u, B, si, so, nh, po, act, res, nif_skip, omega);
+  else hipLaunchKernelGGL(k_given_w_generic, grid, block, 0, st, x, w, u, B, si, so, n, nh, po, act, res, nif_skip, omega);
+}
+
+// ============================================================================================
+// model_lr_to_w: w[a][s] = sum_k lr[a][k] Wh[k][s] + bh[s]   (siren.py:514-522 / Dense model.py:220-230)
+// write-bound (4*po bytes per point); each block keeps a slab of Wh rows in registers across points
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
+                                                     long po, const float* __restrict__ lr, long B,
+                                                     float* __restrict__ w) {
+  // grid.x over slot chunks of 256, grid.y over point groups
+  const long s = (long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= po) return;
+  const float bias = theta[off_bh + s];
+  for (long a = blockIdx.y; a < B; a += gridDim.y) {
+    float acc = bias;
+    for (int k = 0; k < r; ++k) acc = fmaf(lr[a * r + k], theta[off_Wh + (long)k * po + s], acc);
+    w[a * po + s] = acc;
+  }
+}
+void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B, float* w,
+                        hipStream_t st) {
+  dim3 grid((unsigned)((po + 255) / 256), (unsigned)(B < 1024 ? B : 1024)), block(256);
+  hipLaunchKernelGGL(k_latent_to_w, grid, block, 0, st, theta, off_Wh, off_bh, r, po, lr, B, w);
+}
+
+// ============================================================================================
+// gradient rows -> flat gradient (fixed summation order), loss partials -> g[P]
+// ============================================================================================
+__global__ void k_reduce(const float* __restrict__ partial, long pstride, int rows, const float* __restrict__ lossp,
+                         int nloss, float* __restrict__ g, long P) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P) {
+    float s = 0.f;
+    for (int rrow = 0; rrow < rows; ++rrow) s += partial[(long)rrow * pstride + i];
+    g[i] = s;
+  } else if (i == P) {
+    // Kahan-compensated, fixed order: the loss is a sum of up to B/128 block partials
+    float s = 0.f, c = 0.f;
+    for (int b = 0; b < nloss; ++b) {
+      const float yv = lossp[b] - c;
+      const float t = s + yv;
+      c = (t - s) - yv;
+      s = t;
+    }
+    g[P] = s;
+  }
+}
+void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss, float* g, long P,
+                   hipStream_t st) {
+  dim3 grid((unsigned)((P + 1 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_reduce, grid, block, 0, st, partial, pstride, rows, loss_partial, nloss, g, P);
+}
+
+// Keras-2.11 Adam (SURVEY a-11): lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host
+__global__ void k_adam(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long P, float lr_t, float b1, float b2, float eps) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+  const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+  m[i] = mi; v[i] = vi;
+  theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+void launch_adam(float* theta, const float* g, float* m, float* v, long P, float lr_t, float b1, float b2, float eps,
+                 hipStream_t st) {
+  dim3 grid((unsigned)((P + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_adam, grid, block, 0, st, theta, g, m, v, P, lr_t, b1, b2, eps);
+}
+
+// rows [B][c]  <->  tiles [ceil(B/32)][c][32]
+__global__ void k_rows_to_tiles(const float* __restrict__ rows, long B, int c, float* __restrict__ tiles) {
+  const long ntot = ((B + 31) / 32) * 32 * c;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < ntot; idx += (long)gridDim.x * blockDim.x) {
+    const long t = idx / (32L * c);
+    const int rem = (int)(idx - t * 32L * c);
+    const int cc = rem / 32, p = rem % 32;
+    long pt = t * 32 + p;
+    if (pt >= B) pt = B - 1;
+    tiles[idx] = rows[pt * c + cc];
+  }
+}
+__global__ void k_tiles_to_rows(const float* __restrict__ tiles, long B, int c, float* __restrict__ rows) {
+  const long ntot = B * c;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < ntot; idx += (long)gridDim.x * blockDim.x) {
+    const long pt = idx / c;
+    const int cc = (int)(idx - pt * c);
+    rows[idx] = tiles[((pt / 32) * c + cc) * 32 + (pt % 32)];
+  }
+}
+void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st) {
+  const long ntot = ((B + 31) / 32) * 32 * c;
+  long grid = (ntot + 255) / 256; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_rows_to_tiles, dim3((unsigned)grid), dim3(256), 0, st, rows, B, c, tiles);
+}
+void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st) {
+  const long ntot = B * c;
+  long grid = (ntot + 255) / 256; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned)grid), dim3(256), 0, st, tiles, B, c, rows);
+}

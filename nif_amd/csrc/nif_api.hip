@@ -1,0 +1,647 @@
+// nif_api.hip -- C-ABI of libnif_hip.so (include/nif_hip.h): context, parameter layout, kernel
+// orchestration.  gfx950 only; there is no CPU fallback.
+#include "../../include/nif_hip.h"
+#include "nif_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(NIF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+struct nif_ctx {
+  nif_cfg cfg;
+  int dev = 0;
+  hipStream_t st = nullptr;
+  // derived sizes
+  int kind, pi, si, so, n, L, nst, lst, r, nh, nm, NB, NSTB;
+  long po, P;
+  std::vector<nif_tensor_desc> layout;
+  // theta offsets
+  long first_w, first_b, hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
+  long bott_w, bott_b, last_w, last_b;
+  // device state
+  float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+  long step = 0;
+  bool have_params = false, packed = false;
+  f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr;
+  // workspaces (capacity in points)
+  long cap = 0;
+  float *stash_s = nullptr, *stash_p = nullptr, *Z = nullptr, *DZ = nullptr, *DU = nullptr, *ZL = nullptr;
+  long slot_s = 0, slot_p = 0;
+  float* partial = nullptr; int rows_cap = 0; long pstride = 0;
+  float* loss_partial = nullptr; long nloss_cap = 0;
+  // profiling: (group id, start, stop) event triples recorded on st
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  double prof_ms[NIF_PROF_N] = {0};
+  long prof_cnt[NIF_PROF_N] = {0};
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // staging for the host-pointer API
+  float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
+  long cap_a = 0, cap_b = 0, cap_c = 0, cap_d = 0;
+};
+
+// RAII-ish helper: records an event pair around a kernel group when profiling is on
+struct ProfScope {
+  nif_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(nif_ctx* c_, int id_) : c(c_), id(id_) {
+    if (!c->prof_on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, c->st);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->st);
+    c->recs.push_back({id, a, b});
+  }
+};
+
+extern "C" const char* nif_last_error(void) { return g_err.c_str(); }
+extern "C" int nif_abi_version(void) { return NIF_ABI_VERSION; }
+extern "C" int nif_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static void add_desc(nif_ctx* c, const char* name, long& off, int rows, int cols) {
+  nif_tensor_desc d;
+  memset(&d, 0, sizeof(d));
+  snprintf(d.name, sizeof(d.name), "%s", name);
+  d.offset = off; d.rows = rows; d.cols = cols;
+  c->layout.push_back(d);
+  off += (long)rows * (cols ? cols : 1);
+}
+
+// Keras variable order (nif/model.py:178-231, :591-734, :1162-1215)
+static int build_layout(nif_ctx* c) {
+  long off = 0;
+  char nm[48];
+  c->first_w = off; add_desc(c, "pnet_first_w", off, c->pi, c->nst);
+  c->first_b = off; add_desc(c, "pnet_first_b", off, c->nst, 0);
+  for (int i = 0; i < c->lst; ++i) {
+    snprintf(nm, sizeof(nm), "pnet_h%d_w", i); c->hid_w[i] = off; add_desc(c, nm, off, c->nst, c->nst);
+    snprintf(nm, sizeof(nm), "pnet_h%d_b", i); c->hid_b[i] = off; add_desc(c, nm, off, c->nst, 0);
+    if (c->cfg.p_resblock) {
+      snprintf(nm, sizeof(nm), "pnet_h%d_w2", i); c->hid_w2[i] = off; add_desc(c, nm, off, c->nst, c->nst);
+      snprintf(nm, sizeof(nm), "pnet_h%d_b2", i); c->hid_b2[i] = off; add_desc(c, nm, off, c->nst, 0);
+    }
+  }
+  c->bott_w = off; add_desc(c, "pnet_bottleneck_w", off, c->nst, c->r);
+  c->bott_b = off; add_desc(c, "pnet_bottleneck_b", off, c->r, 0);
+  c->last_w = off; add_desc(c, "pnet_last_w", off, c->r, (int)c->po);
+  c->last_b = off; add_desc(c, "pnet_last_b", off, (int)c->po, 0);
+  c->P = off;
+  return 0;
+}
+
+extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
+  if (!cfg || !out) return fail(NIF_ERR_INVALID, "null argument");
+  if (cfg->abi_version != NIF_ABI_VERSION) return fail(NIF_ERR_INVALID, "abi_version mismatch");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NIF_ERR_NODEVICE, "no HIP device visible: libnif_hip has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(NIF_ERR_INVALID, "device_id out of range");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NIF_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", libnif_hip is built for gfx950 only");
+  if (cfg->kind != NIF_KIND_NIF && cfg->kind != NIF_KIND_MULTISCALE)
+    return fail(NIF_ERR_INVALID, "kind not supported by this build (NIF and NIFMultiScale are)");
+  if (cfg->pi_dim < 1 || cfg->si_dim < 1 || cfg->so_dim < 1 || cfg->latent_dim < 1)
+    return fail(NIF_ERR_INVALID, "dims must be >= 1");
+  if (cfg->n_sx < 1 || cfg->n_sx > 128 || cfg->n_st < 1 || cfg->n_st > 128)
+    return fail(NIF_ERR_INVALID, "units must be in [1,128]");
+  if (cfg->latent_dim > 64) return fail(NIF_ERR_INVALID, "latent_dim must be <= 64");
+  if (cfg->pi_dim > 16 || cfg->si_dim > 16 || cfg->so_dim > 16)
+    return fail(NIF_ERR_INVALID, "input/output dims must be <= 16");
+  const int nh = cfg->l_sx * (cfg->s_resblock ? 2 : 1);
+  const int nm = cfg->l_st * (cfg->p_resblock ? 2 : 1);
+  if (cfg->l_sx < 0 || nh > NIF_MAX_HID || cfg->l_st < 0 || cfg->l_st > NIF_MAX_HID)
+    return fail(NIF_ERR_INVALID, "too many layers");
+  if (cfg->kind == NIF_KIND_NIF && (cfg->s_resblock || cfg->p_resblock || cfg->p_act == NIF_ACT_SINE))
+    return fail(NIF_ERR_INVALID, "class NIF has no resblock / sine ParameterNet");
+  if (cfg->p_resblock && cfg->kind == NIF_KIND_NIF) return fail(NIF_ERR_INVALID, "bad cfg");
+
+  nif_ctx* c = new nif_ctx();
+  c->cfg = *cfg;
+  c->dev = device_id;
+  c->kind = cfg->kind; c->pi = cfg->pi_dim; c->si = cfg->si_dim; c->so = cfg->so_dim;
+  c->n = cfg->n_sx; c->L = cfg->l_sx; c->nst = cfg->n_st; c->lst = cfg->l_st; c->r = cfg->latent_dim;
+  c->nh = nh; c->nm = nm;
+  c->NB = c->n <= 32 ? 1 : (c->n <= 64 ? 2 : 4);
+  c->NSTB = c->nst <= 32 ? 1 : (c->nst <= 64 ? 2 : 4);
+  c->po = (long)nh * c->n * c->n + (long)(c->si + c->so + 1 + nh) * c->n + c->so;
+  build_layout(c);
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+  const size_t pb = (size_t)(c->P + 1) * sizeof(float);
+  if (e == hipSuccess) e = hipMalloc(&c->theta, pb);
+  if (e == hipSuccess) e = hipMalloc(&c->grad, pb);
+  if (e == hipSuccess) e = hipMalloc(&c->m, pb);
+  if (e == hipSuccess) e = hipMalloc(&c->v, pb);
+  if (e == hipSuccess) e = hipMemset(c->m, 0, pb);
+  if (e == hipSuccess) e = hipMemset(c->v, 0, pb);
+  if (e == hipSuccess) e = hipMemset(c->grad, 0, pb);
+  const size_t pk_p = (size_t)(nm > 0 ? nm : 1) * c->NSTB * c->NSTB * 256 * sizeof(f32x4);
+  const size_t pk_s = (size_t)(nh > 0 ? nh : 1) * (c->r + 1) * c->NB * c->NB * 256 * sizeof(f32x4);
+  if (e == hipSuccess) e = hipMalloc(&c->pWF, pk_p);
+  if (e == hipSuccess) e = hipMalloc(&c->pWB, pk_p);
+  if (e == hipSuccess) e = hipMalloc(&c->sWF, pk_s);
+  if (e == hipSuccess) e = hipMalloc(&c->sWB, pk_s);
+  if (e != hipSuccess) {
+    std::string msg = std::string("nif_create: ") + hipGetErrorString(e);
+    delete c;
+    return fail(NIF_ERR_HIP, msg);
+  }
+  *out = c;
+  return NIF_OK;
+}
+
+extern "C" int nif_destroy(nif_ctx* c) {
+  if (!c) return NIF_OK;
+  hipSetDevice(c->dev);
+  if (c->st) hipStreamSynchronize(c->st);
+  void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->d_a, c->d_b, c->d_c, c->d_d};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->st) hipStreamDestroy(c->st);
+  delete c;
+  return NIF_OK;
+}
+
+extern "C" int nif_param_count(nif_ctx* c, int64_t* n) { if (!c || !n) return fail(NIF_ERR_INVALID, "null"); *n = c->P; return NIF_OK; }
+extern "C" int nif_po_dim(nif_ctx* c, int64_t* po) { if (!c || !po) return fail(NIF_ERR_INVALID, "null"); *po = c->po; return NIF_OK; }
+extern "C" int nif_param_layout(nif_ctx* c, nif_tensor_desc* descs, int32_t* n_inout) {
+  if (!c || !n_inout) return fail(NIF_ERR_INVALID, "null");
+  const int need = (int)c->layout.size();
+  if (!descs || *n_inout < need) { *n_inout = need; return descs ? fail(NIF_ERR_INVALID, "descs too small") : NIF_OK; }
+  memcpy(descs, c->layout.data(), sizeof(nif_tensor_desc) * need);
+  *n_inout = need;
+  return NIF_OK;
+}
+
+extern "C" int nif_set_params(nif_ctx* c, const float* host, int64_t n) {
+  if (!c || !host) return fail(NIF_ERR_INVALID, "null");
+  if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(c->theta, host, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  c->have_params = true; c->packed = false;
+  return NIF_OK;
+}
+extern "C" int nif_get_params(nif_ctx* c, float* host, int64_t n) {
+  if (!c || !host) return fail(NIF_ERR_INVALID, "null");
+  if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(host, c->theta, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+extern "C" int nif_get_opt_state(nif_ctx* c, float* mh, float* vh, int64_t n, int64_t* step) {
+  if (!c || !mh || !vh || !step) return fail(NIF_ERR_INVALID, "null");
+  if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(mh, c->m, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(vh, c->v, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  *step = c->step;
+  return NIF_OK;
+}
+extern "C" int nif_set_opt_state(nif_ctx* c, const float* mh, const float* vh, int64_t n, int64_t step) {
+  if (!c || !mh || !vh) return fail(NIF_ERR_INVALID, "null");
+  if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(c->m, mh, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipMemcpyAsync(c->v, vh, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  c->step = step;
+  return NIF_OK;
+}
+
+extern "C" int nif_dev_alloc(nif_ctx* c, int64_t bytes, void** dptr) {
+  if (!c || !dptr || bytes < 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMalloc(dptr, bytes > 0 ? (size_t)bytes : 4));
+  return NIF_OK;
+}
+extern "C" int nif_dev_free(nif_ctx* c, void* dptr) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  if (dptr) HIPCHK(hipFree(dptr));
+  return NIF_OK;
+}
+extern "C" int nif_h2d(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c || !dst || !src) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+extern "C" int nif_d2h(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c || !dst || !src) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+extern "C" int nif_sync(nif_ctx* c) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+extern "C" void* nif_stream(nif_ctx* c) { return c ? (void*)c->st : nullptr; }
+extern "C" void* nif_grad_dev(nif_ctx* c) { return c ? (void*)c->grad : nullptr; }
+extern "C" void* nif_params_dev(nif_ctx* c) { return c ? (void*)c->theta : nullptr; }
+
+// ------------------------------------------------------------------------------------------
+// internal orchestration
+// ------------------------------------------------------------------------------------------
+static int grow(float** p, long* cap, long need) {
+  if (need <= *cap) return NIF_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  HIPCHK(hipMalloc(p, sizeof(float) * (size_t)need));
+  *cap = need;
+  return NIF_OK;
+}
+
+static int ensure_capacity(nif_ctx* c, long B, bool train) {
+  const long ntiles = (B + 31) / 32;
+  const long pts = ntiles * 32;
+  if (pts > c->cap || (train && !c->stash_s)) {
+    HIPCHK(hipStreamSynchronize(c->st));
+    const long newcap = pts > c->cap ? pts : c->cap;
+    float** ws[] = {&c->Z, &c->DZ, &c->DU, &c->ZL};
+    const long wsz[] = {(long)c->r * newcap, (long)c->r * newcap, (long)c->so * newcap, (long)c->r * newcap};
+    if (newcap > c->cap)
+      for (int i = 0; i < 4; ++i) {
+        if (*ws[i]) HIPCHK(hipFree(*ws[i]));
+        *ws[i] = nullptr;
+        HIPCHK(hipMalloc(ws[i], sizeof(float) * (size_t)wsz[i]));
+      }
+    if (train) {
+      if (c->stash_s) HIPCHK(hipFree(c->stash_s));
+      if (c->stash_p) HIPCHK(hipFree(c->stash_p));
+      c->stash_s = c->stash_p = nullptr;
+      c->slot_s = (long)c->NB * 32 * newcap;
+      c->slot_p = (long)c->NSTB * 32 * newcap;
+      HIPCHK(hipMalloc(&c->stash_s, sizeof(float) * (size_t)(c->slot_s * 2 * (c->nh + 1))));
+      HIPCHK(hipMalloc(&c->stash_p, sizeof(float) * (size_t)(c->slot_p * (2 * c->nm + 2))));
+    } else if (newcap > c->cap && c->stash_s) {
+      HIPCHK(hipFree(c->stash_s)); HIPCHK(hipFree(c->stash_p));
+      c->stash_s = c->stash_p = nullptr;
+    }
+    c->cap = newcap;
+  }
+  if (train) {
+    const long nblk = (ntiles + 3) / 4;
+    if (nblk > c->nloss_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      if (c->loss_partial) HIPCHK(hipFree(c->loss_partial));
+      c->loss_partial = nullptr;
+      HIPCHK(hipMalloc(&c->loss_partial, sizeof(float) * (size_t)nblk));
+      c->nloss_cap = nblk;
+    }
+    if (!c->partial) {
+      c->rows_cap = 256;
+      c->pstride = (c->P + 1 + 63) / 64 * 64;
+      HIPCHK(hipMalloc(&c->partial, sizeof(float) * (size_t)c->rows_cap * c->pstride));
+    }
+  }
+  return NIF_OK;
+}
+
+static MatRef dense_ref(long w_off, int nin, int nout) { MatRef m; m.r = 0; m.base_k = 0; m.kstride = 0; m.base_last = w_off; m.ld = nout; m.nin = nin; m.nout = nout; return m; }
+static MatRef vec_ref(long b_off, int nout) { MatRef m; m.r = 0; m.base_k = 0; m.kstride = 0; m.base_last = b_off; m.ld = 0; m.nin = 1; m.nout = nout; return m; }
+static MatRef hyper_ref(const nif_ctx* c, long slot, int ld, int nin, int nout) {
+  MatRef m; m.r = c->r; m.base_k = c->last_w + slot; m.kstride = c->po; m.base_last = c->last_b + slot; m.ld = ld; m.nin = nin; m.nout = nout; return m;
+}
+
+static void fill_pnet(const nif_ctx* c, PNetArgs& a, const float* xin, long B) {
+  memset(&a, 0, sizeof(a));
+  a.theta = c->theta; a.xin = xin; a.ncol = c->pi + c->si; a.col0 = 0; a.B = B;
+  a.pi = c->pi; a.nst = c->nst; a.lst = c->lst; a.r = c->r;
+  a.act = c->cfg.p_act; a.res = c->cfg.p_resblock; a.siren = (c->cfg.p_act == NIF_ACT_SINE);
+  a.omega = a.siren ? c->cfg.p_omega0 : 1.0f;
+  a.first_w = c->first_w; a.first_b = c->first_b;
+  for (int i = 0; i < c->lst; ++i) { a.hid_w[i] = c->hid_w[i]; a.hid_b[i] = c->hid_b[i]; a.hid_w2[i] = c->hid_w2[i]; a.hid_b2[i] = c->hid_b2[i]; }
+  a.bott_w = c->bott_w; a.bott_b = c->bott_b; a.ll_kind = 0; a.last_w = c->last_w; a.last_b = c->last_b;
+  a.WF = c->pWF; a.WB = c->pWB; a.stash = c->stash_p; a.slot_stride = c->slot_p;
+  a.Z = c->Z; a.DZ = c->DZ; a.ZL = c->ZL;
+}
+static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
+  memset(&a, 0, sizeof(a));
+  a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
+  a.si = c->si; a.so = c->so; a.n = c->n; a.nh = c->nh; a.r = c->r; a.po = c->po;
+  a.act = c->kind == NIF_KIND_NIF ? c->cfg.s_act : NIF_ACT_SINE;
+  a.res = c->cfg.s_resblock; a.nif_skip = (c->kind == NIF_KIND_NIF);
+  a.omega = c->kind == NIF_KIND_NIF ? 1.0f : c->cfg.s_omega0;
+  a.off_Wh = c->last_w; a.off_bh = c->last_b;
+  a.Z = c->Z; a.WF = c->sWF; a.WB = c->sWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
+  a.DU = c->DU; a.DZ = c->DZ;
+}
+
+static int ensure_packed(nif_ctx* c) {
+  if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
+  if (c->packed) return NIF_OK;
+  ProfScope ps_(c, NIF_PROF_PACK);
+  const long plane_p = (long)c->NSTB * c->NSTB * 256;
+  for (int i = 0; i < c->lst; ++i) {
+    if (!c->cfg.p_resblock) {
+      launch_pack(c->theta, dense_ref(c->hid_w[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + i * plane_p, c->pWB + i * plane_p, c->st);
+    } else {
+      launch_pack(c->theta, dense_ref(c->hid_w[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + (2 * i) * plane_p, c->pWB + (2 * i) * plane_p, c->st);
+      launch_pack(c->theta, dense_ref(c->hid_w2[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + (2 * i + 1) * plane_p, c->pWB + (2 * i + 1) * plane_p, c->st);
+    }
+  }
+  const long plane_s = (long)c->NB * c->NB * 256;
+  for (int j = 0; j < c->nh; ++j) {
+    const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
+    launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, c->sWF + (long)j * (c->r + 1) * plane_s,
+                c->sWB + (long)j * (c->r + 1) * plane_s, c->st);
+  }
+  HIPCHK(hipGetLastError());
+  c->packed = true;
+  return NIF_OK;
+}
+
+extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u) {
+  if (!c || !xin || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, false, c->st); }
+  SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
+  sa.u_out = u;
+  { ProfScope p_(c, NIF_PROF_SNET_FWD); launch_snet(sa, c->NB, false, c->st); }
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
+static int stage(nif_ctx* c, float** buf, long* cap, const float* host, long n) {
+  int rc = grow(buf, cap, n); if (rc) return rc;
+  if (host) HIPCHK(hipMemcpyAsync(*buf, host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_forward(nif_ctx* c, const float* xin, int64_t B, float* u) {
+  if (!c || !xin || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
+  rc = nif_forward_dev(c, c->d_a, B, c->d_d); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(u, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr) {
+  if (!c || !p || !lr || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  rc = stage(c, &c->d_a, &c->cap_a, p, B * c->pi); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->r); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+  pa.ncol = c->pi;
+  launch_pnet(pa, c->NSTB, false, c->st);
+  launch_tiles_to_rows(c->Z, B, c->r, c->d_d, c->st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(lr, c->d_d, sizeof(float) * (size_t)(B * c->r), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_latent_to_w_dev(nif_ctx* c, const float* lr, int64_t B, float* w) {
+  if (!c || !lr || !w || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
+  HIPCHK(hipSetDevice(c->dev));
+  { ProfScope p_(c, NIF_PROF_LATENT_TO_W); launch_latent_to_w(c->theta, c->last_w, c->last_b, c->r, c->po, lr, B, w, c->st); }
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+extern "C" int nif_latent_to_w(nif_ctx* c, const float* lr, int64_t B, float* w) {
+  if (!c || !lr || !w || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = stage(c, &c->d_a, &c->cap_a, lr, B * c->r); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->po); if (rc) return rc;
+  rc = nif_latent_to_w_dev(c, c->d_a, B, c->d_b); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(w, c->d_b, sizeof(float) * (size_t)(B * c->po), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_shapenet_given_w_dev(nif_ctx* c, const float* x, const float* w, int64_t B, float* u) {
+  if (!c || !x || !w || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  const int act = c->kind == NIF_KIND_NIF ? c->cfg.s_act : NIF_ACT_SINE;
+  const float om = c->kind == NIF_KIND_NIF ? 1.0f : c->cfg.s_omega0;
+  { ProfScope p_(c, NIF_PROF_GIVEN_W);
+    launch_given_w(x, w, u, B, c->si, c->so, c->n, c->nh, c->po, act, c->cfg.s_resblock, c->kind == NIF_KIND_NIF, om, c->st); }
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, int64_t B, float* u) {
+  if (!c || !x || !w || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = stage(c, &c->d_a, &c->cap_a, x, B * c->si); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, w, B * c->po); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
+  rc = nif_shapenet_given_w_dev(c, c->d_a, c->d_b, B, c->d_d); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(u, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg) {
+  if (!c || !xin || !y || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_capacity(c, B, true); if (rc) return rc;
+  const long ntiles = (B + 31) / 32;
+  const int ncol = c->pi + c->si;
+  // forward + adjoint
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
+  SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
+  sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+  { ProfScope p_(c, NIF_PROF_SNET); launch_snet(sa, c->NB, true, c->st); }
+  { ProfScope p_(c, NIF_PROF_PNET_BWD); launch_pnet_bwd(pa, c->NSTB, c->st); }
+  ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
+  // weight gradients -> partial rows
+  int rows = (int)((ntiles + 3) / 4);
+  if (rows > c->rows_cap) rows = c->rows_cap;
+  if (rows < 1) rows = 1;
+  GwArgs g;
+  auto base = [&](GwArgs& q) {
+    memset(&q, 0, sizeof(q));
+    q.ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride; q.has_bias = 1; q.scale = 1.0f;
+  };
+  const float om_s = sa.omega, om_p = pa.omega;
+  float* sIN = c->stash_s; float* sDA = c->stash_s + (long)(c->nh + 1) * c->slot_s;
+  // ShapeNet first layer
+  base(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = c->Z; g.r = c->r; g.scale = om_s;
+  g.W = hyper_ref(c, 0, c->n, c->si, c->n);
+  g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
+  launch_gw_first(g, c->NB, rows, c->st);
+  // ShapeNet hidden matrices
+  for (int j = 0; j < c->nh; ++j) {
+    base(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = c->Z; g.r = c->r; g.scale = om_s;
+    const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
+    const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
+    g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
+    g.Bv = hyper_ref(c, bslot, 0, 1, c->n);
+    launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
+  }
+  // ShapeNet last layer
+  {
+    base(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = c->DU; g.nc = c->so; g.Z = c->Z; g.r = c->r; g.scale = 1.0f;
+    const long wslot = (long)c->si * c->n + (long)c->nh * c->n * c->n;
+    const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
+    g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
+    g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
+    launch_gw_out(g, c->NB, rows, c->st);
+  }
+  // ParameterNet: first, hidden matrices, bottleneck
+  float* pST = c->stash_p;
+  base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.r = 0; g.scale = om_p;
+  g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
+  launch_gw_first(g, c->NSTB, rows, c->st);
+  for (int mi = 0; mi < c->nm; ++mi) {
+    base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.r = 0; g.scale = om_p;
+    long w_off, b_off;
+    if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
+    else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
+    g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
+    launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
+  }
+  base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->DZ; g.nc = c->r; g.r = 0; g.scale = 1.0f;
+  g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
+  launch_gw_out(g, c->NSTB, rows, c->st);
+  delete pgw;
+  // rows -> flat gradient, loss
+  ProfScope pr_(c, NIF_PROF_REDUCE);
+  launch_reduce(c->partial, c->pstride, rows, c->loss_partial, (int)((ntiles + 3) / 4), c->grad, c->P, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
+extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
+  if (!c || !opt) return fail(NIF_ERR_INVALID, "null");
+  if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
+  HIPCHK(hipSetDevice(c->dev));
+  c->step += 1;
+  const double t = (double)c->step;
+  const double lr_t = (double)opt->lr * std::sqrt(1.0 - std::pow((double)opt->beta2, t)) / (1.0 - std::pow((double)opt->beta1, t));
+  { ProfScope p_(c, NIF_PROF_ADAM);
+    launch_adam(c->theta, c->grad, c->m, c->v, c->P, (float)lr_t, opt->beta1, opt->beta2, opt->eps, c->st); }
+  HIPCHK(hipGetLastError());
+  c->packed = false;
+  return NIF_OK;
+}
+
+extern "C" int nif_last_loss(nif_ctx* c, float* loss) {
+  if (!c || !loss) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+static int stage_batch(nif_ctx* c, const float* xin, const float* y, const float* sw, long B) {
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, y, B * c->so); if (rc) return rc;
+  if (sw) { rc = stage(c, &c->d_c, &c->cap_c, sw, B); if (rc) return rc; }
+  return NIF_OK;
+}
+
+extern "C" int nif_loss_and_grad(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, float* loss,
+                                 float* grad) {
+  if (!c || !xin || !y || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
+  rc = nif_loss_grad_dev(c, c->d_a, c->d_b, sw ? c->d_c : nullptr, B, B); if (rc) return rc;
+  if (grad) HIPCHK(hipMemcpyAsync(grad, c->grad, sizeof(float) * (size_t)c->P, hipMemcpyDeviceToHost, c->st));
+  if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+extern "C" int nif_train_step(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B,
+                              const nif_adam* opt, float* loss) {
+  if (!c || !xin || !y || !opt || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
+  rc = nif_loss_grad_dev(c, c->d_a, c->d_b, sw ? c->d_c : nullptr, B, B); if (rc) return rc;
+  rc = nif_adam_step_dev(c, opt); if (rc) return rc;
+  if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------
+static int drain_profile(nif_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (auto& r : c->recs) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    c->prof_ms[r.id] += ms; c->prof_cnt[r.id] += 1;
+    c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
+  }
+  c->recs.clear();
+  return NIF_OK;
+}
+extern "C" int nif_profile_enable(nif_ctx* c, int on) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = drain_profile(c); if (rc) return rc;
+  c->prof_on = on != 0;
+  return NIF_OK;
+}
+extern "C" int nif_profile_read(nif_ctx* c, float* ms, int64_t* cnt, int n, int reset) {
+  if (!c || !ms || !cnt || n < NIF_PROF_N) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = drain_profile(c); if (rc) return rc;
+  for (int i = 0; i < NIF_PROF_N; ++i) { ms[i] = (float)c->prof_ms[i]; cnt[i] = c->prof_cnt[i]; }
+  if (reset) for (int i = 0; i < NIF_PROF_N; ++i) { c->prof_ms[i] = 0; c->prof_cnt[i] = 0; }
+  return NIF_OK;
+}
+extern "C" int nif_timer_start(nif_ctx* c) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->t0) { HIPCHK(hipEventCreate(&c->t0)); HIPCHK(hipEventCreate(&c->t1)); }
+  HIPCHK(hipEventRecord(c->t0, c->st));
+  return NIF_OK;
+}
+extern "C" int nif_timer_stop(nif_ctx* c, float* ms) {
+  if (!c || !ms || !c->t0) return fail(NIF_ERR_INVALID, "timer not started");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipEventRecord(c->t1, c->st));
+  HIPCHK(hipEventSynchronize(c->t1));
+  HIPCHK(hipEventElapsedTime(ms, c->t0, c->t1));
+  return NIF_OK;
+}

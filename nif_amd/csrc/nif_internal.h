@@ -1,0 +1,259 @@
+// nif_internal.h -- shared between the HIP translation units of libnif_hip.so (gfx950 only).
+//
+// Data layout conventions:
+//   * a "tile" is 32 consecutive points; one wavefront owns one tile.  Lane l serves point
+//     p = l & 31; the two lane halves hf = l >> 5 hold different features of that point.
+//   * an activation tile of width 32*NB lives in registers as f32x16 h[NB]: element v of block b
+//     on lane (p, hf) is feature 32*b + fmap(v, hf) of point p.  This is exactly the C/D layout of
+//     v_mfma_f32_32x32x2_f32 with features on rows and points on columns, AND a legal B-operand
+//     sequence for the next layer's MFMAs (K order permuted consistently in the packed weights),
+//     so an MLP chain never leaves registers.
+//   * "stash" arrays (activations kept for the adjoint and for the weight-gradient GEMMs) are
+//     [tile][feature][32 points] fp32: every wave store/load is two full 128-B lines.
+//   * small per-point vectors (latent z, dL/dz, dL/du) use the same [tile][c][32] layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NIF_MAX_HID 16      // max pnet hidden layers / snet hidden layers supported
+#define NIF_TP 32           // points per tile
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+enum { ACT_LINEAR = 0, ACT_SINE = 1, ACT_SWISH = 2, ACT_TANH = 3, ACT_RELU = 4, ACT_SIGMOID = 5,
+       ACT_ELU = 6, ACT_SOFTPLUS = 7, ACT_GELU = 8 };
+
+// Reference to a (possibly hypernetwork-generated) matrix inside the flat parameter / gradient
+// vector.  element(k, in, out) lives at (k < r ? base_k + k*kstride : base_last) + in*ld + out.
+// A plain dense matrix has r == 0 (only the "last" plane exists).
+struct MatRef {
+  int r;
+  long base_k, kstride, base_last;
+  int ld, nin, nout;
+};
+__host__ __device__ inline long matref_index(const MatRef& m, int k, int in, int out) {
+  return (k < m.r ? m.base_k + (long)k * m.kstride : m.base_last) + (long)in * m.ld + out;
+}
+
+// ------------------------------------------------------------------------------------------
+// ParameterNet (shared-weight MLP) kernels
+// ------------------------------------------------------------------------------------------
+struct PNetArgs {
+  const float* theta;
+  const float* xin; int ncol; int col0;   // input rows [B][ncol], pnet reads columns col0..col0+pi
+  long B;
+  int pi, nst, lst, r;
+  int act, res, siren; float omega;
+  long first_w, first_b;
+  long hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
+  long bott_w, bott_b;
+  int ll_kind; long last_w, last_b;       // last-layer class: pnet_out = z @ W[r,r] + b
+  const f32x4* WF; const f32x4* WB;       // packed MFMA operands, mat m at m*NSTB*NSTB*256 f32x4
+  float* stash; long slot_stride;         // slot s at stash + s*slot_stride  (floats)
+  float* Z;                               // out: [tiles][r][32]
+  float* DZ;                              // in (bwd): [tiles][r][32]
+  float* ZL;                              // LL kind: latent before the r x r map [tiles][r][32]
+};
+// stash slots of the pnet: IN_m (input of hidden matrix m) = m, IN_bott = nm, DA_first = nm+1,
+// DA_m = nm+2+m.   nm = lst * (res ? 2 : 1)
+
+// ------------------------------------------------------------------------------------------
+// hypernetwork ShapeNet kernels (NIF / NIFMultiScale)
+// ------------------------------------------------------------------------------------------
+struct SNetArgs {
+  const float* theta;
+  const float* xin; int ncol; int col0;   // coordinates are columns col0..col0+si
+  long B;
+  int si, so, n, nh, r; long po;
+  int act, res, nif_skip; float omega;
+  long off_Wh, off_bh;                    // theta offsets of the hyper kernel [r,po] and bias [po]
+  const float* Z;                         // [tiles][r][32]
+  const f32x4* WF; const f32x4* WB;       // packed, plane (j*(r+1)+k) at *NB*NB*256 f32x4
+  float* stash; long slot_stride;         // slots: IN_l (l=1..nh+1) = l-1 ; DA_l (l=0..nh) = nh+1+l
+  float* DU;                              // [tiles][so][32]
+  float* DZ;                              // [tiles][r][32]
+  const float* y; const float* sw;        // [B][so], [B] or null
+  float* u_out;                           // [B][so] or null
+  float* loss_partial;                    // [gridDim.x]
+  float inv_bg;                           // 1 / B_global
+};
+// slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
+__host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }
+__host__ __device__ inline long slot_wh(const SNetArgs& a, int j) { return (long)a.si * a.n + (long)j * a.n * a.n; }
+__host__ __device__ inline long slot_wl(const SNetArgs& a) { return (long)a.si * a.n + (long)a.nh * a.n * a.n; }
+__host__ __device__ inline long slot_b1(const SNetArgs& a) { return slot_wl(a) + (long)a.n * a.so; }
+__host__ __device__ inline long slot_bh(const SNetArgs& a, int j) { return slot_b1(a) + a.n + (long)j * a.n; }
+__host__ __device__ inline long slot_bl(const SNetArgs& a) { return slot_b1(a) + a.n + (long)a.nh * a.n; }
+
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernels: C[k][in][out] = scale * sum_p zt_k[p] * IN[p][in] * DA[p][out]
+// ------------------------------------------------------------------------------------------
+struct GwArgs {
+  const float* IN;      // stash [tiles][32*NBI][32]   (mfma / out kernels)
+  const float* DA;      // stash [tiles][32*NBO][32]   (mfma / first kernels)
+  const float* SM;      // small per-point vectors [tiles][nc][32] (out kernel: dL/dout)
+  const float* xin; int ncol; int col0; int nd;   // first kernel: input columns
+  int nc;               // out kernel: number of output columns
+  const float* Z; int r;    // latent [tiles][r][32] or null (r = 0)
+  long ntiles; long B;
+  float scale;
+  MatRef W;             // where the matrix gradient goes
+  MatRef Bv;            // bias gradient (nin = 1, ld = 0): element(k, 0, out)
+  float* partial; long pstride;   // partial[row*pstride + index], row = blockIdx.x
+  int has_bias;
+};
+
+// launchers (implemented in the .hip files); all enqueue on `st`
+void launch_pack(const float* theta, const MatRef& m, int NBI, int NBO, f32x4* WF, f32x4* WB, hipStream_t st);
+void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st);
+void launch_pnet_bwd(const PNetArgs& a, int NSTB, hipStream_t st);
+void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
+void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st);
+void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st);
+void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st);
+void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss,
+                   float* g, long P, hipStream_t st);
+void launch_adam(float* theta, const float* g, float* m, float* v, long P, float lr_t, float b1, float b2,
+                 float eps, hipStream_t st);
+void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B,
+                        float* w, hipStream_t st);
+void launch_given_w(const float* x, const float* w, float* u, long B, int si, int so, int n, int nh, long po,
+                    int act, int res, int nif_skip, float omega, hipStream_t st);
+void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st);
+void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int fmap(int v, int hf) { return 8 * (v >> 2) + 4 * hf + (v & 3); }
+
+// sin and cos of x in one go: 3-term Cody-Waite reduction by pi/2 (exact products via fma) and the
+// cephes single-precision minimax kernels on [-pi/4, pi/4].  |error| <~ 2e-7 for |x| < 32768;
+// larger arguments take the ocml slow path.
+__device__ __forceinline__ void nif_sincosf(float x, float* sp, float* cp) {
+  if (__builtin_expect(!(fabsf(x) < 32768.0f), 0)) {
+    float s, c;
+    sincosf(x, &s, &c);
+    *sp = s; *cp = c;
+    return;
+  }
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.371138828673793e-08f, r);
+  r = fmaf(-k, -1.7151245100058819e-15f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float s = fmaf(ps * r2, r, r);
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float c = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k;
+  const float ss = (q & 1) ? c : s;
+  const float cc = (q & 1) ? s : c;
+  *sp = (q & 2) ? -ss : ss;
+  *cp = ((q + 1) & 2) ? -cc : cc;
+}
+
+// h = f(a), d = f'(a) for the Keras activation ACT (compile time)
+template <int ACT>
+__device__ __forceinline__ void act_eval(float a, float* h, float* d) {
+  if (ACT == ACT_SINE) {
+    nif_sincosf(a, h, d);
+  } else if (ACT == ACT_SWISH) {
+    const float s = 1.0f / (1.0f + expf(-a));
+    *h = a * s; *d = s * (1.0f + a * (1.0f - s));
+  } else if (ACT == ACT_TANH) {
+    const float t = tanhf(a); *h = t; *d = 1.0f - t * t;
+  } else if (ACT == ACT_RELU) {
+    *h = a > 0.f ? a : 0.f; *d = a > 0.f ? 1.f : 0.f;
+  } else if (ACT == ACT_SIGMOID) {
+    const float s = 1.0f / (1.0f + expf(-a)); *h = s; *d = s * (1.0f - s);
+  } else if (ACT == ACT_ELU) {
+    const float e = expf(fminf(a, 0.f)); *h = a > 0.f ? a : e - 1.0f; *d = a > 0.f ? 1.0f : e;
+  } else if (ACT == ACT_SOFTPLUS) {
+    *h = fmaxf(a, 0.f) + log1pf(expf(-fabsf(a)));
+    *d = 1.0f / (1.0f + expf(-a));
+  } else if (ACT == ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f));
+    *h = a * cdf; *d = cdf + a * 0.3989422804014327f * expf(-0.5f * a * a);
+  } else {
+    *h = a; *d = 1.0f;
+  }
+}
+
+// activation of a whole register tile; features >= n (padding) are forced to h = 0, d = 0
+template <int NB, int ACT>
+__device__ __forceinline__ void act_tile_t(const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      float hv, dv;
+      act_eval<ACT>(a[b][v], &hv, &dv);
+      const bool ok = (32 * b + fmap(v, hf)) < n;
+      h[b][v] = ok ? hv : 0.f;
+      d[b][v] = ok ? dv : 0.f;
+    }
+}
+// wave-uniform dispatch on the runtime activation id (one switch per tile, not per element)
+template <int NB>
+__device__ __forceinline__ void act_tile(int act, const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
+  switch (act) {
+    case ACT_SINE: act_tile_t<NB, ACT_SINE>(a, h, d, n, hf); break;
+    case ACT_SWISH: act_tile_t<NB, ACT_SWISH>(a, h, d, n, hf); break;
+    case ACT_TANH: act_tile_t<NB, ACT_TANH>(a, h, d, n, hf); break;
+    case ACT_RELU: act_tile_t<NB, ACT_RELU>(a, h, d, n, hf); break;
+    case ACT_SIGMOID: act_tile_t<NB, ACT_SIGMOID>(a, h, d, n, hf); break;
+    case ACT_ELU: act_tile_t<NB, ACT_ELU>(a, h, d, n, hf); break;
+    case ACT_SOFTPLUS: act_tile_t<NB, ACT_SOFTPLUS>(a, h, d, n, hf); break;
+    case ACT_GELU: act_tile_t<NB, ACT_GELU>(a, h, d, n, hf); break;
+    default: act_tile_t<NB, ACT_LINEAR>(a, h, d, n, hf); break;
+  }
+}
+
+// T[ob] = sum over in-blocks/steps of A(packed weights) x B(hin): one 32x32x2 fp32 MFMA per K-pair.
+// Wp: packed plane of NBO*NBI blocks, block (ob,ib) = 4 quads x 64 lanes of f32x4.
+template <int NBI, int NBO>
+__device__ __forceinline__ void dense_mfma(const f32x4* __restrict__ Wp, const f32x16 (&hin)[NBI], f32x16 (&T)[NBO],
+                                           int lane) {
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob) {
+    f32x16 t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib) {
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const f32x4 a = Wp[((ob * NBI + ib) * 4 + vq) * 64 + lane];
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], hin[ib][4 * vq + 0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], hin[ib][4 * vq + 1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], hin[ib][4 * vq + 2], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], hin[ib][4 * vq + 3], t, 0, 0, 0);
+      }
+    }
+    T[ob] = t;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void stash_store(float* __restrict__ slot, long tile, const f32x16 (&h)[NB], int p, int hf) {
+  float* t = slot + tile * (long)(NB * 32 * 32);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) t[(32 * b + fmap(v, hf)) * 32 + p] = h[b][v];
+}
+template <int NB>
+__device__ __forceinline__ void stash_load(const float* __restrict__ slot, long tile, f32x16 (&h)[NB], int p, int hf) {
+  const float* t = slot + tile * (long)(NB * 32 * 32);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) h[b][v] = t[(32 * b + fmap(v, hf)) * 32 + p];
+}
+#endif  // __HIPCC__

@@ -1,0 +1,217 @@
+"""Engine: one libnif_hip context + the host-side conveniences around it (weights as a list of
+NumPy arrays in Keras order, device-resident datasets, the train step)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DeviceArray(object):
+    """A float32 device buffer owned by an Engine (hipMalloc through the C-ABI)."""
+
+    def __init__(self, engine, n_floats):
+        self.engine = engine
+        self.n = int(n_floats)
+        p = C.c_void_p()
+        check(engine.lib.nif_dev_alloc(engine.ctx, self.n * 4, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, float_offset):
+        return C.c_void_p(self.ptr + 4 * int(float_offset))
+
+    def upload(self, host, float_offset=0):
+        host = _f32(host)
+        assert host.size + float_offset <= self.n
+        check(self.engine.lib.nif_h2d(self.engine.ctx, self.at(float_offset), ptr(host), host.size * 4))
+
+    def download(self, n_floats=None, float_offset=0):
+        n = self.n - float_offset if n_floats is None else int(n_floats)
+        out = np.empty((n,), dtype=np.float32)
+        check(self.engine.lib.nif_d2h(self.engine.ctx, ptr(out), self.at(float_offset), n * 4))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.nif_dev_free(self.engine.ctx, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine(object):
+    def __init__(self, spec, device_id=0):
+        self.spec = spec
+        self.lib = _lib.load()
+        if self.lib.nif_device_count() <= 0:
+            raise _lib.NifError("no HIP device visible: nif_amd runs on MI355X (gfx950) only, there is no CPU path")
+        cfg = spec.to_cfg()
+        ctx = C.c_void_p()
+        check(self.lib.nif_create(C.byref(cfg), int(device_id), C.byref(ctx)))
+        self.ctx = ctx
+        n = C.c_int64()
+        check(self.lib.nif_param_count(self.ctx, C.byref(n)))
+        self.n_params = int(n.value)
+        assert self.n_params == spec.n_params(), (self.n_params, spec.n_params())
+        self.shapes = spec.param_shapes()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nif_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def layout(self):
+        n = C.c_int32(0)
+        check(self.lib.nif_param_layout(self.ctx, None, C.byref(n)))
+        descs = (_lib.nif_tensor_desc * n.value)()
+        check(self.lib.nif_param_layout(self.ctx, descs, C.byref(n)))
+        return [(d.name.decode(), int(d.offset), int(d.rows), int(d.cols)) for d in descs]
+
+    def set_weights(self, weights):
+        if len(weights) != len(self.shapes):
+            raise ValueError("You called `set_weights(weights)` with a weight list of length %d, but the model "
+                             "was expecting %d weights." % (len(weights), len(self.shapes)))
+        for w, (nm, s) in zip(weights, self.shapes):
+            if tuple(np.shape(w)) != tuple(s):
+                raise ValueError("Layer weight shape %s not compatible with provided weight shape %s (%s)"
+                                 % (tuple(s), tuple(np.shape(w)), nm))
+        flat = np.concatenate([_f32(w).ravel() for w in weights])
+        self.set_flat(flat)
+
+    def set_flat(self, flat):
+        flat = _f32(flat)
+        check(self.lib.nif_set_params(self.ctx, ptr(flat), flat.size))
+
+    def get_flat(self):
+        out = np.empty((self.n_params,), dtype=np.float32)
+        check(self.lib.nif_get_params(self.ctx, ptr(out), out.size))
+        return out
+
+    def get_weights(self):
+        flat = self.get_flat()
+        out, off = [], 0
+        for _, s in self.shapes:
+            k = int(np.prod(s))
+            out.append(flat[off:off + k].reshape(s).copy())
+            off += k
+        return out
+
+    def get_opt_state(self):
+        m = np.empty((self.n_params,), dtype=np.float32)
+        v = np.empty((self.n_params,), dtype=np.float32)
+        step = C.c_int64()
+        check(self.lib.nif_get_opt_state(self.ctx, ptr(m), ptr(v), m.size, C.byref(step)))
+        return m, v, int(step.value)
+
+    def set_opt_state(self, m, v, step):
+        m, v = _f32(m), _f32(v)
+        check(self.lib.nif_set_opt_state(self.ctx, ptr(m), ptr(v), m.size, int(step)))
+
+    # ---- inference ------------------------------------------------------------------------------
+    def forward(self, inputs):
+        x = _f32(inputs)
+        s = self.spec
+        if x.ndim != 2 or x.shape[1] < s.pi_dim + s.si_dim:
+            raise ValueError("expected inputs of shape (batch, %d), got %s" % (s.pi_dim + s.si_dim, x.shape))
+        if x.shape[1] != s.pi_dim + s.si_dim:
+            x = _f32(x[:, :s.pi_dim + s.si_dim])  # model.py:142-143 slices the first pi+si columns
+        out = np.empty((x.shape[0], s.so_dim), dtype=np.float32)
+        if x.shape[0]:
+            check(self.lib.nif_forward(self.ctx, ptr(x), x.shape[0], ptr(out)))
+        return out
+
+    def p_to_lr(self, p):
+        p = _f32(p)
+        out = np.empty((p.shape[0], self.spec.pi_hidden), dtype=np.float32)
+        if p.shape[0]:
+            check(self.lib.nif_pnet_latent(self.ctx, ptr(p), p.shape[0], ptr(out)))
+        return out
+
+    def lr_to_w(self, lr):
+        lr = _f32(lr)
+        out = np.empty((lr.shape[0], self.spec.po_dim), dtype=np.float32)
+        if lr.shape[0]:
+            check(self.lib.nif_latent_to_w(self.ctx, ptr(lr), lr.shape[0], ptr(out)))
+        return out
+
+    def x_to_u_given_w(self, x, w):
+        x, w = _f32(x), _f32(w)
+        if w.shape != (x.shape[0], self.spec.po_dim):
+            raise ValueError("expected w of shape (%d, %d), got %s" % (x.shape[0], self.spec.po_dim, w.shape))
+        out = np.empty((x.shape[0], self.spec.so_dim), dtype=np.float32)
+        if x.shape[0]:
+            check(self.lib.nif_shapenet_given_w(self.ctx, ptr(x), ptr(w), x.shape[0], ptr(out)))
+        return out
+
+    # ---- training -------------------------------------------------------------------------------
+    def loss_and_grad(self, inputs, y, sample_weight=None):
+        x, y = _f32(inputs), _f32(y)
+        sw = None if sample_weight is None else _f32(sample_weight)
+        g = np.empty((self.n_params,), dtype=np.float32)
+        loss = C.c_float()
+        check(self.lib.nif_loss_and_grad(self.ctx, ptr(x), ptr(y), ptr(sw), x.shape[0], C.byref(loss), ptr(g)))
+        return float(loss.value), g
+
+    def train_step(self, inputs, y, sample_weight, adam):
+        x, y = _f32(inputs), _f32(y)
+        sw = None if sample_weight is None else _f32(sample_weight)
+        loss = C.c_float()
+        check(self.lib.nif_train_step(self.ctx, ptr(x), ptr(y), ptr(sw), x.shape[0], C.byref(adam), C.byref(loss)))
+        return float(loss.value)
+
+    # device-pointer flavour (datasets resident in HBM; optional cross-rank gradient all-reduce)
+    def loss_grad_dev(self, d_x, d_y, d_sw, b_local, b_global):
+        check(self.lib.nif_loss_grad_dev(self.ctx, d_x, d_y, d_sw, int(b_local), int(b_global)))
+
+    def adam_step_dev(self, adam):
+        check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
+
+    def last_loss(self):
+        loss = C.c_float()
+        check(self.lib.nif_last_loss(self.ctx, C.byref(loss)))
+        return float(loss.value)
+
+    def sync(self):
+        check(self.lib.nif_sync(self.ctx))
+
+    def grad_dev_ptr(self):
+        return self.lib.nif_grad_dev(self.ctx)
+
+    def stream_ptr(self):
+        return self.lib.nif_stream(self.ctx)
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        check(self.lib.nif_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        """{group: (total_ms, launches)} measured with HIP events on the context's stream."""
+        n = len(_lib.PROF_NAMES)
+        ms = (C.c_float * n)()
+        cnt = (C.c_int64 * n)()
+        check(self.lib.nif_profile_read(self.ctx, ms, cnt, n, 1 if reset else 0))
+        return {nm: (float(ms[i]), int(cnt[i])) for i, nm in enumerate(_lib.PROF_NAMES)}
+
+    def timer_start(self):
+        check(self.lib.nif_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.nif_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,317 @@
+"""Drop-in Python surface of reference nif/model.py for the point-wise training path:
+NIF / NIFMultiScale / NIFMultiScaleLastLayerParameterized with build/model/compile/fit/predict and
+the sub-model extractors.  Same constructor arguments, attribute names and error behaviour as the
+reference (file:line cited per method); every number comes from libnif_hip.so (HIP, gfx950)."""
+import json
+import time
+
+import numpy as np
+
+from . import _lib
+from . import distributed as dist
+from .engine import DeviceArray, Engine
+from .optimizers import Adam, get as get_optimizer
+from .spec import Spec
+
+_global_rng = [np.random.default_rng()]
+
+
+def set_seed(seed):
+    """Seed for the initial weights of models constructed afterwards (tf.random.set_seed analogue)."""
+    _global_rng[0] = np.random.default_rng(seed)
+
+
+class History(object):
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class Variable(object):
+    """What `model.trainable_variables` lists: name, shape, numpy()."""
+
+    def __init__(self, model, index, name, shape):
+        self._model, self._index, self.name, self.shape = model, index, name, tuple(shape)
+
+    def numpy(self):
+        return self._model.get_weights()[self._index]
+
+
+class Model(object):
+    """The subset of tf.keras.Model the reference's README uses (README.md:23-37, :71-117, :179-195)."""
+
+    def __init__(self, owner, role, n_inputs=1):
+        self._owner = owner
+        self._role = role  # 'full' | 'p_to_lr' | 'p_to_w' | 'lr_to_w' | 'x_to_u_given_w' | 'x_to_phi'
+        self.optimizer = None
+        self.loss = None
+        self.stop_training = False
+        self.history = None
+        self._n_inputs = n_inputs
+
+    # ---- weights ---------------------------------------------------------------------------------
+    @property
+    def _engine(self):
+        return self._owner._engine
+
+    def get_weights(self):
+        return self._engine.get_weights()
+
+    def set_weights(self, weights):
+        self._engine.set_weights(weights)
+
+    @property
+    def trainable_variables(self):
+        return [Variable(self, i, nm, s) for i, (nm, s) in enumerate(self._engine.shapes)]
+
+    weights = trainable_variables
+
+    def count_params(self):
+        return self._engine.n_params
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s" (%s)' % (self._owner.__class__.__name__, self._role))
+        for nm, s in self._engine.shapes:
+            print_fn("  %-24s %-16s %d" % (nm, str(tuple(s)), int(np.prod(s))))
+        print_fn("Total params: %d" % self._engine.n_params)
+
+    def save_weights(self, filepath):
+        """Flat parameters in Keras variable order + Adam slots, as .npz (the reference's TF-checkpoint
+        format, README.md:179-195, is a TensorFlow artefact and out of scope)."""
+        ws = self.get_weights()
+        m, v, step = self._engine.get_opt_state()
+        arrs = {"w%03d" % i: w for i, w in enumerate(ws)}
+        np.savez(filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz",
+                 names=np.array([nm for nm, _ in self._engine.shapes]), adam_m=m, adam_v=v,
+                 adam_step=np.int64(step), **arrs)
+
+    def load_weights(self, filepath):
+        f = filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz"
+        d = np.load(f)
+        n = len(self._engine.shapes)
+        self.set_weights([d["w%03d" % i] for i in range(n)])
+        if "adam_m" in d:
+            self._engine.set_opt_state(d["adam_m"], d["adam_v"], int(d["adam_step"]))
+
+    # ---- inference -------------------------------------------------------------------------------
+    def _run(self, x):
+        e = self._engine
+        if self._role == "full":
+            return e.forward(x)
+        if self._role == "p_to_lr":
+            return e.p_to_lr(x)
+        if self._role == "p_to_w":
+            return e.lr_to_w(e.p_to_lr(x))
+        if self._role == "lr_to_w":
+            return e.lr_to_w(x)
+        if self._role == "x_to_u_given_w":
+            if not (isinstance(x, (list, tuple)) and len(x) == 2):
+                raise ValueError("model_x_to_u_given_w expects [x, w]")
+            return e.x_to_u_given_w(x[0], x[1])
+        raise NotImplementedError(self._role)
+
+    def predict(self, x, batch_size=None, verbose=0, **kwargs):
+        # Keras' default predict batch_size=32 is a host-loop artefact; the result does not depend on it.
+        return self._run(x)
+
+    def __call__(self, x, training=False):
+        return self._run(x)
+
+    # ---- training --------------------------------------------------------------------------------
+    def compile(self, optimizer="adam", loss="mse", **kwargs):
+        if self._role != "full":
+            raise ValueError("only the full model can be compiled for training")
+        name = loss if isinstance(loss, str) else getattr(loss, "name", None)
+        if name not in ("mse", "mean_squared_error", "MSE"):
+            raise NotImplementedError("only loss='mse' is built (README.md:33)")
+        self.optimizer = get_optimizer(optimizer)
+        self.loss = "mse"
+
+    def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
+        u = self.predict(x)
+        per = ((u.astype(np.float64) - np.asarray(y, dtype=np.float64)) ** 2).mean(axis=1)
+        if sample_weight is not None:
+            per = per * np.asarray(sample_weight, dtype=np.float64)
+        return float(per.sum() / u.shape[0])
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
+            sample_weight=None, initial_epoch=0, **kwargs):
+        """Keras Model.fit semantics for in-memory arrays: per epoch optionally shuffle, walk batches of
+        `batch_size` (default 32, last one partial), one Adam step per batch; the epoch 'loss' is the
+        sample-weighted mean of the batch losses.  The epoch's (shuffled) table is made resident in HBM
+        once; batches are device-pointer slices.  Under `nif_amd.distributed` every rank walks its own
+        shard and the flat gradient is SUM-all-reduced (RCCL) before the identical Adam update
+        (tf.distribute.MirroredStrategy, README.md:39-49)."""
+        if self.optimizer is None:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+        s = self._owner._spec
+        e = self._engine
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        if y.ndim == 1:
+            y = y[:, None]
+        ncol = s.pi_dim + s.si_dim
+        if x.shape[1] != ncol:
+            x = np.ascontiguousarray(x[:, :ncol])
+        N = x.shape[0]
+        sw = None if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float32)
+        bs = 32 if batch_size is None else int(batch_size)
+        callbacks = list(callbacks or [])
+        hist = History()
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+        for cb in callbacks:
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin({})
+        d_x, d_y = DeviceArray(e, N * ncol), DeviceArray(e, N * s.so_dim)
+        d_sw = DeviceArray(e, N) if sw is not None else None
+        rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
+        resident = False
+        world = dist.world_size()
+        try:
+            for epoch in range(initial_epoch, epochs):
+                if self.stop_training:
+                    break
+                for cb in callbacks:
+                    if hasattr(cb, "on_epoch_begin"):
+                        cb.on_epoch_begin(epoch, {})
+                t0 = time.time()
+                if shuffle or not resident:
+                    if shuffle:
+                        perm = rng.permutation(N)
+                        d_x.upload(x[perm]); d_y.upload(y[perm])
+                        if sw is not None:
+                            d_sw.upload(sw[perm])
+                    else:
+                        d_x.upload(x); d_y.upload(y)
+                        if sw is not None:
+                            d_sw.upload(sw)
+                    resident = True
+                adam = self.optimizer.as_struct()
+                tot, cnt = 0.0, 0
+                for b0 in range(0, N, bs):
+                    b = min(bs, N - b0)
+                    bg = dist.all_reduce_scalar_sum(b) if world > 1 else b
+                    e.loss_grad_dev(d_x.at(b0 * ncol), d_y.at(b0 * s.so_dim),
+                                    d_sw.at(b0) if d_sw is not None else None, b, bg)
+                    if world > 1:
+                        dist.all_reduce_grad(e)
+                    e.adam_step_dev(adam)
+                    if verbose or callbacks or b0 + bs >= N:
+                        tot += e.last_loss() * bg
+                        cnt += bg
+                logs = {"loss": tot / max(cnt, 1)}
+                hist.epoch.append(epoch)
+                for k, v in logs.items():
+                    hist.history.setdefault(k, []).append(v)
+                for cb in callbacks:
+                    if hasattr(cb, "on_epoch_end"):
+                        cb.on_epoch_end(epoch, logs)
+                if verbose:
+                    print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
+        finally:
+            e.sync()
+            d_x.free(); d_y.free()
+            if d_sw is not None:
+                d_sw.free()
+        for cb in callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end({})
+        self.history = hist
+        return hist
+
+
+class NIF(object):
+    """reference nif/model.py:48 `class NIF(object)`: a factory of Keras-like models that share one set
+    of variables."""
+    _KIND = "NIF"
+
+    def __init__(self, cfg_shape_net, cfg_parameter_net, mixed_policy="float32"):
+        self._spec = Spec(self._KIND, cfg_shape_net, cfg_parameter_net, mixed_policy)
+        s = self._spec
+        # attribute names of the reference (model.py:83-99)
+        self.cfg_shape_net = cfg_shape_net
+        self.cfg_parameter_net = cfg_parameter_net
+        self.si_dim, self.so_dim, self.n_sx, self.l_sx = s.si_dim, s.so_dim, s.n_sx, s.l_sx
+        self.pi_dim, self.pi_hidden, self.n_st, self.l_st = s.pi_dim, s.pi_hidden, s.n_st, s.l_st
+        self.p_jac_reg = cfg_parameter_net.get("jac_reg", None)
+        self.p_l1_reg = cfg_parameter_net.get("l1_reg", None)
+        self.p_l2_reg = cfg_parameter_net.get("l2_reg", None)
+        self.p_act_l1_reg = cfg_parameter_net.get("act_l1_reg", None)
+        self.p_act_l2_reg = cfg_parameter_net.get("act_l2_reg", None)
+        for nm in ("p_jac_reg", "p_l1_reg", "p_l2_reg", "p_act_l1_reg", "p_act_l2_reg"):
+            if isinstance(getattr(self, nm), (float, int)):
+                raise NotImplementedError("cfg_parameter_net regulariser %s is outside the built hot path" % nm)
+        self.mixed_policy_name = mixed_policy
+        self.variable_Dtype = "float32"
+        self.compute_Dtype = "float32"
+        self.po_dim = s.po_dim
+        self.pnet_list = [nm for nm, _ in s.param_shapes() if nm.startswith("pnet_") and nm.endswith("_w")]
+        self.__engine = None
+        self._init_weights = s.initial_weights(_global_rng[0])
+
+    @property
+    def _engine(self):
+        # the HIP context is created on first use (constructing the object needs no GPU, like the
+        # reference's constructor needs no data)
+        if self.__engine is None:
+            self.__engine = Engine(self._spec, device_id=dist.local_device())
+            self.__engine.set_weights(self._init_weights)
+        return self.__engine
+
+    def call(self, inputs, training=None, mask=None):
+        """model.py:130-154 / :510-539 / :1044-1068"""
+        return self._engine.forward(inputs)
+
+    def build(self):
+        """model.py:345-377 (the jac_reg branch is outside the hot path and rejected in __init__)."""
+        return self.model()
+
+    def model(self):
+        """model.py:379-389"""
+        return Model(self, "full")
+
+    def model_p_to_w(self):
+        """model.py:391-404"""
+        return Model(self, "p_to_w")
+
+    def model_p_to_lr(self):
+        """model.py:406-420"""
+        return Model(self, "p_to_lr")
+
+    def model_lr_to_w(self):
+        """model.py:422-433"""
+        return Model(self, "lr_to_w")
+
+    def model_x_to_u_given_w(self):
+        """model.py:435-464 / :956-986"""
+        return Model(self, "x_to_u_given_w", n_inputs=2)
+
+    def save_config(self, filename="config.json"):
+        """model.py:466-480"""
+        config = {
+            "cfg_shape_net": self.cfg_shape_net,
+            "cfg_parameter_net": self.cfg_parameter_net,
+            "mixed_policy": self.mixed_policy_name,
+        }
+        with open(filename, "w") as write_file:
+            json.dump(config, write_file, indent=4)
+
+
+class NIFMultiScale(NIF):
+    """reference nif/model.py:483"""
+    _KIND = "NIFMultiScale"
+
+
+class NIFMultiScaleLastLayerParameterized(NIFMultiScale):
+    """reference nif/model.py:989"""
+    _KIND = "NIFMultiScaleLastLayerParameterized"
+
+    def model_lr_to_w(self):
+        """model.py:1106-1115"""
+        raise ValueError("In this class: NIFMultiScaleLastLayerParameterization, `w` is the same as `lr`")
+
+    def model_x_to_phi(self):
+        """model.py:1085-1104"""
+        return Model(self, "x_to_phi")

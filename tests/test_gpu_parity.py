@@ -1,0 +1,199 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI / the drop-in Python surface) against
+the fp64 NumPy oracle on identical inputs and weights.  Tolerances: predictions and loss within
+1e-5 rel-L2 (BASELINE.json north_star, fp32); gradients within 2e-4 rel-L2 per tensor (fp32
+accumulation over the batch vs fp64)."""
+import numpy as np
+import pytest
+
+from oracle import nif_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(kind, n, L, nst, lst, r, si, so, pi, s_res=False, p_act="sine", p_res=False, act="swish", omega=30.0):
+    if kind == "NIF":
+        cs = {"input_dim": si, "output_dim": so, "units": n, "nlayers": L, "activation": act}
+        cp = {"input_dim": pi, "latent_dim": r, "units": nst, "nlayers": lst, "activation": act}
+    else:
+        cs = {"input_dim": si, "output_dim": so, "units": n, "nlayers": L, "use_resblock": s_res,
+              "connectivity": "full", "omega_0": omega, "weight_init_factor": 0.01}
+        cp = {"input_dim": pi, "latent_dim": r, "units": nst, "nlayers": lst, "activation": p_act,
+              "use_resblock": p_res, "omega_0": omega}
+    return kind, cs, cp
+
+
+CONFIGS = {
+    # name: (cfg, batch)
+    "nif_cfg1_32x2": (_cfg("NIF", 32, 2, 32, 2, 1, 1, 1, 1), 300),
+    "nif_pad_n30_tanh_r2_so2": (_cfg("NIF", 30, 2, 20, 1, 2, 2, 2, 2, act="tanh"), 257),
+    "ms_cfg2_64x4": (_cfg("NIFMultiScale", 64, 4, 32, 2, 1, 1, 1, 1), 515),
+    "ms_64x2_mlp_pnet_r3": (_cfg("NIFMultiScale", 64, 2, 32, 2, 3, 2, 1, 1, p_act="swish"), 129),
+    "ms_res_48x2_pres": (_cfg("NIFMultiScale", 48, 2, 40, 2, 2, 2, 2, 1, s_res=True, p_res=True), 200),
+    "ms_mlp_pres_so2": (_cfg("NIFMultiScale", 32, 1, 32, 1, 1, 1, 2, 2, p_act="tanh", p_res=True), 64),
+    "ms_cfg3_128x3": (_cfg("NIFMultiScale", 128, 3, 64, 2, 1, 2, 1, 1), 160),
+    "ms_res_128x1_nst128": (_cfg("NIFMultiScale", 128, 1, 128, 1, 1, 2, 1, 1, s_res=True), 96),
+    "ms_tiny_b1": (_cfg("NIFMultiScale", 8, 1, 6, 1, 1, 1, 1, 1), 1),
+}
+
+
+def _make(name, seed=0, boost=20.0):
+    import nif_amd
+    (kind, cs, cp), B = CONFIGS[name]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(seed)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    if kind != "NIF":
+        names = [nm for nm, _ in spec.param_shapes()]
+        ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * boost).astype(np.float32)
+    cls = getattr(nif_amd, kind)
+    m = cls(cs, cp)
+    model = m.build()
+    model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    return m, model, spec, ws64, x, y, sw
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_forward_matches_oracle(name):
+    m, model, spec, ws, x, y, sw = _make(name)
+    u = model.predict(x)
+    ref = O.forward(spec, ws, x.astype(np.float64))
+    assert u.shape == ref.shape and u.dtype == np.float32
+    assert _rel(u, ref) < 1e-5, _rel(u, ref)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_weights_round_trip_and_layout(name):
+    m, model, spec, ws, x, y, sw = _make(name)
+    got = model.get_weights()
+    assert len(got) == len(ws)
+    for g, w in zip(got, ws):
+        assert np.array_equal(g, w.astype(np.float32))
+    lay = m._engine.layout()
+    assert [(nm, r * (c if c else 1)) for nm, _, r, c in lay] == [(nm, int(np.prod(s))) for nm, s in spec.param_shapes()]
+
+
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres",
+                                  "ms_cfg3_128x3", "nif_pad_n30_tanh_r2_so2"])
+def test_three_stage_factorisation(name):
+    """README.md:99-117: lr = model_p_to_lr(p); w = model_lr_to_w(lr); u = model_x_to_u_given_w([x, w])."""
+    m, model, spec, ws, x, y, sw = _make(name)
+    p, xs = x[:, :spec.pi], x[:, spec.pi:]
+    lr = m.model_p_to_lr().predict(p)
+    lr_ref = O.model_p_to_lr(spec, ws, p.astype(np.float64))
+    assert _rel(lr, lr_ref) < 1e-5
+    w = m.model_lr_to_w().predict(lr)
+    assert w.shape == (x.shape[0], spec.po)
+    assert _rel(w, O.model_lr_to_w(spec, ws, lr.astype(np.float64))) < 1e-6
+    u3 = m.model_x_to_u_given_w().predict([xs, w])
+    ref = O.shapenet_given_w(spec, xs.astype(np.float64), w.astype(np.float64))
+    assert _rel(u3, ref) < 1e-5, _rel(u3, ref)
+    assert _rel(u3, model.predict(x).astype(np.float64)) < 2e-5
+    w2 = m.model_p_to_w().predict(p)
+    assert _rel(w2, w.astype(np.float64)) < 1e-6
+
+
+def test_given_w_arbitrary_weights():
+    """model_x_to_u_given_w must take ANY per-sample w, not only ones produced by the hypernetwork."""
+    m, model, spec, ws, x, y, sw = _make("ms_cfg2_64x4")
+    rng = np.random.default_rng(5)
+    B = 77
+    xs = rng.uniform(-1, 1, size=(B, spec.si)).astype(np.float32)
+    w = (rng.standard_normal((B, spec.po)) * 0.05).astype(np.float32)
+    u = m.model_x_to_u_given_w().predict([xs, w])
+    ref = O.shapenet_given_w(spec, xs.astype(np.float64), w.astype(np.float64))
+    assert _rel(u, ref) < 1e-5, _rel(u, ref)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("weighted", [False, True])
+def test_loss_and_grad_match_oracle(name, weighted):
+    m, model, spec, ws, x, y, sw = _make(name)
+    s = sw if weighted else None
+    loss, g = m._engine.loss_and_grad(x, y, s)
+    lref, gref = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64),
+                                 None if s is None else s.astype(np.float64))
+    assert abs(loss - lref) <= 1e-5 * abs(lref), (loss, lref)
+    off = 0
+    gnorm = np.linalg.norm(O.flatten(gref))
+    for (nm, shp), gr in zip(spec.param_shapes(), gref):
+        k = int(np.prod(shp))
+        gg = g[off:off + k].reshape(shp)
+        off += k
+        err = np.linalg.norm(gg - gr)
+        assert err <= 2e-4 * np.linalg.norm(gr) + 1e-6 * gnorm, (nm, err, np.linalg.norm(gr))
+    assert _rel(g, O.flatten(gref)) < 1e-4
+
+
+def test_adam_steps_follow_oracle():
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make("ms_cfg2_64x4")
+    model.compile(nif_amd.Adam(learning_rate=2e-3), loss="mse")
+    hist = model.fit(x, y, epochs=3, batch_size=x.shape[0], shuffle=False, verbose=0)
+    th = O.flatten(ws)
+    mm = np.zeros_like(th); vv = np.zeros_like(th)
+    losses = []
+    for t in range(1, 4):
+        l, g = O.loss_and_grad(spec, O.unflatten(spec, th), x.astype(np.float64), y.astype(np.float64))
+        losses.append(l)
+        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=2e-3)
+    got = O.flatten(model.get_weights())
+    assert np.allclose(hist.history["loss"], losses, rtol=2e-4)
+    # Adam normalises the step to ~lr, so compare the displacement
+    assert np.abs(got - th).max() < 0.05 * 2e-3 * 3
+
+
+def test_fit_batches_partial_last_batch_and_sample_weight():
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make("nif_cfg1_32x2")
+    model.compile("adam", loss="mse")
+    hist = model.fit(x, y, epochs=2, batch_size=128, shuffle=False, verbose=0, sample_weight=sw)
+    th = O.flatten(ws); mm = np.zeros_like(th); vv = np.zeros_like(th)
+    t = 0
+    ep_losses = []
+    for ep in range(2):
+        tot = 0.0
+        for b0 in range(0, x.shape[0], 128):
+            xb, yb, sb = x[b0:b0 + 128], y[b0:b0 + 128], sw[b0:b0 + 128]
+            l, g = O.loss_and_grad(spec, O.unflatten(spec, th), xb.astype(np.float64), yb.astype(np.float64),
+                                   sb.astype(np.float64))
+            t += 1
+            th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t)
+            tot += l * xb.shape[0]
+        ep_losses.append(tot / x.shape[0])
+    assert np.allclose(hist.history["loss"], ep_losses, rtol=5e-4)
+
+
+def test_training_reduces_loss_on_travelling_wave():
+    """End-to-end README workflow on the reference's own dataset (nif/demo/dataset/traveling_wave.npz)."""
+    import os
+    import nif_amd
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "traveling_wave.npz"))["data"]
+    data, mean, std = O.standard_normalize(d.astype(np.float64))
+    x, y = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
+    kind, cs, cp = _cfg("NIFMultiScale", 32, 2, 32, 2, 1, 1, 1, 1, p_act="swish")
+    nif_amd.set_seed(1)
+    model = nif_amd.NIFMultiScale(cs, cp).build()
+    model.compile(nif_amd.Adam(1e-3), loss="mse")
+    sched = nif_amd.callbacks.LearningRateScheduler(lambda ep, lr: lr if ep < 30 else 5e-4)
+    h = model.fit(x, y, epochs=40, batch_size=500, shuffle=True, verbose=0, callbacks=[sched])
+    assert h.history["loss"][-1] < 0.5 * h.history["loss"][0]
+    assert abs(model.evaluate(x, y) - O.mse_loss(model.predict(x).astype(np.float64), y)) < 1e-9
+
+
+def test_bad_arguments_raise():
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make("nif_cfg1_32x2")
+    with pytest.raises(ValueError):
+        model.set_weights(ws[:-1])
+    with pytest.raises(ValueError):
+        m.model_x_to_u_given_w().predict([x[:, 1:], np.zeros((x.shape[0], 3), np.float32)])
+    with pytest.raises(RuntimeError):
+        nif_amd.NIF(*CONFIGS["nif_cfg1_32x2"][0][1:]).build().fit(x, y)
