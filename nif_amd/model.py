@@ -198,9 +198,8 @@ class Model(object):
                     if world > 1:
                         dist.all_reduce_grad(e)
                     e.adam_step_dev(adam)
-                    if verbose or callbacks or b0 + bs >= N:
-                        tot += e.last_loss() * bg
-                        cnt += bg
+                    tot += e.last_loss() * bg   # Keras' loss metric: sample-weighted mean over the batches
+                    cnt += bg
                 logs = {"loss": tot / max(cnt, 1)}
                 hist.epoch.append(epoch)
                 for k, v in logs.items():
