@@ -212,28 +212,35 @@ void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, lon
 // ============================================================================================
 // gradient rows -> flat gradient (fixed summation order), loss partials -> g[P]
 // ============================================================================================
-__global__ void k_reduce(const float* __restrict__ partial, long pstride, int rows, const float* __restrict__ lossp,
-                         int nloss, float* __restrict__ g, long P) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < P) {
-    float s = 0.f;
-    for (int rrow = 0; rrow < rows; ++rrow) s += partial[(long)rrow * pstride + i];
-    g[i] = s;
-  } else if (i == P) {
-    // Kahan-compensated, fixed order: the loss is a sum of up to B/128 block partials
-    float s = 0.f, c = 0.f;
-    for (int b = 0; b < nloss; ++b) {
-      const float yv = lossp[b] - c;
-      const float t = s + yv;
-      c = (t - s) - yv;
-      s = t;
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ partial, long pstride, int rows,
+                                                const float* __restrict__ lossp, int nloss, float* __restrict__ g, long P) {
+  // block = 64 columns x 4 row groups; fixed summation order => deterministic
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (i < P)
+    for (int rrow = rg; rrow < rows; rrow += 4) s += partial[(long)rrow * pstride + i];
+  red[rg][col] = s;
+  __syncthreads();
+  if (rg == 0 && i < P) g[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (blockIdx.x == gridDim.x - 1) {
+    // the loss: every thread sums a strided subset in a fixed order, then a fixed tree
+    __syncthreads();
+    float ls = 0.f;
+    for (int b = threadIdx.x; b < nloss; b += 256) ls += lossp[b];
+    red[rg][col] = ls;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (threadIdx.x == 0) g[P] = v;
     }
-    g[P] = s;
   }
 }
 void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss, float* g, long P,
                    hipStream_t st) {
-  dim3 grid((unsigned)((P + 1 + 255) / 256)), block(256);
+  dim3 grid((unsigned)((P + 63) / 64)), block(256);
   hipLaunchKernelGGL(k_reduce, grid, block, 0, st, partial, pstride, rows, loss_partial, nloss, g, P);
 }
 

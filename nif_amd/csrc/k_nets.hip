@@ -253,8 +253,8 @@ __device__ __forceinline__ float hyp(const SNetArgs& A, int k, long slot) {
   return k < A.r ? A.theta[A.off_Wh + (long)k * A.po + slot] : A.theta[A.off_bh + slot];
 }
 
-template <int NB, bool TRAIN>
-__global__ __launch_bounds__(256) void k_snet(SNetArgs A) {
+template <int NB, bool TRAIN, int ACT>
+__global__ __launch_bounds__(256, (NB <= 2 ? 2 : 1)) void k_snet(SNetArgs A) {
   extern __shared__ float smem[];  // per wave: dzs[r][64], sks[r][64]; then lsum[4]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int p = lane & 31, hf = lane >> 5;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_snet(SNetArgs A) {
           }
         }
     }
-    act_tile<NB>(A.act, acc, h, d, n, hf);
+    act_tile_sel<NB, ACT>(A.act, acc, h, d, n, hf);
     if (TRAIN) stash_store<NB>(DA0, tile, d, p, hf);
 
     // ---- hidden hyper-matrices ---------------------------------------------------------------
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_snet(SNetArgs A) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) ublk[b] = h[b];
       }
-      act_tile<NB>(A.act, acc, T, d, n, hf);
+      act_tile_sel<NB, ACT>(A.act, acc, T, d, n, hf);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         f32x16 hn = T[b];
@@ -472,8 +472,13 @@ void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st) {
   dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
   const size_t shm = (size_t)(4 * 2 * a.r * 64 + 4) * sizeof(float);
 #define SN(NB_) \
-  if (train) hipLaunchKernelGGL((k_snet<NB_, true>), grid, block, shm, st, a); \
-  else hipLaunchKernelGGL((k_snet<NB_, false>), grid, block, shm, st, a);
+  if (a.act == ACT_SINE) { \
+    if (train) hipLaunchKernelGGL((k_snet<NB_, true, ACT_SINE>), grid, block, shm, st, a); \
+    else hipLaunchKernelGGL((k_snet<NB_, false, ACT_SINE>), grid, block, shm, st, a); \
+  } else { \
+    if (train) hipLaunchKernelGGL((k_snet<NB_, true, -1>), grid, block, shm, st, a); \
+    else hipLaunchKernelGGL((k_snet<NB_, false, -1>), grid, block, shm, st, a); \
+  }
   if (NB == 1) { SN(1) } else if (NB == 2) { SN(2) } else { SN(4) }
 #undef SN
 }

@@ -32,7 +32,7 @@ struct nif_ctx {
   // device state
   float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
   long step = 0;
-  bool have_params = false, packed = false;
+  bool have_params = false, packed = false, use_snet3 = false;
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -40,6 +40,7 @@ struct nif_ctx {
   long slot_s = 0, slot_p = 0;
   float* partial = nullptr; int rows_cap = 0; long pstride = 0;
   float* loss_partial = nullptr; long nloss_cap = 0;
+  float* dring = nullptr; long dring_cap = 0;
   // profiling: (group id, start, stop) event triples recorded on st
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
@@ -157,7 +158,11 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->v, 0, pb);
   if (e == hipSuccess) e = hipMemset(c->grad, 0, pb);
   const size_t pk_p = (size_t)(nm > 0 ? nm : 1) * c->NSTB * c->NSTB * 256 * sizeof(f32x4);
-  const size_t pk_s = (size_t)(nh > 0 ? nh : 1) * (c->r + 1) * c->NB * c->NB * 256 * sizeof(f32x4);
+  size_t pk_s = (size_t)(nh > 0 ? nh : 1) * (c->r + 1) * c->NB * c->NB * 256 * sizeof(f32x4);
+  {
+    const size_t pk16 = (size_t)(nh > 0 ? nh : 1) * (c->r + 1) * snet3_plane_floats(c->n) * sizeof(float);
+    if (pk16 > pk_s) pk_s = pk16;
+  }
   if (e == hipSuccess) e = hipMalloc(&c->pWF, pk_p);
   if (e == hipSuccess) e = hipMalloc(&c->pWB, pk_p);
   if (e == hipSuccess) e = hipMalloc(&c->sWF, pk_s);
@@ -176,7 +181,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -355,6 +360,8 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.off_Wh = c->last_w; a.off_bh = c->last_b;
   a.Z = c->Z; a.WF = c->sWF; a.WB = c->sWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
   a.DU = c->DU; a.DZ = c->DZ;
+  a.nsm = c->si * c->n + c->n * c->so + c->n + c->nh * c->n + c->so;
+  a.dring = c->dring;
 }
 
 static int ensure_packed(nif_ctx* c) {
@@ -370,11 +377,18 @@ static int ensure_packed(nif_ctx* c) {
       launch_pack(c->theta, dense_ref(c->hid_w2[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + (2 * i + 1) * plane_p, c->pWB + (2 * i + 1) * plane_p, c->st);
     }
   }
-  const long plane_s = (long)c->NB * c->NB * 256;
+  SNetArgs probe; fill_snet(c, probe, nullptr, 0, 0, 32);
+  c->use_snet3 = snet3_supported(probe);
+  const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
   for (int j = 0; j < c->nh; ++j) {
     const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
-    launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, c->sWF + (long)j * (c->r + 1) * plane_s,
-                c->sWB + (long)j * (c->r + 1) * plane_s, c->st);
+    f32x4* wf = c->sWF + (long)j * (c->r + 1) * plane_s;
+    f32x4* wb = c->sWB + (long)j * (c->r + 1) * plane_s;
+    if (c->use_snet3) {
+      launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
+    } else {
+      launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, wf, wb, c->st);
+    }
   }
   HIPCHK(hipGetLastError());
   c->packed = true;
@@ -390,7 +404,11 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, false, c->st); }
   SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
   sa.u_out = u;
-  { ProfScope p_(c, NIF_PROF_SNET_FWD); launch_snet(sa, c->NB, false, c->st); }
+  {
+    ProfScope p_(c, NIF_PROF_SNET_FWD);
+    if (c->use_snet3) launch_snet3(sa, false, false, nullptr, c->st);
+    else launch_snet(sa, c->NB, false, c->st);
+  }
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
@@ -486,7 +504,23 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
   SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
-  { ProfScope p_(c, NIF_PROF_SNET); launch_snet(sa, c->NB, true, c->st); }
+  int nloss = (int)((ntiles + 3) / 4);
+  if (c->use_snet3) {
+    int waves = 4;
+    const int nblk = launch_snet3(sa, true, true, &waves, c->st);
+    const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    sa.dring = c->dring;
+    nloss = nblk;
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_snet3(sa, true, false, nullptr, c->st);
+  } else {
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_snet(sa, c->NB, true, c->st);
+  }
   { ProfScope p_(c, NIF_PROF_PNET_BWD); launch_pnet_bwd(pa, c->NSTB, c->st); }
   ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
   // weight gradients -> partial rows
@@ -542,7 +576,7 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   delete pgw;
   // rows -> flat gradient, loss
   ProfScope pr_(c, NIF_PROF_REDUCE);
-  launch_reduce(c->partial, c->pstride, rows, c->loss_partial, (int)((ntiles + 3) / 4), c->grad, c->P, c->st);
+  launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }

@@ -78,6 +78,8 @@ struct SNetArgs {
   float* u_out;                           // [B][so] or null
   float* loss_partial;                    // [gridDim.x]
   float inv_bg;                           // 1 / B_global
+  float* dring;                           // k_snet3: per-wave ring for act'(a) (register-dump order)
+  int nsm;                                // k_snet3: floats per k of the LDS copy of the small hyper-vectors
 };
 // slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
 __host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }
@@ -110,6 +112,14 @@ void launch_pack(const float* theta, const MatRef& m, int NBI, int NBO, f32x4* W
 void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st);
 void launch_pnet_bwd(const PNetArgs& a, int NSTB, hipStream_t st);
 void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
+// persistent, LDS-staged, 16-point-tile variant (k_snet3.hip).  launch_snet3 returns the number of
+// workgroups (query_only: without launching) and the waves per workgroup, for sizing dring / loss_partial.
+int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out, hipStream_t st);
+bool snet3_supported(const SNetArgs& a);
+int snet3_nbl(int n);
+long snet3_plane_floats(int n);
+long snet3_ring_floats_per_wave(int n, int nh);
+void launch_pack16(const float* theta, const MatRef& m, int NBL, f32x4* WF, f32x4* WB, hipStream_t st);
 void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st);
 void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st);
 void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st);
@@ -131,19 +141,9 @@ void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStr
 __device__ __forceinline__ int fmap(int v, int hf) { return 8 * (v >> 2) + 4 * hf + (v & 3); }
 
 // sin and cos of x in one go: 3-term Cody-Waite reduction by pi/2 (exact products via fma) and the
-// cephes single-precision minimax kernels on [-pi/4, pi/4].  |error| <~ 2e-7 for |x| < 32768;
-// larger arguments take the ocml slow path.
-__device__ __forceinline__ void nif_sincosf(float x, float* sp, float* cp) {
-  if (__builtin_expect(!(fabsf(x) < 32768.0f), 0)) {
-    float s, c;
-    sincosf(x, &s, &c);
-    *sp = s; *cp = c;
-    return;
-  }
-  const float k = rintf(x * 0.63661977236758134308f);
-  float r = fmaf(-k, 1.57079637050628662109375f, x);
-  r = fmaf(-k, -4.371138828673793e-08f, r);
-  r = fmaf(-k, -1.7151245100058819e-15f, r);
+// cephes single-precision minimax kernels on [-pi/4, pi/4].  Max abs error 1.1e-7 for |x| < 2^20
+// (checked against fp64 on 2e6 samples per decade); larger arguments reduce in double precision.
+__device__ __forceinline__ void nif_sincos_poly(float r, int q, float* sp, float* cp) {
   const float r2 = r * r;
   float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
   ps = fmaf(ps, r2, -1.6666654611e-1f);
@@ -151,11 +151,31 @@ __device__ __forceinline__ void nif_sincosf(float x, float* sp, float* cp) {
   float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
   pc = fmaf(pc, r2, 4.166664568298827e-2f);
   const float c = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
-  const int q = (int)k;
   const float ss = (q & 1) ? c : s;
   const float cc = (q & 1) ? s : c;
   *sp = (q & 2) ? -ss : ss;
   *cp = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ void nif_sincosf_core(float x, float* sp, float* cp) {
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.371138828673793e-08f, r);
+  r = fmaf(-k, -1.7151245100058819e-15f, r);
+  nif_sincos_poly(r, (int)k, sp, cp);
+}
+// |x| >= 2^20: same kernels, argument reduction in fp64 (2-term Cody-Waite, k < 2^52)
+__device__ __forceinline__ void nif_sincosf_big(float x, float* sp, float* cp) {
+  const double xd = (double)x;
+  const double k = rint(xd * 0.63661977236758134308);
+  double r = fma(-k, 1.5707963267948966, xd);
+  r = fma(-k, 6.123233995736766e-17, r);
+  const long long kq = (long long)fmod(k, 4.0);
+  nif_sincos_poly((float)r, (int)(kq & 3), sp, cp);
+}
+#define NIF_SINCOS_FAST_LIMIT 1048576.0f
+__device__ __forceinline__ void nif_sincosf(float x, float* sp, float* cp) {
+  if (__builtin_expect(!(fabsf(x) < NIF_SINCOS_FAST_LIMIT), 0)) nif_sincosf_big(x, sp, cp);
+  else nif_sincosf_core(x, sp, cp);
 }
 
 // h = f(a), d = f'(a) for the Keras activation ACT (compile time)
@@ -199,11 +219,45 @@ __device__ __forceinline__ void act_tile_t(const f32x16 (&a)[NB], f32x16 (&h)[NB
       d[b][v] = ok ? dv : 0.f;
     }
 }
+// SIREN tile: one wave-uniform range check for the whole tile instead of a branch per element.
+// sched_barriers keep the scheduler from interleaving all 16*NB sincos chains (register pressure).
+template <int NB>
+__device__ __forceinline__ void sine_tile(const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
+  float mx = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
+  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        float hv, dv;
+        nif_sincosf_big(a[b][v], &hv, &dv);
+        const bool ok = (32 * b + fmap(v, hf)) < n;
+        h[b][v] = ok ? hv : 0.f;
+        d[b][v] = ok ? dv : 0.f;
+      }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      float hv, dv;
+      nif_sincosf_core(a[b][v], &hv, &dv);
+      const bool ok = (32 * b + fmap(v, hf)) < n;
+      h[b][v] = ok ? hv : 0.f;
+      d[b][v] = ok ? dv : 0.f;
+    }
+}
+
 // wave-uniform dispatch on the runtime activation id (one switch per tile, not per element)
 template <int NB>
 __device__ __forceinline__ void act_tile(int act, const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
   switch (act) {
-    case ACT_SINE: act_tile_t<NB, ACT_SINE>(a, h, d, n, hf); break;
+    case ACT_SINE: sine_tile<NB>(a, h, d, n, hf); break;
     case ACT_SWISH: act_tile_t<NB, ACT_SWISH>(a, h, d, n, hf); break;
     case ACT_TANH: act_tile_t<NB, ACT_TANH>(a, h, d, n, hf); break;
     case ACT_RELU: act_tile_t<NB, ACT_RELU>(a, h, d, n, hf); break;
@@ -230,6 +284,39 @@ __device__ __forceinline__ void dense_mfma(const f32x4* __restrict__ Wp, const f
 #pragma unroll
       for (int vq = 0; vq < 4; ++vq) {
         const f32x4 a = Wp[((ob * NBI + ib) * 4 + vq) * 64 + lane];
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], hin[ib][4 * vq + 0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], hin[ib][4 * vq + 1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], hin[ib][4 * vq + 2], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], hin[ib][4 * vq + 3], t, 0, 0, 0);
+      }
+    }
+    T[ob] = t;
+  }
+}
+
+// ACT >= 0: activation fixed at compile time (the SIREN hot path); ACT < 0: runtime id
+template <int NB, int ACT>
+__device__ __forceinline__ void act_tile_sel(int act, const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
+  if (ACT == ACT_SINE) sine_tile<NB>(a, h, d, n, hf);
+  else act_tile<NB>(act, a, h, d, n, hf);
+}
+
+// same, A operands from an LDS-resident plane; ACCUM keeps the incoming T
+template <int NBI, int NBO, bool ACCUM>
+__device__ __forceinline__ void dense_mfma_lds(const f32x4* plane, const f32x16 (&hin)[NBI], f32x16 (&T)[NBO], int lane) {
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob) {
+    f32x16 t;
+    if (ACCUM) t = T[ob];
+    else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib) {
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const f32x4 a = plane[((ob * NBI + ib) * 4 + vq) * 64 + lane];
         t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], hin[ib][4 * vq + 0], t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], hin[ib][4 * vq + 1], t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], hin[ib][4 * vq + 2], t, 0, 0, 0);
