@@ -23,6 +23,9 @@
 // Keras 'mse' (README.md:33), adjoint per SURVEY a-10.
 #include "nif_internal.h"
 
+// Ablation switches for timing experiments (NEVER set in a product build: results become wrong).
+//   NIF_ABL_NOSTORE  skip the stash / ring stores      NIF_ABL_NOACT   cheap stand-in for the activation
+//   NIF_ABL_NOBAR    skip the per-plane barrier         NIF_ABL_NOMFMA  skip the MFMAs
 #ifndef NIF_S3_OCC4
 #define NIF_S3_OCC4 2   // waves/SIMD requested for the 64-wide (NBL = 4) instantiation
 #endif
@@ -79,13 +82,20 @@ __device__ __forceinline__ void mfma16(const f32x4* plane, const f32x4 (&hin)[NB
     for (int v = 0; v < 4; ++v)
 #pragma unroll
       for (int ob = 0; ob < NBL; ++ob)
+#ifdef NIF_ABL_NOMFMA
+        T[ob][v] += a[ob][v] * hin[ib][v];
+#else
         T[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][v], hin[ib][v], T[ob], 0, 0, 0);
+#endif
   }
 }
 
 // stash [tile32][feature][32]: this wave's 16-point tile is half `hx` of tile32
 template <int NBL>
 __device__ __forceinline__ void st_store16(float* __restrict__ slot, long row0, const f32x4 (&h)[NBL], int g) {
+#ifdef NIF_ABL_NOSTORE
+  if (h[0][0] != 12345.678f) return;
+#endif
   // row0 = (tile32 * FP) * 32 + 16*half + p   (floats); feature f lives at row0 + f*32
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
@@ -100,7 +110,8 @@ __device__ __forceinline__ void st_load16(const float* __restrict__ slot, long r
     for (int v = 0; v < 4; ++v) h[b][v] = slot[row0 + (long)(16 * b + 4 * g + v) * 32];
 }
 
-// activation of a tile (features >= n forced to h = 0, d = 0)
+// activation of a tile.  Padded features (>= n) need no masking: their weight rows/columns in the packed
+// planes and their entries in the LDS small vectors are zero, so whatever act(0) is never propagates.
 template <int NBL, int ACT>
 __device__ __forceinline__ void act16_t(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
 #pragma unroll
@@ -109,36 +120,45 @@ __device__ __forceinline__ void act16_t(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], 
     for (int v = 0; v < 4; ++v) {
       float hv, dv;
       act_eval<ACT>(a[b][v], &hv, &dv);
-      const bool ok = (16 * b + 4 * g + v) < n;
-      h[b][v] = ok ? hv : 0.f;
-      d[b][v] = ok ? dv : 0.f;
+      h[b][v] = hv; d[b][v] = dv;
     }
 }
 template <int NBL>
-__device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
+__device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
   float mx = 0.f;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
     for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
-  const bool big = __any(!(mx < NIF_SINCOS_FAST_LIMIT));
+  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) {   // wave-uniform, once per tile
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float hv, dv;
+        nif_sincosf_big(a[b][v], &hv, &dv);
+        h[b][v] = hv; d[b][v] = dv;
+      }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       float hv, dv;
-      if (__builtin_expect(big, 0)) nif_sincosf_big(a[b][v], &hv, &dv);
-      else nif_sincosf_core(a[b][v], &hv, &dv);
-      const bool ok = (16 * b + 4 * g + v) < n;
-      h[b][v] = ok ? hv : 0.f;
-      d[b][v] = ok ? dv : 0.f;
+      nif_sincosf_core(a[b][v], &hv, &dv);
+      h[b][v] = hv; d[b][v] = dv;
     }
 }
 template <int NBL, int ACT>
 __device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
-  if (ACT == ACT_SINE) { sine16<NBL>(a, h, d, n, g); return; }
+#ifdef NIF_ABL_NOACT
+  _Pragma("unroll") for (int b = 0; b < NBL; ++b) { f32x4 t = a[b]; h[b] = t * 0.5f; d[b] = t + 1.0f; }
+  return;
+#endif
+  if (ACT == ACT_SINE) { sine16<NBL>(a, h, d); return; }
   switch (act) {
-    case ACT_SINE: sine16<NBL>(a, h, d, n, g); break;
+    case ACT_SINE: sine16<NBL>(a, h, d); break;
     case ACT_SWISH: act16_t<NBL, ACT_SWISH>(a, h, d, n, g); break;
     case ACT_TANH: act16_t<NBL, ACT_TANH>(a, h, d, n, g); break;
     case ACT_RELU: act16_t<NBL, ACT_RELU>(a, h, d, n, g); break;
@@ -168,10 +188,14 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
   f32x4* planes = reinterpret_cast<f32x4*>(smem);
   float* sm = smem + 2 * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  float* dzs = sm + sm_tot + (long)wid * (2 * r * 64);   // per wave [r][64]
+  float* dzs = sm + sm_tot + (long)wid * (2 * r * 64 + r * 16);   // per wave [r][64]
   float* sks = dzs + r * 64;
-  float* lsum = sm + sm_tot + (long)WAVES * (2 * r * 64);
-  const int o_w1 = 0, o_wl = si * n, o_b1 = o_wl + n * so, o_bh = o_b1 + n, o_bl = o_bh + nh * n;
+  float* zs = sks + r * 64;                                        // per wave [r][16]: this tile's latent
+  float* lsum = sm + sm_tot + (long)WAVES * (2 * r * 64 + r * 16);
+  // LDS copy of the small hyper-vectors, per k: feature-contiguous, zero-padded to NP = 16*NBL so that a
+  // lane fetches its 4 features of a block with one ds_read_b128 and needs no bounds checks
+  constexpr int NP = 16 * NBL;
+  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
   const int NPL = nh * (r + 1);
   const int nplanes = TRAIN ? 2 * NPL : NPL;
@@ -183,11 +207,17 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
   };
 
   {  // prologue: small hyper-vectors and plane 0 into LDS
-    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_wl = (long)si * n + (long)nh * n * n;        // pnet_output slots (model.py:253-300)
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
     for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
       const int k = idx / nsm, e = idx - k * nsm;
-      const long slot = e < si * n ? e : s_wl + (e - si * n);
-      sm[idx] = hyp3(A, k, slot);
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
     }
     if (nplanes > 0) {
       const f32x4* src = plane_src(0);
@@ -203,6 +233,11 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
   float* IN0 = A.stash;
   float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
 
+#ifdef NIF_ABL_NOBAR
+#define NIF_BAR() __builtin_amdgcn_wave_barrier()
+#else
+#define NIF_BAR() __syncthreads()
+#endif
 #define NIF_PLANE(...)                                                                        \
   {                                                                                           \
     const bool has_next = (pl + 1 < nplanes) || !last_group;                                  \
@@ -219,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       _Pragma("unroll") for (int q = 0; q < PF4; ++q)                                         \
         if (PEXACT || tid + NT * q < PLANE / 4) dst[tid + NT * q] = pre[q];                   \
     }                                                                                         \
-    __syncthreads();                                                                          \
+    NIF_BAR();                                                                                \
     ++gpar; ++pl;                                                                             \
   }
 
@@ -234,7 +269,11 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
     const bool valid = active && pt < A.B;
     const long ptc = pt < A.B ? pt : A.B - 1;
     const float* xrow = A.xin + ptc * A.ncol + A.col0;
-    const float* zt_base = A.Z + tile32 * r * 32 + poff;    // zt_k = zt_base[k*32]
+    // the latent of this tile goes through LDS: a global load inside a plane would make its s_waitcnt
+    // vmcnt drain the in-flight prefetch of the next weight plane (vmcnt retires in order)
+    if (g == 0)
+      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+    const float* zt_base = zs + p;                           // zt_k = zt_base[k*16]
     const long row0 = tile32 * (long)FP * 32 + poff;
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
@@ -244,19 +283,14 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
 #pragma unroll
     for (int b = 0; b < NBL; ++b) { acc[b][0] = 0.f; acc[b][1] = 0.f; acc[b][2] = 0.f; acc[b][3] = 0.f; }
     for (int k = 0; k <= r; ++k) {
-      const float zt = k < r ? zt_base[k * 32] : 1.0f;
-      const float* s0 = sm + k * nsm;
+      const float zt = k < r ? zt_base[k * 16] : 1.0f;
+      const float* s0 = sm + k * nsm + 4 * g;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int f = 16 * b + 4 * g + v;
-          if (f < n) {
-            float s = 0.f;
-            for (int dd = 0; dd < si; ++dd) s = fmaf(xrow[dd], s0[o_w1 + dd * n + f], s);
-            acc[b][v] = fmaf(zt, fmaf(A.omega, s, s0[o_b1 + f]), acc[b][v]);
-          }
-        }
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+      }
     }
     {
       f32x4 d[NBL];
@@ -277,7 +311,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       for (int k = 0; k <= r; ++k) {
         NIF_PLANE({
           if (k < r) {
-            const float zt = zt_base[k * 32];
+            const float zt = zt_base[k * 16];
             f32x4 hz[NBL];
             _Pragma("unroll") for (int b = 0; b < NBL; ++b) hz[b] = zt * h[b];
             mfma16<NBL, true>(cur, hz, acc, lane);
@@ -289,15 +323,10 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
 #pragma unroll
       for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
       for (int k = 0; k <= r; ++k) {
-        const float zt = k < r ? zt_base[k * 32] : 1.0f;
-        const float* sb = sm + k * nsm + o_bh + j * n;
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int f = 16 * b + 4 * g + v;
-            if (f < n) acc[b][v] = fmaf(zt, sb[f], acc[b][v]);
-          }
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
       }
       {
         f32x4 d[NBL];
@@ -337,18 +366,15 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       for (int b = 0; b < NBL; ++b) { wg[b][0] = 0.f; wg[b][1] = 0.f; wg[b][2] = 0.f; wg[b][3] = 0.f; }
       float part = 0.f, bias = 0.f;
       for (int k = 0; k <= r; ++k) {
-        const float zt = k < r ? zt_base[k * 32] : 1.0f;
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
         const float* s0 = sm + k * nsm;
         float sk = 0.f;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int f = 16 * b + 4 * g + v;
-            const float w = f < n ? s0[o_wl + f * so + o] : 0.f;
-            sk = fmaf(h[b][v], w, sk);
-            if (TRAIN) wg[b][v] = fmaf(zt, w, wg[b][v]);
-          }
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          if (TRAIN) wg[b] += zt * w;
+        }
         part = fmaf(zt, sk, part);
         bias = fmaf(zt, s0[o_bl + o], bias);
         if (TRAIN && k < r) sks[k * 64 + lane] = sk;
@@ -375,43 +401,50 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
+      // act'(a_j) and h_{j-1} are fetched one layer ahead so that their L2/HBM latency hides behind the
+      // previous layer's MFMA planes
       f32x4 skip[MODE == 0 ? 1 : NBL];
+      f32x4 dnext[NBL], hin[NBL];
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[(nh * NBL + b) * 64 + lane];
+      if (nh > 0 && r > 0) st_load16<NBL>(IN0 + (long)(nh - 1) * A.slot_stride, row0, hin, g);
       for (int j = nh - 1; j >= 0; --j) {
         f32x4 ga[NBL];
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) ga[b] = reinterpret_cast<const f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane];
         if (MODE == 1 && (j & 1)) {
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) { skip[b] = 0.5f * gh[b]; ga[b] *= skip[b]; }
+          for (int b = 0; b < NBL; ++b) { skip[b] = 0.5f * gh[b]; ga[b] = dnext[b] * skip[b]; }
         } else {
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) ga[b] *= gh[b];
+          for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
           if (MODE == 2) {
 #pragma unroll
             for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
           }
         }
+        // next layer's act'(a) (layer j-1, or the first layer's when j == 0)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[(j * NBL + b) * 64 + lane];
         if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) { gh[b][0] = 0.f; gh[b][1] = 0.f; gh[b][2] = 0.f; gh[b][3] = 0.f; }
         for (int k = 0; k <= r; ++k) {
           NIF_PLANE({
             if (k < r) {
-              const float zt = zt_base[k * 32];
+              const float zt = zt_base[k * 16];
               f32x4 U[NBL];
               mfma16<NBL, false>(cur, ga, U, lane);
               _Pragma("unroll") for (int b = 0; b < NBL; ++b) gh[b] += zt * U[b];
-              f32x4 hin[NBL];
-              st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
-              const float* sb = sm + k * nsm + o_bh + j * n;
+              const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
               float s = 0.f, sbv = 0.f;
-              _Pragma("unroll") for (int b = 0; b < NBL; ++b)
+              _Pragma("unroll") for (int b = 0; b < NBL; ++b) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
                 _Pragma("unroll") for (int v = 0; v < 4; ++v) {
-                  const int f = 16 * b + 4 * g + v;
                   s = fmaf(hin[b][v], U[b][v], s);
-                  if (f < n) sbv = fmaf(ga[b][v], sb[f], sbv);
+                  sbv = fmaf(ga[b][v], bb[v], sbv);
                 }
+              }
               dzs[k * 64 + lane] += fmaf(A.omega, s, sbv);
+              if (k == r - 1 && j > 0) st_load16<NBL>(IN0 + (long)(j - 1) * A.slot_stride, row0, hin, g);
             } else {
               mfma16<NBL, true>(cur, ga, gh, lane);
             }
@@ -427,22 +460,18 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       {
         f32x4 ga[NBL];
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) ga[b] = reinterpret_cast<const f32x4*>(dring)[b * 64 + lane] * gh[b];
+        for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
         if (active) st_store16<NBL>(DA0, row0, ga, g);
         for (int k = 0; k < r; ++k) {
-          const float* s0 = sm + k * nsm;
+          const float* s0 = sm + k * nsm + 4 * g;
           float s = 0.f;
 #pragma unroll
-          for (int b = 0; b < NBL; ++b)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int f = 16 * b + 4 * g + v;
-              if (f < n) {
-                float xw = 0.f;
-                for (int dd = 0; dd < si; ++dd) xw = fmaf(xrow[dd], s0[o_w1 + dd * n + f], xw);
-                s = fmaf(ga[b][v], fmaf(A.omega, xw, s0[o_b1 + f]), s);
-              }
-            }
+          for (int b = 0; b < NBL; ++b) {
+            f32x4 xw = {0.f, 0.f, 0.f, 0.f};
+            for (int dd = 0; dd < si; ++dd) xw += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+            const f32x4 t = A.omega * xw + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+            s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
+          }
           float tot = dzs[k * 64 + lane] + s;
           tot += __shfl_xor(tot, 16);
           tot += __shfl_xor(tot, 32);
@@ -470,12 +499,13 @@ static int nbl_of(int n) {
   return c <= 4 ? c : (c <= 6 ? 6 : 8);
 }
 int snet3_nbl(int n) { return nbl_of(n); }
+int snet3_nsm(int si, int so, int nh, int n) { return (si + so + 1 + nh) * 16 * nbl_of(n) + ((so + 3) & ~3); }
 static int waves_of(int NBL) { (void)NBL; return 4; }
 
 static size_t snet3_shmem(const SNetArgs& a, int NBL, int waves) {
   const size_t plane = (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  return (2 * plane + sm_tot + (size_t)waves * 2 * a.r * 64 + 8) * sizeof(float);
+  return (2 * plane + sm_tot + (size_t)waves * (2 * a.r * 64 + a.r * 16) + 8) * sizeof(float);
 }
 bool snet3_supported(const SNetArgs& a) {
   const int NBL = nbl_of(a.n);

@@ -360,7 +360,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.off_Wh = c->last_w; a.off_bh = c->last_b;
   a.Z = c->Z; a.WF = c->sWF; a.WB = c->sWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
   a.DU = c->DU; a.DZ = c->DZ;
-  a.nsm = c->si * c->n + c->n * c->so + c->n + c->nh * c->n + c->so;
+  a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
   a.dring = c->dring;
 }
 

@@ -117,6 +117,7 @@ void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
 int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out, hipStream_t st);
 bool snet3_supported(const SNetArgs& a);
 int snet3_nbl(int n);
+int snet3_nsm(int si, int so, int nh, int n);
 long snet3_plane_floats(int n);
 long snet3_ring_floats_per_wave(int n, int nh);
 void launch_pack16(const float* theta, const MatRef& m, int NBL, f32x4* WF, f32x4* WB, hipStream_t st);
