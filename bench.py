@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20, help="points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--given-w-points", type=int, default=1 << 17)
+    ap.add_argument("--force-dist", action="store_true", help="join the process group and all-reduce even at world size 1")
     args = ap.parse_args()
 
     import nif_amd
@@ -79,7 +80,8 @@ def main():
     from nif_amd.engine import DeviceArray
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         rank, world = dist.init("nccl")
     else:
         rank = 0
@@ -98,13 +100,13 @@ def main():
 
     def step():
         e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
-        if world > 1:
+        if use_dist:
             dist.all_reduce_grad(e)
         e.adam_step_dev(adam)
 
     def fence():
         e.sync()
-        if world > 1:
+        if use_dist:
             import torch
             import torch.distributed as td
             td.barrier()
@@ -118,7 +120,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as td
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -141,7 +143,7 @@ def main():
         n_w = s.si_dim * s.n_sx + s.n_hidden_mats * s.n_sx ** 2 + s.n_sx * s.so_dim
         flops_snet = 4.0 * (s.pi_hidden + 1) * n_w * B          # fwd + data-adjoint GEMMs of the fused kernel
         ach = flops_snet / (kern_ms["snet"] * 1e-3) / 1e12 if kern_ms["snet"] > 0 else 0.0
-        roofline = {"kernel": "k_snet<2,true> (ShapeNet fwd + MSE + adjoint, fp32 MFMA)", "bound": "mfma",
+        roofline = {"kernel": "k_snet3<4,4,true,SINE,0> (ShapeNet fwd + MSE + data adjoint, 16x16x4 fp32 MFMA)", "bound": "mfma",
                     "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
                     "traffic": None, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w}
         # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
@@ -189,7 +191,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         fence()
         dist.shutdown()
 
