@@ -123,6 +123,8 @@ int nif_forward(nif_ctx* ctx, const float* xin_host, int64_t B, float* u_host);
 int nif_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, float* u_dev);
 /* model_p_to_lr().predict(p): model.py:406-420 (last-layer class: :1070-1083).  p [B,pi] -> [B,r] */
 int nif_pnet_latent(nif_ctx* ctx, const float* p_host, int64_t B, float* lr_host);
+/* model_x_to_phi().predict(x) of the last-layer class: model.py:1085-1104.  x [B,si] -> phi [B,so,r] */
+int nif_x_to_phi(nif_ctx* ctx, const float* x_host, int64_t B, float* phi_host);
 /* model_lr_to_w().predict(lr): model.py:422-433 == last pnet layer (siren.py:514-522).
  * lr [B,r] -> w [B,po].  NIF_ERR_INVALID for the last-layer class (model.py:1106-1115). */
 int nif_latent_to_w(nif_ctx* ctx, const float* lr_host, int64_t B, float* w_host);

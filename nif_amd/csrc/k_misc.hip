@@ -291,3 +291,65 @@ void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStr
   long grid = (ntot + 255) / 256; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned)grid), dim3(256), 0, st, tiles, B, c, rows);
 }
+
+// ============================================================================================
+// last-layer-parameterised class: u = Dot(axes=(2,1))([phi, a]) + last_layer_bias
+// (nif/model.py:1264-1269), Keras 'mse', and the adjoint w.r.t. phi, a and (through the r x r last
+// ParameterNet layer) the latent.  One thread per point; everything is [tile][c][32] so accesses coalesce.
+// ============================================================================================
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_ll_out(LLArgs A) {
+  __shared__ float lsum[4];
+  const long pt = (long)blockIdx.x * 256 + threadIdx.x;
+  const long ntiles = (A.B + 31) / 32;
+  const long tile = pt >> 5;
+  const int p = (int)(pt & 31);
+  const int r = A.r, so = A.so;
+  float loss_lane = 0.f;
+  if (tile < ntiles) {
+    const bool valid = pt < A.B;
+    const long ptc = valid ? pt : A.B - 1;
+    const float* phi = A.PHI + tile * (long)(so * r) * 32 + p;
+    const float* z = A.Z + tile * (long)r * 32 + p;
+    const float wsamp = TRAIN ? (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f) : 0.f;
+    float se = 0.f;
+    for (int s = 0; s < so; ++s) {
+      float u = A.theta[A.bias_off + s];
+      for (int j = 0; j < r; ++j) u = fmaf(phi[(s * r + j) * 32], z[j * 32], u);
+      if (valid && A.u_out) A.u_out[pt * so + s] = u;
+      if (TRAIN) {
+        const float e = u - A.y[ptc * so + s];
+        se = fmaf(e, e, se);
+        const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        A.DU[(tile * so + s) * 32 + p] = du;
+        for (int j = 0; j < r; ++j) A.DPHI[(tile * (long)(so * r) + s * r + j) * 32 + p] = du * z[j * 32];
+      }
+    }
+    if (TRAIN) {
+      loss_lane = wsamp * se / (float)so * A.inv_bg;
+      for (int j = 0; j < r; ++j) {
+        float da = 0.f;
+        for (int s = 0; s < so; ++s) da = fmaf(phi[(s * r + j) * 32], A.DU[(tile * so + s) * 32 + p], da);
+        A.DA[(tile * r + j) * 32 + p] = da;
+      }
+      for (int k = 0; k < r; ++k) {
+        float dz = 0.f;
+        for (int c = 0; c < r; ++c) dz = fmaf(A.DA[(tile * r + c) * 32 + p], A.theta[A.last_w + (long)k * r + c], dz);
+        A.DZL[(tile * r + k) * 32 + p] = dz;
+      }
+    }
+  }
+  if (TRAIN) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
+    if (lane == 0) lsum[wid] = loss_lane;
+    __syncthreads();
+    if (threadIdx.x == 0) A.loss_partial[blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  }
+}
+void launch_ll_out(const LLArgs& a, bool train, hipStream_t st) {
+  const long ntiles = (a.B + 31) / 32;
+  dim3 grid((unsigned)((ntiles * 32 + 255) / 256)), block(256);
+  if (train) hipLaunchKernelGGL((k_ll_out<true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_ll_out<false>), grid, block, 0, st, a);
+}

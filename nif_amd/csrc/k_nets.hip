@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   }
   if (TRAIN) stash_store<NB>(A.stash + (long)nm * A.slot_stride, tile, h, p, hf);
   // bottleneck (linear, nst -> r): per-lane partial dot products + one cross-half exchange
+  extern __shared__ float zl_lds[];   // LL kind only: [4 waves][r][32]
+  float* zl = zl_lds + (long)wid * A.r * 32;
   for (int c = 0; c < A.r; ++c) {
     float s = 0.f;
 #pragma unroll
@@ -151,13 +153,17 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       }
     s += __shfl_xor(s, 32);
     s += A.theta[A.bott_b + c];
-    if (hf == 0) (A.ll_kind ? A.ZL : A.Z)[(tile * A.r + c) * 32 + p] = s;
+    if (A.ll_kind) {
+      if (hf == 0) { zl[c * 32 + p] = s; A.ZL[(tile * A.zl_rows + c) * 32 + p] = s; }
+    } else if (hf == 0) {
+      A.Z[(tile * A.r + c) * 32 + p] = s;
+    }
   }
   if (A.ll_kind) {
     // last-layer class: pnet_out = latent @ W[r,r] + b   (HyperLinearForSIREN with po = r, model.py:583-585)
     for (int c = hf; c < A.r; c += 2) {
       float s = A.theta[A.last_b + c];
-      for (int kk = 0; kk < A.r; ++kk) s = fmaf(A.ZL[(tile * A.r + kk) * 32 + p], A.theta[A.last_w + (long)kk * A.r + c], s);
+      for (int kk = 0; kk < A.r; ++kk) s = fmaf(zl[kk * 32 + p], A.theta[A.last_w + (long)kk * A.r + c], s);
       A.Z[(tile * A.r + c) * 32 + p] = s;
     }
   }
@@ -232,9 +238,10 @@ __global__ __launch_bounds__(256) void k_pnet_bwd(PNetArgs A) {
 void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st) {
   const long ntiles = (a.B + 31) / 32;
   dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+  const size_t shm = a.ll_kind ? (size_t)4 * a.r * 32 * sizeof(float) : 0;
 #define PN(NB_) \
-  if (train) hipLaunchKernelGGL((k_pnet<NB_, true>), grid, block, 0, st, a); \
-  else hipLaunchKernelGGL((k_pnet<NB_, false>), grid, block, 0, st, a);
+  if (train) hipLaunchKernelGGL((k_pnet<NB_, true>), grid, block, shm, st, a); \
+  else hipLaunchKernelGGL((k_pnet<NB_, false>), grid, block, shm, st, a);
   if (NSTB == 1) { PN(1) } else if (NSTB == 2) { PN(2) } else { PN(4) }
 #undef PN
 }

@@ -29,11 +29,15 @@ struct nif_ctx {
   // theta offsets
   long first_w, first_b, hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
   long bott_w, bott_b, last_w, last_b;
+  // last-layer class: shared-weight SIREN ShapeNet (model.py:1147-1217) + last_layer_bias
+  long s_first_w = 0, s_first_b = 0, s_hid_w[NIF_MAX_HID], s_hid_b[NIF_MAX_HID], s_hid_w2[NIF_MAX_HID], s_hid_b2[NIF_MAX_HID];
+  long s_bott_w = 0, s_bott_b = 0, ll_bias = 0;
+  int RB = 1;   // ZL rows per tile = 32*RB
   // device state
   float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
   long step = 0;
   bool have_params = false, packed = false, use_snet3 = false;
-  f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr;
+  f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
   float *stash_s = nullptr, *stash_p = nullptr, *Z = nullptr, *DZ = nullptr, *DU = nullptr, *ZL = nullptr;
@@ -41,6 +45,7 @@ struct nif_ctx {
   float* partial = nullptr; int rows_cap = 0; long pstride = 0;
   float* loss_partial = nullptr; long nloss_cap = 0;
   float* dring = nullptr; long dring_cap = 0;
+  float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
   // profiling: (group id, start, stop) event triples recorded on st
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
@@ -105,6 +110,22 @@ static int build_layout(nif_ctx* c) {
   c->bott_b = off; add_desc(c, "pnet_bottleneck_b", off, c->r, 0);
   c->last_w = off; add_desc(c, "pnet_last_w", off, c->r, (int)c->po);
   c->last_b = off; add_desc(c, "pnet_last_b", off, (int)c->po, 0);
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    const int nout = (int)c->po * c->so;
+    c->s_first_w = off; add_desc(c, "snet_first_w", off, c->si, c->n);
+    c->s_first_b = off; add_desc(c, "snet_first_b", off, c->n, 0);
+    for (int i = 0; i < c->L; ++i) {
+      snprintf(nm, sizeof(nm), "snet_h%d_w", i); c->s_hid_w[i] = off; add_desc(c, nm, off, c->n, c->n);
+      snprintf(nm, sizeof(nm), "snet_h%d_b", i); c->s_hid_b[i] = off; add_desc(c, nm, off, c->n, 0);
+      if (c->cfg.s_resblock) {
+        snprintf(nm, sizeof(nm), "snet_h%d_w2", i); c->s_hid_w2[i] = off; add_desc(c, nm, off, c->n, c->n);
+        snprintf(nm, sizeof(nm), "snet_h%d_b2", i); c->s_hid_b2[i] = off; add_desc(c, nm, off, c->n, 0);
+      }
+    }
+    c->s_bott_w = off; add_desc(c, "snet_bottleneck_w", off, c->n, nout);
+    c->s_bott_b = off; add_desc(c, "snet_bottleneck_b", off, nout, 0);
+    c->ll_bias = off; add_desc(c, "last_layer_bias", off, c->so, 0);
+  }
   c->P = off;
   return 0;
 }
@@ -120,8 +141,10 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(NIF_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", libnif_hip is built for gfx950 only");
-  if (cfg->kind != NIF_KIND_NIF && cfg->kind != NIF_KIND_MULTISCALE)
-    return fail(NIF_ERR_INVALID, "kind not supported by this build (NIF and NIFMultiScale are)");
+  if (cfg->kind != NIF_KIND_NIF && cfg->kind != NIF_KIND_MULTISCALE && cfg->kind != NIF_KIND_LASTLAYER)
+    return fail(NIF_ERR_INVALID, "unknown model kind");
+  if (cfg->kind == NIF_KIND_LASTLAYER && cfg->latent_dim * cfg->so_dim > 64)
+    return fail(NIF_ERR_INVALID, "last-layer class: latent_dim * output_dim must be <= 64");
   if (cfg->pi_dim < 1 || cfg->si_dim < 1 || cfg->so_dim < 1 || cfg->latent_dim < 1)
     return fail(NIF_ERR_INVALID, "dims must be >= 1");
   if (cfg->n_sx < 1 || cfg->n_sx > 128 || cfg->n_st < 1 || cfg->n_st > 128)
@@ -146,6 +169,8 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   c->NB = c->n <= 32 ? 1 : (c->n <= 64 ? 2 : 4);
   c->NSTB = c->nst <= 32 ? 1 : (c->nst <= 64 ? 2 : 4);
   c->po = (long)nh * c->n * c->n + (long)(c->si + c->so + 1 + nh) * c->n + c->so;
+  if (c->kind == NIF_KIND_LASTLAYER) c->po = c->r;   // model.py:583-585
+  c->RB = (c->r + 31) / 32;
   build_layout(c);
   hipError_t e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
@@ -167,6 +192,9 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&c->pWB, pk_p);
   if (e == hipSuccess) e = hipMalloc(&c->sWF, pk_s);
   if (e == hipSuccess) e = hipMalloc(&c->sWB, pk_s);
+  const size_t pk_l = (size_t)(nh > 0 ? nh : 1) * c->NB * c->NB * 256 * sizeof(f32x4);
+  if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWF, pk_l);
+  if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWB, pk_l);
   if (e != hipSuccess) {
     std::string msg = std::string("nif_create: ") + hipGetErrorString(e);
     delete c;
@@ -181,7 +209,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->lWF, c->lWB, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -292,10 +320,12 @@ static int ensure_capacity(nif_ctx* c, long B, bool train) {
   if (pts > c->cap || (train && !c->stash_s)) {
     HIPCHK(hipStreamSynchronize(c->st));
     const long newcap = pts > c->cap ? pts : c->cap;
-    float** ws[] = {&c->Z, &c->DZ, &c->DU, &c->ZL};
-    const long wsz[] = {(long)c->r * newcap, (long)c->r * newcap, (long)c->so * newcap, (long)c->r * newcap};
+    const bool ll = c->kind == NIF_KIND_LASTLAYER;
+    float** ws[] = {&c->Z, &c->DZ, &c->DU, &c->ZL, &c->PHI, &c->DPHI, &c->DA, &c->DZL};
+    const long wsz[] = {(long)c->r * newcap, (long)c->r * newcap, (long)c->so * newcap, (long)32 * c->RB * newcap,
+                        (long)c->r * c->so * newcap, (long)c->r * c->so * newcap, (long)c->r * newcap, (long)c->r * newcap};
     if (newcap > c->cap)
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < (ll ? 8 : 4); ++i) {
         if (*ws[i]) HIPCHK(hipFree(*ws[i]));
         *ws[i] = nullptr;
         HIPCHK(hipMalloc(ws[i], sizeof(float) * (size_t)wsz[i]));
@@ -346,9 +376,28 @@ static void fill_pnet(const nif_ctx* c, PNetArgs& a, const float* xin, long B) {
   a.omega = a.siren ? c->cfg.p_omega0 : 1.0f;
   a.first_w = c->first_w; a.first_b = c->first_b;
   for (int i = 0; i < c->lst; ++i) { a.hid_w[i] = c->hid_w[i]; a.hid_b[i] = c->hid_b[i]; a.hid_w2[i] = c->hid_w2[i]; a.hid_b2[i] = c->hid_b2[i]; }
-  a.bott_w = c->bott_w; a.bott_b = c->bott_b; a.ll_kind = 0; a.last_w = c->last_w; a.last_b = c->last_b;
+  a.bott_w = c->bott_w; a.bott_b = c->bott_b; a.last_w = c->last_w; a.last_b = c->last_b;
+  a.ll_kind = (c->kind == NIF_KIND_LASTLAYER); a.zl_rows = 32 * c->RB;
   a.WF = c->pWF; a.WB = c->pWB; a.stash = c->stash_p; a.slot_stride = c->slot_p;
-  a.Z = c->Z; a.DZ = c->DZ; a.ZL = c->ZL;
+  a.Z = c->Z; a.DZ = a.ll_kind ? c->DZL : c->DZ; a.ZL = c->ZL;
+}
+// last-layer class: the shared-weight SIREN ShapeNet x -> phi is the same MLP machinery (model.py:1219-1238)
+static void fill_snet_mlp(const nif_ctx* c, PNetArgs& a, const float* xin, int ncol, int col0, long B) {
+  memset(&a, 0, sizeof(a));
+  a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
+  a.pi = c->si; a.nst = c->n; a.lst = c->L; a.r = c->r * c->so;
+  a.act = NIF_ACT_SINE; a.res = c->cfg.s_resblock; a.siren = 1; a.omega = c->cfg.s_omega0;
+  a.first_w = c->s_first_w; a.first_b = c->s_first_b;
+  for (int i = 0; i < c->L; ++i) { a.hid_w[i] = c->s_hid_w[i]; a.hid_b[i] = c->s_hid_b[i]; a.hid_w2[i] = c->s_hid_w2[i]; a.hid_b2[i] = c->s_hid_b2[i]; }
+  a.bott_w = c->s_bott_w; a.bott_b = c->s_bott_b; a.ll_kind = 0;
+  a.WF = c->lWF; a.WB = c->lWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
+  a.Z = c->PHI; a.DZ = c->DPHI; a.ZL = nullptr;
+}
+static void fill_ll(const nif_ctx* c, LLArgs& a, long B) {
+  memset(&a, 0, sizeof(a));
+  a.theta = c->theta; a.bias_off = c->ll_bias; a.last_w = c->last_w;
+  a.PHI = c->PHI; a.Z = c->Z; a.B = B; a.r = c->r; a.so = c->so;
+  a.DU = c->DU; a.DPHI = c->DPHI; a.DA = c->DA; a.DZL = c->DZL; a.loss_partial = c->loss_partial;
 }
 static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
@@ -377,6 +426,20 @@ static int ensure_packed(nif_ctx* c) {
       launch_pack(c->theta, dense_ref(c->hid_w2[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + (2 * i + 1) * plane_p, c->pWB + (2 * i + 1) * plane_p, c->st);
     }
   }
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    const long plane_l = (long)c->NB * c->NB * 256;
+    for (int i = 0; i < c->L; ++i) {
+      if (!c->cfg.s_resblock) {
+        launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + i * plane_l, c->lWB + i * plane_l, c->st);
+      } else {
+        launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i) * plane_l, c->lWB + (2 * i) * plane_l, c->st);
+        launch_pack(c->theta, dense_ref(c->s_hid_w2[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i + 1) * plane_l, c->lWB + (2 * i + 1) * plane_l, c->st);
+      }
+    }
+    HIPCHK(hipGetLastError());
+    c->packed = true;
+    return NIF_OK;
+  }
   SNetArgs probe; fill_snet(c, probe, nullptr, 0, 0, 32);
   c->use_snet3 = snet3_supported(probe);
   const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
@@ -402,6 +465,15 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, false, c->st); }
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    ProfScope p_(c, NIF_PROF_SNET_FWD);
+    PNetArgs ma; fill_snet_mlp(c, ma, xin, c->pi + c->si, c->pi, B);
+    launch_pnet(ma, c->NB, false, c->st);
+    LLArgs la; fill_ll(c, la, B); la.u_out = u;
+    launch_ll_out(la, false, c->st);
+    HIPCHK(hipGetLastError());
+    return NIF_OK;
+  }
   SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
   sa.u_out = u;
   {
@@ -449,9 +521,29 @@ extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr)
   return NIF_OK;
 }
 
+extern "C" int nif_x_to_phi(nif_ctx* c, const float* x, int64_t B, float* phi) {
+  if (!c || !x || !phi || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  if (c->kind != NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "model_x_to_phi exists only for the last-layer class");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  rc = stage(c, &c->d_a, &c->cap_a, x, B * c->si); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so * c->r); if (rc) return rc;
+  PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, c->si, 0, B);
+  launch_pnet(ma, c->NB, false, c->st);
+  launch_tiles_to_rows(c->PHI, B, c->so * c->r, c->d_d, c->st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(phi, c->d_d, sizeof(float) * (size_t)(B * c->so * c->r), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
 extern "C" int nif_latent_to_w_dev(nif_ctx* c, const float* lr, int64_t B, float* w) {
   if (!c || !lr || !w || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
+  if (c->kind == NIF_KIND_LASTLAYER)
+    return fail(NIF_ERR_INVALID, "In this class: NIFMultiScaleLastLayerParameterization, `w` is the same as `lr`");
   HIPCHK(hipSetDevice(c->dev));
   { ProfScope p_(c, NIF_PROF_LATENT_TO_W); launch_latent_to_w(c->theta, c->last_w, c->last_b, c->r, c->po, lr, B, w, c->st); }
   HIPCHK(hipGetLastError());
@@ -472,6 +564,17 @@ extern "C" int nif_latent_to_w(nif_ctx* c, const float* lr, int64_t B, float* w)
 extern "C" int nif_shapenet_given_w_dev(nif_ctx* c, const float* x, const float* w, int64_t B, float* u) {
   if (!c || !x || !w || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  if (c->kind == NIF_KIND_LASTLAYER) {   // u = Dot(phi(x), w) + bias with caller-supplied w [B, r]
+    int rc = ensure_packed(c); if (rc) return rc;
+    rc = ensure_capacity(c, B, false); if (rc) return rc;
+    PNetArgs ma; fill_snet_mlp(c, ma, x, c->si, 0, B);
+    launch_pnet(ma, c->NB, false, c->st);
+    launch_rows_to_tiles(w, B, c->r, c->Z, c->st);
+    LLArgs la; fill_ll(c, la, B); la.u_out = u;
+    launch_ll_out(la, false, c->st);
+    HIPCHK(hipGetLastError());
+    return NIF_OK;
+  }
   const int act = c->kind == NIF_KIND_NIF ? c->cfg.s_act : NIF_ACT_SINE;
   const float om = c->kind == NIF_KIND_NIF ? 1.0f : c->cfg.s_omega0;
   { ProfScope p_(c, NIF_PROF_GIVEN_W);
@@ -484,11 +587,85 @@ extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, 
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = stage(c, &c->d_a, &c->cap_a, x, B * c->si); if (rc) return rc;
-  rc = stage(c, &c->d_b, &c->cap_b, w, B * c->po); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, w, B * c->po); if (rc) return rc;   // po == r for the last-layer class
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
   rc = nif_shapenet_given_w_dev(c, c->d_a, c->d_b, B, c->d_d); if (rc) return rc;
   HIPCHK(hipMemcpyAsync(u, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
+  return NIF_OK;
+}
+
+// ---- last-layer-parameterised class: loss and gradient ---------------------------------------------
+static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const float* sw, long B, long Bg) {
+  const long ntiles = (B + 31) / 32;
+  const int ncol = c->pi + c->si;
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
+  LLArgs la; fill_ll(c, la, B);
+  la.y = y; la.sw = sw; la.inv_bg = 1.0f / (float)Bg;
+  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
+  {
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_pnet(ma, c->NB, true, c->st);
+    launch_ll_out(la, true, c->st);
+    launch_pnet_bwd(ma, c->NB, c->st);
+  }
+  { ProfScope p_(c, NIF_PROF_PNET_BWD); launch_pnet_bwd(pa, c->NSTB, c->st); }
+  int rows = (int)((ntiles + 3) / 4);
+  if (rows > c->rows_cap) rows = c->rows_cap;
+  if (rows < 1) rows = 1;
+  {
+    ProfScope p_(c, NIF_PROF_GW);
+    GwArgs g;
+    auto base = [&](GwArgs& q) {
+      memset(&q, 0, sizeof(q));
+      q.ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride; q.has_bias = 1; q.scale = 1.0f; q.r = 0;
+    };
+    const int nms = c->nh;  // hidden matrices of the ShapeNet (2L with resblocks)
+    float* sST = c->stash_s;
+    // ShapeNet (dense SIREN): first, hidden matrices, bottleneck (n -> r*so), last_layer_bias
+    base(g); g.DA = sST + (long)(nms + 1) * c->slot_s; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.scale = ma.omega;
+    g.W = dense_ref(c->s_first_w, c->si, c->n); g.Bv = vec_ref(c->s_first_b, c->n);
+    launch_gw_first(g, c->NB, rows, c->st);
+    for (int mi = 0; mi < nms; ++mi) {
+      base(g); g.IN = sST + (long)mi * c->slot_s; g.DA = sST + (long)(nms + 2 + mi) * c->slot_s; g.scale = ma.omega;
+      long w_off, b_off;
+      if (!c->cfg.s_resblock) { w_off = c->s_hid_w[mi]; b_off = c->s_hid_b[mi]; }
+      else { const int i = mi / 2; w_off = (mi & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (mi & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
+      g.W = dense_ref(w_off, c->n, c->n); g.Bv = vec_ref(b_off, c->n);
+      launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
+    }
+    base(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
+    g.W = dense_ref(c->s_bott_w, c->n, c->r * c->so); g.Bv = vec_ref(c->s_bott_b, c->r * c->so);
+    launch_gw_out(g, c->NB, rows, c->st);
+    base(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DU; g.nc = c->so;   // only the bias part: W.nin = 0
+    g.W = dense_ref(0, 0, c->so); g.Bv = vec_ref(c->ll_bias, c->so);
+    launch_gw_out(g, c->NB, rows, c->st);
+    // ParameterNet: first, hidden matrices, bottleneck, last (r x r)
+    float* pST = c->stash_p;
+    base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.scale = pa.omega;
+    g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
+    launch_gw_first(g, c->NSTB, rows, c->st);
+    for (int mi = 0; mi < c->nm; ++mi) {
+      base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.scale = pa.omega;
+      long w_off, b_off;
+      if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
+      else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
+      g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
+      launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
+    }
+    base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->DZL; g.nc = c->r;
+    g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
+    launch_gw_out(g, c->NSTB, rows, c->st);
+    base(g); g.IN = c->ZL; g.SM = c->DA; g.nc = c->r;   // latent (padded rows) x dL/da
+    g.W = dense_ref(c->last_w, c->r, c->r); g.Bv = vec_ref(c->last_b, c->r);
+    launch_gw_out(g, c->RB, rows, c->st);
+  }
+  {
+    ProfScope pr_(c, NIF_PROF_REDUCE);
+    launch_reduce(c->partial, c->pstride, rows, c->loss_partial, (int)((ntiles * 32 + 255) / 256), c->grad, c->P, c->st);
+  }
+  HIPCHK(hipGetLastError());
   return NIF_OK;
 }
 
@@ -497,6 +674,7 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, true); if (rc) return rc;
+  if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
   const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
   // forward + adjoint

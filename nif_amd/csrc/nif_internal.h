@@ -54,7 +54,8 @@ struct PNetArgs {
   float* stash; long slot_stride;         // slot s at stash + s*slot_stride  (floats)
   float* Z;                               // out: [tiles][r][32]
   float* DZ;                              // in (bwd): [tiles][r][32]
-  float* ZL;                              // LL kind: latent before the r x r map [tiles][r][32]
+  float* ZL;                              // LL kind: latent before the r x r map [tiles][zl_rows][32]
+  int zl_rows;                            //          rows per tile of ZL (r padded to a multiple of 32)
 };
 // stash slots of the pnet: IN_m (input of hidden matrix m) = m, IN_bott = nm, DA_first = nm+1,
 // DA_m = nm+2+m.   nm = lst * (res ? 2 : 1)
@@ -132,6 +133,21 @@ void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, lon
                         float* w, hipStream_t st);
 void launch_given_w(const float* x, const float* w, float* u, long B, int si, int so, int n, int nh, long po,
                     int act, int res, int nif_skip, float omega, hipStream_t st);
+// last-layer-parameterised class: u = Dot(phi(x), a) + bias and its adjoint (nif/model.py:1240-1269)
+struct LLArgs {
+  const float* theta; long bias_off; long last_w;   // last_layer_bias [so]; pnet last layer W[r][r]
+  const float* PHI;     // [tiles][so*r][32]  (row s*r + j)
+  const float* Z;       // [tiles][r][32]     pnet output a
+  long B; int r, so;
+  const float* y; const float* sw; float inv_bg;
+  float* u_out;         // [B][so] or null
+  float* DU;            // [tiles][so][32]
+  float* DPHI;          // [tiles][so*r][32]
+  float* DA;            // [tiles][r][32]   dL/da
+  float* DZL;           // [tiles][r][32]   dL/d latent (through the r x r map)
+  float* loss_partial;  // [gridDim.x]
+};
+void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
 void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st);
 void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st);
 

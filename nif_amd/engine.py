@@ -143,6 +143,14 @@ class Engine(object):
             check(self.lib.nif_pnet_latent(self.ctx, ptr(p), p.shape[0], ptr(out)))
         return out
 
+    def x_to_phi(self, x):
+        x = _f32(x)
+        s = self.spec
+        out = np.empty((x.shape[0], s.so_dim, s.pi_hidden), dtype=np.float32)
+        if x.shape[0]:
+            check(self.lib.nif_x_to_phi(self.ctx, ptr(x), x.shape[0], ptr(out)))
+        return out
+
     def lr_to_w(self, lr):
         lr = _f32(lr)
         out = np.empty((lr.shape[0], self.spec.po_dim), dtype=np.float32)

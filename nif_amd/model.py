@@ -108,6 +108,8 @@ class Model(object):
             if not (isinstance(x, (list, tuple)) and len(x) == 2):
                 raise ValueError("model_x_to_u_given_w expects [x, w]")
             return e.x_to_u_given_w(x[0], x[1])
+        if self._role == "x_to_phi":
+            return e.x_to_phi(x)
         raise NotImplementedError(self._role)
 
     def predict(self, x, batch_size=None, verbose=0, **kwargs):

@@ -11,6 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _cfg(kind, n, L, nst, lst, r, si, so, pi, s_res=False, p_act="sine", p_res=False, act="swish", omega=30.0):
+    if kind == "LL":
+        _, cs, cp = _cfg("NIFMultiScale", n, L, nst, lst, r, si, so, pi, s_res, p_act, p_res, act, omega)
+        cs["connectivity"] = "last_layer"
+        return "NIFMultiScaleLastLayerParameterized", cs, cp
     if kind == "NIF":
         cs = {"input_dim": si, "output_dim": so, "units": n, "nlayers": L, "activation": act}
         cp = {"input_dim": pi, "latent_dim": r, "units": nst, "nlayers": lst, "activation": act}
@@ -33,6 +37,10 @@ CONFIGS = {
     "ms_cfg3_128x3": (_cfg("NIFMultiScale", 128, 3, 64, 2, 1, 2, 1, 1), 160),
     "ms_res_128x1_nst128": (_cfg("NIFMultiScale", 128, 1, 128, 1, 1, 2, 1, 1, s_res=True), 96),
     "ms_tiny_b1": (_cfg("NIFMultiScale", 8, 1, 6, 1, 1, 1, 1, 1), 1),
+    # last-layer-parameterised class (config 4 family)
+    "ll_plain_32x2_r3": (_cfg("LL", 32, 2, 32, 1, 3, 2, 2, 1), 257),
+    "ll_res_48x2_r4": (_cfg("LL", 48, 2, 40, 2, 4, 3, 1, 2, s_res=True, p_res=True, p_act="swish"), 130),
+    "ll_cfg4_128x2_r10_so3": (_cfg("LL", 128, 2, 32, 2, 10, 3, 3, 1), 96),
 }
 
 
@@ -42,9 +50,13 @@ def _make(name, seed=0, boost=2.0):
     spec = O.Spec(kind, cs, cp)
     rng = np.random.default_rng(seed)
     ws = O.init_weights(spec, rng, dtype=np.float32)
-    if kind != "NIF":
+    if kind == "NIFMultiScale":
         names = [nm for nm, _ in spec.param_shapes()]
         ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * boost).astype(np.float32)
+    if kind == "NIFMultiScaleLastLayerParameterized":
+        # weight_init_factor = 0.01 makes the r x r map ~0: give the output a usable scale
+        names = [nm for nm, _ in spec.param_shapes()]
+        ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 30.0).astype(np.float32)
     cls = getattr(nif_amd, kind)
     m = cls(cs, cp)
     model = m.build()
@@ -98,6 +110,25 @@ def test_three_stage_factorisation(name):
     assert _rel(u3, model.predict(x).astype(np.float64)) < 2e-5
     w2 = m.model_p_to_w().predict(p)
     assert _rel(w2, w.astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3"])
+def test_last_layer_class_submodels(name):
+    """model.py:1070-1145: p -> lr (= pnet output), x -> phi, u = Dot(phi, lr) + bias; lr_to_w raises."""
+    m, model, spec, ws, x, y, sw = _make(name)
+    p, xs = x[:, :spec.pi], x[:, spec.pi:]
+    lr = m.model_p_to_lr().predict(p)
+    assert lr.shape == (x.shape[0], spec.r)
+    assert _rel(lr, O.model_p_to_lr(spec, ws, p.astype(np.float64))) < 1e-5
+    phi = m.model_x_to_phi().predict(xs)
+    assert phi.shape == (x.shape[0], spec.so, spec.r)
+    assert _rel(phi, O.model_x_to_phi(spec, ws, xs.astype(np.float64))) < 1e-5
+    u = m.model_x_to_u_given_w().predict([xs, lr])
+    ref = np.einsum("bsj,bj->bs", phi.astype(np.float64), lr.astype(np.float64)) + ws[-1]
+    assert _rel(u, ref) < 1e-5
+    assert _rel(u, model.predict(x).astype(np.float64)) < 1e-5
+    with pytest.raises(ValueError):
+        m.model_lr_to_w()
 
 
 def test_given_w_arbitrary_weights():
