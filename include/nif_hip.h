@@ -134,6 +134,13 @@ int nif_latent_to_w_dev(nif_ctx* ctx, const float* lr_dev, int64_t B, float* w_d
 int nif_shapenet_given_w(nif_ctx* ctx, const float* x_host, const float* w_host, int64_t B, float* u_host);
 int nif_shapenet_given_w_dev(nif_ctx* ctx, const float* x_dev, const float* w_dev, int64_t B, float* u_dev);
 
+/* JacobianLayer(model, y_index, x_index)(x): nif/layers/gradient.py:36-49, :207-231.
+ * y_out [B, so] (all outputs, like the reference) and dydx_out [B, ny, nx] with
+ * dydx[a,i,j] = d y[a, y_idx[i]] / d input[a, x_idx[j]].  Built for coordinate columns
+ * (pi <= x_idx < pi+si) of NIF / NIFMultiScale; other requests return NIF_ERR_INVALID. */
+int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* y_idx, int32_t ny,
+                 const int32_t* x_idx, int32_t nx, float* y_out, float* dydx_out);
+
 /* ---- training ------------------------------------------------------------------------- */
 /* Keras train_step body without the update: loss = mse(y, model(x), sample_weight) and
  * d loss / d theta (GradientTape).  Result stays on the device in nif_grad_dev():

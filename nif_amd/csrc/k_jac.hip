@@ -1,0 +1,265 @@
+// k_jac.hip -- JacobianLayer for the hypernetwork classes (reference nif/layers/gradient.py:36-49,
+// :207-231): (y, dy/dx) w.r.t. the coordinate columns of the model input, by forward-mode tangents
+// carried next to the primal through the same register-resident MFMA chain as k_snet3:
+//
+//   first layer   a0' = w0 * sum_k zt_k W1^(k)[d][:]            h0' = act'(a0) * a0'
+//   hidden        a'  = w0 * sum_k zt_k (h' . M^(k))            plain: h' = act'(a) a'
+//                                                              NIF:   h' = act'(a) a' + h'_in
+//                                                              res:   t' = act'(a1) a1';  u' = 0.5 (u'_in + act'(a2) a2')
+//   last          u'  = h' . Wl(a)
+//
+// The per-sample weights do not depend on x, so one extra B operand per seed reuses every A operand
+// (weight plane) already in LDS.  The reference needs len(y_index) extra reverse sweeps instead.
+#include "k_snet3_dev.h"
+
+#define NIF_JAC_MAXSEED 3
+
+struct JacArgs {
+  SNetArgs s;                 // primal arguments (u_out = y)
+  int ns;                     // seeds in this launch (<= NIF_JAC_MAXSEED)
+  int seed[NIF_JAC_MAXSEED];  // coordinate index d (0..si-1) of each seed
+  int nx_total, x0;           // dydx row stride (number of requested x columns) and first column of this launch
+  float* dydx;                // [B][so][nx_total]
+};
+
+template <int NBL, int ACT, int MODE>
+__global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SNetArgs& A = J.s;
+  constexpr int NT = 256, WAVES = 4, NS = NIF_JAC_MAXSEED;
+  constexpr int PLANE = NBL * NBL * 256;
+  constexpr int PF4 = (PLANE / 4 + NT - 1) / NT;
+  constexpr bool PEXACT = (PLANE / 4) % NT == 0;
+  constexpr int NP = 16 * NBL;
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm, ns = J.ns;
+  const long nt16 = 2 * ((A.B + 31) / 32);
+  const long ngroups = (nt16 + WAVES - 1) / WAVES;
+
+  f32x4* planes = reinterpret_cast<f32x4*>(smem);
+  float* sm = smem + 2 * PLANE;
+  const int sm_tot = ((r + 1) * nsm + 3) & ~3;
+  float* zs = sm + sm_tot + (long)wid * (r * 16);
+  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
+  const int nplanes = nh * (r + 1);
+
+  {
+    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
+      const int k = idx / nsm, e = idx - k * nsm;
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
+    }
+    if (nplanes > 0) {
+#pragma unroll
+      for (int q = 0; q < PF4; ++q)
+        if (PEXACT || tid + NT * q < PLANE / 4) planes[tid + NT * q] = A.WF[tid + NT * q];
+    }
+  }
+  __syncthreads();
+  int gpar = 0;
+
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    const bool last_group = tg + gridDim.x >= ngroups;
+    const long t16_raw = tg * WAVES + wid;
+    const bool active = t16_raw < nt16;
+    const long t16 = active ? t16_raw : nt16 - 1;
+    const long tile32 = t16 >> 1;
+    const int poff = 16 * (int)(t16 & 1) + p;
+    const long pt = t16 * 16 + p;
+    const bool valid = active && pt < A.B;
+    const long ptc = pt < A.B ? pt : A.B - 1;
+    const float* xrow = A.xin + ptc * A.ncol + A.col0;
+    if (g == 0)
+      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+    const float* zt_base = zs + p;
+
+    f32x4 h[NBL], acc[NBL], hd[NS][NBL], accd[NS][NBL];
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) {
+      acc[b][0] = 0.f; acc[b][1] = 0.f; acc[b][2] = 0.f; acc[b][3] = 0.f;
+#pragma unroll
+      for (int d = 0; d < NS; ++d) { accd[d][b][0] = 0.f; accd[d][b][1] = 0.f; accd[d][b][2] = 0.f; accd[d][b][3] = 0.f; }
+    }
+    // ---- first layer ---------------------------------------------------------------------------
+    for (int k = 0; k <= r; ++k) {
+      const float zt = k < r ? zt_base[k * 16] : 1.0f;
+      const float* s0 = sm + k * nsm + 4 * g;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          if (d < ns) accd[d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
+      }
+    }
+    {
+      f32x4 dv[NBL];
+      act16<NBL, ACT>(A.act, acc, h, dv, n, g);
+#pragma unroll
+      for (int d = 0; d < NS; ++d)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) hd[d][b] = dv[b] * accd[d][b];
+    }
+    // ---- hidden hyper-matrices -------------------------------------------------------------------
+    int pl = 0;
+    f32x4 ublk[MODE == 1 ? NBL : 1], ublkd[MODE == 1 ? NS : 1][MODE == 1 ? NBL : 1];
+    for (int j = 0; j < nh; ++j) {
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        acc[b][0] = 0.f; acc[b][1] = 0.f; acc[b][2] = 0.f; acc[b][3] = 0.f;
+#pragma unroll
+        for (int d = 0; d < NS; ++d) { accd[d][b][0] = 0.f; accd[d][b][1] = 0.f; accd[d][b][2] = 0.f; accd[d][b][3] = 0.f; }
+      }
+      for (int k = 0; k <= r; ++k) {
+        const bool has_next = (pl + 1 < nplanes) || !last_group;
+        f32x4 pre[PF4];
+        if (has_next) {
+          const f32x4* src = A.WF + (long)(pl + 1 < nplanes ? pl + 1 : 0) * (PLANE / 4);
+#pragma unroll
+          for (int q = 0; q < PF4; ++q)
+            if (PEXACT || tid + NT * q < PLANE / 4) pre[q] = src[tid + NT * q];
+        }
+        const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        {
+          f32x4 hz[NBL];
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) hz[b] = zt * h[b];
+          mfma16<NBL, true>(cur, hz, acc, lane);
+        }
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          if (d < ns) {
+            f32x4 hz[NBL];
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) hz[b] = zt * hd[d][b];
+            mfma16<NBL, true>(cur, hz, accd[d], lane);
+          }
+        if (has_next) {
+          f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);
+#pragma unroll
+          for (int q = 0; q < PF4; ++q)
+            if (PEXACT || tid + NT * q < PLANE / 4) dst[tid + NT * q] = pre[q];
+        }
+        __syncthreads();
+        ++gpar; ++pl;
+      }
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
+      }
+      f32x4 dv[NBL];
+      act16<NBL, ACT>(A.act, acc, acc, dv, n, g);
+      // tangents: a' = w0 * accd ; then the layer's combination rule
+#pragma unroll
+      for (int d = 0; d < NS; ++d)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 t = dv[b] * (A.omega * accd[d][b]);
+          if (MODE == 0) hd[d][b] = t;
+          else if (MODE == 2) hd[d][b] += t;
+          else {
+            if (!(j & 1)) { ublkd[d][b] = hd[d][b]; hd[d][b] = t; }
+            else hd[d][b] = 0.5f * (ublkd[d][b] + t);
+          }
+        }
+      if (MODE == 0) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) h[b] = acc[b];
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) h[b] += acc[b];
+      } else {
+        if (!(j & 1)) {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) { ublk[b] = h[b]; h[b] = acc[b]; }
+        } else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) h[b] = 0.5f * (ublk[b] + acc[b]);
+        }
+      }
+    }
+    // ---- last layer: u and u' ---------------------------------------------------------------------
+    for (int o = 0; o < so; ++o) {
+      float part = 0.f, bias = 0.f, pd[NS];
+#pragma unroll
+      for (int d = 0; d < NS; ++d) pd[d] = 0.f;
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* s0 = sm + k * nsm;
+        float sk = 0.f, skd[NS];
+#pragma unroll
+        for (int d = 0; d < NS; ++d) skd[d] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+#pragma unroll
+          for (int d = 0; d < NS; ++d)
+            skd[d] += (hd[d][b][0] * w[0] + hd[d][b][1] * w[1]) + (hd[d][b][2] * w[2] + hd[d][b][3] * w[3]);
+        }
+        part = fmaf(zt, sk, part);
+        bias = fmaf(zt, s0[o_bl + o], bias);
+#pragma unroll
+        for (int d = 0; d < NS; ++d) pd[d] = fmaf(zt, skd[d], pd[d]);
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+#pragma unroll
+      for (int d = 0; d < NS; ++d) { pd[d] += __shfl_xor(pd[d], 16); pd[d] += __shfl_xor(pd[d], 32); }
+      if (valid && g == 0) {
+        if (A.u_out) A.u_out[pt * so + o] = part + bias;
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          if (d < ns) J.dydx[(pt * so + o) * J.nx_total + J.x0 + d] = pd[d];
+      }
+    }
+  }
+}
+
+void launch_jac(const SNetArgs& a, int ns, const int* seeds, int nx_total, int x0, float* dydx, hipStream_t st) {
+  JacArgs J;
+  J.s = a; J.ns = ns; J.nx_total = nx_total; J.x0 = x0; J.dydx = dydx;
+  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
+  const int NBL = snet3_nbl(a.n);
+  const long nt16 = 2 * ((a.B + 31) / 32);
+  const long ngroups = (nt16 + 3) / 4;
+  const long cap = NBL <= 4 ? 512 : 256;
+  dim3 grid((unsigned)(ngroups < cap ? ngroups : cap)), block(256);
+  const size_t plane = (size_t)NBL * NBL * 256;
+  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  const size_t shm = (2 * plane + sm_tot + 4 * (size_t)a.r * 16 + 8) * sizeof(float);
+#define JL(NBL_, ACT_, MODE_)                                                                                        \
+  {                                                                                                                  \
+    if (shm > 48 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)k_jac<NBL_, ACT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)shm);                                                                           \
+    hipLaunchKernelGGL((k_jac<NBL_, ACT_, MODE_>), grid, block, shm, st, J);                                         \
+  }
+#define JK(NBL_)                                                      \
+  if (a.nif_skip) JL(NBL_, -1, 2) else if (a.res) JL(NBL_, ACT_SINE, 1) else JL(NBL_, ACT_SINE, 0)
+  switch (NBL) {
+    case 1: JK(1) break;
+    case 2: JK(2) break;
+    case 3: JK(3) break;
+    case 4: JK(4) break;
+    case 6: JK(6) break;
+    default: JK(8) break;
+  }
+#undef JK
+#undef JL
+}

@@ -21,7 +21,7 @@
 //
 // Semantics: NIF._call_shape_net nif/model.py:233-324, NIFMultiScale._call_shape_net_mres :738-954,
 // Keras 'mse' (README.md:33), adjoint per SURVEY a-10.
-#include "nif_internal.h"
+#include "k_snet3_dev.h"
 
 // Ablation switches for timing experiments (NEVER set in a product build: results become wrong).
 //   NIF_ABL_NOSTORE  skip the stash / ring stores      NIF_ABL_NOACT   cheap stand-in for the activation
@@ -30,9 +30,6 @@
 #define NIF_S3_OCC4 2   // waves/SIMD requested for the 64-wide (NBL = 4) instantiation
 #endif
 
-__device__ __forceinline__ float hyp3(const SNetArgs& A, int k, long slot) {
-  return k < A.r ? A.theta[A.off_Wh + (long)k * A.po + slot] : A.theta[A.off_bh + slot];
-}
 
 // ---- packing for the 16x16x4 path -------------------------------------------------------------
 //   fwd plane: ((ob*NBL + ib)*64 + lane)*4 + v : M[in = 16ib + 4(lane>>4) + v][out = 16ob + (lane&15)]
@@ -62,112 +59,6 @@ void launch_pack16(const float* theta, const MatRef& m, int NBL, f32x4* WF, f32x
   int grid = (int)((total + 255) / 256);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_pack16, dim3(grid), dim3(256), 0, st, theta, m, NBL, (float*)WF, (float*)WB);
-}
-
-// ---- device helpers ---------------------------------------------------------------------------
-// T[ob] (+)= sum_ib,v A(plane) x B(hin): 16x16x4 fp32 MFMAs, output blocks rotated innermost so that
-// consecutive MFMAs hit independent accumulators
-template <int NBL, bool ACCUM>
-__device__ __forceinline__ void mfma16(const f32x4* plane, const f32x4 (&hin)[NBL], f32x4 (&T)[NBL], int lane) {
-  if (!ACCUM) {
-#pragma unroll
-    for (int ob = 0; ob < NBL; ++ob) { T[ob][0] = 0.f; T[ob][1] = 0.f; T[ob][2] = 0.f; T[ob][3] = 0.f; }
-  }
-#pragma unroll
-  for (int ib = 0; ib < NBL; ++ib) {
-    f32x4 a[NBL];
-#pragma unroll
-    for (int ob = 0; ob < NBL; ++ob) a[ob] = plane[(ob * NBL + ib) * 64 + lane];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int ob = 0; ob < NBL; ++ob)
-#ifdef NIF_ABL_NOMFMA
-        T[ob][v] += a[ob][v] * hin[ib][v];
-#else
-        T[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][v], hin[ib][v], T[ob], 0, 0, 0);
-#endif
-  }
-}
-
-// stash [tile32][feature][32]: this wave's 16-point tile is half `hx` of tile32
-template <int NBL>
-__device__ __forceinline__ void st_store16(float* __restrict__ slot, long row0, const f32x4 (&h)[NBL], int g) {
-#ifdef NIF_ABL_NOSTORE
-  if (h[0][0] != 12345.678f) return;
-#endif
-  // row0 = (tile32 * FP) * 32 + 16*half + p   (floats); feature f lives at row0 + f*32
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) slot[row0 + (long)(16 * b + 4 * g + v) * 32] = h[b][v];
-}
-template <int NBL>
-__device__ __forceinline__ void st_load16(const float* __restrict__ slot, long row0, f32x4 (&h)[NBL], int g) {
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) h[b][v] = slot[row0 + (long)(16 * b + 4 * g + v) * 32];
-}
-
-// activation of a tile.  Padded features (>= n) need no masking: their weight rows/columns in the packed
-// planes and their entries in the LDS small vectors are zero, so whatever act(0) is never propagates.
-template <int NBL, int ACT>
-__device__ __forceinline__ void act16_t(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      float hv, dv;
-      act_eval<ACT>(a[b][v], &hv, &dv);
-      h[b][v] = hv; d[b][v] = dv;
-    }
-}
-template <int NBL>
-__device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
-  float mx = 0.f;
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
-  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) {   // wave-uniform, once per tile
-#pragma unroll
-    for (int b = 0; b < NBL; ++b)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float hv, dv;
-        nif_sincosf_big(a[b][v], &hv, &dv);
-        h[b][v] = hv; d[b][v] = dv;
-      }
-    return;
-  }
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      float hv, dv;
-      nif_sincosf_core(a[b][v], &hv, &dv);
-      h[b][v] = hv; d[b][v] = dv;
-    }
-}
-template <int NBL, int ACT>
-__device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
-#ifdef NIF_ABL_NOACT
-  _Pragma("unroll") for (int b = 0; b < NBL; ++b) { f32x4 t = a[b]; h[b] = t * 0.5f; d[b] = t + 1.0f; }
-  return;
-#endif
-  if (ACT == ACT_SINE) { sine16<NBL>(a, h, d); return; }
-  switch (act) {
-    case ACT_SINE: sine16<NBL>(a, h, d); break;
-    case ACT_SWISH: act16_t<NBL, ACT_SWISH>(a, h, d, n, g); break;
-    case ACT_TANH: act16_t<NBL, ACT_TANH>(a, h, d, n, g); break;
-    case ACT_RELU: act16_t<NBL, ACT_RELU>(a, h, d, n, g); break;
-    case ACT_SIGMOID: act16_t<NBL, ACT_SIGMOID>(a, h, d, n, g); break;
-    case ACT_ELU: act16_t<NBL, ACT_ELU>(a, h, d, n, g); break;
-    case ACT_SOFTPLUS: act16_t<NBL, ACT_SOFTPLUS>(a, h, d, n, g); break;
-    case ACT_GELU: act16_t<NBL, ACT_GELU>(a, h, d, n, g); break;
-    default: act16_t<NBL, ACT_LINEAR>(a, h, d, n, g); break;
-  }
 }
 
 // MODE: 0 = plain (NIFMultiScale without resblock), 1 = SIREN resblock, 2 = NIF skip connection

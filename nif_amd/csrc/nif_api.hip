@@ -503,6 +503,45 @@ extern "C" int nif_forward(nif_ctx* c, const float* xin, int64_t B, float* u) {
   return NIF_OK;
 }
 
+extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32_t* y_idx, int32_t ny,
+                            const int32_t* x_idx, int32_t nx, float* y_out, float* dydx_out) {
+  if (!c || !xin || !y_idx || !x_idx || !y_out || !dydx_out || B <= 0 || ny <= 0 || nx <= 0)
+    return fail(NIF_ERR_INVALID, "bad argument");
+  if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "JacobianLayer is not built for the last-layer class yet");
+  for (int i = 0; i < ny; ++i)
+    if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
+  for (int j = 0; j < nx; ++j)
+    if (x_idx[j] < c->pi || x_idx[j] >= c->pi + c->si)
+      return fail(NIF_ERR_INVALID, "JacobianLayer: only coordinate columns (x_index >= pi_dim) are built");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = ensure_packed(c); if (rc) return rc;
+  if (!c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+  launch_pnet(pa, c->NSTB, false, c->st);
+  SNetArgs sa; fill_snet(c, sa, c->d_a, c->pi + c->si, c->pi, B);
+  for (int x0 = 0; x0 < nx; x0 += 3) {
+    int seeds[3] = {0, 0, 0};
+    const int ns = nx - x0 < 3 ? nx - x0 : 3;
+    for (int d = 0; d < ns; ++d) seeds[d] = x_idx[x0 + d] - c->pi;
+    sa.u_out = x0 == 0 ? c->d_d : nullptr;
+    launch_jac(sa, ns, seeds, nx, x0, c->d_b, c->st);
+  }
+  HIPCHK(hipGetLastError());
+  std::vector<float> full((size_t)B * c->so * nx);
+  HIPCHK(hipMemcpyAsync(y_out, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(full.data(), c->d_b, sizeof(float) * full.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (int64_t a = 0; a < B; ++a)
+    for (int i = 0; i < ny; ++i)
+      for (int j = 0; j < nx; ++j) dydx_out[(a * ny + i) * nx + j] = full[((size_t)a * c->so + y_idx[i]) * nx + j];
+  return NIF_OK;
+}
+
 extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr) {
   if (!c || !p || !lr || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));

@@ -143,6 +143,17 @@ class Engine(object):
             check(self.lib.nif_pnet_latent(self.ctx, ptr(p), p.shape[0], ptr(out)))
         return out
 
+    def jacobian(self, inputs, y_index, x_index):
+        x = _f32(inputs)
+        s = self.spec
+        yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
+        xi = np.ascontiguousarray(list(x_index), dtype=np.int32)
+        y = np.empty((x.shape[0], s.so_dim), dtype=np.float32)
+        d = np.empty((x.shape[0], yi.size, xi.size), dtype=np.float32)
+        check(self.lib.nif_jacobian(self.ctx, ptr(x), x.shape[0], yi.ctypes.data_as(C.POINTER(C.c_int32)), yi.size,
+                                    xi.ctypes.data_as(C.POINTER(C.c_int32)), xi.size, ptr(y), ptr(d)))
+        return y, d
+
     def x_to_phi(self, x):
         x = _f32(x)
         s = self.spec

@@ -223,6 +223,25 @@ class Model(object):
         return hist
 
 
+class JacobianLayer(object):
+    """reference nif/layers/gradient.py:4-49: `y, dys_dxs = JacobianLayer(model, y_index, x_index)(x)` with
+    dys_dxs[a, i, j] = d y[a, y_index[i]] / d x[a, x_index[j]] w.r.t. the model *input vector* (parameter
+    columns first, then coordinates).  Built as a forward-mode tangent HIP kernel for coordinate columns of
+    the NIF / NIFMultiScale models (`k_jac`); the reference runs len(y_index) extra reverse sweeps."""
+
+    def __init__(self, model, y_index, x_index, **kwargs):
+        if not isinstance(model, Model) or model._role != "full":
+            raise TypeError("JacobianLayer expects the model returned by NIF(...).build() / .model()")
+        self.model = model
+        self.y_index = [y_index] if isinstance(y_index, int) else list(y_index)
+        self.x_index = [x_index] if isinstance(x_index, int) else list(x_index)
+
+    def call(self, x, **kwargs):
+        return self.model._engine.jacobian(x, self.y_index, self.x_index)
+
+    __call__ = call
+
+
 class NIF(object):
     """reference nif/model.py:48 `class NIF(object)`: a factory of Keras-like models that share one set
     of variables."""

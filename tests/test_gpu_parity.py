@@ -131,6 +131,29 @@ def test_last_layer_class_submodels(name):
         m.model_lr_to_w()
 
 
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3",
+                                  "ms_res_48x2_pres", "ms_cfg3_128x3"])
+def test_jacobian_layer_matches_oracle(name):
+    """gradient.py:36-49: (y, dy/dx) w.r.t. the coordinate columns; oracle = analytic tangent in fp64 (itself
+    pinned by central differences and torch autograd in tests/test_oracle.py)."""
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make(name)
+    yi = list(range(spec.so))
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    yv, J = nif_amd.JacobianLayer(model, yi, xi)(x)
+    yr, Jr = O.jacobian_analytic(spec, ws, x.astype(np.float64), yi, xi)
+    assert yv.shape == (x.shape[0], spec.so) and J.shape == (x.shape[0], len(yi), len(xi))
+    assert _rel(yv, yr) < 1e-5
+    assert _rel(J, Jr) < 2e-5, _rel(J, Jr)
+    # index selection / ordering like tf.gather (gradient.py:228-229)
+    if spec.si > 1:
+        y2, J2 = nif_amd.JacobianLayer(model, [spec.so - 1], [xi[-1], xi[0]])(x)
+        assert np.allclose(J2[:, 0, 0], J[:, spec.so - 1, -1], rtol=1e-4, atol=1e-5)
+        assert np.allclose(J2[:, 0, 1], J[:, spec.so - 1, 0], rtol=1e-4, atol=1e-5)
+    with pytest.raises(nif_amd._lib.NifError):
+        nif_amd.JacobianLayer(model, yi, [0])(x)   # parameter column: not built yet
+
+
 def test_given_w_arbitrary_weights():
     """model_x_to_u_given_w must take ANY per-sample w, not only ones produced by the hypernetwork."""
     m, model, spec, ws, x, y, sw = _make("ms_cfg2_64x4")
