@@ -29,39 +29,40 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 HBM_PEAK_GBS = 8000.0        # spec; 6290 measured-achievable
 
 
-def cpu_baseline(sample_points=8192, micro=4096):
-    """The oracle (NumPy restatement of the reference formulation, materialising pnet_output
-    [b, po] and the per-sample einsum) timed on this box's host cores: one train step =
-    loss+grad+Adam on `sample_points` points in micro-batches of `micro` (fp32)."""
+def cpu_baseline(sample_points=65536, micro=4096):
+    """The reference FORMULATION restated in C/OpenMP (oracle/nif_ref_cpu.c: materialised pnet_output
+    [b, po], per-sample einsum chain, reverse sweep with a materialised [b, po] gradient, Adam) timed on this
+    box's host cores, all of them, on a bounded sample of the same workload: train steps of `sample_points`
+    points executed as micro-batches of `micro` (fp32).  It stands in for the reference's tf.distribute CPU
+    path, which cannot run here (TensorFlow 2.11.1 is not installed and the reference's Python cannot travel)."""
     from oracle import nif_oracle as O
+    from oracle import ref_cpu as R
+    import ctypes as C
     spec = O.Spec("NIFMultiScale", CFG_SHAPE, CFG_PARAM)
     rng = np.random.default_rng(1)
-    ws = O.init_weights(spec, rng, dtype=np.float32)
+    th = O.flatten(O.init_weights(spec, rng, dtype=np.float32)).astype(np.float32)
     x, y = O.synthetic_wave_batch(sample_points, seed=0)
-    th = O.flatten(ws)
+    lib = R.load()
+    cfg = R.make_cfg(spec)
     m = np.zeros_like(th); v = np.zeros_like(th)
+    cores = lib.nifref_max_threads()
 
     def step(t):
-        nonlocal th, m, v
-        g = np.zeros_like(th)
-        wl = O.unflatten(spec, th)
-        for b0 in range(0, sample_points, micro):
-            _, gg = O.loss_and_grad(spec, wl, x[b0:b0 + micro], y[b0:b0 + micro], batch_global=sample_points)
-            g += O.flatten(gg)
-        th, m, v = O.adam_step(th, g, m, v, t)
-        th = th.astype(np.float32); m = m.astype(np.float32); v = v.astype(np.float32)
+        _, g = R.loss_and_grad(lib, cfg, th, x, y, None, micro=micro)
+        lib.nifref_adam(th.ctypes.data, g.ctypes.data, m.ctypes.data, v.ctypes.data, th.size, t, 1e-3, 0.9, 0.999, 1e-7)
 
     step(1)  # warm-up
     t0 = time.perf_counter()
     nrep, t = 0, 2
     while True:
         step(t); t += 1; nrep += 1
-        if time.perf_counter() - t0 > 12.0 or nrep >= 20:
+        if time.perf_counter() - t0 > 12.0 or nrep >= 50:
             break
     dt = time.perf_counter() - t0
-    return {"value": sample_points * nrep / dt, "unit": "points/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of %d points (micro-batches of %d), NumPy fp32 restatement of the reference "
-                      "formulation (materialised [b,po] + einsum), not TensorFlow" % (nrep, sample_points, micro)}
+    return {"value": sample_points * nrep / dt, "unit": "points/s", "cores": int(cores), "kind": "port",
+            "sample": "%d train steps of %d points (micro-batches of %d) of the benchmark model; C/OpenMP fp32 "
+                      "restatement of the reference formulation (materialised [b,po] + per-sample einsum), "
+                      "OMP threads = %d; not TensorFlow" % (nrep, sample_points, micro, cores)}
 
 
 def main():
