@@ -144,9 +144,19 @@ def main():
         n_w = s.si_dim * s.n_sx + s.n_hidden_mats * s.n_sx ** 2 + s.n_sx * s.so_dim
         flops_snet = 4.0 * (s.pi_hidden + 1) * n_w * B          # fwd + data-adjoint GEMMs of the fused kernel
         ach = flops_snet / (kern_ms["snet"] * 1e-3) / 1e12 if kern_ms["snet"] > 0 else 0.0
+        traffic, traffic_gw, tnote = None, None, None
+        try:  # HBM traffic of the same kernels from the committed PMC run (bench.py cannot run rocprofv3 on itself)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = (2.0 * tj["k_snet3"]["FETCH_SIZE_KB"] + tj["k_snet3"]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["points"]
+            traffic_gw = (2.0 * tj["k_given_w"]["FETCH_SIZE_KB"] + tj["k_given_w"]["WRITE_SIZE_KB"]) * 1024.0 \
+                * args.given_w_points / tj["k_given_w"]["points"]
+            tnote = tj["source"] + "; " + tj["calibration"]
+        except Exception:
+            pass
         roofline = {"kernel": "k_snet3<4,4,true,SINE,0> (ShapeNet fwd + MSE + data adjoint, 16x16x4 fp32 MFMA)", "bound": "mfma",
                     "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                    "traffic": None, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w}
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, scaled to this batch)",
+                    "traffic_note": tnote, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w}
         # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
         Bw = args.given_w_points
         rng = np.random.default_rng(7)
@@ -173,7 +183,8 @@ def main():
         gbs = bytes_gw / (gw_ms * 1e-3) / 1e9 if gw_ms > 0 else 0.0
         roofline_given_w = {"kernel": "k_given_w<64> (model_x_to_u_given_w, per-sample batched matvec)", "bound": "hbm",
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "frac_of_measured_peak_6290": gbs / 6290.0, "traffic": None, "avg_ms": gw_ms,
+                            "frac_of_measured_peak_6290": gbs / 6290.0, "traffic": traffic_gw, "algorithmic_bytes": bytes_gw,
+                            "avg_ms": gw_ms,
                             "points": Bw, "bytes_per_point": 4.0 * (s.si_dim + s.po_dim + s.so_dim),
                             "latent_to_w_GBs": 4.0 * s.po_dim * Bw / (l2w_ms * 1e-3) / 1e9 if l2w_ms > 0 else 0.0}
         out = {
