@@ -176,6 +176,9 @@ typedef enum {
 int nif_profile_enable(nif_ctx* ctx, int on);
 /* synchronises, then adds the elapsed milliseconds / launch counts per group since the last reset */
 int nif_profile_read(nif_ctx* ctx, float* ms_out, int64_t* count_out, int n, int reset);
+/* measurement builds (-DNIF_TIMELINE): (id, s_memtime) stamps of one wavefront of the dominant kernel.
+ * The first call arms the buffer; later calls copy out up to n_pairs pairs and clear it. */
+int nif_debug_timeline(nif_ctx* ctx, int64_t* out_pairs, int32_t n_pairs);
 /* a plain stopwatch on the stream */
 int nif_timer_start(nif_ctx* ctx);
 int nif_timer_stop(nif_ctx* ctx, float* ms_out);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "nif_last_loss": (C.c_int, [_CTX, _FP]),
     "nif_profile_enable": (C.c_int, [_CTX, C.c_int]),
     "nif_profile_read": (C.c_int, [_CTX, _FP, C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    "nif_debug_timeline": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),
     "nif_timer_start": (C.c_int, [_CTX]),
     "nif_timer_stop": (C.c_int, [_CTX, _FP]),
 }

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
     for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = 0.f;
   }
 
-  for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
-    f32x4 af[NBI][4], bf[OBC][4], zq[KC][4];
+  // register double buffering: the next tile's operands are in flight while the current tile feeds the
+  // matrix cores (this kernel runs one wave per SIMD, so nothing else would hide the HBM latency)
+  auto load_tile = [&](long t, f32x4 (&af)[NBI][4], f32x4 (&bf)[OBC][4], f32x4 (&zq)[KC][4]) {
 #pragma unroll
     for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
         if (k < A.r) zq[kk][q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
         else { zq[kk][q][0] = 1.f; zq[kk][q][1] = 1.f; zq[kk][q][2] = 1.f; zq[kk][q][3] = 1.f; }
       }
+  };
+  auto compute_tile = [&](const f32x4 (&af)[NBI][4], const f32x4 (&bf)[OBC][4], const f32x4 (&zq)[KC][4]) {
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       if (k0 + kk > A.r) break;
@@ -88,6 +91,21 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
 #pragma unroll
           for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(zt, bf[ob][q][c], bacc[kk][ob]);
         }
+    }
+  };
+  {
+    f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4], af1[NBI][4], bf1[OBC][4], zq1[KC][4];
+    long t = (long)blockIdx.x * 4 + wid;
+    if (t < A.ntiles) load_tile(t, af0, bf0, zq0);
+    while (t < A.ntiles) {
+      const long t1 = t + nwaves;
+      if (t1 < A.ntiles) load_tile(t1, af1, bf1, zq1);
+      compute_tile(af0, bf0, zq0);
+      if (t1 >= A.ntiles) break;
+      const long t2 = t1 + nwaves;
+      if (t2 < A.ntiles) load_tile(t2, af0, bf0, zq0);
+      compute_tile(af1, bf1, zq1);
+      t = t2;
     }
   }
 

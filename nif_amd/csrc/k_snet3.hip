@@ -26,8 +26,14 @@
 // Ablation switches for timing experiments (NEVER set in a product build: results become wrong).
 //   NIF_ABL_NOSTORE  skip the stash / ring stores      NIF_ABL_NOACT   cheap stand-in for the activation
 //   NIF_ABL_NOBAR    skip the per-plane barrier         NIF_ABL_NOMFMA  skip the MFMAs
+#ifndef NIF_S3_PREFETCH_ADJ
+#define NIF_S3_PREFETCH_ADJ 0   // fetch act'(a) and h_in one layer ahead in the adjoint
+#endif
+#ifndef NIF_S3_LDSDMA
+#define NIF_S3_LDSDMA 1          // stage weight planes with global_load_lds instead of through registers
+#endif
 #ifndef NIF_S3_OCC4
-#define NIF_S3_OCC4 2   // waves/SIMD requested for the 64-wide (NBL = 4) instantiation
+#define NIF_S3_OCC4 3   // waves/SIMD requested for the 64-wide (NBL = 4) instantiation
 #endif
 
 
@@ -118,20 +124,56 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
     }
   }
   __syncthreads();
+#ifdef NIF_S3_STAGGER
+  // de-phase the workgroups that share a CU (the second wave of residents starts NIF_S3_STAGGER*64 cycles
+  // late), so that one wave's VALU epilogue overlaps its SIMD partner's MFMA plane instead of colliding
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(NIF_S3_STAGGER);
+#endif
   int gpar = 0;
+  int tlc = 0; (void)tlc;
   float loss_lane = 0.f;
   float* dring = TRAIN ? A.dring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (NBL * 256) : nullptr;
   float* IN0 = A.stash;
   float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
 
+#ifdef NIF_TIMELINE
+#define NIF_TL(id) do { if (A.tl && blockIdx.x == 0 && tid == 0 && tlc < 250) { A.tl[2 * tlc] = (id); A.tl[2 * tlc + 1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
+#else
+#define NIF_TL(id) do { } while (0)
+#endif
+#ifdef NIF_ABL_NOPREFETCH
+#define NIF_HAS_NEXT false
+#else
+#define NIF_HAS_NEXT ((pl + 1 < nplanes) || !last_group)
+#endif
 #ifdef NIF_ABL_NOBAR
 #define NIF_BAR() __builtin_amdgcn_wave_barrier()
 #else
 #define NIF_BAR() __syncthreads()
 #endif
+#if NIF_S3_LDSDMA
+// the next plane goes L2 -> LDS by DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, our plane
+// image is lane-linear), no staging registers; hipcc drains it (vmcnt(0)) in front of the barrier
 #define NIF_PLANE(...)                                                                        \
   {                                                                                           \
-    const bool has_next = (pl + 1 < nplanes) || !last_group;                                  \
+    if (NIF_HAS_NEXT) {                                                                       \
+      const f32x4* src = plane_src(pl + 1 < nplanes ? pl + 1 : 0);                            \
+      f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);                                   \
+      _Pragma("unroll") for (int q = 0; q < PF4; ++q)                                         \
+        if (PEXACT || wid * 64 + NT * q < PLANE / 4)                                          \
+          __builtin_amdgcn_global_load_lds(                                                   \
+              (const __attribute__((address_space(1))) void*)(src + tid + NT * q),            \
+              (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);  \
+    }                                                                                         \
+    const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);                                     \
+    __VA_ARGS__                                                                               \
+    NIF_BAR();                                                                                \
+    ++gpar; ++pl;                                                                             \
+  }
+#else
+#define NIF_PLANE(...)                                                                        \
+  {                                                                                           \
+    const bool has_next = NIF_HAS_NEXT;                                                       \
     f32x4 pre[PF4];                                                                           \
     if (has_next) {                                                                           \
       const f32x4* src = plane_src(pl + 1 < nplanes ? pl + 1 : 0);                            \
@@ -148,6 +190,8 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
     NIF_BAR();                                                                                \
     ++gpar; ++pl;                                                                             \
   }
+
+#endif
 
   for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
     const bool last_group = tg + gridDim.x >= ngroups;
@@ -169,6 +213,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
 
+    NIF_TL(1);
     f32x4 h[NBL], acc[NBL];
     // ---- first layer: a0 = sum_k zt_k (w0 * x . W1^(k) + b1^(k)) --------------------------------
 #pragma unroll
@@ -192,11 +237,13 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       }
     }
 
+    NIF_TL(2);
     // ---- hidden hyper-matrices -------------------------------------------------------------------
     int pl = 0;
     f32x4 ublk[MODE == 1 ? NBL : 1];
     for (int j = 0; j < nh; ++j) {
       if (TRAIN && active) st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g);
+      NIF_TL(10 + j);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) { acc[b][0] = 0.f; acc[b][1] = 0.f; acc[b][2] = 0.f; acc[b][3] = 0.f; }
       for (int k = 0; k <= r; ++k) {
@@ -211,6 +258,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
           }
         })
       }
+      NIF_TL(30 + j);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
       for (int k = 0; k <= r; ++k) {
@@ -244,6 +292,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       }
     }
 
+    NIF_TL(3);
     // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
     if (TRAIN && active) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
     f32x4 gh[NBL];
@@ -290,17 +339,24 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
     }
     if (TRAIN) {
       if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+      NIF_TL(4);
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       // act'(a_j) and h_{j-1} are fetched one layer ahead so that their L2/HBM latency hides behind the
       // previous layer's MFMA planes
       f32x4 skip[MODE == 0 ? 1 : NBL];
       f32x4 dnext[NBL], hin[NBL];
+#if NIF_S3_PREFETCH_ADJ
 #pragma unroll
       for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[(nh * NBL + b) * 64 + lane];
       if (nh > 0 && r > 0) st_load16<NBL>(IN0 + (long)(nh - 1) * A.slot_stride, row0, hin, g);
+#endif
       for (int j = nh - 1; j >= 0; --j) {
         f32x4 ga[NBL];
+#if !NIF_S3_PREFETCH_ADJ
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane];
+#endif
         if (MODE == 1 && (j & 1)) {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) { skip[b] = 0.5f * gh[b]; ga[b] = dnext[b] * skip[b]; }
@@ -312,10 +368,13 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
             for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
           }
         }
+#if NIF_S3_PREFETCH_ADJ
         // next layer's act'(a) (layer j-1, or the first layer's when j == 0)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[(j * NBL + b) * 64 + lane];
+#endif
         if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
+        NIF_TL(50 + j);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) { gh[b][0] = 0.f; gh[b][1] = 0.f; gh[b][2] = 0.f; gh[b][3] = 0.f; }
         for (int k = 0; k <= r; ++k) {
@@ -325,6 +384,9 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
               f32x4 U[NBL];
               mfma16<NBL, false>(cur, ga, U, lane);
               _Pragma("unroll") for (int b = 0; b < NBL; ++b) gh[b] += zt * U[b];
+#if !NIF_S3_PREFETCH_ADJ
+              st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
+#endif
               const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
               float s = 0.f, sbv = 0.f;
               _Pragma("unroll") for (int b = 0; b < NBL; ++b) {
@@ -335,21 +397,29 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
                 }
               }
               dzs[k * 64 + lane] += fmaf(A.omega, s, sbv);
+#if NIF_S3_PREFETCH_ADJ
               if (k == r - 1 && j > 0) st_load16<NBL>(IN0 + (long)(j - 1) * A.slot_stride, row0, hin, g);
+#endif
             } else {
               mfma16<NBL, true>(cur, ga, gh, lane);
             }
           })
         }
+        NIF_TL(70 + j);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           gh[b] *= A.omega;
           if (MODE == 2 || (MODE == 1 && !(j & 1))) gh[b] += skip[b];
         }
       }
+      NIF_TL(5);
       // ---- first layer ---------------------------------------------------------------------------
       {
         f32x4 ga[NBL];
+#if !NIF_S3_PREFETCH_ADJ
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[b * 64 + lane];
+#endif
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
         if (active) st_store16<NBL>(DA0, row0, ga, g);

@@ -45,6 +45,7 @@ struct nif_ctx {
   float* partial = nullptr; int rows_cap = 0; long pstride = 0;
   float* loss_partial = nullptr; long nloss_cap = 0;
   float* dring = nullptr; long dring_cap = 0;
+  long long* tl = nullptr;   // timeline stamps (measurement builds)
   float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
   // profiling: (group id, start, stop) event triples recorded on st
   bool prof_on = false;
@@ -411,6 +412,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
   a.dring = c->dring;
+  a.tl = c->tl;
 }
 
 static int ensure_packed(nif_ctx* c) {
@@ -879,6 +881,19 @@ extern "C" int nif_profile_read(nif_ctx* c, float* ms, int64_t* cnt, int n, int 
   int rc = drain_profile(c); if (rc) return rc;
   for (int i = 0; i < NIF_PROF_N; ++i) { ms[i] = (float)c->prof_ms[i]; cnt[i] = c->prof_cnt[i]; }
   if (reset) for (int i = 0; i < NIF_PROF_N; ++i) { c->prof_ms[i] = 0; c->prof_cnt[i] = 0; }
+  return NIF_OK;
+}
+extern "C" int nif_debug_timeline(nif_ctx* c, int64_t* out, int32_t n_pairs) {
+  if (!c || n_pairs < 0 || n_pairs > 256) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  if (!c->tl) {
+    HIPCHK(hipMalloc(&c->tl, 512 * sizeof(long long)));
+    HIPCHK(hipMemset(c->tl, 0, 512 * sizeof(long long)));
+    return NIF_OK;   // first call arms the buffer
+  }
+  if (out && n_pairs > 0) HIPCHK(hipMemcpy(out, c->tl, sizeof(long long) * 2 * n_pairs, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(c->tl, 0, 512 * sizeof(long long)));
   return NIF_OK;
 }
 extern "C" int nif_timer_start(nif_ctx* c) {

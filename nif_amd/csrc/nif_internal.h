@@ -81,6 +81,7 @@ struct SNetArgs {
   float inv_bg;                           // 1 / B_global
   float* dring;                           // k_snet3: per-wave ring for act'(a) (register-dump order)
   int nsm;                                // k_snet3: floats per k of the LDS copy of the small hyper-vectors
+  long long* tl;                          // -DNIF_TIMELINE builds: s_memtime stamps of wave 0 of block 0
 };
 // slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
 __host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }

@@ -251,3 +251,70 @@ def test_bad_arguments_raise():
         m.model_x_to_u_given_w().predict([x[:, 1:], np.zeros((x.shape[0], 3), np.float32)])
     with pytest.raises(RuntimeError):
         nif_amd.NIF(*CONFIGS["nif_cfg1_32x2"][0][1:]).build().fit(x, y)
+
+
+# ---- BASELINE.json full size (2^20 points, ShapeNet 4x64): size-independent properties ---------------------
+def _full_size_setup():
+    import nif_amd
+    import bench
+    nif_amd.set_seed(1)
+    m = nif_amd.NIFMultiScale(bench.CFG_SHAPE, bench.CFG_PARAM)
+    model = m.build()
+    x, y = nif_amd.data.synthetic_wave_batch(1 << 20, seed=5)
+    return m, model, x, y
+
+
+def test_full_size_shard_sum_equals_full_batch_and_is_deterministic():
+    """What the 8-GPU run relies on: the SUM over 8 contiguous shards of [grad | loss], each scaled
+    by 1/B_global inside the kernels, equals the full-batch result; and a repeated launch is bit-identical
+    (fixed reduction order, no atomics)."""
+    m, model, x, y = _full_size_setup()
+    e = m._engine
+    from nif_amd.engine import DeviceArray
+    from nif_amd import distributed as dist
+    B = x.shape[0]
+    d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
+    d_x.upload(x); d_y.upload(y)
+
+    def grad_of(lo, hi):
+        e.loss_grad_dev(d_x.at(lo * 2), d_y.at(lo), None, hi - lo, B)
+        buf = DeviceArray.__new__(DeviceArray)
+        buf.engine, buf.n, buf.ptr = e, e.n_params + 1, e.grad_dev_ptr()
+        out = buf.download()
+        buf.ptr = None
+        return out.astype(np.float64)
+
+    full = grad_of(0, B)
+    again = grad_of(0, B)
+    assert np.array_equal(full, again)
+    acc = np.zeros_like(full)
+    for r in range(8):
+        lo, hi = dist.shard_bounds(B, 8, r)
+        acc += grad_of(lo, hi)
+    assert abs(acc[-1] - full[-1]) < 1e-6 * abs(full[-1])
+    assert np.linalg.norm(acc[:-1] - full[:-1]) < 1e-5 * np.linalg.norm(full[:-1])
+    # the oracle on a sample of the same batch pins the magnitude (it cannot run 2^20 points)
+    ws = [w.astype(np.float64) for w in model.get_weights()]
+    spec = O.Spec("NIFMultiScale", m.cfg_shape_net, m.cfg_parameter_net)
+    lref, _ = O.loss_and_grad(spec, ws, x[:4096].astype(np.float64), y[:4096].astype(np.float64))
+    e.loss_grad_dev(d_x.at(0), d_y.at(0), None, 4096, 4096)
+    assert abs(e.last_loss() - lref) < 1e-5 * abs(lref)
+
+
+def test_full_size_predict_factorisation_and_permutation():
+    """model([p,x]) == model_x_to_u_given_w(x, model_lr_to_w(model_p_to_lr(p))) and row-permutation
+    equivariance at 2^20 / 2^16 points (the factorised path materialises [B, po], so it runs on a slice)."""
+    m, model, x, y = _full_size_setup()
+    u = model.predict(x)
+    assert u.shape == (x.shape[0], 1) and np.isfinite(u).all()
+    perm = np.random.default_rng(0).permutation(x.shape[0])
+    up = model.predict(x[perm])
+    assert np.array_equal(up, u[perm])          # points are independent rows: bitwise equivariant
+    sl = slice(0, 1 << 16)
+    lr = m.model_p_to_lr().predict(x[sl, :1])
+    w = m.model_lr_to_w().predict(lr)
+    u3 = m.model_x_to_u_given_w().predict([x[sl, 1:], w])
+    assert _rel(u3, u[sl].astype(np.float64)) < 2e-5
+    ws = [wt.astype(np.float64) for wt in model.get_weights()]
+    spec = O.Spec("NIFMultiScale", m.cfg_shape_net, m.cfg_parameter_net)
+    assert _rel(u[:2048], O.forward(spec, ws, x[:2048].astype(np.float64))) < 1e-5
