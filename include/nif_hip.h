@@ -155,6 +155,13 @@ int nif_loss_and_grad(nif_ctx* ctx, const float* xin_host, const float* y_host, 
                       int64_t B, float* loss_out, float* grad_host);        /* lbfgs.py:66-74 */
 int nif_train_step(nif_ctx* ctx, const float* xin_host, const float* y_host, const float* sw_host_or_null,
                    int64_t B, const nif_adam* opt, float* loss_out);        /* Model.fit's train_step */
+/* Weight regularisers of cfg_parameter_net["l1_reg"/"l2_reg"] (nif/model.py:109-117: L2(l2) or else L1(l1) on
+ * every ParameterNet kernel and bias): loss += l2*sum(w^2) + l1*sum(|w|) over theta[lo, hi); the gradient
+ * term is added once, after the cross-rank all-reduce, inside nif_adam_step_dev / nif_loss_and_grad. */
+int nif_set_regularizer(nif_ctx* ctx, float l1, float l2, int64_t lo, int64_t hi);
+/* Keras' epoch loss metric without a host sync per batch: sum += weight * grad[P], count += weight (device side) */
+int nif_metric_accumulate(nif_ctx* ctx, float weight);
+int nif_metric_read(nif_ctx* ctx, double* sum_out, double* count_out, int reset);
 /* reads grad[P] (the loss of the last nif_loss_grad_dev) */
 int nif_last_loss(nif_ctx* ctx, float* loss_out);
 

@@ -353,3 +353,35 @@ void launch_ll_out(const LLArgs& a, bool train, hipStream_t st) {
   if (train) hipLaunchKernelGGL((k_ll_out<true>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_ll_out<false>), grid, block, 0, st, a);
 }
+
+// ============================================================================================
+// weight regularisers (Keras L1 / L2 on the ParameterNet variables, nif/model.py:109-117): gradient term and
+// loss term, deterministic single-block reduction of the penalty
+// ============================================================================================
+__global__ __launch_bounds__(1024) void k_reg(const float* __restrict__ theta, float* __restrict__ g, long lo, long hi,
+                                              long P, float l1, float l2) {
+  __shared__ float red[1024];
+  float pen = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 1024) {
+    const float w = theta[i];
+    g[i] += 2.0f * l2 * w + (w > 0.f ? l1 : (w < 0.f ? -l1 : 0.f));
+    pen += l2 * w * w + l1 * fabsf(w);
+  }
+  red[threadIdx.x] = pen;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) g[P] += red[0];
+}
+void launch_reg(const float* theta, float* g, long lo, long hi, long P, float l1, float l2, hipStream_t st) {
+  hipLaunchKernelGGL(k_reg, dim3(1), dim3(1024), 0, st, theta, g, lo, hi, P, l1, l2);
+}
+__global__ void k_metric(const float* __restrict__ g, long P, float weight, double* __restrict__ acc) {
+  acc[0] += (double)weight * (double)g[P];
+  acc[1] += (double)weight;
+}
+void launch_metric(const float* g, long P, float weight, double* acc, hipStream_t st) {
+  hipLaunchKernelGGL(k_metric, dim3(1), dim3(1), 0, st, g, P, weight, acc);
+}

@@ -46,6 +46,8 @@ struct nif_ctx {
   float* loss_partial = nullptr; long nloss_cap = 0;
   float* dring = nullptr; long dring_cap = 0;
   long long* tl = nullptr;   // timeline stamps (measurement builds)
+  float reg_l1 = 0.f, reg_l2 = 0.f; long reg_lo = 0, reg_hi = 0; bool reg_applied = false;
+  double* metric = nullptr;  // device {sum, count}
   float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
   // profiling: (group id, start, stop) event triples recorded on st
   bool prof_on = false;
@@ -210,7 +212,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->lWF, c->lWB, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -715,6 +717,7 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, true); if (rc) return rc;
+  c->reg_applied = false;
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
   const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
@@ -800,10 +803,42 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   return NIF_OK;
 }
 
+static void apply_reg(nif_ctx* c) {
+  if ((c->reg_l1 != 0.f || c->reg_l2 != 0.f) && c->reg_hi > c->reg_lo && !c->reg_applied) {
+    launch_reg(c->theta, c->grad, c->reg_lo, c->reg_hi, c->P, c->reg_l1, c->reg_l2, c->st);
+    c->reg_applied = true;
+  }
+}
+extern "C" int nif_set_regularizer(nif_ctx* c, float l1, float l2, int64_t lo, int64_t hi) {
+  if (!c || lo < 0 || hi > c->P || lo > hi || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
+  c->reg_l1 = l1; c->reg_l2 = l2; c->reg_lo = lo; c->reg_hi = hi;
+  return NIF_OK;
+}
+extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
+  launch_metric(c->grad, c->P, weight, c->metric, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+extern "C" int nif_metric_read(nif_ctx* c, double* sum, double* cnt, int reset) {
+  if (!c || !sum || !cnt) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  double h[2] = {0.0, 0.0};
+  if (c->metric) {
+    HIPCHK(hipMemcpyAsync(h, c->metric, 2 * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (reset) HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st));
+  }
+  *sum = h[0]; *cnt = h[1];
+  return NIF_OK;
+}
 extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   if (!c || !opt) return fail(NIF_ERR_INVALID, "null");
   if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
   HIPCHK(hipSetDevice(c->dev));
+  apply_reg(c);
   c->step += 1;
   const double t = (double)c->step;
   const double lr_t = (double)opt->lr * std::sqrt(1.0 - std::pow((double)opt->beta2, t)) / (1.0 - std::pow((double)opt->beta1, t));
@@ -836,6 +871,7 @@ extern "C" int nif_loss_and_grad(nif_ctx* c, const float* xin, const float* y, c
   HIPCHK(hipSetDevice(c->dev));
   int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
   rc = nif_loss_grad_dev(c, c->d_a, c->d_b, sw ? c->d_c : nullptr, B, B); if (rc) return rc;
+  apply_reg(c);
   if (grad) HIPCHK(hipMemcpyAsync(grad, c->grad, sizeof(float) * (size_t)c->P, hipMemcpyDeviceToHost, c->st));
   if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));

@@ -129,6 +129,8 @@ void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st);
 void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st);
 void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss,
                    float* g, long P, hipStream_t st);
+void launch_reg(const float* theta, float* g, long lo, long hi, long P, float l1, float l2, hipStream_t st);
+void launch_metric(const float* g, long P, float weight, double* acc, hipStream_t st);
 void launch_adam(float* theta, const float* g, float* m, float* v, long P, float lr_t, float b1, float b2,
                  float eps, hipStream_t st);
 void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B,

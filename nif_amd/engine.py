@@ -201,6 +201,17 @@ class Engine(object):
     def adam_step_dev(self, adam):
         check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
 
+    def set_regularizer(self, l1, l2, lo, hi):
+        check(self.lib.nif_set_regularizer(self.ctx, float(l1), float(l2), int(lo), int(hi)))
+
+    def metric_accumulate(self, weight):
+        check(self.lib.nif_metric_accumulate(self.ctx, float(weight)))
+
+    def metric_read(self, reset=True):
+        s, n = C.c_double(), C.c_double()
+        check(self.lib.nif_metric_read(self.ctx, C.byref(s), C.byref(n), 1 if reset else 0))
+        return float(s.value), float(n.value)
+
     def last_loss(self):
         loss = C.c_float()
         check(self.lib.nif_last_loss(self.ctx, C.byref(loss)))

@@ -191,7 +191,7 @@ class Model(object):
                             d_sw.upload(sw)
                     resident = True
                 adam = self.optimizer.as_struct()
-                tot, cnt = 0.0, 0
+                e.metric_read(reset=True)
                 for b0 in range(0, N, bs):
                     b = min(bs, N - b0)
                     bg = dist.all_reduce_scalar_sum(b) if world > 1 else b
@@ -200,9 +200,9 @@ class Model(object):
                     if world > 1:
                         dist.all_reduce_grad(e)
                     e.adam_step_dev(adam)
-                    tot += e.last_loss() * bg   # Keras' loss metric: sample-weighted mean over the batches
-                    cnt += bg
-                logs = {"loss": tot / max(cnt, 1)}
+                    e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
+                tot, cnt = e.metric_read(reset=True)   # accumulated on the device: one host sync per epoch
+                logs = {"loss": tot / max(cnt, 1.0)}
                 hist.epoch.append(epoch)
                 for k, v in logs.items():
                     hist.history.setdefault(k, []).append(v)
@@ -260,9 +260,15 @@ class NIF(object):
         self.p_l2_reg = cfg_parameter_net.get("l2_reg", None)
         self.p_act_l1_reg = cfg_parameter_net.get("act_l1_reg", None)
         self.p_act_l2_reg = cfg_parameter_net.get("act_l2_reg", None)
-        for nm in ("p_jac_reg", "p_l1_reg", "p_l2_reg", "p_act_l1_reg", "p_act_l2_reg"):
+        for nm in ("p_jac_reg", "p_act_l1_reg", "p_act_l2_reg"):
             if isinstance(getattr(self, nm), (float, int)):
                 raise NotImplementedError("cfg_parameter_net regulariser %s is outside the built hot path" % nm)
+        # kernel/bias regularisers of every ParameterNet layer: L2 wins over L1 (model.py:109-117)
+        self._reg = (0.0, 0.0)
+        if isinstance(self.p_l2_reg, (float, int)):
+            self._reg = (0.0, float(self.p_l2_reg))
+        elif isinstance(self.p_l1_reg, (float, int)):
+            self._reg = (float(self.p_l1_reg), 0.0)
         self.mixed_policy_name = mixed_policy
         self.variable_Dtype = "float32"
         self.compute_Dtype = "float32"
@@ -278,6 +284,9 @@ class NIF(object):
         if self.__engine is None:
             self.__engine = Engine(self._spec, device_id=dist.local_device())
             self.__engine.set_weights(self._init_weights)
+            if self._reg != (0.0, 0.0):
+                n_pnet = sum(int(np.prod(s)) for nm, s in self._spec.param_shapes() if nm.startswith("pnet_"))
+                self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
         return self.__engine
 
     def call(self, inputs, training=None, mask=None):

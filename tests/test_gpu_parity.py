@@ -318,3 +318,48 @@ def test_full_size_predict_factorisation_and_permutation():
     ws = [wt.astype(np.float64) for wt in model.get_weights()]
     spec = O.Spec("NIFMultiScale", m.cfg_shape_net, m.cfg_parameter_net)
     assert _rel(u[:2048], O.forward(spec, ws, x[:2048].astype(np.float64))) < 1e-5
+
+
+def test_weight_regularisers_l2_and_l1():
+    """cfg_parameter_net l2_reg / l1_reg (model.py:109-117): Keras adds l2*sum(w^2) (or l1*sum|w|) over every
+    ParameterNet kernel and bias to the loss; L2 takes precedence over L1."""
+    import nif_amd
+    (kind, cs, cp), B = CONFIGS["ms_64x2_mlp_pnet_r3"]
+    for reg, val in (("l2_reg", 1e-3), ("l1_reg", 2e-4)):
+        cp2 = dict(cp); cp2[reg] = val
+        spec = O.Spec(kind, cs, cp)
+        rng = np.random.default_rng(0)
+        ws = O.init_weights(spec, rng, dtype=np.float32)
+        m = nif_amd.NIFMultiScale(cs, cp2)
+        model = m.build(); model.set_weights(ws)
+        x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+        y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+        loss, g = m._engine.loss_and_grad(x, y)
+        ws64 = [w.astype(np.float64) for w in ws]
+        lref, gref = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64))
+        th = O.flatten(ws64); gref = O.flatten(gref)
+        if reg == "l2_reg":
+            lref += val * (th ** 2).sum(); gref = gref + 2 * val * th
+        else:
+            lref += val * np.abs(th).sum(); gref = gref + val * np.sign(th)
+        assert abs(loss - lref) < 1e-5 * abs(lref)
+        assert _rel(g, gref) < 1e-4
+
+
+def test_lbfgs_fine_tuning_reduces_loss():
+    """README.md:51-69: Adam first, then TFPLBFGS(model, loss, X, Y).minimize(rounds, max_iter)."""
+    import os
+    import nif_amd
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "traveling_wave.npz"))["data"]
+    data, _, _ = O.standard_normalize(d.astype(np.float64))
+    x, y = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
+    kind, cs, cp = _cfg("NIFMultiScale", 32, 2, 32, 2, 1, 1, 1, 1, p_act="swish")
+    nif_amd.set_seed(1)
+    model = nif_amd.NIFMultiScale(cs, cp).build()
+    model.compile(nif_amd.Adam(1e-3), loss="mse")
+    model.fit(x, y, epochs=20, batch_size=500, verbose=0)
+    l0 = model.evaluate(x, y)
+    tuner = nif_amd.optimizers.TFPLBFGS(model, "mse", x, y, display_epoch=10)
+    hist = tuner.minimize(rounds=3, max_iter=20)
+    l1 = model.evaluate(x, y)
+    assert l1 < l0 and len(hist) > 5 and abs(hist[-1] - l1) < 1e-4 * max(l1, 1e-8) + 1e-7
