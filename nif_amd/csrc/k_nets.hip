@@ -14,6 +14,8 @@
 //   loss           Keras 'mse' (README.md:33); adjoint hand-derived (SURVEY a-10)
 #include "nif_internal.h"
 
+// (forcing a higher occupancy on the ParameterNet kernels with launch bounds was measured: 2-3x slower, spills)
+
 // ============================================================================================
 // weight packing: theta -> MFMA A-operand order
 //   fwd plane: block (ob,ib), quad vq, lane, c : M[in = 32ib + fmap(4vq+c, lane>>5)][out = 32ob + (lane&31)]

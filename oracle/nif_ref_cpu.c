@@ -85,15 +85,26 @@ int nifref_loss_grad(const ref_cfg* c, const float* theta, const float* xin, con
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-  float* pout = (float*)malloc(sizeof(float) * (size_t)B * po);   /* [B, po]  the tensor TF materialises */
-  float* gp = (float*)malloc(sizeof(float) * (size_t)B * po);     /* its gradient */
-  float* pa = (float*)malloc(sizeof(float) * (size_t)B * (lst + 1) * nst);  /* pnet pre-activations */
-  float* ph = (float*)malloc(sizeof(float) * (size_t)B * (lst + 1) * nst);  /* pnet layer outputs */
-  float* z = (float*)malloc(sizeof(float) * (size_t)B * r);
-  float* sa_ = (float*)malloc(sizeof(float) * (size_t)B * (L + 1) * n);     /* snet pre-activations */
-  float* sh = (float*)malloc(sizeof(float) * (size_t)B * (L + 1) * n);      /* snet layer outputs */
-  float* gz = (float*)malloc(sizeof(float) * (size_t)B * r);
-  if (!pout || !gp || !pa || !ph || !z || !sa_ || !sh || !gz) return -1;
+  /* workspace is kept between calls (a framework would reuse its arena too; re-faulting 0.5 GB per micro-batch
+   * on a many-core host otherwise dominates) */
+  static float* ws = NULL;
+  static size_t ws_cap = 0;
+  const size_t n_pout = (size_t)B * po, n_pn = (size_t)B * (lst + 1) * nst, n_sn = (size_t)B * (L + 1) * n, n_z = (size_t)B * r;
+  const size_t need = 2 * n_pout + 2 * n_pn + 2 * n_sn + 2 * n_z;
+  if (need > ws_cap) {
+    free(ws);
+    ws = (float*)malloc(sizeof(float) * need);
+    ws_cap = ws ? need : 0;
+    if (!ws) return -1;
+  }
+  float* pout = ws;                 /* [B, po]  the tensor TF materialises */
+  float* gp = pout + n_pout;        /* its gradient */
+  float* pa = gp + n_pout;          /* pnet pre-activations */
+  float* ph = pa + n_pn;            /* pnet layer outputs */
+  float* sa_ = ph + n_pn;           /* snet pre-activations */
+  float* sh = sa_ + n_sn;           /* snet layer outputs */
+  float* z = sh + n_sn;
+  float* gz = z + n_z;
   double loss = 0.0;
 
   /* ---- forward ------------------------------------------------------------------------------------- */
@@ -284,7 +295,6 @@ int nifref_loss_grad(const ref_cfg* c, const float* theta, const float* xin, con
   for (int t = 0; t < nth; ++t)
     for (long q = 0; q < Pp; ++q) grad[q] += acc[(size_t)t * Pp + q];
   free(acc);
-  free(pout); free(gp); free(pa); free(ph); free(z); free(sa_); free(sh); free(gz);
   *loss_out += loss;
   return 0;
 }
