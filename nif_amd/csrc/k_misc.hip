@@ -193,19 +193,40 @@ void launch_given_w(const float* x, const float* w, float* u, long B, int si, in
 __global__ __launch_bounds__(256) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
                                                      long po, const float* __restrict__ lr, long B,
                                                      float* __restrict__ w) {
-  // grid.x over slot chunks of 256, grid.y over point groups
-  const long s = (long)blockIdx.x * 256 + threadIdx.x;
-  if (s >= po) return;
-  const float bias = theta[off_bh + s];
+  // a thread owns 4 consecutive slots (16-byte stores; rows of w are only 4-byte aligned since po is odd) and
+  // keeps its bias / first hyper rows in registers while it walks the points of its grid.y stripe
+  const long s0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (s0 >= po) return;
+  const int nv = (int)(po - s0 < 4 ? po - s0 : 4);
+  float bias[4], w0[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bias[c] = c < nv ? theta[off_bh + s0 + c] : 0.f;
+    w0[c] = c < nv ? theta[off_Wh + s0 + c] : 0.f;
+  }
   for (long a = blockIdx.y; a < B; a += gridDim.y) {
-    float acc = bias;
-    for (int k = 0; k < r; ++k) acc = fmaf(lr[a * r + k], theta[off_Wh + (long)k * po + s], acc);
-    w[a * po + s] = acc;
+    float acc[4];
+    const float z0 = lr[a * r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = fmaf(z0, w0[c], bias[c]);
+    for (int k = 1; k < r; ++k) {
+      const float zk = lr[a * r + k];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nv) acc[c] = fmaf(zk, theta[off_Wh + (long)k * po + s0 + c], acc[c]);
+    }
+    float* dst = w + a * po + s0;
+    if (nv == 4) {
+      f32x4u v; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
+      *reinterpret_cast<f32x4u*>(dst) = v;
+    } else {
+      for (int c = 0; c < nv; ++c) dst[c] = acc[c];
+    }
   }
 }
 void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B, float* w,
                         hipStream_t st) {
-  dim3 grid((unsigned)((po + 255) / 256), (unsigned)(B < 1024 ? B : 1024)), block(256);
+  dim3 grid((unsigned)((po + 1023) / 1024), (unsigned)(B < 2048 ? B : 2048)), block(256);
   hipLaunchKernelGGL(k_latent_to_w, grid, block, 0, st, theta, off_Wh, off_bh, r, po, lr, B, w);
 }
 
