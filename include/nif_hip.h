@@ -136,8 +136,8 @@ int nif_shapenet_given_w_dev(nif_ctx* ctx, const float* x_dev, const float* w_de
 
 /* JacobianLayer(model, y_index, x_index)(x): nif/layers/gradient.py:36-49, :207-231.
  * y_out [B, so] (all outputs, like the reference) and dydx_out [B, ny, nx] with
- * dydx[a,i,j] = d y[a, y_idx[i]] / d input[a, x_idx[j]].  Built for coordinate columns
- * (pi <= x_idx < pi+si) of NIF / NIFMultiScale; other requests return NIF_ERR_INVALID. */
+ * dydx[a,i,j] = d y[a, y_idx[i]] / d input[a, x_idx[j]], for any input column (parameters and coordinates)
+ * of all three classes; forward-mode tangents (k_jac, k_mlp_jac). */
 int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* y_idx, int32_t ny,
                  const int32_t* x_idx, int32_t nx, float* y_out, float* dydx_out);
 

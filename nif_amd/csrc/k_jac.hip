@@ -8,6 +8,10 @@
 //                                                              res:   t' = act'(a1) a1';  u' = 0.5 (u'_in + act'(a2) a2')
 //   last          u'  = h' . Wl(a)
 //
+// Parameter columns (p = t, mu): the per-sample weights move too, W'(a) = sum_k z'_k M^(k) with z' = dz/dp from
+// k_mlp_jac, so every layer adds  sum_{k<r} z'_k (h . M^(k))  (+ z'_k b^(k)) -- the unscaled partial products
+// T_k = h . M^(k) the forward pass forms anyway.
+//
 // The per-sample weights do not depend on x, so one extra B operand per seed reuses every A operand
 // (weight plane) already in LDS.  The reference needs len(y_index) extra reverse sweeps instead.
 #include "k_snet3_dev.h"
@@ -17,7 +21,8 @@
 struct JacArgs {
   SNetArgs s;                 // primal arguments (u_out = y)
   int ns;                     // seeds in this launch (<= NIF_JAC_MAXSEED)
-  int seed[NIF_JAC_MAXSEED];  // coordinate index d (0..si-1) of each seed
+  int seed[NIF_JAC_MAXSEED];  // coordinate index d (0..si-1) of a coordinate seed, or -1 for a parameter seed
+  const float* ZD[NIF_JAC_MAXSEED];  // parameter seed: dz/dp_col of the latent, [tiles][r][32] (from k_mlp_jac)
   int nx_total, x0;           // dydx row stride (number of requested x columns) and first column of this launch
   float* dydx;                // [B][so][nx_total]
 };
@@ -40,7 +45,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
   f32x4* planes = reinterpret_cast<f32x4*>(smem);
   float* sm = smem + 2 * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  float* zs = sm + sm_tot + (long)wid * (r * 16);
+  float* zs = sm + sm_tot + (long)wid * ((1 + NIF_JAC_MAXSEED) * r * 16);
+  float* zds = zs + r * 16;   // [seed][r][16]: dz_k/dp for parameter seeds (0 for coordinate seeds)
+  bool anyp = false;
+#pragma unroll
+  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) anyp = anyp || (d < J.ns && J.seed[d] < 0);
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
   const int nplanes = nh * (r + 1);
 
@@ -78,8 +87,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
     const long ptc = pt < A.B ? pt : A.B - 1;
     const float* xrow = A.xin + ptc * A.ncol + A.col0;
     if (g == 0)
-      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+      for (int k = 0; k < r; ++k) {
+        zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          zds[(d * r + k) * 16 + p] = (d < ns && J.seed[d] < 0) ? J.ZD[d][(tile32 * r + k) * 32 + poff] : 0.f;
+      }
     const float* zt_base = zs + p;
+    const float* zd_base = zds + p;   // zd(d,k) = zd_base[(d*r+k)*16]
 
     f32x4 h[NBL], acc[NBL], hd[NS][NBL], accd[NS][NBL];
 #pragma unroll
@@ -96,10 +111,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
       for (int b = 0; b < NBL; ++b) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-        acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+        const f32x4 tk = A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        acc[b] += zt * tk;
 #pragma unroll
         for (int d = 0; d < NS; ++d)
-          if (d < ns) accd[d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
+          if (d < ns) {
+            if (J.seed[d] >= 0) accd[d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
+            else if (k < r) accd[d][b] += zd_base[(d * r + k) * 16] * tk;
+          }
       }
     }
     {
@@ -131,7 +150,20 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
         }
         const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);
         const float zt = k < r ? zt_base[k * 16] : 1.0f;
-        {
+        if (anyp && k < r) {
+          // parameter seeds need the unscaled partial product T_k = h . M^(k)
+          f32x4 Tk[NBL];
+          mfma16<NBL, false>(cur, h, Tk, lane);
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) acc[b] += zt * Tk[b];
+#pragma unroll
+          for (int d = 0; d < NS; ++d)
+            if (d < ns && J.seed[d] < 0) {
+              const float zd = zd_base[(d * r + k) * 16];
+#pragma unroll
+              for (int b = 0; b < NBL; ++b) accd[d][b] += zd * Tk[b];
+            }
+        } else {
           f32x4 hz[NBL];
 #pragma unroll
           for (int b = 0; b < NBL; ++b) hz[b] = zt * h[b];
@@ -162,14 +194,26 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
       }
+      // tangents: a' = w0 * accd (+ sum_k z'_k b^(k) for parameter seeds); then the layer's combination rule
+#pragma unroll
+      for (int d = 0; d < NS; ++d) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) accd[d][b] *= A.omega;
+        if (d < ns && J.seed[d] < 0)
+          for (int k = 0; k < r; ++k) {
+            const float zd = zd_base[(d * r + k) * 16];
+            const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) accd[d][b] += zd * *reinterpret_cast<const f32x4*>(sb + 16 * b);
+          }
+      }
       f32x4 dv[NBL];
       act16<NBL, ACT>(A.act, acc, acc, dv, n, g);
-      // tangents: a' = w0 * accd ; then the layer's combination rule
 #pragma unroll
       for (int d = 0; d < NS; ++d)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
-          const f32x4 t = dv[b] * (A.omega * accd[d][b]);
+          const f32x4 t = dv[b] * accd[d][b];
           if (MODE == 0) hd[d][b] = t;
           else if (MODE == 2) hd[d][b] += t;
           else {
@@ -215,7 +259,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
         part = fmaf(zt, sk, part);
         bias = fmaf(zt, s0[o_bl + o], bias);
 #pragma unroll
-        for (int d = 0; d < NS; ++d) pd[d] = fmaf(zt, skd[d], pd[d]);
+        for (int d = 0; d < NS; ++d) {
+          pd[d] = fmaf(zt, skd[d], pd[d]);
+          if (k < r && d < ns && J.seed[d] < 0) {
+            const float zd = zd_base[(d * r + k) * 16];
+            pd[d] = fmaf(zd, sk, pd[d]);
+            if (g == 0) pd[d] = fmaf(zd, s0[o_bl + o], pd[d]);   // the bias term once per point (pd is summed over g)
+          }
+        }
       }
       part += __shfl_xor(part, 16);
       part += __shfl_xor(part, 32);
@@ -231,10 +282,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
   }
 }
 
-void launch_jac(const SNetArgs& a, int ns, const int* seeds, int nx_total, int x0, float* dydx, hipStream_t st) {
+void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
+                hipStream_t st) {
   JacArgs J;
   J.s = a; J.ns = ns; J.nx_total = nx_total; J.x0 = x0; J.dydx = dydx;
-  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
+  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) { J.seed[d] = d < ns ? seeds[d] : 0; J.ZD[d] = d < ns ? zd[d] : nullptr; }
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
@@ -242,7 +294,7 @@ void launch_jac(const SNetArgs& a, int ns, const int* seeds, int nx_total, int x
   dim3 grid((unsigned)(ngroups < cap ? ngroups : cap)), block(256);
   const size_t plane = (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  const size_t shm = (2 * plane + sm_tot + 4 * (size_t)a.r * 16 + 8) * sizeof(float);
+  const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(1 + NIF_JAC_MAXSEED) * a.r * 16 + 8) * sizeof(float);
 #define JL(NBL_, ACT_, MODE_)                                                                                        \
   {                                                                                                                  \
     if (shm > 48 * 1024)                                                                                             \

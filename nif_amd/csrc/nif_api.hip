@@ -511,38 +511,69 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
                             const int32_t* x_idx, int32_t nx, float* y_out, float* dydx_out) {
   if (!c || !xin || !y_idx || !x_idx || !y_out || !dydx_out || B <= 0 || ny <= 0 || nx <= 0)
     return fail(NIF_ERR_INVALID, "bad argument");
-  if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "JacobianLayer is not built for the last-layer class yet");
   for (int i = 0; i < ny; ++i)
     if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
   for (int j = 0; j < nx; ++j)
-    if (x_idx[j] < c->pi || x_idx[j] >= c->pi + c->si)
-      return fail(NIF_ERR_INVALID, "JacobianLayer: only coordinate columns (x_index >= pi_dim) are built");
+    if (x_idx[j] < 0 || x_idx[j] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "x_index out of range");
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
-  if (!c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
+  const bool ll = c->kind == NIF_KIND_LASTLAYER;
+  if (!ll && !c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
-  rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
+  const long ntiles = (B + 31) / 32;
+  const int ncol = c->pi + c->si;
+  rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
+  // tangent buffers: dz/dp for up to 3 parameter seeds (and d phi / dx for the last-layer class)
+  const long zd_sz = ntiles * 32 * (long)c->r * (ll ? c->so : 1);
+  rc = grow(&c->d_c, &c->cap_c, 3 * zd_sz); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
-  launch_pnet(pa, c->NSTB, false, c->st);
-  SNetArgs sa; fill_snet(c, sa, c->d_a, c->pi + c->si, c->pi, B);
-  for (int x0 = 0; x0 < nx; x0 += 3) {
-    int seeds[3] = {0, 0, 0};
-    const int ns = nx - x0 < 3 ? nx - x0 : 3;
-    for (int d = 0; d < ns; ++d) seeds[d] = x_idx[x0 + d] - c->pi;
-    sa.u_out = x0 == 0 ? c->d_d : nullptr;
-    launch_jac(sa, ns, seeds, nx, x0, c->d_b, c->st);
+  if (ll) {
+    // u = Dot(phi(x), a(p)) + bias: coordinate columns move phi, parameter columns move a
+    rc = nif_forward_dev(c, c->d_a, B, c->d_d); if (rc) return rc;     // leaves PHI and Z (= a) on the device
+    PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, ncol, c->pi, B);
+    for (int j = 0; j < nx; ++j) {
+      if (x_idx[j] >= c->pi) {
+        PNetArgs mj = ma; mj.Z = c->DPHI;   // primal again into a scratch, tangent into d_c
+        launch_mlp_jac(mj, c->NB, x_idx[j] - c->pi, c->d_c, c->st);
+        launch_ll_jac_out(c->PHI, c->Z, c->d_c, nullptr, B, c->r, c->so, nx, j, c->d_b, c->st);
+      } else {
+        PNetArgs pj = pa; pj.Z = c->DA;
+        launch_mlp_jac(pj, c->NSTB, x_idx[j], c->d_c, c->st);
+        launch_ll_jac_out(c->PHI, c->Z, nullptr, c->d_c, B, c->r, c->so, nx, j, c->d_b, c->st);
+      }
+    }
+  } else {
+    launch_pnet(pa, c->NSTB, false, c->st);
+    SNetArgs sa; fill_snet(c, sa, c->d_a, ncol, c->pi, B);
+    for (int x0 = 0; x0 < nx; x0 += 3) {
+      int seeds[3] = {0, 0, 0};
+      const float* zd[3] = {nullptr, nullptr, nullptr};
+      const int ns = nx - x0 < 3 ? nx - x0 : 3;
+      for (int d = 0; d < ns; ++d) {
+        const int col = x_idx[x0 + d];
+        if (col >= c->pi) { seeds[d] = col - c->pi; }
+        else {
+          seeds[d] = -1;
+          PNetArgs pj = pa; pj.Z = c->DZ;     // primal latent again into a scratch
+          launch_mlp_jac(pj, c->NSTB, col, c->d_c + d * zd_sz, c->st);
+          zd[d] = c->d_c + d * zd_sz;
+        }
+      }
+      sa.u_out = x0 == 0 ? c->d_d : nullptr;
+      launch_jac(sa, ns, seeds, zd, nx, x0, c->d_b, c->st);
+    }
   }
   HIPCHK(hipGetLastError());
   std::vector<float> full((size_t)B * c->so * nx);
   HIPCHK(hipMemcpyAsync(y_out, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(full.data(), c->d_b, sizeof(float) * full.size(), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
-  for (int64_t a = 0; a < B; ++a)
+  for (int64_t a_ = 0; a_ < B; ++a_)
     for (int i = 0; i < ny; ++i)
-      for (int j = 0; j < nx; ++j) dydx_out[(a * ny + i) * nx + j] = full[((size_t)a * c->so + y_idx[i]) * nx + j];
+      for (int j = 0; j < nx; ++j) dydx_out[(a_ * ny + i) * nx + j] = full[((size_t)a_ * c->so + y_idx[i]) * nx + j];
   return NIF_OK;
 }
 

@@ -122,7 +122,11 @@ int snet3_nbl(int n);
 int snet3_nsm(int si, int so, int nh, int n);
 long snet3_plane_floats(int n);
 long snet3_ring_floats_per_wave(int n, int nh);
-void launch_jac(const SNetArgs& a, int ns, const int* seeds, int nx_total, int x0, float* dydx, hipStream_t st);
+void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
+                hipStream_t st);
+void launch_mlp_jac(const PNetArgs& a, int NB, int seed, float* ZD, hipStream_t st);
+void launch_ll_jac_out(const float* PHI, const float* Z, const float* PHID, const float* ZD, long B, int r, int so,
+                       int nx_total, int xcol, float* dydx, hipStream_t st);
 void launch_pack16(const float* theta, const MatRef& m, int NBL, f32x4* WF, f32x4* WB, hipStream_t st);
 void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st);
 void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st);

@@ -150,8 +150,27 @@ def test_jacobian_layer_matches_oracle(name):
         y2, J2 = nif_amd.JacobianLayer(model, [spec.so - 1], [xi[-1], xi[0]])(x)
         assert np.allclose(J2[:, 0, 0], J[:, spec.so - 1, -1], rtol=1e-4, atol=1e-5)
         assert np.allclose(J2[:, 0, 1], J[:, spec.so - 1, 0], rtol=1e-4, atol=1e-5)
-    with pytest.raises(nif_amd._lib.NifError):
-        nif_amd.JacobianLayer(model, yi, [0])(x)   # parameter column: not built yet
+    # parameter columns (e.g. du/dt): the hypernetwork weights move too; oracle = fp64 central differences
+    pcols = list(range(spec.pi))
+    _, Jp = nif_amd.JacobianLayer(model, yi, pcols)(x)
+    _, Jpr = O.jacobian(spec, ws, x.astype(np.float64), yi, pcols)
+    assert _rel(Jp, Jpr) < 1e-4, _rel(Jp, Jpr)
+    # mixed request, more than 3 seeds' worth of columns when available
+    allc = list(range(spec.pi + spec.si))
+    _, Ja = nif_amd.JacobianLayer(model, yi, allc)(x)
+    assert _rel(Ja[:, :, :spec.pi], Jp.astype(np.float64)) < 2e-5 and _rel(Ja[:, :, spec.pi:], J.astype(np.float64)) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3"])
+def test_jacobian_layer_last_layer_class(name):
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make(name)
+    yi = list(range(spec.so))
+    allc = list(range(spec.pi + spec.si))
+    yv, J = nif_amd.JacobianLayer(model, yi, allc)(x)
+    yr, Jr = O.jacobian(spec, ws, x.astype(np.float64), yi, allc)   # fp64 central differences
+    assert _rel(yv, yr) < 1e-5
+    assert _rel(J, Jr) < 1e-4, _rel(J, Jr)
 
 
 def test_given_w_arbitrary_weights():
