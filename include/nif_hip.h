@@ -148,6 +148,18 @@ int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* 
  * over shards gives the global-batch mean (tf.distribute.MirroredStrategy, README.md:39-49). */
 int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* sw_dev_or_null,
                       int64_t B_local, int64_t B_global);
+/* Sobolev training: the Keras model  Model(x, JacobianLayer(nif, y_index=all, x_index)(x))  compiled with
+ * loss='mse', loss_weights=[1, w_jac]  (nif/layers/gradient.py:36-49 used as a trainable output; Keras then
+ * differentiates THROUGH the Jacobian).  loss = mse(u, y) + w_jac * mse(du/dx, dydx) with
+ * dydx [B, so, nx]; x_idx are input-vector columns and must be coordinate columns (1..3 of them).  Built as
+ * forward tangents + their hand-derived adjoint in one kernel (k_sob.hip) for NIFMultiScale (with or without
+ * resblocks).  Same conventions as nif_loss_grad_dev (result in nif_grad_dev(), scaled by 1/B_global). */
+int nif_sobolev_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
+                              const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,
+                              int32_t nx, float w_jac);
+/* predict() of that two-output model: u [B,so] and du/dx [B,so,nx], device pointers */
+int nif_sobolev_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, const int32_t* x_idx, int32_t nx, float* u_dev,
+                            float* dudx_dev);
 /* optimizer.apply_gradients with Adam on the (already all-reduced) nif_grad_dev() buffer */
 int nif_adam_step_dev(nif_ctx* ctx, const nif_adam* opt);
 /* host-pointer conveniences */

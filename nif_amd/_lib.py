@@ -76,6 +76,9 @@ SIGNATURES = {
     "nif_shapenet_given_w": (C.c_int, [_CTX, _VP, _VP, C.c_int64, _VP]),
     "nif_shapenet_given_w_dev": (C.c_int, [_CTX, _VP, _VP, C.c_int64, _VP]),
     "nif_loss_grad_dev": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.c_int64]),
+    "nif_sobolev_loss_grad_dev": (C.c_int, [_CTX, _VP, _VP, _VP, _VP, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
+                                            C.c_float]),
+    "nif_sobolev_forward_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
     "nif_loss_and_grad": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, _FP, _VP]),
     "nif_train_step": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.POINTER(nif_adam), _FP]),

@@ -68,11 +68,12 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = k0 + kk;
-        if (k < A.r) zq[kk][q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+        if (k < A.r) zq[kk][q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
         else { zq[kk][q][0] = 1.f; zq[kk][q][1] = 1.f; zq[kk][q][2] = 1.f; zq[kk][q][3] = 1.f; }
       }
   };
-  auto compute_tile = [&](const f32x4 (&af)[NBI][4], const f32x4 (&bf)[OBC][4], const f32x4 (&zq)[KC][4]) {
+  auto compute_tile = [&](long t, const f32x4 (&af)[NBI][4], const f32x4 (&bf)[OBC][4], const f32x4 (&zq)[KC][4]) {
+    const bool wbias = t < A.bias_ntiles;   // tangent pseudo-tiles (Sobolev) carry no bias gradient
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       if (k0 + kk > A.r) break;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
               acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[ob][q][c], acc[kk][ib][ob], 0, 0, 0);
           }
 #pragma unroll
-          for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(zt, bf[ob][q][c], bacc[kk][ob]);
+          for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(wbias ? zt : 0.f, bf[ob][q][c], bacc[kk][ob]);
         }
     }
   };
@@ -100,11 +101,11 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
     while (t < A.ntiles) {
       const long t1 = t + nwaves;
       if (t1 < A.ntiles) load_tile(t1, af1, bf1, zq1);
-      compute_tile(af0, bf0, zq0);
+      compute_tile(t, af0, bf0, zq0);
       if (t1 >= A.ntiles) break;
       const long t2 = t1 + nwaves;
       if (t2 < A.ntiles) load_tile(t2, af0, bf0, zq0);
-      compute_tile(af1, bf1, zq1);
+      compute_tile(t1, af1, bf1, zq1);
       t = t2;
     }
   }
@@ -135,7 +136,15 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
   }
 }
 
-void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st) {
+static GwArgs gw_fix(const GwArgs& in) {
+  GwArgs a = in;
+  if (a.zt_mod <= 0) a.zt_mod = a.ntiles > 0 ? a.ntiles : 1;
+  if (a.bias_ntiles <= 0) a.bias_ntiles = a.ntiles;
+  return a;
+}
+
+void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
+  const GwArgs a = gw_fix(a_);
   dim3 block(256);
   if (NBI == 1 && NBO == 1) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
@@ -174,10 +183,13 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
       for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * ob + i) * 32 + 16 * hf + 4 * q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (k < A.r) zq[q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+      if (k < A.r) zq[q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
       else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
     }
+    // Sobolev pseudo-tiles (t >= bias_ntiles): the "input" of tangent stream d is the one-hot e_seed[d]
+    const int pseudo = t < A.bias_ntiles ? -1 : A.seed[(int)(t / A.zt_mod) - 1];
     for (int dd = 0; dd <= A.nd; ++dd) {  // dd == nd : the bias (x = 1)
+      if (pseudo >= 0 && dd != pseudo) continue;
       float s[NBO];
 #pragma unroll
       for (int ob = 0; ob < NBO; ++ob) s[ob] = 0.f;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
         for (int c = 0; c < 4; ++c) {
           long pt = t * 32 + 16 * hf + 4 * q + c;
           if (pt >= A.B) pt = A.B - 1;
-          const float xv = dd < A.nd ? A.xin[pt * A.ncol + A.col0 + dd] : 1.0f;
+          const float xv = (dd < A.nd && pseudo < 0) ? A.xin[pt * A.ncol + A.col0 + dd] : 1.0f;
           const float w = xv * zq[q][c];
 #pragma unroll
           for (int ob = 0; ob < NBO; ++ob) s[ob] = fmaf(w, bf[ob][q][c], s[ob]);
@@ -210,7 +222,8 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
     }
 }
 
-void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st) {
+void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
+  const GwArgs a = gw_fix(a_);
   dim3 grid(rows, a.r + 1), block(256);
   const size_t shm = (size_t)(192 + 4 * (a.nd + 1) * NBO * 64) * sizeof(float);
   if (NBO == 1) hipLaunchKernelGGL((k_gw_first<1>), grid, block, shm, st, a);
@@ -243,9 +256,10 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
       for (int q = 0; q < 4; ++q) af[ib][q] = ld4(A.IN + t * FI + (long)(32 * ib + i) * 32 + 16 * hf + 4 * q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (k < A.r) zq[q] = ld4(A.Z + (t * A.r + k) * 32 + 16 * hf + 4 * q);
+      if (k < A.r) zq[q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
       else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
     }
+    const bool wbias = t < A.bias_ntiles;
     for (int c = 0; c < A.nc; ++c) {
       float s[NBI + 1];
 #pragma unroll
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
           const float w = dq[e] * zq[q][e];
 #pragma unroll
           for (int ib = 0; ib < NBI; ++ib) s[ib] = fmaf(w, af[ib][q][e], s[ib]);
-          s[NBI] += w;
+          s[NBI] += wbias ? w : 0.f;
         }
       }
 #pragma unroll
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
     }
 }
 
-void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st) {
+void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
+  const GwArgs a = gw_fix(a_);
   dim3 grid(rows, a.r + 1), block(256);
   const size_t shm = (size_t)(192 + 4 * a.nc * (NBI + 1) * 64) * sizeof(float);
   if (NBI == 1) hipLaunchKernelGGL((k_gw_out<1>), grid, block, shm, st, a);

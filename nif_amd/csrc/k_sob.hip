@@ -1,0 +1,453 @@
+// k_sob.hip -- Sobolev training step of the SIREN hypernetwork ShapeNet (BASELINE config 5): the model
+// outputs (u, du/dx_d) through JacobianLayer (reference nif/layers/gradient.py:36-49) and the loss is
+//     mse(u, y) + w_J * mse(du/dx, g)                      (Keras: two outputs, loss='mse', loss_weights)
+// Forward = primal + forward-mode tangents (as k_jac); backward = the hand-derived adjoint of that pair:
+// with lambda = dL/dh, mu^d = dL/dh'^d, c = cos(a), s = sin(a), a'^d the tangent pre-activation,
+//     nu^d  = mu^d * c                        (dL/da'^d)
+//     da    = lambda * c - sum_d mu^d * s * a'^d
+//     lambda_in = w0 W(a) da ,  mu_in^d = w0 W(a) nu^d          (same MFMA planes, 1+ns right-hand sides)
+//     dL/dM^(k) = w0 sum_p zt_k (h_in da^T + sum_d h'_in^d nu^dT)   -> the weight-gradient GEMMs simply see
+//                 (1+ns) x more "points": the tangent pairs are stashed as pseudo-tiles
+//     dL/dz_k  += w0 <h_in, M^(k) da> + <da, b^(k)> + w0 sum_d <h'_in^d, M^(k) nu^d>
+// Coordinate seeds only (spatial derivatives); NIFMultiScale with or without resblocks.
+#include "k_snet3_dev.h"
+
+#define NIF_SOB_MAXSEED 3
+
+struct SobArgs {
+  SNetArgs s;
+  int ns;                       // number of seeds (<= NIF_SOB_MAXSEED)
+  int seed[NIF_SOB_MAXSEED];    // coordinate index d of each seed
+  const float* gt;              // target derivatives [B][so][ns]
+  float wj;                     // loss weight of the derivative term
+  float* ring;                  // per wave [(nh+1)][2+NS][NBL][64][4]
+  float* JU;                    // optional outputs du/dx [B][so][ns] (predict) or null
+};
+
+template <int NBL, int MODE, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SNetArgs& A = J.s;
+  constexpr int NT = 256, WAVES = 4, NS = NIF_SOB_MAXSEED, NQ = 1 + NS;
+  constexpr int PLANE = NBL * NBL * 256;
+  constexpr int PF4 = (PLANE / 4 + NT - 1) / NT;
+  constexpr bool PEXACT = (PLANE / 4) % NT == 0;
+  constexpr int NP = 16 * NBL;
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm, ns = J.ns;
+  const int FP = ((n + 31) / 32) * 32;
+  const long nt32 = (A.B + 31) / 32;
+  const long nt16 = 2 * nt32;
+  const long ngroups = (nt16 + WAVES - 1) / WAVES;
+
+  f32x4* planes = reinterpret_cast<f32x4*>(smem);
+  float* sm = smem + 2 * PLANE;
+  const int sm_tot = ((r + 1) * nsm + 3) & ~3;
+  float* dzs = sm + sm_tot + (long)wid * (r * 64 + r * 16);   // per wave dz partials [r][64], latent [r][16]
+  float* zs = dzs + r * 64;
+  float* lsum = sm + sm_tot + (long)WAVES * (r * 64 + r * 16);
+  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
+  const int NPL = nh * (r + 1);
+  const int nplanes = TRAIN ? 2 * NPL : NPL;
+  auto plane_src = [&](int i) -> const f32x4* {
+    if (i < NPL) return A.WF + (long)i * (PLANE / 4);
+    const int ii = i - NPL;
+    const int j = nh - 1 - ii / (r + 1), k = ii % (r + 1);
+    return A.WB + ((long)j * (r + 1) + k) * (PLANE / 4);
+  };
+  {
+    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
+      const int k = idx / nsm, e = idx - k * nsm;
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
+    }
+    if (nplanes > 0) {
+      const f32x4* src = plane_src(0);
+#pragma unroll
+      for (int q = 0; q < PF4; ++q)
+        if (PEXACT || tid + NT * q < PLANE / 4) planes[tid + NT * q] = src[tid + NT * q];
+    }
+  }
+  __syncthreads();
+  int gpar = 0;
+  float loss_lane = 0.f;
+  // ring: per layer l: block index (l*(2+NS) + which)*NBL + b, which = 0: cos(a), 1: sin(a), 2+d: a'^d
+  f32x4* ring = TRAIN ? reinterpret_cast<f32x4*>(J.ring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (2 + NS) * (NBL * 256))
+                      : nullptr;
+  float* IN0 = A.stash;
+  float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
+
+#define SOB_PLANE(...)                                                                        \
+  {                                                                                           \
+    if ((pl + 1 < nplanes) || !last_group) {                                                  \
+      const f32x4* src = plane_src(pl + 1 < nplanes ? pl + 1 : 0);                            \
+      f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);                                   \
+      _Pragma("unroll") for (int q = 0; q < PF4; ++q)                                         \
+        if (PEXACT || wid * 64 + NT * q < PLANE / 4)                                          \
+          __builtin_amdgcn_global_load_lds(                                                   \
+              (const __attribute__((address_space(1))) void*)(src + tid + NT * q),            \
+              (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);  \
+    }                                                                                         \
+    const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);                                     \
+    __VA_ARGS__                                                                               \
+    __syncthreads();                                                                          \
+    ++gpar; ++pl;                                                                             \
+  }
+#define ZERO4(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }
+
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    const bool last_group = tg + gridDim.x >= ngroups;
+    const long t16_raw = tg * WAVES + wid;
+    const bool active = t16_raw < nt16;
+    const long t16 = active ? t16_raw : nt16 - 1;
+    const long tile32 = t16 >> 1;
+    const int poff = 16 * (int)(t16 & 1) + p;
+    const long pt = t16 * 16 + p;
+    const bool valid = active && pt < A.B;
+    const long ptc = pt < A.B ? pt : A.B - 1;
+    const float* xrow = A.xin + ptc * A.ncol + A.col0;
+    if (g == 0)
+      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+    const float* zt_base = zs + p;
+    // stash rows of stream q (0 = primal, 1+d = tangent d): pseudo-tile q*nt32 + tile32
+    auto row0 = [&](int q) -> long { return ((long)q * nt32 + tile32) * (long)FP * 32 + poff; };
+    if (TRAIN)
+      for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
+
+    // hq[0] = h, hq[1+d] = h'^d ; aq likewise for the pre-activation accumulators
+    f32x4 hq[NQ][NBL], aq[NQ][NBL];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ZERO4(aq[q][b]);
+    // ---- first layer ---------------------------------------------------------------------------
+    for (int k = 0; k <= r; ++k) {
+      const float zt = k < r ? zt_base[k * 16] : 1.0f;
+      const float* s0 = sm + k * nsm + 4 * g;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        aq[0][b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          if (d < ns) aq[1 + d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
+      }
+    }
+    {
+      f32x4 c[NBL];
+      sine16<NBL>(aq[0], hq[0], c);
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        if (TRAIN) { ring[0 * NBL * 64 + b * 64 + lane] = c[b]; ring[1 * NBL * 64 + b * 64 + lane] = hq[0][b]; }
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+          if (TRAIN) ring[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
+          hq[1 + d][b] = c[b] * aq[1 + d][b];
+        }
+      }
+    }
+    // ---- hidden hyper-matrices -------------------------------------------------------------------
+    int pl = 0;
+    f32x4 ub[MODE == 1 ? NQ : 1][MODE == 1 ? NBL : 1];
+    for (int j = 0; j < nh; ++j) {
+      if (TRAIN && active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q <= ns) st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0(q), hq[q], g);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) ZERO4(aq[q][b]);
+      for (int k = 0; k <= r; ++k) {
+        SOB_PLANE({
+          const float zt = k < r ? zt_base[k * 16] : 1.0f;
+          _Pragma("unroll") for (int q = 0; q < NQ; ++q)
+            if (q <= ns) {
+              f32x4 hz[NBL];
+              _Pragma("unroll") for (int b = 0; b < NBL; ++b) hz[b] = zt * hq[q][b];
+              mfma16<NBL, true>(cur, hz, aq[q], lane);
+            }
+        })
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) aq[q][b] *= A.omega;
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) aq[0][b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
+      }
+      f32x4 sn[NBL], c[NBL];
+      sine16<NBL>(aq[0], sn, c);
+      f32x4* rl = ring + (long)(j + 1) * (2 + NS) * NBL * 64;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        if (TRAIN) { rl[0 * NBL * 64 + b * 64 + lane] = c[b]; rl[1 * NBL * 64 + b * 64 + lane] = sn[b]; }
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+          if (TRAIN) rl[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 t = q == 0 ? sn[b] : c[b] * aq[q][b];   // sin(a) | cos(a) a'
+          if (MODE == 0) hq[q][b] = t;
+          else if (!(j & 1)) { ub[q][b] = hq[q][b]; hq[q][b] = t; }
+          else hq[q][b] = 0.5f * (ub[q][b] + t);
+        }
+    }
+    // ---- last layer, loss, start of the adjoint ------------------------------------------------
+    if (TRAIN && active) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (q <= ns) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0(q), hq[q], g);
+    }
+    f32x4 lam[NQ][NBL];   // lam[0] = dL/dh, lam[1+d] = dL/dh'^d
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ZERO4(lam[q][b]);
+    const float wsamp = (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f);
+    float se = 0.f, sej = 0.f;
+    for (int o = 0; o < so; ++o) {
+      f32x4 wg[NBL];
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ZERO4(wg[b]);
+      float part[NQ], bias = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) part[q] = 0.f;
+      // sk[q][k] partial dots are needed again for dz: recompute in a second k loop below
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* s0 = sm + k * nsm;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            part[q] = fmaf(zt, (hq[q][b][0] * w[0] + hq[q][b][1] * w[1]) + (hq[q][b][2] * w[2] + hq[q][b][3] * w[3]), part[q]);
+          if (TRAIN) wg[b] += zt * w;
+        }
+        bias = fmaf(zt, s0[o_bl + o], bias);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { part[q] += __shfl_xor(part[q], 16); part[q] += __shfl_xor(part[q], 32); }
+      const float uo = part[0] + bias;
+      if (valid && g == 0) {
+        if (A.u_out) A.u_out[pt * so + o] = uo;
+        if (J.JU)
+#pragma unroll
+          for (int d = 0; d < NS; ++d)
+            if (d < ns) J.JU[(pt * so + o) * ns + d] = part[1 + d];
+      }
+      if (TRAIN) {
+        float dq[NQ];
+        const float e = uo - A.y[ptc * so + o];
+        se = fmaf(e, e, se);
+        dq[0] = 2.0f * wsamp * e * A.inv_bg / (float)so;
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+          dq[1 + d] = 0.f;
+          if (d < ns) {
+            const float ej = part[1 + d] - J.gt[(ptc * so + o) * ns + d];
+            sej = fmaf(ej, ej, sej);
+            dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(so * ns);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (q <= ns && active && g == 0) A.DU[(((long)q * nt32 + tile32) * so + o) * 32 + poff] = dq[q];
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) lam[q][b] += dq[q] * wg[b];
+        }
+        // dL/dz_k += sum_q dq[q] * <hq[q], Wl^(k)[:,o]>  + dq[0] * bl^(k)[o]
+        for (int k = 0; k < r; ++k) {
+          const float* s0 = sm + k * nsm;
+          float t = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              t = fmaf(dq[q], (hq[q][b][0] * w[0] + hq[q][b][1] * w[1]) + (hq[q][b][2] * w[2] + hq[q][b][3] * w[3]), t);
+          }
+          if (g == 0) t = fmaf(dq[0], s0[o_bl + o], t);
+          dzs[k * 64 + lane] += t;
+        }
+      }
+    }
+    if (TRAIN) {
+      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)so + J.wj * sej / (float)(so * ns));
+
+      // ---- adjoint through the hidden hyper-matrices --------------------------------------------
+      f32x4 skip[MODE == 1 ? NQ : 1][MODE == 1 ? NBL : 1];
+      for (int j = nh - 1; j >= 0; --j) {
+        const f32x4* rl = ring + (long)(j + 1) * (2 + NS) * NBL * 64;
+        f32x4 vq[NQ][NBL];   // vq[0] = da, vq[1+d] = nu^d
+        if (MODE == 1 && (j & 1)) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) { lam[q][b] *= 0.5f; skip[q][b] = lam[q][b]; }
+        }
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 c = rl[0 * NBL * 64 + b * 64 + lane], sn = rl[1 * NBL * 64 + b * 64 + lane];
+          f32x4 da = lam[0][b] * c;
+#pragma unroll
+          for (int d = 0; d < NS; ++d) {
+            vq[1 + d][b] = lam[1 + d][b] * c;
+            if (d < ns) da -= lam[1 + d][b] * sn * rl[(2 + d) * NBL * 64 + b * 64 + lane];
+          }
+          vq[0][b] = da;
+        }
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q <= ns) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0(q), vq[q], g);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) ZERO4(lam[q][b]);
+        for (int k = 0; k <= r; ++k) {
+          SOB_PLANE({
+            const float zt = k < r ? zt_base[k * 16] : 1.0f;
+            float dzk = 0.f;
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)
+              if (q <= ns) {
+                if (k < r) {
+                  f32x4 U[NBL], hin[NBL];
+                  mfma16<NBL, false>(cur, vq[q], U, lane);
+                  st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0(q), hin, g);
+                  _Pragma("unroll") for (int b = 0; b < NBL; ++b) {
+                    lam[q][b] += zt * U[b];
+                    dzk += (hin[b][0] * U[b][0] + hin[b][1] * U[b][1]) + (hin[b][2] * U[b][2] + hin[b][3] * U[b][3]);
+                  }
+                } else {
+                  mfma16<NBL, true>(cur, vq[q], lam[q], lane);
+                }
+              }
+            if (k < r) {
+              const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+              float sbv = 0.f;
+              _Pragma("unroll") for (int b = 0; b < NBL; ++b) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+                sbv += (vq[0][b][0] * bb[0] + vq[0][b][1] * bb[1]) + (vq[0][b][2] * bb[2] + vq[0][b][3] * bb[3]);
+              }
+              dzs[k * 64 + lane] += fmaf(A.omega, dzk, sbv);
+            }
+          })
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            lam[q][b] *= A.omega;
+            if (MODE == 1 && !(j & 1)) lam[q][b] += skip[q][b];
+          }
+      }
+      // ---- first layer ---------------------------------------------------------------------------
+      {
+        f32x4 vq[NQ][NBL];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 c = ring[0 * NBL * 64 + b * 64 + lane], sn = ring[1 * NBL * 64 + b * 64 + lane];
+          f32x4 da = lam[0][b] * c;
+#pragma unroll
+          for (int d = 0; d < NS; ++d) {
+            vq[1 + d][b] = lam[1 + d][b] * c;
+            if (d < ns) da -= lam[1 + d][b] * sn * ring[(2 + d) * NBL * 64 + b * 64 + lane];
+          }
+          vq[0][b] = da;
+        }
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q <= ns) st_store16<NBL>(DA0, row0(q), vq[q], g);
+        }
+        for (int k = 0; k < r; ++k) {
+          const float* s0 = sm + k * nsm + 4 * g;
+          float s = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            f32x4 xw = {0.f, 0.f, 0.f, 0.f};
+            for (int dd = 0; dd < si; ++dd) xw += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+            const f32x4 t = A.omega * xw + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+            s += (vq[0][b][0] * t[0] + vq[0][b][1] * t[1]) + (vq[0][b][2] * t[2] + vq[0][b][3] * t[3]);
+#pragma unroll
+            for (int d = 0; d < NS; ++d)
+              if (d < ns) {
+                const f32x4 wd = A.omega * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
+                s += (vq[1 + d][b][0] * wd[0] + vq[1 + d][b][1] * wd[1]) + (vq[1 + d][b][2] * wd[2] + vq[1 + d][b][3] * wd[3]);
+              }
+          }
+          float tot = dzs[k * 64 + lane] + s;
+          tot += __shfl_xor(tot, 16);
+          tot += __shfl_xor(tot, 32);
+          if (active && g == 0) A.DZ[(tile32 * r + k) * 32 + poff] = tot;
+        }
+      }
+    }
+  }
+#undef SOB_PLANE
+#undef ZERO4
+  if (TRAIN) {
+    for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
+    if (lane == 0) lsum[wid] = loss_lane;
+    __syncthreads();
+    if (tid == 0) A.loss_partial[blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  }
+}
+
+long sob_ring_floats_per_wave(int n, int nh) { return (long)(nh + 1) * (2 + NIF_SOB_MAXSEED) * snet3_nbl(n) * 256; }
+
+int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
+               bool query_only, hipStream_t st) {
+  const int NBL = snet3_nbl(a.n);
+  const long nt16 = 2 * ((a.B + 31) / 32);
+  const long ngroups = (nt16 + 3) / 4;
+  const int nblk = (int)(ngroups < 256 ? ngroups : 256);
+  if (query_only) return nblk;
+  SobArgs J;
+  J.s = a; J.ns = ns; J.gt = gt; J.wj = wj; J.ring = ring; J.JU = ju;
+  for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
+  dim3 grid(nblk), block(256);
+  const size_t plane = (size_t)NBL * NBL * 256;
+  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
+#define SBL(NBL_, MODE_, TR_)                                                                                   \
+  {                                                                                                             \
+    if (shm > 48 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shm);                                                                      \
+    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_>), grid, block, shm, st, J);                                     \
+  }
+#define SBK(NBL_)                                                                    \
+  if (a.res) { if (train) SBL(NBL_, 1, true) else SBL(NBL_, 1, false) }             \
+  else { if (train) SBL(NBL_, 0, true) else SBL(NBL_, 0, false) }
+  switch (NBL) {
+    case 1: SBK(1) break;
+    case 2: SBK(2) break;
+    case 3: SBK(3) break;
+    case 4: SBK(4) break;
+    case 6: SBK(6) break;
+    default: SBK(8) break;
+  }
+#undef SBK
+#undef SBL
+  return nblk;
+}

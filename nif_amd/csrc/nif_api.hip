@@ -743,14 +743,21 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   return NIF_OK;
 }
 
-extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg) {
-  if (!c || !xin || !y || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
+// ns = 0: loss = mse(u, y).  ns > 0 (Sobolev): + wj * mse(du/dx_seed, gt), k_sob instead of k_snet3; the
+// ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
+static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
+                          const int* seeds, const float* gt, float wj) {
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
-  rc = ensure_capacity(c, B, true); if (rc) return rc;
+  const long ntiles = (B + 31) / 32;
+  if (ns > 0) {
+    if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
+      return fail(NIF_ERR_INVALID, "Sobolev training is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
+    if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
+  }
+  rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
   c->reg_applied = false;
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
-  const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
   // forward + adjoint
   PNetArgs pa; fill_pnet(c, pa, xin, B);
@@ -758,7 +765,17 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
   int nloss = (int)((ntiles + 3) / 4);
-  if (c->use_snet3) {
+  if (ns > 0) {
+    const int nblk = launch_sob(sa, true, ns, seeds, gt, wj, nullptr, nullptr, true, c->st);
+    const long need = (long)nblk * 4 * sob_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    nloss = nblk;
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
+  } else if (c->use_snet3) {
     int waves = 4;
     const int nblk = launch_snet3(sa, true, true, &waves, c->st);
     const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
@@ -785,16 +802,21 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
     memset(&q, 0, sizeof(q));
     q.ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride; q.has_bias = 1; q.scale = 1.0f;
   };
+  auto sbase = [&](GwArgs& q) {   // ShapeNet reductions also run over the tangent pseudo-tiles
+    base(q);
+    q.ntiles = ntiles * (1 + ns); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
+    for (int d = 0; d < 3; ++d) q.seed[d] = (seeds && d < ns) ? seeds[d] : 0;
+  };
   const float om_s = sa.omega, om_p = pa.omega;
   float* sIN = c->stash_s; float* sDA = c->stash_s + (long)(c->nh + 1) * c->slot_s;
   // ShapeNet first layer
-  base(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = c->Z; g.r = c->r; g.scale = om_s;
+  sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = c->Z; g.r = c->r; g.scale = om_s;
   g.W = hyper_ref(c, 0, c->n, c->si, c->n);
   g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
   launch_gw_first(g, c->NB, rows, c->st);
   // ShapeNet hidden matrices
   for (int j = 0; j < c->nh; ++j) {
-    base(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = c->Z; g.r = c->r; g.scale = om_s;
+    sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = c->Z; g.r = c->r; g.scale = om_s;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
     g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
@@ -803,7 +825,7 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   }
   // ShapeNet last layer
   {
-    base(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = c->DU; g.nc = c->so; g.Z = c->Z; g.r = c->r; g.scale = 1.0f;
+    sbase(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = c->DU; g.nc = c->so; g.Z = c->Z; g.r = c->r; g.scale = 1.0f;
     const long wslot = (long)c->si * c->n + (long)c->nh * c->n * c->n;
     const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
     g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
@@ -830,6 +852,46 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
   // rows -> flat gradient, loss
   ProfScope pr_(c, NIF_PROF_REDUCE);
   launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
+extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg) {
+  if (!c || !xin || !y || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
+  return loss_grad_core(c, xin, y, sw, B, Bg, 0, nullptr, nullptr, 0.f);
+}
+
+static int sobolev_seeds(nif_ctx* c, const int32_t* x_idx, int32_t nx, int* seeds) {
+  if (!x_idx || nx < 1 || nx > 3) return fail(NIF_ERR_INVALID, "Sobolev training takes 1..3 coordinate columns");
+  for (int d = 0; d < nx; ++d) {
+    if (x_idx[d] < c->pi || x_idx[d] >= c->pi + c->si)
+      return fail(NIF_ERR_INVALID, "Sobolev x_index must address coordinate columns (pi_dim <= i < pi_dim + si_dim)");
+    seeds[d] = x_idx[d] - c->pi;
+  }
+  return NIF_OK;
+}
+extern "C" int nif_sobolev_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* dydx, const float* sw,
+                                         int64_t B, int64_t Bg, const int32_t* x_idx, int32_t nx, float w_jac) {
+  if (!c || !xin || !y || !dydx || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
+  int seeds[3] = {0, 0, 0};
+  int rc = sobolev_seeds(c, x_idx, nx, seeds); if (rc) return rc;
+  return loss_grad_core(c, xin, y, sw, B, Bg, nx, seeds, dydx, w_jac);
+}
+extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, const int32_t* x_idx, int32_t nx, float* u,
+                                       float* dudx) {
+  if (!c || !xin || !u || !dudx || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
+  int seeds[3] = {0, 0, 0};
+  int rc = sobolev_seeds(c, x_idx, nx, seeds); if (rc) return rc;
+  HIPCHK(hipSetDevice(c->dev));
+  rc = ensure_packed(c); if (rc) return rc;
+  if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
+    return fail(NIF_ERR_INVALID, "Sobolev path is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  launch_pnet(pa, c->NSTB, false, c->st);
+  SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
+  sa.u_out = u;
+  launch_sob(sa, false, nx, seeds, nullptr, 0.f, nullptr, dudx, false, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }

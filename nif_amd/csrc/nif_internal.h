@@ -107,6 +107,11 @@ struct GwArgs {
   MatRef Bv;            // bias gradient (nin = 1, ld = 0): element(k, 0, out)
   float* partial; long pstride;   // partial[row*pstride + index], row = blockIdx.x
   int has_bias;
+  // Sobolev training (k_sob.hip): the stashes hold (1+ns) * zt_mod tiles -- the real tiles followed by one
+  // block of tangent pseudo-tiles per seed.  Z is indexed by t % zt_mod; tiles >= bias_ntiles carry no bias
+  // gradient and (first layer) use the one-hot input e_seed[t / zt_mod - 1].  0 = plain batch (launchers fix up).
+  long zt_mod, bias_ntiles;
+  int seed[3];
 };
 
 // launchers (implemented in the .hip files); all enqueue on `st`
@@ -117,6 +122,10 @@ void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
 // persistent, LDS-staged, 16-point-tile variant (k_snet3.hip).  launch_snet3 returns the number of
 // workgroups (query_only: without launching) and the waves per workgroup, for sizing dring / loss_partial.
 int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out, hipStream_t st);
+// Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
+long sob_ring_floats_per_wave(int n, int nh);
+int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
+               bool query_only, hipStream_t st);
 bool snet3_supported(const SNetArgs& a);
 int snet3_nbl(int n);
 int snet3_nsm(int si, int so, int nh, int n);

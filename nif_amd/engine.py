@@ -198,6 +198,45 @@ class Engine(object):
     def loss_grad_dev(self, d_x, d_y, d_sw, b_local, b_global):
         check(self.lib.nif_loss_grad_dev(self.ctx, d_x, d_y, d_sw, int(b_local), int(b_global)))
 
+    # Sobolev (two-output model u, du/dx; include/nif_hip.h nif_sobolev_*)
+    def sobolev_loss_grad_dev(self, d_x, d_y, d_g, d_sw, b_local, b_global, x_index, w_jac):
+        xi = (C.c_int32 * len(x_index))(*[int(i) for i in x_index])
+        check(self.lib.nif_sobolev_loss_grad_dev(self.ctx, d_x, d_y, d_g, d_sw, int(b_local), int(b_global), xi, len(x_index),
+                                                 float(w_jac)))
+
+    def sobolev_forward(self, inputs, x_index):
+        x = _f32(inputs)
+        B, nx, so = x.shape[0], len(x_index), self.spec.so_dim
+        xi = (C.c_int32 * nx)(*[int(i) for i in x_index])
+        d_x, d_u, d_j = DeviceArray(self, x.size), DeviceArray(self, B * so), DeviceArray(self, B * so * nx)
+        try:
+            d_x.upload(x)
+            check(self.lib.nif_sobolev_forward_dev(self.ctx, d_x.at(0), B, xi, nx, d_u.at(0), d_j.at(0)))
+            u = d_u.download().reshape(B, so)
+            j = d_j.download().reshape(B, so, nx)
+        finally:
+            d_x.free(); d_u.free(); d_j.free()
+        return u, j
+
+    def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None):
+        x, y, g = _f32(inputs), _f32(y), _f32(dydx)
+        B = x.shape[0]
+        d_x, d_y, d_g = DeviceArray(self, x.size), DeviceArray(self, y.size), DeviceArray(self, g.size)
+        d_sw = DeviceArray(self, B) if sample_weight is not None else None
+        try:
+            d_x.upload(x); d_y.upload(y); d_g.upload(g)
+            if d_sw is not None:
+                d_sw.upload(_f32(sample_weight))
+            self.sobolev_loss_grad_dev(d_x.at(0), d_y.at(0), d_g.at(0), d_sw.at(0) if d_sw is not None else None, B, B,
+                                       x_index, w_jac)
+            buf = np.empty((self.n_params + 1,), dtype=np.float32)
+            check(self.lib.nif_d2h(self.ctx, ptr(buf), self.grad_dev_ptr(), buf.nbytes))
+        finally:
+            d_x.free(); d_y.free(); d_g.free()
+            if d_sw is not None:
+                d_sw.free()
+        return float(buf[-1]), buf[:-1].copy()
+
     def adam_step_dev(self, adam):
         check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
 

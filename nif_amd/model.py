@@ -136,6 +136,18 @@ class Model(object):
             per = per * np.asarray(sample_weight, dtype=np.float64)
         return float(per.sum() / u.shape[0])
 
+    # hooks the two-output Sobolev model overrides
+    def _targets(self, y, n_rows):
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        if y.ndim == 1:
+            y = y[:, None]
+        if y.shape != (n_rows, self._owner._spec.so_dim):
+            raise ValueError("y must have shape (N, so_dim=%d), got %r" % (self._owner._spec.so_dim, y.shape))
+        return [y]
+
+    def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
+        e.loss_grad_dev(d_x, d_targets[0], d_sw, b, bg)
+
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
             sample_weight=None, initial_epoch=0, **kwargs):
         """Keras Model.fit semantics for in-memory arrays: per epoch optionally shuffle, walk batches of
@@ -149,9 +161,7 @@ class Model(object):
         s = self._owner._spec
         e = self._engine
         x = np.ascontiguousarray(x, dtype=np.float32)
-        y = np.ascontiguousarray(y, dtype=np.float32)
-        if y.ndim == 1:
-            y = y[:, None]
+        targets = self._targets(y, x.shape[0])   # list of [N, width] tables that travel with x
         ncol = s.pi_dim + s.si_dim
         if x.shape[1] != ncol:
             x = np.ascontiguousarray(x[:, :ncol])
@@ -166,7 +176,8 @@ class Model(object):
         for cb in callbacks:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
-        d_x, d_y = DeviceArray(e, N * ncol), DeviceArray(e, N * s.so_dim)
+        d_x = DeviceArray(e, N * ncol)
+        d_t = [DeviceArray(e, t.size) for t in targets]
         d_sw = DeviceArray(e, N) if sw is not None else None
         rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
         resident = False
@@ -182,11 +193,15 @@ class Model(object):
                 if shuffle or not resident:
                     if shuffle:
                         perm = rng.permutation(N)
-                        d_x.upload(x[perm]); d_y.upload(y[perm])
+                        d_x.upload(x[perm])
+                        for dt, t in zip(d_t, targets):
+                            dt.upload(t[perm])
                         if sw is not None:
                             d_sw.upload(sw[perm])
                     else:
-                        d_x.upload(x); d_y.upload(y)
+                        d_x.upload(x)
+                        for dt, t in zip(d_t, targets):
+                            dt.upload(t)
                         if sw is not None:
                             d_sw.upload(sw)
                     resident = True
@@ -195,8 +210,8 @@ class Model(object):
                 for b0 in range(0, N, bs):
                     b = min(bs, N - b0)
                     bg = dist.all_reduce_scalar_sum(b) if world > 1 else b
-                    e.loss_grad_dev(d_x.at(b0 * ncol), d_y.at(b0 * s.so_dim),
-                                    d_sw.at(b0) if d_sw is not None else None, b, bg)
+                    self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * t.shape[1]) for dt, t in zip(d_t, targets)],
+                                        d_sw.at(b0) if d_sw is not None else None, b, bg)
                     if world > 1:
                         dist.all_reduce_grad(e)
                     e.adam_step_dev(adam)
@@ -213,7 +228,9 @@ class Model(object):
                     print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
         finally:
             e.sync()
-            d_x.free(); d_y.free()
+            d_x.free()
+            for dt in d_t:
+                dt.free()
             if d_sw is not None:
                 d_sw.free()
         for cb in callbacks:
@@ -240,6 +257,67 @@ class JacobianLayer(object):
         return self.model._engine.jacobian(x, self.y_index, self.x_index)
 
     __call__ = call
+
+
+class SobolevModel(Model):
+    """The Keras idiom  `tf.keras.Model(inp, JacobianLayer(nif_model, y_index, x_index)(inp))`  compiled with
+    loss='mse' and loss_weights=[1, w]: a two-output model (u, du/dx) whose training differentiates through
+    the Jacobian (reference nif/layers/gradient.py:36-49, SURVEY 3.4 / BASELINE config 5 "Sobolev training").
+    Built for NIFMultiScale, all outputs (y_index = range(so)), 1..3 coordinate columns in x_index.
+        m = SobolevModel(JacobianLayer(model, y_index, x_index)); m.compile("adam", "mse", loss_weights=[1, .1])
+        m.fit(x, [y, dydx], ...);  u, dudx = m.predict(x)"""
+
+    def __init__(self, jac_layer):
+        if not isinstance(jac_layer, JacobianLayer):
+            raise TypeError("SobolevModel wraps a JacobianLayer")
+        base = jac_layer.model
+        Model.__init__(self, base._owner, "full")
+        so = base._owner._spec.so_dim
+        if list(jac_layer.y_index) != list(range(so)):
+            raise NotImplementedError("Sobolev training is built for y_index = all outputs")
+        self.x_index = list(jac_layer.x_index)
+        self.loss_weights = [1.0, 1.0]
+
+    def compile(self, optimizer="adam", loss="mse", loss_weights=None, **kwargs):
+        if isinstance(loss, (list, tuple)):
+            if len(set(loss)) != 1:
+                raise NotImplementedError("both outputs use loss='mse'")
+            loss = loss[0]
+        Model.compile(self, optimizer=optimizer, loss=loss, **kwargs)
+        if loss_weights is not None:
+            lw = [float(v) for v in loss_weights]
+            if len(lw) != 2 or lw[0] <= 0.0:
+                raise ValueError("loss_weights = [w_u > 0, w_dudx]")
+            self.loss_weights = lw
+
+    def _run(self, x):
+        u, j = self._engine.sobolev_forward(x, self.x_index)
+        return [u, j]
+
+    def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
+        u, j = self._run(x)
+        ty, tj = self._targets(y, u.shape[0])
+        per = ((u.astype(np.float64) - ty) ** 2).mean(axis=1) * self.loss_weights[0] \
+            + ((j.reshape(tj.shape).astype(np.float64) - tj) ** 2).mean(axis=1) * self.loss_weights[1]
+        if sample_weight is not None:
+            per = per * np.asarray(sample_weight, dtype=np.float64)
+        return float(per.sum() / u.shape[0])
+
+    def _targets(self, y, n_rows):
+        if not (isinstance(y, (list, tuple)) and len(y) == 2):
+            raise ValueError("the Sobolev model has two outputs: fit(x, [y, dydx])")
+        so, nx = self._owner._spec.so_dim, len(self.x_index)
+        ty = Model._targets(self, y[0], n_rows)[0]
+        tj = np.ascontiguousarray(y[1], dtype=np.float32).reshape(n_rows, so * nx)
+        return [ty, tj]
+
+    def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
+        # Keras total loss = w0*mse(u) + w1*mse(dudx); the kernel computes mse(u) + wj*mse(dudx) and the flat
+        # gradient / loss are linear in the overall scale, so fold w0 into wj and rescale when w0 != 1
+        w0, w1 = self.loss_weights
+        if w0 != 1.0:
+            raise NotImplementedError("loss_weights[0] must be 1 (scale the learning rate instead)")
+        e.sobolev_loss_grad_dev(d_x, d_targets[0], d_targets[1], d_sw, b, bg, self.x_index, w1 / w0)
 
 
 class NIF(object):

@@ -657,6 +657,97 @@ def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None):
     return loss, pnet_backward(spec, ws, ptape, g_pout)
 
 
+def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
+    """Sobolev training step (BASELINE config 5): the two-output Keras model
+        y, dys_dxs = JacobianLayer(model, y_index=all, x_index)(inputs)      (nif/layers/gradient.py:36-49)
+    compiled with loss='mse', loss_weights=[1, w_jac]:   loss = mse(y) + w_jac * mse(dys_dxs)   (Keras 'mse' =
+    mean over the last axis, then the sample-weighted mean over the batch; for dys_dxs [B,so,nx] that is the
+    mean over B*so*nx).  GradientTape differentiates through the inner tape; here: forward tangents
+    (jacobian_analytic) and their adjoint, w.r.t. the materialised per-sample weights pnet_out [B,po], then
+    pnet_backward -- the reference formulation.  NIFMultiScale only; x_index = coordinate columns.
+    Returns (loss, grads in Keras order, u, dudx)."""
+    assert spec.kind == KIND_MS
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    si, so, n, om = spec.si, spec.so, spec.n, spec.omega_s
+    seeds = [j - spec.pi for j in x_index]
+    assert all(0 <= d < si for d in seeds)
+    nx = len(seeds)
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + si]
+    pout, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    sl = spec.slices()
+    W = [pout[:, sl["w1"][0]:sl["w1"][1]].reshape(B, si, n)] + [pout[:, a:b].reshape(B, n, n) for (a, b) in sl["wh"]]
+    bv = [pout[:, sl["b1"][0]:sl["b1"][1]]] + [pout[:, a:b] for (a, b) in sl["bh"]]
+    Wl = pout[:, sl["wl"][0]:sl["wl"][1]].reshape(B, n, so)
+    bl = pout[:, sl["bl"][0]:sl["bl"][1]]
+    nl = len(W)                     # sine layers: first + hidden matrices
+    # ---- forward: primal h and tangents hd[d] -----------------------------------------------------
+    h = x
+    hd = [np.tile(np.eye(si, dtype=x.dtype)[d], (B, 1)) for d in seeds]
+    tape = []
+    blk_in = None
+    for l in range(nl):
+        a = om * _ein(h, W[l]) + bv[l]
+        ad = [om * _ein(v, W[l]) for v in hd]
+        sn, cs = np.sin(a), np.cos(a)
+        tape.append((h, hd, sn, cs, ad))
+        t, td = sn, [cs * v for v in ad]
+        if spec.s_res and l >= 1:
+            if (l - 1) % 2 == 0:
+                blk_in = (h, hd)
+                h, hd = t, td
+            else:
+                h = 0.5 * (blk_in[0] + t)
+                hd = [0.5 * (u0 + v) for u0, v in zip(blk_in[1], td)]
+        else:
+            h, hd = t, td
+    u = _ein(h, Wl) + bl
+    ud = [_ein(v, Wl) for v in hd]
+    J = np.stack(ud, axis=2)                                     # [B, so, nx]
+    # ---- loss ------------------------------------------------------------------------------------
+    w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
+    e = u - y
+    ej = J - np.asarray(dydx).reshape(B, so, nx)
+    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
+    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    # ---- adjoint ---------------------------------------------------------------------------------
+    gw = np.zeros((B, spec.po), dtype=u.dtype)
+    gWl = h[:, :, None] * g_u[:, None, :]
+    for v, g in zip(hd, g_ud):
+        gWl = gWl + v[:, :, None] * g[:, None, :]
+    gw[:, sl["wl"][0]:sl["wl"][1]] = gWl.reshape(B, -1)
+    gw[:, sl["bl"][0]:sl["bl"][1]] = g_u
+    lam = np.einsum("aij,aj->ai", Wl, g_u)
+    mu = [np.einsum("aij,aj->ai", Wl, g) for g in g_ud]
+    wslices = [sl["w1"]] + list(sl["wh"])
+    bslices = [sl["b1"]] + list(sl["bh"])
+    skip = None
+    for l in reversed(range(nl)):
+        hin, hdin, sn, cs, ad = tape[l]
+        if spec.s_res and l >= 1 and (l - 1) % 2 == 1:           # second layer of a block: h = .5 (u + t)
+            lam = 0.5 * lam
+            mu = [0.5 * m for m in mu]
+            skip = (lam, mu)
+        nu = [m * cs for m in mu]
+        da = lam * cs
+        for m, v in zip(mu, ad):
+            da = da - m * sn * v
+        gW = hin[:, :, None] * da[:, None, :]
+        for v, g in zip(hdin, nu):
+            gW = gW + v[:, :, None] * g[:, None, :]
+        gw[:, wslices[l][0]:wslices[l][1]] = (om * gW).reshape(B, -1)
+        gw[:, bslices[l][0]:bslices[l][1]] = da
+        if l > 0:
+            lam = om * np.einsum("aij,aj->ai", W[l], da)
+            mu = [om * np.einsum("aij,aj->ai", W[l], g) for g in nu]
+            if spec.s_res and (l - 1) % 2 == 0:                  # first layer of a block: add the skip path
+                lam = lam + skip[0]
+                mu = [m + s_ for m, s_ in zip(mu, skip[1])]
+    return loss, pnet_backward(spec, ws, ptape, gw), u, J
+
+
 def flatten(arrs):
     return np.concatenate([np.asarray(a).ravel() for a in arrs])
 

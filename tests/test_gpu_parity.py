@@ -382,3 +382,100 @@ def test_lbfgs_fine_tuning_reduces_loss():
     hist = tuner.minimize(rounds=3, max_iter=20)
     l1 = model.evaluate(x, y)
     assert l1 < l0 and len(hist) > 5 and abs(hist[-1] - l1) < 1e-4 * max(l1, 1e-8) + 1e-7
+
+
+# ---- Sobolev training (BASELINE config 5): JacobianLayer as a trained output -----------------------------
+SOB = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1"]
+
+
+@pytest.mark.parametrize("name", SOB)
+@pytest.mark.parametrize("weighted", [False, True])
+def test_sobolev_loss_and_grad_match_oracle(name, weighted):
+    """loss = mse(u, y) + w * mse(du/dx, g): forward tangents + their adjoint in one kernel (k_sob) against the
+    oracle's reference-formulation adjoint (itself pinned to torch double-backward in tests/test_oracle.py)."""
+    m, model, spec, ws, x, y, sw = _make(name)
+    B = x.shape[0]
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    rng = np.random.default_rng(11)
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    sample_weight = sw if weighted else None
+    wj = 0.05
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, wj, sample_weight)
+    x64 = x.astype(np.float64)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x64, y.astype(np.float64), g.astype(np.float64), xi, wj,
+                                             None if sample_weight is None else sample_weight.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    off = 0
+    for (nm, shp), r_ in zip(spec.param_shapes(), rg):
+        k = int(np.prod(shp))
+        got = grad[off:off + k].reshape(shp)
+        off += k
+        err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+        assert err < 3e-4, (nm, err)
+    # predict() of the two-output model
+    from nif_amd import JacobianLayer, SobolevModel
+    sm = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi))
+    u, J = sm.predict(x)
+    assert u.shape == (B, spec.so) and J.shape == (B, spec.so, len(xi))
+    assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
+
+
+def test_sobolev_single_seed_and_zero_weight_degenerates():
+    m, model, spec, ws, x, y, sw = _make("ms_64x2_mlp_pnet_r3")      # si = 2: differentiate w.r.t. the 2nd coordinate only
+    B = x.shape[0]
+    xi = [spec.pi + 1]
+    g = np.random.default_rng(2).uniform(-1, 1, size=(B, spec.so, 1)).astype(np.float32)
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.2, sw)
+    rl, rg, _, _ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi,
+                                           0.2, sw.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl)
+    assert _rel(grad, O.flatten(rg)) < 3e-4
+    # w = 0: the plain training step
+    l0, g0 = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.0, sw)
+    l1, g1 = m._engine.loss_and_grad(x, y, sw)
+    assert abs(l0 - l1) <= 1e-6 * abs(l1) and _rel(g0, g1.astype(np.float64)) < 1e-5
+    # plain step afterwards still right (stash geometry is shared)
+    l2, g2 = m._engine.loss_and_grad(x, y, sw)
+    assert l2 == l1 and np.array_equal(g1, g2)
+    # parameter columns / other classes are refused loudly
+    import nif_amd
+    with pytest.raises(nif_amd._lib.NifError):
+        m._engine.sobolev_loss_and_grad(x, y, g, [0], 0.2, sw)
+    m2, model2, spec2, ws2, x2, y2, sw2 = _make("nif_cfg1_32x2")
+    with pytest.raises(nif_amd._lib.NifError):
+        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], 1, 1), np.float32), [1], 0.2, None)
+
+
+def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
+    """Train u(t,x) on values AND du/dx of the closed-form travelling wave; both errors must drop, and the
+    derivative error must end lower than with value-only training on the same few points."""
+    import nif_amd
+    from nif_amd import JacobianLayer, SobolevModel
+    kind, cs, cp = _cfg("NIFMultiScale", 32, 2, 16, 1, 1, 1, 1, 1, omega=30.0)
+    rng = np.random.default_rng(0)
+    N = 512
+    t = rng.uniform(-1, 1, size=N); xx = rng.uniform(-1, 1, size=N)
+    c, x0, om = 0.6, 0.2, 4.0   # u = exp(-50 s^2) sin(om s), s = x - x0 - c t   (normalised units)
+    s_ = xx - x0 - c * t
+    u = np.exp(-50 * s_ ** 2) * np.sin(om * s_)
+    dudx = np.exp(-50 * s_ ** 2) * (om * np.cos(om * s_) - 100 * s_ * np.sin(om * s_))
+    X = np.stack([t, xx], 1).astype(np.float32)
+    Y = u[:, None].astype(np.float32)
+    G = dudx[:, None, None].astype(np.float32)
+
+    def run(sobolev):
+        nif_amd.set_seed(3)
+        m = nif_amd.NIFMultiScale(cs, cp)
+        base = m.build()
+        sm = SobolevModel(JacobianLayer(base, [0], [1]))
+        sm.compile(nif_amd.Adam(2e-3), "mse", loss_weights=[1.0, 0.02 if sobolev else 0.0])
+        sm._shuffle_seed = 0
+        e0 = sm.evaluate(X, [Y, G])
+        h = sm.fit(X, [Y, G], batch_size=128, epochs=150, verbose=0)
+        uu, jj = sm.predict(X)
+        return e0, h.history["loss"], float(np.mean((uu - Y) ** 2)), float(np.mean((jj - G) ** 2))
+
+    e0, hist, mse_u, mse_j = run(True)
+    assert hist[-1] < 0.2 * hist[0], (hist[0], hist[-1])
+    _, _, mse_u_plain, mse_j_plain = run(False)
+    assert mse_j < mse_j_plain, (mse_j, mse_j_plain)

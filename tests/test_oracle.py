@@ -95,6 +95,30 @@ def test_jacobian_fd_vs_analytic_vs_autograd(name):
     assert np.allclose(Jp, tJ[:, :, :spec.pi], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres"])
+def test_sobolev_loss_and_grad_match_torch_double_backward(name):
+    """Sobolev step (JacobianLayer as a trained output): the oracle's hand-derived adjoint of the tangent
+    program against torch autograd through the input gradient, with and without sample weights."""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=7)
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    rng = np.random.default_rng(5)
+    dydx = rng.uniform(-1, 1, size=(7, spec.so, len(xi)))
+    for sample_weight in (None, sw):
+        loss, grads, u, J = O.sobolev_loss_and_grad(spec, ws, inputs, y, dydx, xi, 0.3, sample_weight)
+        tl, tg, tu, tJ = T.sobolev_loss_and_grad(kind, cs, cp, ws, inputs, y, dydx, xi, 0.3, sample_weight)
+        assert np.allclose(u, tu, rtol=1e-12, atol=1e-12) and np.allclose(J, tJ, rtol=1e-10, atol=1e-12)
+        assert abs(loss - tl) <= 1e-12 * max(1.0, abs(tl))
+        for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
+            assert t is not None, nm
+            assert np.abs(g - t).max() / max(np.abs(t).max(), 1e-30) < 1e-9, nm
+    # w_jac = 0 degenerates to the plain step
+    l0, g0, _, _ = O.sobolev_loss_and_grad(spec, ws, inputs, y, dydx, xi, 0.0, sw)
+    l1, g1 = O.loss_and_grad(spec, ws, inputs, y, sw)
+    assert abs(l0 - l1) < 1e-14 and all(np.allclose(a, b, rtol=1e-12, atol=1e-14) for a, b in zip(g0, g1))
+
+
 def test_jacobian_shape_contract_notebook4():
     # tutorial/4 cells 12-18: JacobianLayer output shapes (B, ny), (B, len(y_index), len(x_index))
     kind, cs, cp, spec, ws, inputs, y, sw = _setup("nif_tanh_r2_so2", B=10)

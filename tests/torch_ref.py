@@ -131,3 +131,24 @@ def jacobian(kind, cs, cp, ws_np, inputs_np):
         g, = torch.autograd.grad(u[:, i].sum(), inputs, retain_graph=True)
         rows.append(g)
     return u.detach().numpy(), torch.stack(rows, 1).numpy()
+
+
+def sobolev_loss_and_grad(kind, cs, cp, ws_np, inputs_np, y_np, dydx_np, x_index, w_jac, sw_np=None):
+    """What Keras does for Model(x, JacobianLayer(model, all, x_index)(x)) with loss_weights [1, w_jac]:
+    autograd THROUGH the input-gradient (double backward)."""
+    ws = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws_np]
+    inputs = torch.tensor(inputs_np, dtype=torch.float64, requires_grad=True)
+    y = torch.tensor(y_np, dtype=torch.float64)
+    g_t = torch.tensor(dydx_np, dtype=torch.float64)
+    u = forward(kind, cs, cp, ws, inputs)
+    rows = []
+    for i in range(u.shape[1]):
+        g, = torch.autograd.grad(u[:, i].sum(), inputs, create_graph=True)
+        rows.append(g[:, list(x_index)])
+    J = torch.stack(rows, 1)
+    per = ((u - y) ** 2).mean(dim=1) + w_jac * ((J - g_t.reshape(J.shape)) ** 2).mean(dim=(1, 2))
+    if sw_np is not None:
+        per = per * torch.tensor(sw_np, dtype=torch.float64)
+    loss = per.sum() / u.shape[0]
+    grads = torch.autograd.grad(loss, ws, allow_unused=True)
+    return (loss.item(), [g.numpy() if g is not None else None for g in grads], u.detach().numpy(), J.detach().numpy())
