@@ -1,0 +1,480 @@
+// k_snet4.hip -- k_snet3 with every n x n product on the BF16 matrix cores at fp32 accuracy.
+//
+// gfx950 runs v_mfma_f32_16x16x32_bf16 at 16x the rate of the f32-input MFMAs (1024 vs 64 FLOP/clk/SIMD).
+// An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 significand bits, same exponent range):
+//     x = x0 + x1 + x2 ,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+// and bf16 x bf16 products are exact in the fp32 accumulator, so
+//     a.b  =  a0b0 + (a0b1 + a1b0) + (a0b2 + a2b0 + a1b1) + O(2^-24 |a||b|)
+// Six MFMAs (small terms first) reproduce the fp32 product to 4.2e-8 rms / 4.3e-7 max of sum|a_k b_k| at K = 64 --
+// slightly BETTER than v_mfma_f32_16x16x4_f32 itself (6.1e-8 / 5.9e-7; tools/exp/bf16_split_mfma.hip, measured
+// on MI355X) -- in 6 x 16 = 96 matrix-pipe cycles per 16x16x32 block instead of 8 x 32 = 256.  The forward pass
+// (predictions and loss, 1e-5 bar) uses the 6-product form; the data adjoint, whose bar is the gradient
+// tolerance, the 3-product form (a0b0 + a0b1 + a1b0, 1.9e-6 rms) in 48 cycles.
+//
+// Weight planes are pre-split at pack time (k_pack16b) into bf16 A operands; the activation tile (B operand) is
+// split once per layer in registers and shared by all r+1 planes: the per-point latent factor zt_k is applied
+// to the PRODUCT (column scaling commutes with the GEMM).  Planes stream L2 -> LDS by DMA in K-step chunks
+// (32 input features x all outputs: NBL x 3 KiB forward, NBL x 2 KiB adjoint), double buffered, one barrier per
+// chunk -> 24 KiB of plane LDS per workgroup for the 64-wide net.
+//
+// Everything else (tiles, stashes, ring, first / last layer, loss, modes) is k_snet3's; see there.
+#include "k_snet3_dev.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef NIF_S4_OCC
+#define NIF_S4_OCC 3
+#endif
+
+// ---- packing ------------------------------------------------------------------------------------
+// K-slot (g, t), g = lane >> 4, t = 0..7 of K-step ks  <->  feature 16*(2ks + (t >> 2)) + 4g + (t & 3): exactly what a
+// lane of the previous layer's C/D tile holds in blocks 2ks, 2ks+1 -- the activation tile is the B operand as is.
+//   fwd chunk (plane, ks): unit ((ob*3 + s)*64 + lane), 8 bf16: split s of M[in = slot(ks,g,t)][out = 16ob + (lane&15)]
+//   bwd chunk (plane, ks): unit ((ib*2 + s)*64 + lane), 8 bf16: split s of M[in = 16ib + (lane&15)][out = slot(ks,g,t)]
+__global__ void k_pack16b(const float* __restrict__ theta, MatRef m, int NBL, __bf16* __restrict__ WF, __bf16* __restrict__ WB) {
+  const int NCH = NBL / 2;
+  const long fwd_plane = (long)NCH * NBL * 3 * 64 * 8, bwd_plane = (long)NCH * NBL * 2 * 64 * 8;
+  const long total_f = fwd_plane * (m.r + 1), total_b = bwd_plane * (m.r + 1);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
+    const bool fwd = idx < total_f;
+    const long e = fwd ? idx : idx - total_f;
+    const int ns = fwd ? 3 : 2;
+    const long per_plane = fwd ? fwd_plane : bwd_plane;
+    const int k = (int)(e / per_plane);
+    long rem = e - (long)k * per_plane;
+    const int t = rem & 7; rem >>= 3;
+    const int lane = rem & 63; rem >>= 6;
+    const int s = (int)(rem % ns); rem /= ns;
+    const int blk = (int)(rem % NBL);
+    const int ks = (int)(rem / NBL);
+    const int slot = 16 * (2 * ks + (t >> 2)) + 4 * (lane >> 4) + (t & 3);
+    const int row = 16 * blk + (lane & 15);
+    const int in = fwd ? slot : row, out = fwd ? row : slot;
+    const float x = (in < m.nin && out < m.nout) ? theta[matref_index(m, k, in, out)] : 0.f;
+    const __bf16 x0 = (__bf16)x;
+    const float r1 = x - (float)x0;
+    const __bf16 x1 = (__bf16)r1;
+    const __bf16 x2 = (__bf16)(r1 - (float)x1);
+    (fwd ? WF : WB)[e] = s == 0 ? x0 : (s == 1 ? x1 : x2);
+  }
+}
+void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st) {
+  const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m.r + 1);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pack16b, dim3(grid), dim3(256), 0, st, theta, m, NBL, (__bf16*)WF, (__bf16*)WB);
+}
+
+// ---- device helpers -------------------------------------------------------------------------------
+template <int NBL>
+__device__ __forceinline__ void split3(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2], bf16x8 (&s2)[NBL / 2]) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = h[2 * ks + (t >> 2)][t & 3];
+      const __bf16 x0 = (__bf16)x;
+      const float r1 = x - (float)x0;
+      const __bf16 x1 = (__bf16)r1;
+      s0[ks][t] = x0; s1[ks][t] = x1; s2[ks][t] = (__bf16)(r1 - (float)x1);
+    }
+}
+template <int NBL>
+__device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2]) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = h[2 * ks + (t >> 2)][t & 3];
+      const __bf16 x0 = (__bf16)x;
+      s0[ks][t] = x0; s1[ks][t] = (__bf16)(x - (float)x0);
+    }
+}
+// one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form
+template <int NBL>
+__device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ob = 0; ob < NBL; ++ob) {
+    const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], a1 = cur[(ob * 3 + 1) * 64 + lane], a2 = cur[(ob * 3 + 2) * 64 + lane];
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, T[ob], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, T[ob], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, T[ob], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ob], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ob], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+// one K-step chunk of an adjoint plane, 3-product form
+template <int NBL>
+__device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ib = 0; ib < NBL; ++ib) {
+    const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ib], 0, 0, 0);
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ib], 0, 0, 0);
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+#define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
+
+// MODE: 0 = plain (NIFMultiScale without resblock), 1 = SIREN resblock, 2 = NIF skip connection
+template <int NBL, bool TRAIN, int ACT, int MODE>
+__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNetArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 256, WAVES = 4;
+  constexpr int NCH = NBL / 2;                      // K-step chunks per plane
+  constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  constexpr int QF = (CF + NT - 1) / NT, QB = (CB + NT - 1) / NT;
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
+  const int FP = ((n + 31) / 32) * 32;
+  const long nt16 = 2 * ((A.B + 31) / 32);
+  const long ngroups = (nt16 + WAVES - 1) / WAVES;
+
+  bf16x8* chunks = reinterpret_cast<bf16x8*>(smem);            // 2 x CF units
+  float* sm = smem + 2 * CF * 4;
+  const int sm_tot = ((r + 1) * nsm + 3) & ~3;
+  float* dzs = sm + sm_tot + (long)wid * (2 * r * 64 + r * 16);
+  float* sks = dzs + r * 64;
+  float* zs = sks + r * 64;
+  float* lsum = sm + sm_tot + (long)WAVES * (2 * r * 64 + r * 16);
+  constexpr int NP = 16 * NBL;
+  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
+
+  const int NPL = nh * (r + 1);
+  const int nfwd = NPL * NCH;
+  const int nchunks = TRAIN ? 2 * nfwd : nfwd;
+  const bf16x8* WF = reinterpret_cast<const bf16x8*>(A.WF4);
+  const bf16x8* WB = reinterpret_cast<const bf16x8*>(A.WB4);
+  auto chunk_src = [&](int i) -> const bf16x8* {
+    if (i < nfwd) return WF + (long)i * CF;
+    const int ii = i - nfwd;
+    const int pp = ii / NCH, ks = ii - pp * NCH;
+    const int j = nh - 1 - pp / (r + 1), k = pp % (r + 1);
+    return WB + (((long)j * (r + 1) + k) * NCH + ks) * CB;
+  };
+  auto dma = [&](int i, int buf) {
+    const bf16x8* src = chunk_src(i);
+    bf16x8* dst = chunks + buf * CF;
+    const bool fwd = i < nfwd;
+#pragma unroll
+    for (int q = 0; q < QF; ++q)
+      if (wid * 64 + NT * q < (fwd ? CF : CB))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + NT * q),
+                                         (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
+  };
+  {
+    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
+      const int k = idx / nsm, e = idx - k * nsm;
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
+    }
+    if (nchunks > 0) dma(0, 0);
+  }
+  __syncthreads();
+  int gpar = 0;
+  float loss_lane = 0.f;
+  float* dring = TRAIN ? A.dring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (NBL * 256) : nullptr;
+  float* IN0 = A.stash;
+  float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
+
+// one chunk step: start the DMA of the next chunk into the other buffer, compute on the current one, barrier
+// (hipcc drains the DMA with s_waitcnt vmcnt(0) in front of the barrier)
+#define NIF_CHUNK(...)                                                        \
+  {                                                                           \
+    if ((cc + 1 < nchunks) || !last_group) dma(cc + 1 < nchunks ? cc + 1 : 0, (gpar + 1) & 1); \
+    const bf16x8* cur = chunks + (gpar & 1) * CF;                             \
+    __VA_ARGS__                                                               \
+    __syncthreads();                                                          \
+    ++gpar; ++cc;                                                             \
+  }
+
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+    const bool last_group = tg + gridDim.x >= ngroups;
+    const long t16_raw = tg * WAVES + wid;
+    const bool active = t16_raw < nt16;
+    const long t16 = active ? t16_raw : nt16 - 1;
+    const long tile32 = t16 >> 1;
+    const int poff = 16 * (int)(t16 & 1) + p;
+    const long pt = t16 * 16 + p;
+    const bool valid = active && pt < A.B;
+    const long ptc = pt < A.B ? pt : A.B - 1;
+    const float* xrow = A.xin + ptc * A.ncol + A.col0;
+    if (g == 0)
+      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+    const float* zt_base = zs + p;
+    const long row0 = tile32 * (long)FP * 32 + poff;
+    if (TRAIN)
+      for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
+
+    f32x4 h[NBL], acc[NBL];
+    // ---- first layer ---------------------------------------------------------------------------
+    ZERO_T(acc)
+    for (int k = 0; k <= r; ++k) {
+      const float zt = k < r ? zt_base[k * 16] : 1.0f;
+      const float* s0 = sm + k * nsm + 4 * g;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+      }
+    }
+    {
+      f32x4 d[NBL];
+      act16<NBL, ACT>(A.act, acc, h, d, n, g);
+      if (TRAIN) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) reinterpret_cast<f32x4*>(dring)[b * 64 + lane] = d[b];
+      }
+    }
+    // ---- hidden hyper-matrices -------------------------------------------------------------------
+    int cc = 0;
+    f32x4 ublk[MODE == 1 ? NBL : 1];
+    for (int j = 0; j < nh; ++j) {
+      if (TRAIN && active) st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g);
+      bf16x8 b0[NCH], b1[NCH], b2[NCH];
+      split3<NBL>(h, b0, b1, b2);
+      ZERO_T(acc)
+      for (int k = 0; k <= r; ++k) {
+        if (k < r) {
+          f32x4 T[NBL];
+          ZERO_T(T)
+#pragma unroll
+          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
+          const float zt = zt_base[k * 16];
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
+      }
+      {
+        f32x4 d[NBL];
+        act16<NBL, ACT>(A.act, acc, acc, d, n, g);
+        if (TRAIN) {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) reinterpret_cast<f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane] = d[b];
+        }
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) h[b] = acc[b];
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) h[b] += acc[b];
+      } else {
+        if (!(j & 1)) {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) { ublk[b] = h[b]; h[b] = acc[b]; }
+        } else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) h[b] = 0.5f * (ublk[b] + acc[b]);
+        }
+      }
+    }
+    // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
+    if (TRAIN && active) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
+    f32x4 gh[NBL];
+    ZERO_T(gh)
+    const float wsamp = (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f);
+    float se = 0.f;
+    for (int o = 0; o < so; ++o) {
+      f32x4 wg[NBL];
+      ZERO_T(wg)
+      float part = 0.f, bias = 0.f;
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+        const float* s0 = sm + k * nsm;
+        float sk = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          if (TRAIN) wg[b] += zt * w;
+        }
+        part = fmaf(zt, sk, part);
+        bias = fmaf(zt, s0[o_bl + o], bias);
+        if (TRAIN && k < r) sks[k * 64 + lane] = sk;
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      const float uo = part + bias;
+      if (valid && g == 0 && A.u_out) A.u_out[pt * so + o] = uo;
+      if (TRAIN) {
+        const float e = uo - A.y[ptc * so + o];
+        se = fmaf(e, e, se);
+        const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
+        for (int k = 0; k < r; ++k) {
+          float t = du * sks[k * 64 + lane];
+          if (g == 0) t = fmaf(du, sm[k * nsm + o_bl + o], t);
+          dzs[k * 64 + lane] += t;
+        }
+      }
+    }
+    if (TRAIN) {
+      if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+      // ---- adjoint through the hidden hyper-matrices --------------------------------------------
+      f32x4 skip[MODE == 0 ? 1 : NBL];
+      f32x4 dnext[NBL], hin[NBL];
+      for (int j = nh - 1; j >= 0; --j) {
+        f32x4 ga[NBL];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane];
+        if (MODE == 1 && (j & 1)) {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) { skip[b] = 0.5f * gh[b]; ga[b] = dnext[b] * skip[b]; }
+        } else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+          if (MODE == 2) {
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
+          }
+        }
+        if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
+        bf16x8 b0[NCH], b1[NCH];
+        split2<NBL>(ga, b0, b1);
+        ZERO_T(gh)
+        for (int k = 0; k <= r; ++k) {
+          if (k < r) {
+            f32x4 U[NBL];
+            ZERO_T(U)
+#pragma unroll
+            for (int ks = 0; ks < NCH; ++ks)
+              NIF_CHUNK({
+                mfma_x3<NBL>(cur, b0[ks], b1[ks], U, lane);
+                if (ks == 0) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
+              })
+            const float zt = zt_base[k * 16];
+            const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+            float s = 0.f, sbv = 0.f;
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) {
+              gh[b] += zt * U[b];
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                s = fmaf(hin[b][v], U[b][v], s);
+                sbv = fmaf(ga[b][v], bb[v], sbv);
+              }
+            }
+            dzs[k * 64 + lane] += fmaf(A.omega, s, sbv);
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL>(cur, b0[ks], b1[ks], gh, lane); })
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          gh[b] *= A.omega;
+          if (MODE == 2 || (MODE == 1 && !(j & 1))) gh[b] += skip[b];
+        }
+      }
+      // ---- first layer ---------------------------------------------------------------------------
+      {
+        f32x4 ga[NBL];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[b * 64 + lane];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+        if (active) st_store16<NBL>(DA0, row0, ga, g);
+        for (int k = 0; k < r; ++k) {
+          const float* s0 = sm + k * nsm + 4 * g;
+          float s = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            f32x4 xw = {0.f, 0.f, 0.f, 0.f};
+            for (int dd = 0; dd < si; ++dd) xw += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+            const f32x4 t = A.omega * xw + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+            s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
+          }
+          float tot = dzs[k * 64 + lane] + s;
+          tot += __shfl_xor(tot, 16);
+          tot += __shfl_xor(tot, 32);
+          if (active && g == 0) A.DZ[(tile32 * r + k) * 32 + poff] = tot;
+        }
+      }
+    }
+  }
+#undef NIF_CHUNK
+  if (TRAIN) {
+    for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
+    if (lane == 0) lsum[wid] = loss_lane;
+    __syncthreads();
+    if (tid == 0) A.loss_partial[blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static size_t snet4_shmem(const SNetArgs& a, int NBL) {
+  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + (size_t)4 * (2 * a.r * 64 + a.r * 16) + 8) * sizeof(float);
+}
+bool snet4_supported(const SNetArgs& a) {
+  const int NBL = snet3_nbl(a.n);
+  if (a.n > 128 || (NBL & 1) || a.nh < 1) return false;
+  return snet4_shmem(a, NBL) <= 160u * 1024u;
+}
+// bf16 elements of the packed forward / adjoint planes of ONE hidden hyper-matrix (all r+1 planes)
+long snet4_fwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 3 * 64 * 8 * (r + 1); }
+long snet4_bwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 2 * 64 * 8 * (r + 1); }
+
+int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st) {
+  const int NBL = snet3_nbl(a.n);
+  const long nt16 = 2 * ((a.B + 31) / 32);
+  const long ngroups = (nt16 + 3) / 4;
+  const long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256;
+  const int nblk = (int)(ngroups < cap ? ngroups : cap);
+  if (query_only) return nblk;
+  dim3 grid(nblk), block(256);
+  const size_t shm = snet4_shmem(a, NBL);
+#define S4L(NBL_, TR_, ACT_, MODE_)                                                                                 \
+  {                                                                                                                 \
+    if (shm > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shm);                                                                          \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_>), grid, block, shm, st, a);                                 \
+  }
+#define S4(NBL_)                                                            \
+  if (a.nif_skip) {                                                         \
+    if (train) S4L(NBL_, true, -1, 2) else S4L(NBL_, false, -1, 2)          \
+  } else if (a.res) {                                                       \
+    if (train) S4L(NBL_, true, ACT_SINE, 1) else S4L(NBL_, false, ACT_SINE, 1) \
+  } else {                                                                  \
+    if (train) S4L(NBL_, true, ACT_SINE, 0) else S4L(NBL_, false, ACT_SINE, 0) \
+  }
+  switch (NBL) {
+    case 2: S4(2) break;
+    case 4: S4(4) break;
+    case 6: S4(6) break;
+    default: S4(8) break;
+  }
+#undef S4
+#undef S4L
+  return nblk;
+}

@@ -2,6 +2,7 @@
 // orchestration.  gfx950 only; there is no CPU fallback.
 #include "../../include/nif_hip.h"
 #include "nif_internal.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdio>
@@ -36,7 +37,8 @@ struct nif_ctx {
   // device state
   float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
   long step = 0;
-  bool have_params = false, packed = false, use_snet3 = false;
+  bool have_params = false, packed = false, use_snet3 = false, use_snet4 = false;
+  void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -195,6 +197,10 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&c->pWB, pk_p);
   if (e == hipSuccess) e = hipMalloc(&c->sWF, pk_s);
   if (e == hipSuccess) e = hipMalloc(&c->sWB, pk_s);
+  if (c->kind != NIF_KIND_LASTLAYER && nh > 0 && !(snet3_nbl(c->n) & 1) && c->n <= 128) {
+    if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, c->r) * 2);
+    if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, c->r) * 2);
+  }
   const size_t pk_l = (size_t)(nh > 0 ? nh : 1) * c->NB * c->NB * 256 * sizeof(f32x4);
   if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWF, pk_l);
   if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWB, pk_l);
@@ -212,7 +218,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -413,6 +419,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.Z = c->Z; a.WF = c->sWF; a.WB = c->sWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
+  a.WF4 = c->sWF4; a.WB4 = c->sWB4;
   a.dring = c->dring;
   a.tl = c->tl;
 }
@@ -446,11 +453,18 @@ static int ensure_packed(nif_ctx* c) {
   }
   SNetArgs probe; fill_snet(c, probe, nullptr, 0, 0, 32);
   c->use_snet3 = snet3_supported(probe);
+  // NIF_FP32_MFMA=1 in the environment keeps every product on the f32-input MFMAs (k_snet3) for A/B runs
+  static const bool fp32_only = [] { const char* e = getenv("NIF_FP32_MFMA"); return e && e[0] == '1'; }();
+  c->use_snet4 = c->use_snet3 && c->sWF4 && !fp32_only && snet4_supported(probe);
   const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
   for (int j = 0; j < c->nh; ++j) {
     const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
     f32x4* wf = c->sWF + (long)j * (c->r + 1) * plane_s;
     f32x4* wb = c->sWB + (long)j * (c->r + 1) * plane_s;
+    if (c->use_snet4)
+      launch_pack16b(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n),
+                     (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(c->n, c->r) * 2,
+                     (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(c->n, c->r) * 2, c->st);
     if (c->use_snet3) {
       launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
     } else {
@@ -482,7 +496,8 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
   sa.u_out = u;
   {
     ProfScope p_(c, NIF_PROF_SNET_FWD);
-    if (c->use_snet3) launch_snet3(sa, false, false, nullptr, c->st);
+    if (c->use_snet4) launch_snet4(sa, false, false, c->st);
+    else if (c->use_snet3) launch_snet3(sa, false, false, nullptr, c->st);
     else launch_snet(sa, c->NB, false, c->st);
   }
   HIPCHK(hipGetLastError());
@@ -777,7 +792,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
   } else if (c->use_snet3) {
     int waves = 4;
-    const int nblk = launch_snet3(sa, true, true, &waves, c->st);
+    const int nblk = c->use_snet4 ? launch_snet4(sa, true, true, c->st) : launch_snet3(sa, true, true, &waves, c->st);
     const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
@@ -786,7 +801,8 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     sa.dring = c->dring;
     nloss = nblk;
     ProfScope p_(c, NIF_PROF_SNET);
-    launch_snet3(sa, true, false, nullptr, c->st);
+    if (c->use_snet4) launch_snet4(sa, true, false, c->st);
+    else launch_snet3(sa, true, false, nullptr, c->st);
   } else {
     ProfScope p_(c, NIF_PROF_SNET);
     launch_snet(sa, c->NB, true, c->st);

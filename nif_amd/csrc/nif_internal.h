@@ -82,6 +82,7 @@ struct SNetArgs {
   float* dring;                           // k_snet3: per-wave ring for act'(a) (register-dump order)
   int nsm;                                // k_snet3: floats per k of the LDS copy of the small hyper-vectors
   long long* tl;                          // -DNIF_TIMELINE builds: s_memtime stamps of wave 0 of block 0
+  const void* WF4; const void* WB4;       // k_snet4: bf16-split planes (k_pack16b), per plane NCH chunks
 };
 // slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
 __host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }
@@ -122,6 +123,12 @@ void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
 // persistent, LDS-staged, 16-point-tile variant (k_snet3.hip).  launch_snet3 returns the number of
 // workgroups (query_only: without launching) and the waves per workgroup, for sizing dring / loss_partial.
 int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out, hipStream_t st);
+// bf16-split variant of k_snet3 (k_snet4.hip): fp32-exact 6-product forward, 3-product adjoint on the bf16 MFMA
+bool snet4_supported(const SNetArgs& a);
+long snet4_fwd_elems(int n, int r);
+long snet4_bwd_elems(int n, int r);
+void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st);
+int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
