@@ -14,6 +14,11 @@
 // (nif/layers/mlp.py:219, nif/model.py:253-300 StridedSliceGrad + AddN; SURVEY a-10).
 #include "nif_internal.h"
 
+#ifndef NIF_GW_BF16
+#define NIF_GW_BF16 1
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // sum a per-lane value over the 4 waves of the block (deterministic order), result valid on wave 0
@@ -72,6 +77,52 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
         else { zq[kk][q][0] = 1.f; zq[kk][q][1] = 1.f; zq[kk][q][2] = 1.f; zq[kk][q][3] = 1.f; }
       }
   };
+#if NIF_GW_BF16
+  // the K = batch GEMM on the bf16 matrix cores: both operands split into bf16 hi + lo, three products
+  // (hi*hi + hi*lo + lo*hi, 1.9e-6 rms of sum|a b| -- well inside the fp32 re-association noise of a sum over
+  // 10^6 points); v_mfma_f32_32x32x16_bf16 takes 8 consecutive points per lane: the two halves of a lane's 16
+  auto compute_tile = [&](long t, const f32x4 (&af)[NBI][4], const f32x4 (&bf)[OBC][4], const f32x4 (&zq)[KC][4]) {
+    const bool wbias = t < A.bias_ntiles;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      bf16x8 bh[OBC], bl[OBC];
+#pragma unroll
+      for (int ob = 0; ob < OBC; ++ob)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
+          const __bf16 x0 = (__bf16)x;
+          bh[ob][e] = x0; bl[ob][e] = (__bf16)(x - (float)x0);
+        }
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        if (k0 + kk > A.r) break;
+#pragma unroll
+        for (int ib = 0; ib < NBI; ++ib) {
+          bf16x8 ah, al;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = af[ib][2 * hh + (e >> 2)][e & 3] * zq[kk][2 * hh + (e >> 2)][e & 3];
+            const __bf16 x0 = (__bf16)x;
+            ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
+          }
+#pragma unroll
+          for (int ob = 0; ob < OBC; ++ob) {
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ob], acc[kk][ib][ob], 0, 0, 0);
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 2 * hh; q < 2 * hh + 2; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(wbias ? zq[kk][q][c] : 0.f, bf[ob][q][c], bacc[kk][ob]);
+      }
+    }
+  };
+#else
   auto compute_tile = [&](long t, const f32x4 (&af)[NBI][4], const f32x4 (&bf)[OBC][4], const f32x4 (&zq)[KC][4]) {
     const bool wbias = t < A.bias_ntiles;   // tangent pseudo-tiles (Sobolev) carry no bias gradient
 #pragma unroll
@@ -94,6 +145,7 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
         }
     }
   };
+#endif
   {
     f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4], af1[NBI][4], bf1[OBC][4], zq1[KC][4];
     long t = (long)blockIdx.x * 4 + wid;

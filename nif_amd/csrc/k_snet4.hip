@@ -185,6 +185,12 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
   }
   __syncthreads();
   int gpar = 0;
+  int tlc = 0; (void)tlc;
+#ifdef NIF_TIMELINE
+#define NIF_TL(id) do { if (A.tl && blockIdx.x == 0 && tid == 0 && tlc < 250) { A.tl[2 * tlc] = (id); A.tl[2 * tlc + 1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
+#else
+#define NIF_TL(id) do { } while (0)
+#endif
   float loss_lane = 0.f;
   float* dring = TRAIN ? A.dring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (NBL * 256) : nullptr;
   float* IN0 = A.stash;
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
 
+    NIF_TL(1);
     f32x4 h[NBL], acc[NBL];
     // ---- first layer ---------------------------------------------------------------------------
     ZERO_T(acc)
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
         for (int b = 0; b < NBL; ++b) reinterpret_cast<f32x4*>(dring)[b * 64 + lane] = d[b];
       }
     }
+    NIF_TL(2);
     // ---- hidden hyper-matrices -------------------------------------------------------------------
     int cc = 0;
     f32x4 ublk[MODE == 1 ? NBL : 1];
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
       if (TRAIN && active) st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g);
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
+      NIF_TL(10 + j);
       ZERO_T(acc)
       for (int k = 0; k <= r; ++k) {
         if (k < r) {
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
           for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
         }
       }
+      NIF_TL(30 + j);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
       for (int k = 0; k <= r; ++k) {
@@ -294,6 +304,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
         }
       }
     }
+    NIF_TL(3);
     // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
     if (TRAIN && active) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
     f32x4 gh[NBL];
@@ -338,6 +349,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     }
     if (TRAIN) {
       if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+      NIF_TL(4);
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       f32x4 skip[MODE == 0 ? 1 : NBL];
       f32x4 dnext[NBL], hin[NBL];
@@ -359,6 +371,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
         if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
         bf16x8 b0[NCH], b1[NCH];
         split2<NBL>(ga, b0, b1);
+        NIF_TL(50 + j);
         ZERO_T(gh)
         for (int k = 0; k <= r; ++k) {
           if (k < r) {
@@ -389,12 +402,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
             for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL>(cur, b0[ks], b1[ks], gh, lane); })
           }
         }
+        NIF_TL(70 + j);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           gh[b] *= A.omega;
           if (MODE == 2 || (MODE == 1 && !(j & 1))) gh[b] += skip[b];
         }
       }
+      NIF_TL(5);
       // ---- first layer ---------------------------------------------------------------------------
       {
         f32x4 ga[NBL];
