@@ -160,16 +160,29 @@ def main():
         traffic, traffic_gw, tnote = None, None, None
         try:  # HBM traffic of the same kernels from the committed PMC run (bench.py cannot run rocprofv3 on itself)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = (2.0 * tj["k_snet3"]["FETCH_SIZE_KB"] + tj["k_snet3"]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["points"]
+            traffic = (2.0 * tj["snet"]["FETCH_SIZE_KB"] + tj["snet"]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["points"]
             traffic_gw = (2.0 * tj["k_given_w"]["FETCH_SIZE_KB"] + tj["k_given_w"]["WRITE_SIZE_KB"]) * 1024.0 \
                 * args.given_w_points / tj["k_given_w"]["points"]
             tnote = tj["source"] + "; " + tj["calibration"]
         except Exception:
             pass
-        roofline = {"kernel": "k_snet3<4,4,true,SINE,0> (ShapeNet fwd + MSE + data adjoint, 16x16x4 fp32 MFMA)", "bound": "mfma",
-                    "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+        # the fused kernel's n x n products run on the bf16 matrix cores as exact 3-way splits of the fp32 operands
+        # (k_snet4.hip: 6 bf16 products per fp32 product forward, 3 in the adjoint): `achieved` is the ALGORITHMIC
+        # fp32 work per second, priced against the fp32 MFMA peak as the survey prescribes; the bf16
+        # flops actually executed and the stash traffic are given next to it
+        nbl_even = (((s.n_sx + 15) // 16) % 2) == 0
+        exec_bf16 = (6.0 + 3.0) * 2.0 * (s.pi_hidden + 1) * (s.n_hidden_mats * s.n_sx ** 2) * B if nbl_even else 0.0
+        stash_bytes = 4.0 * 32 * ((s.n_sx + 31) // 32) * (2 * (s.n_hidden_mats + 1) + s.n_hidden_mats) * B   # h, dL/da written; h re-read
+        sn_s = kern_ms["snet"] * 1e-3
+        roofline = {"kernel": "k_snet4<4,true,SINE,0> (ShapeNet fwd + MSE + data adjoint; fp32 products as bf16 splits on "
+                              "v_mfma_f32_16x16x32_bf16)" if nbl_even else "k_snet3 (16x16x4 fp32 MFMA)",
+                    "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, scaled to this batch)",
-                    "traffic_note": tnote, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w}
+                    "traffic_note": tnote, "avg_ms": kern_ms["snet"], "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w,
+                    "executed_bf16_TFLOPs": exec_bf16 / sn_s / 1e12 if sn_s > 0 else 0.0,
+                    "frac_of_bf16_mfma_peak_2500": exec_bf16 / sn_s / 1e12 / 2500.0 if sn_s > 0 else 0.0,
+                    "stash_GBs": stash_bytes / sn_s / 1e9 if sn_s > 0 else 0.0,
+                    "stash_frac_of_hbm_8000": stash_bytes / sn_s / 1e9 / HBM_PEAK_GBS if sn_s > 0 else 0.0}
         # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
         Bw = args.given_w_points
         rng = np.random.default_rng(7)
