@@ -33,14 +33,29 @@ __device__ __forceinline__ float block_sum4(float v, float* red /*[3*64]*/, int 
 // ------------------------------------------------------------------------------------------
 // n x n blocks on the matrix cores.  grid = (rows, ceil((r+1)/KC), NBO/OBC)
 // ------------------------------------------------------------------------------------------
-template <int NBI, int OBC, int KC>
-__global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
-  __shared__ float red[3 * 64];
+// sum a per-lane value over the WV waves of the block (fixed order), result valid on wave 0
+template <int WV>
+__device__ __forceinline__ float block_sum(float v, float* red /*[(WV-1)*64]*/, int wid, int lane) {
+  if (wid > 0) red[(wid - 1) * 64 + lane] = v;
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int w = 0; w < WV - 1; ++w) v += red[w * 64 + lane];
+  }
+  __syncthreads();
+  return v;
+}
+
+// WV waves per workgroup: with the bf16 path the kernel is a stream of loads + VALU splits + few MFMAs, and two
+// 256-register waves per SIMD overlap one wave's splitting with the other's loads
+template <int NBI, int OBC, int KC, int WV>
+__global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
+  __shared__ float red[(WV - 1) * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const int k0 = blockIdx.y * KC;
   const int ob0 = blockIdx.z * OBC;
-  const long nwaves = (long)gridDim.x * 4;
+  const long nwaves = (long)gridDim.x * WV;
   const long FI = (long)NBI * 32 * 32, FO = (long)NBO * 32 * 32;
 
   f32x16 acc[KC][NBI][OBC];
@@ -146,9 +161,16 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
     }
   };
 #endif
-  {
+  if (WV > 4) {
+    // two waves per SIMD: the partner wave hides the load latency, one register set is enough
+    f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4];
+    for (long t = (long)blockIdx.x * WV + wid; t < A.ntiles; t += nwaves) {
+      load_tile(t, af0, bf0, zq0);
+      compute_tile(t, af0, bf0, zq0);
+    }
+  } else {
     f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4], af1[NBI][4], bf1[OBC][4], zq1[KC][4];
-    long t = (long)blockIdx.x * 4 + wid;
+    long t = (long)blockIdx.x * WV + wid;
     if (t < A.ntiles) load_tile(t, af0, bf0, zq0);
     while (t < A.ntiles) {
       const long t1 = t + nwaves;
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
       for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = block_sum4(acc[kk][ib][ob][e], red, wid, lane);
+          const float v = block_sum<WV>(acc[kk][ib][ob][e], red, wid, lane);
           const int in = 32 * ib + fmap(e, hf), out = 32 * (ob0 + ob) + i;
           if (wid == 0 && k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v;
         }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(256) void k_gw_mfma(GwArgs A, int NBO) {
     for (int ob = 0; ob < OBC; ++ob) {
       float v = bacc[kk][ob];
       v += __shfl_xor(v, 32);
-      v = block_sum4(v, red, wid, lane);
+      v = block_sum<WV>(v, red, wid, lane);
       const int out = 32 * (ob0 + ob) + i;
       if (A.has_bias && wid == 0 && hf == 0 && k <= A.r && out < A.Bv.nout) prow[matref_index(A.Bv, k, 0, out)] = v;
     }
@@ -195,18 +217,22 @@ static GwArgs gw_fix(const GwArgs& in) {
   return a;
 }
 
+#ifndef NIF_GW_WAVES
+#define NIF_GW_WAVES 4   // 8 = two waves per SIMD, single-buffered: spills at 256 registers, slower
+#endif
 void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
-  dim3 block(256);
+  constexpr int WV = NIF_GW_WAVES;
+  dim3 block(64 * WV);
   if (NBI == 1 && NBO == 1) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
-    hipLaunchKernelGGL((k_gw_mfma<1, 1, 2>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<1, 1, 2, WV>), grid, block, 0, st, a, NBO);
   } else if (NBI == 2 && NBO == 2) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
-    hipLaunchKernelGGL((k_gw_mfma<2, 2, 2>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<2, 2, 2, WV>), grid, block, 0, st, a, NBO);
   } else if (NBI == 4 && NBO == 4) {
     dim3 grid(rows, a.r + 1, 2);
-    hipLaunchKernelGGL((k_gw_mfma<4, 2, 1>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<4, 2, 1, WV>), grid, block, 0, st, a, NBO);
   }
 }
 

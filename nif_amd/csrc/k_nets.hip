@@ -81,15 +81,29 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int p = lane & 31, hf = lane >> 5;
   const long ntiles = (A.B + 31) / 32;
-  const long tile = (long)blockIdx.x * 4 + wid;
-  if (tile >= ntiles) return;
-  long pt = tile * 32 + p;
-  const long ptc = pt < A.B ? pt : A.B - 1;
   const int nm = A.lst * (A.res ? 2 : 1);
   const long plane = (long)NB * NB * 256;  // f32x4 per packed matrix
+  extern __shared__ __attribute__((aligned(16))) float pn_lds[];   // [LL kind: 4 waves x r x 32][small vectors]
+  float* zl_lds = pn_lds;
+  const PSmall S = psmall_stage<NB>(A, pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0), threadIdx.x, 256);
+  __syncthreads();
+  for (long tile = (long)blockIdx.x * 4 + wid; tile < ntiles; tile += (long)gridDim.x * 4) {
+  long pt = tile * 32 + p;
+  const long ptc = pt < A.B ? pt : A.B - 1;
 
   f32x16 h[NB], d[NB], T[NB];
-  pnet_first<NB>(A, ptc, hf, h, d);
+  {
+    const float* prow = A.xin + ptc * A.ncol + A.col0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+      for (int dd = 0; dd < A.pi; ++dd) acc += prow[dd] * psmall_get(S.fw + dd * NB * 32, b, hf);
+      h[b] = A.omega * acc + psmall_get(S.fb, b, hf);
+    }
+    act_tile<NB>(A.act, h, h, d, A.nst, hf);
+  }
   if (TRAIN) stash_store<NB>(A.stash + (long)(nm + 1) * A.slot_stride, tile, d, p, hf);
 
   for (int i = 0; i < A.lst; ++i) {
@@ -98,12 +112,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       if (TRAIN) stash_store<NB>(A.stash + (long)i * A.slot_stride, tile, h, p, hf);
       dense_mfma<NB, NB>(A.WF + (long)i * plane, h, T, lane);
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int f = 32 * b + fmap(v, hf);
-          T[b][v] = f < A.nst ? A.omega * T[b][v] + A.theta[A.hid_b[i] + f] : 0.f;
-        }
+      for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
       act_tile<NB>(A.act, T, T, d, A.nst, hf);
 #pragma unroll
       for (int b = 0; b < NB; ++b) h[b] = A.siren ? T[b] : h[b] + T[b];
@@ -114,12 +123,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       if (TRAIN) stash_store<NB>(A.stash + (long)(2 * i) * A.slot_stride, tile, h, p, hf);
       dense_mfma<NB, NB>(A.WF + (long)(2 * i) * plane, h, T, lane);
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int f = 32 * b + fmap(v, hf);
-          T[b][v] = f < A.nst ? A.omega * T[b][v] + A.theta[A.hid_b[i] + f] : 0.f;
-        }
+      for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
       act_tile<NB>(A.act, T, t, d, A.nst, hf);
       if (TRAIN) {
         stash_store<NB>(A.stash + (long)(nm + 2 + 2 * i) * A.slot_stride, tile, d, p, hf);
@@ -127,13 +131,10 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       }
       dense_mfma<NB, NB>(A.WF + (long)(2 * i + 1) * plane, t, T, lane);
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int f = 32 * b + fmap(v, hf);
-          const float lin = f < A.nst ? A.omega * T[b][v] + A.theta[A.hid_b2[i] + f] : 0.f;
-          T[b][v] = A.siren ? lin : h[b][v] + lin;
-        }
+      for (int b = 0; b < NB; ++b) {
+        const f32x16 lin = A.omega * T[b] + psmall_get(S.hb2 + i * NB * 32, b, hf);
+        T[b] = A.siren ? lin : h[b] + lin;
+      }
       act_tile<NB>(A.act, T, T, d, A.nst, hf);
 #pragma unroll
       for (int b = 0; b < NB; ++b) h[b] = A.siren ? 0.5f * (h[b] + T[b]) : T[b];
@@ -142,17 +143,15 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   }
   if (TRAIN) stash_store<NB>(A.stash + (long)nm * A.slot_stride, tile, h, p, hf);
   // bottleneck (linear, nst -> r): per-lane partial dot products + one cross-half exchange
-  extern __shared__ float zl_lds[];   // LL kind only: [4 waves][r][32]
   float* zl = zl_lds + (long)wid * A.r * 32;
   for (int c = 0; c < A.r; ++c) {
     float s = 0.f;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+      const f32x16 w = psmall_get(S.bw + c * NB * 32, b, hf);
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int f = 32 * b + fmap(v, hf);
-        if (f < A.nst) s = fmaf(h[b][v], A.theta[A.bott_w + (long)f * A.r + c], s);
-      }
+      for (int v = 0; v < 16; ++v) s = fmaf(h[b][v], w[v], s);
+    }
     s += __shfl_xor(s, 32);
     s += A.theta[A.bott_b + c];
     if (A.ll_kind) {
@@ -168,6 +167,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       for (int kk = 0; kk < A.r; ++kk) s = fmaf(zl[kk * 32 + p], A.theta[A.last_w + (long)kk * A.r + c], s);
       A.Z[(tile * A.r + c) * 32 + p] = s;
     }
+  }
   }
 }
 
@@ -239,8 +239,10 @@ __global__ __launch_bounds__(256) void k_pnet_bwd(PNetArgs A) {
 
 void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st) {
   const long ntiles = (a.B + 31) / 32;
-  dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-  const size_t shm = a.ll_kind ? (size_t)4 * a.r * 32 * sizeof(float) : 0;
+  long nblk = (ntiles + 3) / 4;
+  if (nblk > 2048) nblk = 2048;          // persistent: the small vectors are staged in LDS once per workgroup
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t shm = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)psmall_floats(a, NSTB)) * sizeof(float);
 #define PN(NB_) \
   if (train) hipLaunchKernelGGL((k_pnet<NB_, true>), grid, block, shm, st, a); \
   else hipLaunchKernelGGL((k_pnet<NB_, false>), grid, block, shm, st, a);

@@ -1,0 +1,252 @@
+// k_pnetbw.hip -- ParameterNet adjoint AND its weight gradients in one pass, without any HBM stash.
+//
+// The ParameterNet is tiny (2 x 32 in the benchmark config) but, run as forward-with-stash + adjoint + four
+// gradient-reduction launches, it moved 2.3 KB per point through HBM -- a quarter of the whole step's time
+// for 2 % of its arithmetic.  Here every wave recomputes the forward pass of its 32-point tile from the 4-12
+// input bytes, keeps each layer input in a PRIVATE LDS copy of the stash tile ([feature][32 points], the
+// layout the K = batch gradient GEMM wants: a lane reads 16 consecutive points of one feature), runs the
+// adjoint in registers and accumulates dL/dW of every layer in MFMA accumulators that live for the whole
+// kernel.  HBM traffic: the input columns, dL/dz (4r bytes) -- and one partial-gradient row per workgroup.
+//
+// Built for nst <= 32 (one 32-feature block) and at most two hidden matrices (two Dense / SIREN layers, or
+// one MLP_ResNet / SIREN_ResNet block); everything else takes the stash path (k_nets.hip + k_gw.hip).
+// Same math as k_pnet / k_pnet_bwd (reference nif/layers/mlp.py:62-79, :148-160, siren.py:256-281, :381-410).
+#include "nif_internal.h"
+
+struct PbwArgs {
+  PNetArgs p;
+  float* partial; long pstride;   // partial[row * pstride + theta index], row = blockIdx.x
+};
+
+__device__ __forceinline__ f32x4 lds4(const float* q) { return *reinterpret_cast<const f32x4*>(q); }
+
+// C[in][out] += sum_p IN[p][in] * DA[p][out] over the 32 points of the tile; IN, DA are LDS tiles [feature][32]
+__device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x16& C, int i, int hf) {
+  f32x4 a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = lds4(IN + i * 32 + 16 * hf + 4 * q); b[q] = lds4(DA + i * 32 + 16 * hf + 4 * q); }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) C = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], C, 0, 0, 0);
+}
+// column sums of a DA tile: lane (i, hf) -> sum over its 16 points of feature i (other half via shfl)
+__device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const f32x4 b = lds4(DA + i * 32 + 16 * hf + 4 * q); s += (b[0] + b[1]) + (b[2] + b[3]); }
+  return s;
+}
+
+#ifndef NIF_PBW_WAVES
+#define NIF_PBW_WAVES 4
+#endif
+template <int NM, bool RES>
+__global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
+  const PNetArgs& A = G.p;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WV = NIF_PBW_WAVES;
+  __shared__ float red[(WV - 1) * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int p = lane & 31, hf = lane >> 5, i = p;
+  const long ntiles = (A.B + 31) / 32;
+  constexpr int WLDS = (NM + 2) * 1024 + 256;      // floats of LDS per wave
+  float* hs = lds + (long)wid * WLDS;              // NM+1 layer-input tiles, then the dL/da tile and the X tile
+  float* gaT = hs + (NM + 1) * 1024;
+  float* xT = gaT + 1024;                          // [8 rows: the pi <= 6 inputs, then ones, rest zero][32]
+  const long plane = 256;                           // f32x4 per packed 32x32 matrix
+
+  f32x16 C[NM], C1, Cb;
+  float gbh[NM], gb0 = 0.f, gbb = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { C1[e] = 0.f; Cb[e] = 0.f; }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    gbh[m] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) C[m][e] = 0.f;
+  }
+  for (int q = lane; q < 256; q += 64) xT[q] = 0.f;
+  const PSmall S = psmall_stage<1>(A, lds + (long)WV * WLDS, threadIdx.x, 64 * WV);
+  __syncthreads();
+
+  for (long tile = (long)blockIdx.x * WV + wid; tile < ntiles; tile += (long)gridDim.x * WV) {
+    const long pt = tile * 32 + p;
+    const long ptc = pt < A.B ? pt : A.B - 1;
+    const float* prow = A.xin + ptc * A.ncol + A.col0;
+    // ---- forward (recomputed), layer inputs into the private LDS stash ---------------------------
+    f32x16 h[1], T[1], d[NM + 1][1];
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+      for (int dd = 0; dd < A.pi; ++dd) acc += prow[dd] * psmall_get(S.fw + dd * 32, 0, hf);
+      h[0] = A.omega * acc + psmall_get(S.fb, 0, hf);
+    }
+    act_tile<1>(A.act, h, h, d[0], A.nst, hf);
+    if (hf == 0) {
+      for (int dd = 0; dd < A.pi; ++dd) xT[dd * 32 + p] = prow[dd];
+      xT[A.pi * 32 + p] = 1.0f;
+    }
+    if (!RES) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        stash_store<1>(hs + m * 1024, 0, h, p, hf);
+        dense_mfma<1, 1>(A.WF + (long)m * plane, h, T, lane);
+        T[0] = A.omega * T[0] + psmall_get(S.hb + m * 32, 0, hf);
+        act_tile<1>(A.act, T, T, d[m + 1], A.nst, hf);
+        h[0] = A.siren ? T[0] : h[0] + T[0];
+      }
+    } else {
+      f32x16 t[1];
+      stash_store<1>(hs, 0, h, p, hf);
+      dense_mfma<1, 1>(A.WF, h, T, lane);
+      T[0] = A.omega * T[0] + psmall_get(S.hb, 0, hf);
+      act_tile<1>(A.act, T, t, d[1], A.nst, hf);
+      stash_store<1>(hs + 1024, 0, t, p, hf);
+      dense_mfma<1, 1>(A.WF + plane, t, T, lane);
+      {
+        const f32x16 lin = A.omega * T[0] + psmall_get(S.hb2, 0, hf);
+        T[0] = A.siren ? lin : h[0] + lin;
+      }
+      act_tile<1>(A.act, T, T, d[NM], A.nst, hf);
+      h[0] = A.siren ? 0.5f * (h[0] + T[0]) : T[0];
+    }
+    stash_store<1>(hs + NM * 1024, 0, h, p, hf);
+    // ---- bottleneck: dL/dW_b[f][c] = sum_p h[p][f] dz_c[p]; gh[f] = sum_c dz_c W_b[f][c] -------------
+    f32x16 gh[1], ga[1], U[1];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) gh[0][v] = 0.f;
+    for (int c = 0; c < A.r; ++c) {
+      const float dz = A.DZ[(tile * A.r + c) * 32 + p];
+      gh[0] += dz * psmall_get(S.bw + c * 32, 0, hf);
+    }
+    {
+      // the dz tile in the B-operand layout: lane (j = c, hf) holds dz_c of 16 consecutive points
+      f32x4 a[4], b[4];
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = lds4(hs + NM * 1024 + i * 32 + 16 * hf + 4 * q);
+        if (i < A.r) b[q] = *reinterpret_cast<const f32x4*>(A.DZ + (tile * A.r + i) * 32 + 16 * hf + 4 * q);
+        else { b[q][0] = 0.f; b[q][1] = 0.f; b[q][2] = 0.f; b[q][3] = 0.f; }
+        s += (b[q][0] + b[q][1]) + (b[q][2] + b[q][3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Cb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], Cb, 0, 0, 0);
+      gbb += s;
+    }
+    // ---- adjoint through the hidden matrices, gradient GEMMs on the way -----------------------------
+    if (!RES) {
+#pragma unroll
+      for (int m = NM - 1; m >= 0; --m) {
+        ga[0] = gh[0] * d[m + 1][0];
+        stash_store<1>(gaT, 0, ga, p, hf);
+        grad_mfma(hs + m * 1024, gaT, C[m], i, hf);
+        gbh[m] += col_sum(gaT, i, hf);
+        dense_mfma<1, 1>(A.WB + (long)m * plane, ga, U, lane);
+        gh[0] = A.siren ? A.omega * U[0] : gh[0] + A.omega * U[0];
+      }
+    } else {
+      const float half = A.siren ? 0.5f : 1.0f;
+      ga[0] = half * gh[0] * d[NM][0];
+      stash_store<1>(gaT, 0, ga, p, hf);
+      grad_mfma(hs + 1024, gaT, C[NM - 1], i, hf);
+      gbh[NM - 1] += col_sum(gaT, i, hf);
+      dense_mfma<1, 1>(A.WB + plane, ga, U, lane);
+      f32x16 skip;
+      skip = A.siren ? 0.5f * gh[0] : ga[0];
+      ga[0] = A.omega * U[0] * d[1][0];
+      stash_store<1>(gaT, 0, ga, p, hf);
+      grad_mfma(hs, gaT, C[0], i, hf);
+      gbh[0] += col_sum(gaT, i, hf);
+      dense_mfma<1, 1>(A.WB, ga, U, lane);
+      gh[0] = skip + A.omega * U[0];
+    }
+    // ---- first layer: dL/dW_1[d][f] = w0 sum_p x_d[p] da0[p][f] (rows of X^T), bias = column sums -----
+    ga[0] = gh[0] * d[0][0];
+    stash_store<1>(gaT, 0, ga, p, hf);
+    {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i < 8) a[q] = lds4(xT + i * 32 + 16 * hf + 4 * q);
+        else { a[q][0] = 0.f; a[q][1] = 0.f; a[q][2] = 0.f; a[q][3] = 0.f; }
+        b[q] = lds4(gaT + i * 32 + 16 * hf + 4 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], C1, 0, 0, 0);
+    }
+  }
+
+  // ---- workgroup reduction (fixed order) and this workgroup's partial row --------------------------------
+  float* prow_out = G.partial + (long)blockIdx.x * G.pstride;
+  auto sum8 = [&](float v) -> float {
+    if (wid > 0) red[(wid - 1) * 64 + lane] = v;
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+      for (int w = 0; w < WV - 1; ++w) v += red[w * 64 + lane];
+    }
+    __syncthreads();
+    return v;
+  };
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const long w_off = RES ? (m == 0 ? A.hid_w[0] : A.hid_w2[0]) : A.hid_w[m];
+    const long b_off = RES ? (m == 0 ? A.hid_b[0] : A.hid_b2[0]) : A.hid_b[m];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = sum8(C[m][e]);
+      const int in = fmap(e, hf), out = i;
+      if (wid == 0 && in < A.nst && out < A.nst) prow_out[w_off + (long)in * A.nst + out] = A.omega * v;
+    }
+    float vb = gbh[m];
+    vb += __shfl_xor(vb, 32);
+    vb = sum8(vb);
+    if (wid == 0 && hf == 0 && i < A.nst) prow_out[b_off + i] = vb;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float v1 = sum8(C1[e]);
+    const float vb = sum8(Cb[e]);
+    const int row = fmap(e, hf);
+    if (wid == 0) {
+      if (row < A.pi && i < A.nst) prow_out[A.first_w + (long)row * A.nst + i] = A.omega * v1;
+      if (row == A.pi && i < A.nst) prow_out[A.first_b + i] = v1;
+      if (row < A.nst && i < A.r) prow_out[A.bott_w + (long)row * A.r + i] = vb;
+    }
+  }
+  (void)gb0;
+  {
+    float v = gbb;
+    v += __shfl_xor(v, 32);
+    v = sum8(v);
+    if (wid == 0 && hf == 0 && i < A.r) prow_out[A.bott_b + i] = v;
+  }
+}
+
+bool pnet_bwg_supported(const PNetArgs& a) {
+  const int nm = a.lst * (a.res ? 2 : 1);
+  return a.nst <= 32 && a.pi <= 6 && a.r <= 32 && !a.ll_kind && nm >= 1 && nm <= 2 && (!a.res || a.lst == 1);
+}
+
+void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st) {
+  PbwArgs G; G.p = a; G.partial = partial; G.pstride = pstride;
+  const int nm = a.lst * (a.res ? 2 : 1);
+  dim3 grid(rows), block(64 * NIF_PBW_WAVES);
+  const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)psmall_floats(a, 1)) * sizeof(float);
+#define PBW(NM_, RES_)                                                                                              \
+  {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_pnet_bwg<NM_, RES_>), grid, block, shm, st, G);                                           \
+  }
+  if (a.res) PBW(2, true)
+  else if (nm == 1) PBW(1, false)
+  else PBW(2, false)
+#undef PBW
+}

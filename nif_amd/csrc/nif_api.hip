@@ -776,7 +776,11 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   const int ncol = c->pi + c->si;
   // forward + adjoint
   PNetArgs pa; fill_pnet(c, pa, xin, B);
-  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
+  // small ParameterNets: no stash -- the adjoint kernel recomputes the forward pass and reduces the weight
+  // gradients itself (k_pnetbw.hip).  NIF_PNET_STASH=1 forces the stash path (A/B runs, tests)
+  static const bool force_stash = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
+  const bool fused_p = !force_stash && pnet_bwg_supported(pa);
+  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
   int nloss = (int)((ntiles + 3) / 4);
@@ -807,12 +811,14 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     ProfScope p_(c, NIF_PROF_SNET);
     launch_snet(sa, c->NB, true, c->st);
   }
-  { ProfScope p_(c, NIF_PROF_PNET_BWD); launch_pnet_bwd(pa, c->NSTB, c->st); }
-  ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
   // weight gradients -> partial rows
   int rows = (int)((ntiles + 3) / 4);
   if (rows > c->rows_cap) rows = c->rows_cap;
   if (rows < 1) rows = 1;
+  { ProfScope p_(c, NIF_PROF_PNET_BWD);
+    if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st);
+    else launch_pnet_bwd(pa, c->NSTB, c->st); }
+  ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
   GwArgs g;
   auto base = [&](GwArgs& q) {
     memset(&q, 0, sizeof(q));
@@ -850,6 +856,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   }
   // ParameterNet: first, hidden matrices, bottleneck
   float* pST = c->stash_p;
+  if (!fused_p) {
   base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.r = 0; g.scale = om_p;
   g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
   launch_gw_first(g, c->NSTB, rows, c->st);
@@ -864,6 +871,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->DZ; g.nc = c->r; g.r = 0; g.scale = 1.0f;
   g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
   launch_gw_out(g, c->NSTB, rows, c->st);
+  }
   delete pgw;
   // rows -> flat gradient, loss
   ProfScope pr_(c, NIF_PROF_REDUCE);

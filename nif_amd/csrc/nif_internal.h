@@ -123,6 +123,10 @@ void launch_snet(const SNetArgs& a, int NB, bool train, hipStream_t st);
 // persistent, LDS-staged, 16-point-tile variant (k_snet3.hip).  launch_snet3 returns the number of
 // workgroups (query_only: without launching) and the waves per workgroup, for sizing dring / loss_partial.
 int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out, hipStream_t st);
+// ParameterNet adjoint + weight gradients without a stash (k_pnetbw.hip); writes the ParameterNet columns of
+// `rows` partial-gradient rows
+bool pnet_bwg_supported(const PNetArgs& a);
+void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st);
 // bf16-split variant of k_snet3 (k_snet4.hip): fp32-exact 6-product forward, 3-product adjoint on the bf16 MFMA
 bool snet4_supported(const SNetArgs& a);
 long snet4_fwd_elems(int n, int r);
@@ -243,14 +247,15 @@ __device__ __forceinline__ void act_eval(float a, float* h, float* d) {
   if (ACT == ACT_SINE) {
     nif_sincosf(a, h, d);
   } else if (ACT == ACT_SWISH) {
-    const float s = 1.0f / (1.0f + expf(-a));
+    // sigmoid on v_exp_f32 + v_rcp_f32 (1 ulp each; the IEEE division sequence is ~10 instructions)
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
     *h = a * s; *d = s * (1.0f + a * (1.0f - s));
   } else if (ACT == ACT_TANH) {
     const float t = tanhf(a); *h = t; *d = 1.0f - t * t;
   } else if (ACT == ACT_RELU) {
     *h = a > 0.f ? a : 0.f; *d = a > 0.f ? 1.f : 0.f;
   } else if (ACT == ACT_SIGMOID) {
-    const float s = 1.0f / (1.0f + expf(-a)); *h = s; *d = s * (1.0f - s);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-a)); *h = s; *d = s * (1.0f - s);
   } else if (ACT == ACT_ELU) {
     const float e = expf(fminf(a, 0.f)); *h = a > 0.f ? a : e - 1.0f; *d = a > 0.f ? 1.0f : e;
   } else if (ACT == ACT_SOFTPLUS) {
@@ -351,6 +356,44 @@ __device__ __forceinline__ void dense_mfma(const f32x4* __restrict__ Wp, const f
     }
     T[ob] = t;
   }
+}
+
+// LDS copies of the small ParameterNet vectors (first-layer rows, biases, bottleneck columns) in REGISTER-TILE
+// order: element ((b*2 + hf)*16 + v) = vec[(32b + fmap(v,hf)) * stride], zero beyond n -- a lane fetches its 16
+// features of a block with four ds_read_b128 instead of 16 dependent global loads per tile
+template <int NB>
+__device__ __forceinline__ void psmall_fill(float* dst, const float* __restrict__ src, int n, int stride, int tid, int nthreads) {
+  for (int e = tid; e < NB * 32; e += nthreads) {
+    const int b = e >> 5, hf = (e >> 4) & 1, v = e & 15;
+    const int f = 32 * b + fmap(v, hf);
+    dst[e] = f < n ? src[(long)f * stride] : 0.f;
+  }
+}
+__device__ __forceinline__ f32x16 psmall_get(const float* base, int b, int hf) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(base + (b * 2 + hf) * 16);
+  const f32x4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+  f32x16 r;
+  r[0] = a0[0]; r[1] = a0[1]; r[2] = a0[2]; r[3] = a0[3]; r[4] = a1[0]; r[5] = a1[1]; r[6] = a1[2]; r[7] = a1[3];
+  r[8] = a2[0]; r[9] = a2[1]; r[10] = a2[2]; r[11] = a2[3]; r[12] = a3[0]; r[13] = a3[1]; r[14] = a3[2]; r[15] = a3[3];
+  return r;
+}
+// all small vectors of a ParameterNet: [first_w: pi][first_b][hid_b: lst][hid_b2: lst (resblocks)][bott_w: r], NB*32 each
+struct PSmall { const float *fw, *fb, *hb, *hb2, *bw; };
+__host__ __device__ inline int psmall_floats(const PNetArgs& A, int NB) { return (A.pi + 1 + A.lst * (A.res ? 2 : 1) + A.r) * NB * 32; }
+template <int NB>
+__device__ __forceinline__ PSmall psmall_stage(const PNetArgs& A, float* lds, int tid, int nthreads) {
+  constexpr int S = NB * 32;
+  float* q = lds;
+  PSmall P;
+  P.fw = q; for (int dd = 0; dd < A.pi; ++dd) psmall_fill<NB>(q + dd * S, A.theta + A.first_w + (long)dd * A.nst, A.nst, 1, tid, nthreads);
+  q += A.pi * S;
+  P.fb = q; psmall_fill<NB>(q, A.theta + A.first_b, A.nst, 1, tid, nthreads); q += S;
+  P.hb = q; for (int i = 0; i < A.lst; ++i) psmall_fill<NB>(q + i * S, A.theta + A.hid_b[i], A.nst, 1, tid, nthreads);
+  q += A.lst * S;
+  P.hb2 = q;
+  if (A.res) { for (int i = 0; i < A.lst; ++i) psmall_fill<NB>(q + i * S, A.theta + A.hid_b2[i], A.nst, 1, tid, nthreads); q += A.lst * S; }
+  P.bw = q; for (int c = 0; c < A.r; ++c) psmall_fill<NB>(q + c * S, A.theta + A.bott_w + c, A.nst, A.r, tid, nthreads);
+  return P;
 }
 
 // ACT >= 0: activation fixed at compile time (the SIREN hot path); ACT < 0: runtime id
