@@ -74,6 +74,11 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 
   // register double buffering: the next tile's operands are in flight while the current tile feeds the
   // matrix cores (this kernel runs one wave per SIMD, so nothing else would hide the HBM latency)
+  const int zt_mod = (int)A.zt_mod, nt_all = (int)A.ntiles;
+  auto zmod = [&](long t) -> int {
+    const int ti = __builtin_amdgcn_readfirstlane((int)t);
+    return zt_mod >= nt_all ? ti : ti % zt_mod;
+  };
   auto load_tile = [&](long t, f32x4 (&af)[NBI][4], f32x4 (&bf)[OBC][4], f32x4 (&zq)[KC][4]) {
 #pragma unroll
     for (int ib = 0; ib < NBI; ++ib)
@@ -83,14 +88,17 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
     for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * (ob0 + ob) + i) * 32 + 16 * hf + 4 * q);
+    // unconditional loads (static s_waitcnt counts keep the next tile's prefetch in flight); k >= r reads a valid
+    // dummy row and is replaced by ones.  Tile index of the latent: t mod zt_mod in 32-bit scalar arithmetic
+    const int tz = zmod(t);
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk)
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = k0 + kk;
+      const int kz = k < A.r ? k : (A.r > 0 ? A.r - 1 : 0);
+      const float* zrow = A.Z + ((long)tz * A.r + kz) * 32 + 16 * hf;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = k0 + kk;
-        if (k < A.r) zq[kk][q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
-        else { zq[kk][q][0] = 1.f; zq[kk][q][1] = 1.f; zq[kk][q][2] = 1.f; zq[kk][q][3] = 1.f; }
-      }
+      for (int q = 0; q < 4; ++q) zq[kk][q] = ld4(zrow + 4 * q);   // k >= r: replaced by ones at use (compute_tile)
+    }
   };
 #if NIF_GW_BF16
   // the K = batch GEMM on the bf16 matrix cores: both operands split into bf16 hi + lo, three products
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
           bf16x8 ah, al;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float x = af[ib][2 * hh + (e >> 2)][e & 3] * zq[kk][2 * hh + (e >> 2)][e & 3];
+            const float x = af[ib][2 * hh + (e >> 2)][e & 3] * (k0 + kk < A.r ? zq[kk][2 * hh + (e >> 2)][e & 3] : 1.0f);
             const __bf16 x0 = (__bf16)x;
             ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
           }
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = fmaf(wbias ? zq[kk][q][c] : 0.f, bf[ob][q][c], bacc[kk][ob]);
+            for (int ob = 0; ob < OBC; ++ob)
+              bacc[kk][ob] = fmaf(wbias ? (k0 + kk < A.r ? zq[kk][q][c] : 1.0f) : 0.f, bf[ob][q][c], bacc[kk][ob]);
       }
     }
   };
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float zt = zq[kk][q][c];
+          const float zt = k0 + kk < A.r ? zq[kk][q][c] : 1.0f;
 #pragma unroll
           for (int ib = 0; ib < NBI; ++ib) {
             const float a = af[ib][q][c] * zt;
@@ -169,16 +178,20 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
       compute_tile(t, af0, bf0, zq0);
     }
   } else {
+    // every load_tile is unconditional (beyond the end it re-reads the last tile): hipcc can then count the
+    // outstanding loads statically and the s_waitcnt in front of a tile's compute leaves the NEXT tile's 24 loads
+    // in flight -- with a conditional prefetch it has to drain them
     f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4], af1[NBI][4], bf1[OBC][4], zq1[KC][4];
+    const long last = A.ntiles - 1;
     long t = (long)blockIdx.x * WV + wid;
-    if (t < A.ntiles) load_tile(t, af0, bf0, zq0);
+    load_tile(t < last ? t : last, af0, bf0, zq0);
     while (t < A.ntiles) {
       const long t1 = t + nwaves;
-      if (t1 < A.ntiles) load_tile(t1, af1, bf1, zq1);
+      load_tile(t1 < last ? t1 : last, af1, bf1, zq1);
       compute_tile(t, af0, bf0, zq0);
       if (t1 >= A.ntiles) break;
       const long t2 = t1 + nwaves;
-      if (t2 < A.ntiles) load_tile(t2, af0, bf0, zq0);
+      load_tile(t2 < last ? t2 : last, af0, bf0, zq0);
       compute_tile(t1, af1, bf1, zq1);
       t = t2;
     }
@@ -214,6 +227,7 @@ static GwArgs gw_fix(const GwArgs& in) {
   GwArgs a = in;
   if (a.zt_mod <= 0) a.zt_mod = a.ntiles > 0 ? a.ntiles : 1;
   if (a.bias_ntiles <= 0) a.bias_ntiles = a.ntiles;
+  if (!a.Z) a.Z = a.IN ? a.IN : a.DA;   // r == 0: the (ignored) latent loads of k_gw_mfma need a readable address
   return a;
 }
 
@@ -255,17 +269,18 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
 
   for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
     f32x4 bf[NBO][4], zq[4];
+    const int tz = A.zt_mod >= A.ntiles ? (int)t : (int)t % (int)A.zt_mod;
 #pragma unroll
     for (int ob = 0; ob < NBO; ++ob)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * ob + i) * 32 + 16 * hf + 4 * q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (k < A.r) zq[q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
+      if (k < A.r) zq[q] = ld4(A.Z + ((long)tz * A.r + k) * 32 + 16 * hf + 4 * q);
       else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
     }
     // Sobolev pseudo-tiles (t >= bias_ntiles): the "input" of tangent stream d is the one-hot e_seed[d]
-    const int pseudo = t < A.bias_ntiles ? -1 : A.seed[(int)(t / A.zt_mod) - 1];
+    const int pseudo = t < A.bias_ntiles ? -1 : A.seed[(int)t / (int)A.zt_mod - 1];
     for (int dd = 0; dd <= A.nd; ++dd) {  // dd == nd : the bias (x = 1)
       if (pseudo >= 0 && dd != pseudo) continue;
       float s[NBO];
@@ -328,13 +343,14 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
 
   for (long t = (long)blockIdx.x * 4 + wid; t < A.ntiles; t += nwaves) {
     f32x4 af[NBI][4], zq[4];
+    const int tz = A.zt_mod >= A.ntiles ? (int)t : (int)t % (int)A.zt_mod;
 #pragma unroll
     for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
       for (int q = 0; q < 4; ++q) af[ib][q] = ld4(A.IN + t * FI + (long)(32 * ib + i) * 32 + 16 * hf + 4 * q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (k < A.r) zq[q] = ld4(A.Z + ((t % A.zt_mod) * A.r + k) * 32 + 16 * hf + 4 * q);
+      if (k < A.r) zq[q] = ld4(A.Z + ((long)tz * A.r + k) * 32 + 16 * hf + 4 * q);
       else { zq[q][0] = 1.f; zq[q][1] = 1.f; zq[q][2] = 1.f; zq[q][3] = 1.f; }
     }
     const bool wbias = t < A.bias_ntiles;
