@@ -90,32 +90,45 @@ __device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL /
       s0[ks][t] = x0; s1[ks][t] = (__bf16)(x - (float)x0);
     }
 }
-// one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form
+// one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form.
+// Two output blocks at a time: their 6-MFMA chains interleave (a dependent v_mfma_f32_16x16x32_bf16 cannot issue
+// back to back) and one LDS round trip feeds 12 MFMAs
 template <int NBL>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int ob = 0; ob < NBL; ++ob) {
+  for (int ob = 0; ob < NBL; ob += 2) {
     const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], a1 = cur[(ob * 3 + 1) * 64 + lane], a2 = cur[(ob * 3 + 2) * 64 + lane];
+    const bf16x8 c0 = cur[(ob * 3 + 3) * 64 + lane], c1 = cur[(ob * 3 + 4) * 64 + lane], c2 = cur[(ob * 3 + 5) * 64 + lane];
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b1, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b2, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c2, b0, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b0, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ob + 1], 0, 0, 0);
   }
   __builtin_amdgcn_s_setprio(0);
 }
-// one K-step chunk of an adjoint plane, 3-product form
+// one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
 template <int NBL>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int ib = 0; ib < NBL; ++ib) {
+  for (int ib = 0; ib < NBL; ib += 2) {
     const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
+    const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, T[ib + 1], 0, 0, 0);
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b0, T[ib + 1], 0, 0, 0);
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -232,7 +245,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
   float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
 
 // one chunk step: start the DMA of the next chunk into the other buffer, compute on the current one, barrier
-// (hipcc drains the DMA with s_waitcnt vmcnt(0) in front of the barrier)
+// (hipcc drains the DMA with s_waitcnt vmcnt(0) in front of the barrier).  Tried and not kept (cfg-2, 1.11 ms): whole
+// planes per step (half the barriers, 54 KB LDS, still 3 workgroups/CU): 1.40 ms; 12-wave workgroups (a third of
+// the L2->LDS plane traffic): 1.13 ms.  Ablations: no DMA -8 %, no barrier -3 %, no MFMA/LDS reads -13 %, no stash
+// stores -10 %, no activation -5 %: a latency chain with no dominant term (3 waves/SIMD at 168 VGPRs)
 #define NIF_CHUNK(...)                                                        \
   {                                                                           \
     if ((cc + 1 < nchunks) || !last_group) dma(cc + 1 < nchunks ? cc + 1 : 0, (gpar + 1) & 1); \
