@@ -169,7 +169,10 @@ __device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f
 // only the SIGN of cos(a) is kept -- 4*NBL bits per layer in a 128-bit shift register (4 VGPRs), pushed forward,
 // popped in the adjoint.  Removes 2 x 4n bytes/point/layer of write + re-read traffic.  |error| of the rebuilt
 // cosine <= 2.4e-4 in the measure-zero neighbourhood of cos = 0, ~1e-7 typically: gradient-path only.
-template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN>
+// LL: last-layer-parameterised class (model.py:1044-1068, :1219-1269): the ShapeNet is a shared-weight dense SIREN
+// (r = 0, one plane per layer) whose last layer emits phi [so_u x rl]; u = Dot(phi, a) + bias with the ParameterNet
+// output a; the adjoint starts from dphi = du (x) a and also yields dL/da (and dL/dlatent through the rl x rl map).
+template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
@@ -186,10 +189,18 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
   bf16x8* chunks = reinterpret_cast<bf16x8*>(smem);            // 2 x CF units
   float* sm = smem + 2 * CF * 4;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  float* dzs = sm + sm_tot + (long)wid * (2 * r * 64 + r * 16);
+  const int rl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
+  const int pw = 2 * r * 64 + r * 16 + (LL ? (2 * rl + so + sou) * 16 : 0);   // per-wave LDS floats
+  float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
   float* zs = sks + r * 64;
-  float* lsum = sm + sm_tot + (long)WAVES * (2 * r * 64 + r * 16);
+  float* zl = zs + r * 16;          // LL: a [rl][16], phi / dphi [so][16], dL/da [rl][16], du [sou][16]
+  float* phis = zl + rl * 16;
+  float* das = phis + so * 16;
+  float* dul = das + rl * 16;
+  float* lsum = sm + sm_tot + (long)WAVES * pw;
+  const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((rl * rl + 3) & ~3))) : 0;   // LL extras sit at the end of sm
+  const int o_lw = o_llb + ((sou + 3) & ~3);
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
@@ -226,6 +237,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
       else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      else if (LL && e >= o_llb && e < o_llb + sou) v = hyp3(A, k, s_bl + so + (e - o_llb));
+      else if (LL && e >= o_lw && e < o_lw + rl * rl) v = hyp3(A, k, s_bl + so + sou + (e - o_lw));
       sm[idx] = v;
     }
     if (nchunks > 0) dma(0, 0);
@@ -271,6 +284,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     const float* xrow = A.xin + ptc * A.ncol + A.col0;
     if (g == 0)
       for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
+    if (LL && g == 0)
+      for (int j = 0; j < rl; ++j) zl[j * 16 + p] = A.Z[(tile32 * rl + j) * 32 + poff];
     const float* zt_base = zs + p;
     const long row0 = tile32 * (long)FP * 32 + poff;
     if (TRAIN)
@@ -365,6 +380,59 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     ZERO_T(gh)
     const float wsamp = (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f);
     float se = 0.f;
+    if (LL) {
+      // phi[o] = <h, Wl[:, o]> + bl[o] into the wave's LDS row, then per point u = Dot(phi, a) + bias
+      for (int o = 0; o < so; ++o) {
+        float part = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+          part += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (g == 0) phis[o * 16 + p] = part + sm[o_bl + o];
+      }
+      for (int s_ = 0; s_ < sou; ++s_) {
+        float uo = sm[o_llb + s_];
+        for (int j = 0; j < rl; ++j) uo = fmaf(phis[(s_ * rl + j) * 16 + p], zl[j * 16 + p], uo);
+        if (valid && g == 0 && A.u_out) A.u_out[pt * sou + s_] = uo;
+        if (TRAIN) {
+          const float e = uo - A.y[ptc * sou + s_];
+          se = fmaf(e, e, se);
+          const float du = 2.0f * wsamp * e * A.inv_bg / (float)sou;
+          if (g == 0) {
+            dul[s_ * 16 + p] = du;
+            if (active) A.DU[(tile32 * sou + s_) * 32 + poff] = du;
+          }
+        }
+      }
+      if (TRAIN) {
+        // dL/da[j] = sum_s du[s] phi[s][j]  (lane group g takes j = g, g+4, ..), then dL/dlatent through the rl x rl map
+        for (int j = g; j < rl; j += 4) {
+          float da = 0.f;
+          for (int s_ = 0; s_ < sou; ++s_) da = fmaf(dul[s_ * 16 + p], phis[(s_ * rl + j) * 16 + p], da);
+          das[j * 16 + p] = da;
+          if (active) A.DA_ll[(tile32 * rl + j) * 32 + poff] = da;
+        }
+        for (int k = g; k < rl; k += 4) {
+          float dz = 0.f;
+          for (int c = 0; c < rl; ++c) dz = fmaf(das[c * 16 + p], sm[o_lw + k * rl + c], dz);
+          if (active) A.DZL[(tile32 * rl + k) * 32 + poff] = dz;
+        }
+        // dphi[o] = du[s] a[j] replaces phi in LDS; it is also the "dL/dout" stash of the phi layer's weight gradient
+        for (int o = g; o < so; o += 4) {
+          const float dq = dul[(o / rl) * 16 + p] * zl[(o % rl) * 16 + p];
+          phis[o * 16 + p] = dq;
+          if (active) A.DPHI[(tile32 * so + o) * 32 + poff] = dq;
+        }
+        for (int o = 0; o < so; ++o) {
+          const float dq = phis[o * 16 + p];
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) gh[b] += dq * *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+        }
+      }
+    } else
     for (int o = 0; o < so; ++o) {
       f32x4 wg[NBL];
       ZERO_T(wg)
@@ -402,7 +470,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
       }
     }
     if (TRAIN) {
-      if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+      if (g == 0) loss_lane += wsamp * se / (float)sou * A.inv_bg;
       NIF_TL(4);
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       f32x4 skip[MODE == 0 ? 1 : NBL];
@@ -515,7 +583,20 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
 // ---- host side ---------------------------------------------------------------------------------
 static size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + (size_t)4 * (2 * a.r * 64 + a.r * 16) + 8) * sizeof(float);
+  const size_t pw = 2 * a.r * 64 + a.r * 16 + (a.ll ? (size_t)(2 * a.rl + a.so + a.so_u) * 16 : 0);
+  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);
+}
+// floats per k of the LDS small-vector image (last-layer class: + last_layer_bias and the rl x rl map)
+int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl) {
+  return snet3_nsm(si, sop, nh, n) + ((sou + 3) & ~3) + ((rl * rl + 3) & ~3);
+}
+__global__ void k_ll_slots(const float* __restrict__ theta, LLSlotMap m, float* __restrict__ slots) {
+  for (int sgi = blockIdx.y; sgi < m.nseg; sgi += gridDim.y)
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < m.seg[sgi].len; e += (long)gridDim.x * blockDim.x)
+      slots[m.seg[sgi].dst + e] = theta[m.seg[sgi].src + e];
+}
+void launch_ll_slots(const float* theta, const LLSlotMap& m, float* slots, hipStream_t st) {
+  hipLaunchKernelGGL(k_ll_slots, dim3(16, m.nseg), dim3(256), 0, st, theta, m, slots);
 }
 bool snet4_supported(const SNetArgs& a) {
   const int NBL = snet3_nbl(a.n);
@@ -539,22 +620,26 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   if (query_only) return nblk;
   dim3 grid(nblk), block(256);
   const size_t shm = snet4_shmem(a, NBL);
-#define S4L(NBL_, TR_, ACT_, MODE_, SGN_)                                                                           \
+#define S4L(NBL_, TR_, ACT_, MODE_, SGN_, LL_)                                                                         \
   {                                                                                                                 \
     if (shm > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_>,                                 \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>,                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_>), grid, block, shm, st, a);                           \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>), grid, block, shm, st, a);                           \
   }
 #define S4(NBL_)                                                            \
-  if (a.nif_skip) {                                                         \
-    if (train) S4L(NBL_, true, -1, 2, false) else S4L(NBL_, false, -1, 2, false)          \
+  if (a.ll) {                                                               \
+    if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, true) else S4L(NBL_, false, ACT_SINE, 1, false, true) } \
+    else if (train) { if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, true) else S4L(NBL_, true, ACT_SINE, 0, false, true) } \
+    else S4L(NBL_, false, ACT_SINE, 0, false, true)                         \
+  } else if (a.nif_skip) {                                                  \
+    if (train) S4L(NBL_, true, -1, 2, false, false) else S4L(NBL_, false, -1, 2, false, false) \
   } else if (a.res) {                                                       \
-    if (train) S4L(NBL_, true, ACT_SINE, 1, false) else S4L(NBL_, false, ACT_SINE, 1, false) \
+    if (train) S4L(NBL_, true, ACT_SINE, 1, false, false) else S4L(NBL_, false, ACT_SINE, 1, false, false) \
   } else if (train) {                                                       \
-    if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true) else S4L(NBL_, true, ACT_SINE, 0, false) \
+    if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, false) else S4L(NBL_, true, ACT_SINE, 0, false, false) \
   } else {                                                                  \
-    S4L(NBL_, false, ACT_SINE, 0, false)                                    \
+    S4L(NBL_, false, ACT_SINE, 0, false, false)                             \
   }
   switch (NBL) {
     case 2: S4(2) break;

@@ -39,6 +39,8 @@ struct nif_ctx {
   long step = 0;
   bool have_params = false, packed = false, use_snet3 = false, use_snet4 = false;
   void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
+  bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
+  float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -197,9 +199,13 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&c->pWB, pk_p);
   if (e == hipSuccess) e = hipMalloc(&c->sWF, pk_s);
   if (e == hipSuccess) e = hipMalloc(&c->sWB, pk_s);
-  if (c->kind != NIF_KIND_LASTLAYER && nh > 0 && !(snet3_nbl(c->n) & 1) && c->n <= 128) {
-    if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, c->r) * 2);
-    if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, c->r) * 2);
+  if (nh > 0 && !(snet3_nbl(c->n) & 1) && c->n <= 128) {
+    const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
+    if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
+    if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess)
+      e = hipMalloc(&c->ll_slots, sizeof(float) * (size_t)((long)c->si * c->n + (long)nh * c->n * c->n + (long)c->n * c->so * c->r +
+                                                             c->n + (long)nh * c->n + c->so * c->r + c->so + c->r * c->r + 64));
   }
   const size_t pk_l = (size_t)(nh > 0 ? nh : 1) * c->NB * c->NB * 256 * sizeof(f32x4);
   if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWF, pk_l);
@@ -218,7 +224,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -354,7 +360,9 @@ static int ensure_capacity(nif_ctx* c, long B, bool train) {
     c->cap = newcap;
   }
   if (train) {
-    const long nblk = (ntiles + 3) / 4;
+    // one loss partial per workgroup of the fused kernel: the 16-point-tile kernels launch up to ceil(2*ntiles/4)
+    // workgroups (k_snet3/4, k_sob), k_ll_out ntiles/8, k_snet ntiles/4
+    const long nblk = (2 * ntiles + 3) / 4 + 1;
     if (nblk > c->nloss_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
       if (c->loss_partial) HIPCHK(hipFree(c->loss_partial));
@@ -408,6 +416,19 @@ static void fill_ll(const nif_ctx* c, LLArgs& a, long B) {
   a.PHI = c->PHI; a.Z = c->Z; a.B = B; a.r = c->r; a.so = c->so;
   a.DU = c->DU; a.DPHI = c->DPHI; a.DA = c->DA; a.DZL = c->DZL; a.loss_partial = c->loss_partial;
 }
+// last-layer class on k_snet4: slot offsets as in k_snet4's prologue (r = 0)
+static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
+  memset(&a, 0, sizeof(a));
+  const int sop = c->so * c->r;
+  a.theta = c->ll_slots; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
+  a.si = c->si; a.so = sop; a.n = c->n; a.nh = c->nh; a.r = 0; a.po = 0;
+  a.act = NIF_ACT_SINE; a.res = c->cfg.s_resblock; a.nif_skip = 0; a.omega = c->cfg.s_omega0;
+  a.off_Wh = 0; a.off_bh = 0;
+  a.Z = c->Z; a.WF4 = c->sWF4; a.WB4 = c->sWB4; a.stash = c->stash_s; a.slot_stride = c->slot_s;
+  a.DU = c->DU; a.DZ = nullptr; a.dring = c->dring;
+  a.ll = 1; a.rl = c->r; a.so_u = c->so; a.DPHI = c->DPHI; a.DA_ll = c->DA; a.DZL = c->DZL;
+  a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
+}
 static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
   a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
@@ -447,6 +468,32 @@ static int ensure_packed(nif_ctx* c) {
         launch_pack(c->theta, dense_ref(c->s_hid_w2[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i + 1) * plane_l, c->lWB + (2 * i + 1) * plane_l, c->st);
       }
     }
+    {
+      SNetArgs probe; fill_snet_ll(c, probe, nullptr, 0, 0, 32);
+      static const bool ll_old = [] { const char* e = getenv("NIF_LL_MLP"); return e && e[0] == '1'; }();
+      c->use_ll4 = c->sWF4 && c->ll_slots && !ll_old && snet4_supported(probe);
+    }
+    if (c->use_ll4) {
+      const int n = c->n, nh = c->nh, sop = c->so * c->r;
+      LLSlotMap m; m.nseg = 0;
+      auto seg = [&](long src, long dst, long len) { m.seg[m.nseg].src = src; m.seg[m.nseg].dst = dst; m.seg[m.nseg].len = len; ++m.nseg; };
+      const long s_wl = (long)c->si * n + (long)nh * n * n, s_b1 = s_wl + (long)n * sop, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+      seg(c->s_first_w, 0, (long)c->si * n);
+      seg(c->s_bott_w, s_wl, (long)n * sop);
+      seg(c->s_first_b, s_b1, n);
+      for (int j = 0; j < nh; ++j) {
+        long w_off, b_off;
+        if (!c->cfg.s_resblock) { w_off = c->s_hid_w[j]; b_off = c->s_hid_b[j]; }
+        else { const int i = j / 2; w_off = (j & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (j & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
+        seg(b_off, s_bh + (long)j * n, n);
+        launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
+                       (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2, c->st);
+      }
+      seg(c->s_bott_b, s_bl, sop);
+      seg(c->ll_bias, s_bl + sop, c->so);
+      seg(c->last_w, s_bl + sop + c->so, (long)c->r * c->r);
+      launch_ll_slots(c->theta, m, c->ll_slots, c->st);
+    }
     HIPCHK(hipGetLastError());
     c->packed = true;
     return NIF_OK;
@@ -485,6 +532,13 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, false, c->st); }
   if (c->kind == NIF_KIND_LASTLAYER) {
     ProfScope p_(c, NIF_PROF_SNET_FWD);
+    if (c->use_ll4) {
+      SNetArgs sa; fill_snet_ll(c, sa, xin, c->pi + c->si, c->pi, B);
+      sa.u_out = u;
+      launch_snet4(sa, false, false, c->st);
+      HIPCHK(hipGetLastError());
+      return NIF_OK;
+    }
     PNetArgs ma; fill_snet_mlp(c, ma, xin, c->pi + c->si, c->pi, B);
     launch_pnet(ma, c->NB, false, c->st);
     LLArgs la; fill_ll(c, la, B); la.u_out = u;
@@ -547,8 +601,9 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
   if (ll) {
     // u = Dot(phi(x), a(p)) + bias: coordinate columns move phi, parameter columns move a
-    rc = nif_forward_dev(c, c->d_a, B, c->d_d); if (rc) return rc;     // leaves PHI and Z (= a) on the device
+    rc = nif_forward_dev(c, c->d_a, B, c->d_d); if (rc) return rc;     // leaves Z (= a) on the device
     PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, ncol, c->pi, B);
+    if (c->use_ll4) launch_pnet(ma, c->NB, false, c->st);               // the fused forward keeps phi on chip: compute it here
     for (int j = 0; j < nx; ++j) {
       if (x_idx[j] >= c->pi) {
         PNetArgs mj = ma; mj.Z = c->DPHI;   // primal again into a scratch, tangent into d_c
@@ -693,7 +748,20 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   LLArgs la; fill_ll(c, la, B);
   la.y = y; la.sw = sw; la.inv_bg = 1.0f / (float)Bg;
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
-  {
+  int nloss = (int)((ntiles * 32 + 255) / 256);
+  if (c->use_ll4) {
+    SNetArgs sa; fill_snet_ll(c, sa, xin, ncol, c->pi, B);
+    sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+    nloss = launch_snet4(sa, true, true, c->st);
+    const long need = (long)nloss * 4 * snet3_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      int rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    sa.dring = c->dring;
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_snet4(sa, true, false, c->st);
+  } else {
     ProfScope p_(c, NIF_PROF_SNET);
     launch_pnet(ma, c->NB, true, c->st);
     launch_ll_out(la, true, c->st);
@@ -752,7 +820,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   }
   {
     ProfScope pr_(c, NIF_PROF_REDUCE);
-    launch_reduce(c->partial, c->pstride, rows, c->loss_partial, (int)((ntiles * 32 + 255) / 256), c->grad, c->P, c->st);
+    launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
   }
   HIPCHK(hipGetLastError());
   return NIF_OK;

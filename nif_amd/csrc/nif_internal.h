@@ -83,7 +83,18 @@ struct SNetArgs {
   int nsm;                                // k_snet3: floats per k of the LDS copy of the small hyper-vectors
   long long* tl;                          // -DNIF_TIMELINE builds: s_memtime stamps of wave 0 of block 0
   const void* WF4; const void* WB4;       // k_snet4: bf16-split planes (k_pack16b), per plane NCH chunks
+  // last-layer-parameterised class on k_snet4 (r = 0: shared dense SIREN; theta = the slot-ordered copy built by
+  // launch_ll_slots; so = so_u * rl outputs phi): u = Dot(phi, a) + bias, a = Z [tiles][rl][32]
+  int ll, rl, so_u;
+  float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
+  float* DA_ll;                           // [tiles][rl][32]   dL/da
+  float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
 };
+// slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
+// last_layer_bias | pnet last W (rl x rl)] -- the order k_snet4's prologue indexes (hyp3 with r = 0)
+struct LLSlotSeg { long src, dst, len; };
+struct LLSlotMap { int nseg; LLSlotSeg seg[48]; };
+void launch_ll_slots(const float* theta, const LLSlotMap& m, float* slots, hipStream_t st);
 // slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
 __host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }
 __host__ __device__ inline long slot_wh(const SNetArgs& a, int j) { return (long)a.si * a.n + (long)j * a.n * a.n; }
@@ -133,6 +144,7 @@ long snet4_fwd_elems(int n, int r);
 long snet4_bwd_elems(int n, int r);
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
