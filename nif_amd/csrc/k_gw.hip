@@ -315,8 +315,158 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
     }
 }
 
+// MFMA form of k_gw_first for (r+1)(nd+1) <= 32: the rows of ONE 32-row A operand are the planes x inputs
+//   A[(k, d)][p] = zt_k[p] * x_d[p]   (d = nd: the bias row, x = 1),   B = dL/da tile,   K = the tile's 32 points
+// so a tile costs 16 MFMAs per 32 output features instead of (r+1)(nd+1) VALU passes with LDS accumulators.
+template <int NBO, int WV>
+__global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
+  __shared__ float red[(WV - 1) * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const long nwaves = (long)gridDim.x * WV;
+  const long FO = (long)NBO * 32 * 32;
+  const int nd1 = A.nd + 1;
+  const int k = i / nd1, d = i - k * nd1;
+  const bool row_ok = i < (A.r + 1) * nd1;
+  f32x16 acc[NBO];
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ob][e] = 0.f;
+
+  for (long t = (long)blockIdx.x * WV + wid; t < A.ntiles; t += nwaves) {
+    f32x4 bf[NBO][4], a[4];
+#pragma unroll
+    for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * ob + i) * 32 + 16 * hf + 4 * q);
+    const int tz = A.zt_mod >= A.ntiles ? (int)t : (int)t % (int)A.zt_mod;
+    const int pseudo = t < A.bias_ntiles ? -1 : A.seed[(int)t / (int)A.zt_mod - 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 z = {1.f, 1.f, 1.f, 1.f};
+      if (row_ok && k < A.r) z = ld4(A.Z + ((long)tz * A.r + k) * 32 + 16 * hf + 4 * q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float xv = 0.f;
+        if (row_ok) {
+          if (pseudo >= 0) xv = d == pseudo ? 1.0f : 0.0f;        // tangent stream: one-hot input, no bias row
+          else if (d == A.nd) xv = 1.0f;
+          else {
+            long pt = (long)tz * 32 + 16 * hf + 4 * q + c;
+            if (pt >= A.B) pt = A.B - 1;
+            xv = A.xin[pt * A.ncol + A.col0 + d];
+          }
+        }
+        a[q][c] = xv * z[c];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ob = 0; ob < NBO; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], bf[ob][q][c], acc[ob], 0, 0, 0);
+  }
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = block_sum<WV>(acc[ob][e], red, wid, lane);
+      const int m = fmap(e, hf), f = 32 * ob + i;
+      const int kk = m / nd1, dd = m - kk * nd1;
+      if (wid == 0 && m < (A.r + 1) * nd1) {
+        if (dd < A.nd) { if (f < A.W.nout) prow[matref_index(A.W, kk, dd, f)] = A.scale * v; }
+        else if (A.has_bias && f < A.Bv.nout) prow[matref_index(A.Bv, kk, 0, f)] = v;
+      }
+    }
+}
+
+// MFMA form of k_gw_out for (r+1) nc <= 32: the columns of ONE 32-column B operand are the planes x outputs
+//   A = layer-input tile,   B[p][(k, c)] = zt_k[p] * dL/dout_c[p];   bias gradient = column sums of B (real tiles only)
+template <int NBI, int WV>
+__global__ __launch_bounds__(64 * WV) void k_gw_out_mfma(GwArgs A) {
+  __shared__ float red[(WV - 1) * 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const long nwaves = (long)gridDim.x * WV;
+  const long FI = (long)NBI * 32 * 32;
+  const int k = i / A.nc, c = i - k * A.nc;
+  const bool col_ok = i < (A.r + 1) * A.nc;
+  f32x16 acc[NBI];
+  float bsum = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ib][e] = 0.f;
+  const bool need_w = A.W.nin > 0;
+
+  for (long t = (long)blockIdx.x * WV + wid; t < A.ntiles; t += nwaves) {
+    f32x4 af[NBI][4], b[4];
+    if (need_w) {
+#pragma unroll
+      for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) af[ib][q] = ld4(A.IN + t * FI + (long)(32 * ib + i) * 32 + 16 * hf + 4 * q);
+    }
+    const int tz = A.zt_mod >= A.ntiles ? (int)t : (int)t % (int)A.zt_mod;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (col_ok) {
+        v = ld4(A.SM + (t * A.nc + c) * 32 + 16 * hf + 4 * q);
+        if (k < A.r) v *= ld4(A.Z + ((long)tz * A.r + k) * 32 + 16 * hf + 4 * q);
+      }
+      b[q] = v;
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    if (t < A.bias_ntiles) bsum += s;
+    if (need_w) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ib = 0; ib < NBI; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ib][q][e], b[q][e], acc[ib], 0, 0, 0);
+    }
+  }
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+  if (need_w) {
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = block_sum<WV>(acc[ib][e], red, wid, lane);
+        const int f = 32 * ib + fmap(e, hf);
+        if (wid == 0 && col_ok && f < A.W.nin) prow[matref_index(A.W, k, f, c)] = A.scale * v;
+      }
+  }
+  {
+    float v = bsum;
+    v += __shfl_xor(v, 32);
+    v = block_sum<WV>(v, red, wid, lane);
+    if (A.has_bias && wid == 0 && hf == 0 && col_ok) prow[matref_index(A.Bv, k, 0, c)] = v;
+  }
+}
+
+#ifndef NIF_GW_EDGE_MFMA
+#define NIF_GW_EDGE_MFMA 1
+#endif
+#ifndef NIF_GW_EDGE_WAVES
+#define NIF_GW_EDGE_WAVES 16
+#endif
 void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  if (NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32) {
+    constexpr int WV = NIF_GW_EDGE_WAVES;   // one workgroup per partial row: many waves hide the single-buffered loads
+    dim3 grid(rows);
+    if (NBO == 1) hipLaunchKernelGGL((k_gw_first_mfma<1, WV>), grid, dim3(64 * WV), 0, st, a);
+    else if (NBO == 2) hipLaunchKernelGGL((k_gw_first_mfma<2, WV>), grid, dim3(64 * WV), 0, st, a);
+    else hipLaunchKernelGGL((k_gw_first_mfma<4, 4>), grid, dim3(256), 0, st, a);   // 128+ registers: 4 waves
+    return;
+  }
   dim3 grid(rows, a.r + 1), block(256);
   const size_t shm = (size_t)(192 + 4 * (a.nd + 1) * NBO * 64) * sizeof(float);
   if (NBO == 1) hipLaunchKernelGGL((k_gw_first<1>), grid, block, shm, st, a);
@@ -389,6 +539,14 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
 
 void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  // few columns (e.g. so = 1, r = 1): the VALU kernel below is as fast; from 8 columns on the MFMA form wins big
+  if (NIF_GW_EDGE_MFMA && (a.r + 1) * a.nc <= 32 && (a.r + 1) * a.nc >= 8) {
+    dim3 grid(rows), block(256);
+    if (NBI == 1) hipLaunchKernelGGL((k_gw_out_mfma<1, 4>), grid, block, 0, st, a);
+    else if (NBI == 2) hipLaunchKernelGGL((k_gw_out_mfma<2, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_gw_out_mfma<4, 4>), grid, block, 0, st, a);
+    return;
+  }
   dim3 grid(rows, a.r + 1), block(256);
   const size_t shm = (size_t)(192 + 4 * a.nc * (NBI + 1) * 64) * sizeof(float);
   if (NBI == 1) hipLaunchKernelGGL((k_gw_out<1>), grid, block, shm, st, a);
