@@ -37,7 +37,7 @@ struct nif_ctx {
   // device state
   float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
   long step = 0;
-  bool have_params = false, packed = false, use_snet3 = false, use_snet4 = false;
+  bool have_params = false, packed = false, packed32 = false, use_snet3 = false, use_snet4 = false;
   void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
@@ -248,7 +248,7 @@ extern "C" int nif_set_params(nif_ctx* c, const float* host, int64_t n) {
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipMemcpyAsync(c->theta, host, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
-  c->have_params = true; c->packed = false;
+  c->have_params = true; c->packed = false; c->packed32 = false;
   return NIF_OK;
 }
 extern "C" int nif_get_params(nif_ctx* c, float* host, int64_t n) {
@@ -445,6 +445,23 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.tl = c->tl;
 }
 
+// fp32 MFMA planes of the hidden hyper-matrices: needed by k_snet3 / k_snet (when the bf16-split kernel is not in
+// use), k_jac and k_sob -- packed on demand, the training step on k_snet4 never pays for them
+static int ensure_packed32(nif_ctx* c) {
+  if (c->packed32 || c->kind == NIF_KIND_LASTLAYER) return NIF_OK;
+  ProfScope ps_(c, NIF_PROF_PACK);
+  const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
+  for (int j = 0; j < c->nh; ++j) {
+    const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
+    f32x4* wf = c->sWF + (long)j * (c->r + 1) * plane_s;
+    f32x4* wb = c->sWB + (long)j * (c->r + 1) * plane_s;
+    if (c->use_snet3) launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
+    else launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, wf, wb, c->st);
+  }
+  HIPCHK(hipGetLastError());
+  c->packed32 = true;
+  return NIF_OK;
+}
 static int ensure_packed(nif_ctx* c) {
   if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
   if (c->packed) return NIF_OK;
@@ -503,23 +520,17 @@ static int ensure_packed(nif_ctx* c) {
   // NIF_FP32_MFMA=1 in the environment keeps every product on the f32-input MFMAs (k_snet3) for A/B runs
   static const bool fp32_only = [] { const char* e = getenv("NIF_FP32_MFMA"); return e && e[0] == '1'; }();
   c->use_snet4 = c->use_snet3 && c->sWF4 && !fp32_only && snet4_supported(probe);
-  const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
+  c->packed32 = false;
   for (int j = 0; j < c->nh; ++j) {
     const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
-    f32x4* wf = c->sWF + (long)j * (c->r + 1) * plane_s;
-    f32x4* wb = c->sWB + (long)j * (c->r + 1) * plane_s;
     if (c->use_snet4)
       launch_pack16b(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n),
                      (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(c->n, c->r) * 2,
                      (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(c->n, c->r) * 2, c->st);
-    if (c->use_snet3) {
-      launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
-    } else {
-      launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, wf, wb, c->st);
-    }
   }
   HIPCHK(hipGetLastError());
   c->packed = true;
+  if (!c->use_snet4) return ensure_packed32(c);
   return NIF_OK;
 }
 
@@ -587,6 +598,7 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_packed32(c); if (rc) return rc;
   const bool ll = c->kind == NIF_KIND_LASTLAYER;
   if (!ll && !c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -833,6 +845,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B + 31) / 32;
+  if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
   if (ns > 0) {
     if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
       return fail(NIF_ERR_INVALID, "Sobolev training is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
@@ -976,6 +989,7 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   int rc = sobolev_seeds(c, x_idx, nx, seeds); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_packed32(c); if (rc) return rc;
   if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
     return fail(NIF_ERR_INVALID, "Sobolev path is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -1030,7 +1044,7 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   { ProfScope p_(c, NIF_PROF_ADAM);
     launch_adam(c->theta, c->grad, c->m, c->v, c->P, (float)lr_t, opt->beta1, opt->beta2, opt->eps, c->st); }
   HIPCHK(hipGetLastError());
-  c->packed = false;
+  c->packed = false; c->packed32 = false;
   return NIF_OK;
 }
 
