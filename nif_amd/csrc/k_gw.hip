@@ -51,6 +51,7 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[(WV-1)*64]*/, 
 template <int NBI, int OBC, int KC, int WV>
 __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
   __shared__ float red[(WV - 1) * 64];
+  __shared__ float red16[(WV - 1) * 16 * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const int k0 = blockIdx.y * KC;
@@ -207,11 +208,27 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 #pragma unroll
       for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = block_sum<WV>(acc[kk][ib][ob][e], red, wid, lane);
-          const int in = 32 * ib + fmap(e, hf), out = 32 * (ob0 + ob) + i;
-          if (wid == 0 && k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v;
+      {
+        // a whole 32x32 accumulator block per round: 2 barriers per 16 values instead of per value
+        f32x16 v = acc[kk][ib][ob];
+        if (wid > 0) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red16[((wid - 1) * 16 + e) * 64 + lane] = v[e];
         }
+        __syncthreads();
+        if (wid == 0) {
+#pragma unroll
+          for (int w = 0; w < WV - 1; ++w)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += red16[(w * 16 + e) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int in = 32 * ib + fmap(e, hf), out = 32 * (ob0 + ob) + i;
+            if (k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v[e];
+          }
+        }
+        __syncthreads();
+      }
 #pragma unroll
     for (int ob = 0; ob < OBC; ++ob) {
       float v = bacc[kk][ob];
