@@ -87,6 +87,17 @@ def main():
         rec = {"points": B, "ms_per_step": round(msstep, 4), "Mpts_per_s": round(B / msstep / 1e3, 2),
                "params": int(e.n_params),
                "kernel_ms": {k: round(v[0] / a.steps, 4) for k, v in prof.items() if v[1] > 0}}
+        if name.startswith("cfg2"):
+            # the same step when the boundary hands over HOST buffers (nif_train_step: H2D of x, y + step + loss readback)
+            import time
+            for _ in range(2):
+                e.train_step(x, y, None, adam)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                e.train_step(x, y, None, adam)
+            dt = (time.perf_counter() - t0) / a.steps
+            rec["host_buffers_ms_per_step"] = round(dt * 1e3, 4)
+            rec["host_buffers_Mpts_per_s"] = round(B / dt / 1e6, 2)
         out[name] = rec
         print(name, json.dumps(rec), flush=True)
         d_x.free(); d_y.free()
