@@ -48,7 +48,7 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[(WV-1)*64]*/, 
 
 // WV waves per workgroup: with the bf16 path the kernel is a stream of loads + VALU splits + few MFMAs, and two
 // 256-register waves per SIMD overlap one wave's splitting with the other's loads
-template <int NBI, int OBC, int KC, int WV>
+template <int NBI, int OBC, int KC, int WV, bool DBUF>
 __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
   __shared__ float red[(WV - 1) * 64];
   __shared__ float red16[(WV - 1) * 16 * 64];
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
     }
   };
 #endif
-  if (WV > 4) {
-    // two waves per SIMD: the partner wave hides the load latency, one register set is enough
+  if (!DBUF) {
+    // one register set (wide variants whose accumulators already fill the file)
     f32x4 af0[NBI][4], bf0[OBC][4], zq0[KC][4];
     for (long t = (long)blockIdx.x * WV + wid; t < A.ntiles; t += nwaves) {
       load_tile(t, af0, bf0, zq0);
@@ -206,9 +206,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 #pragma unroll
     for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
-      for (int ob = 0; ob < OBC; ++ob)
-#pragma unroll
-      {
+      for (int ob = 0; ob < OBC; ++ob) {
         // a whole 32x32 accumulator block per round: 2 barriers per 16 values instead of per value
         f32x16 v = acc[kk][ib][ob];
         if (wid > 0) {
@@ -248,6 +246,9 @@ static GwArgs gw_fix(const GwArgs& in) {
   return a;
 }
 
+#ifndef NIF_GW_WIDE_KC2
+#define NIF_GW_WIDE_KC2 1
+#endif
 #ifndef NIF_GW_WAVES
 #define NIF_GW_WAVES 4   // 8 = two waves per SIMD, single-buffered: spills at 256 registers, slower
 #endif
@@ -257,13 +258,20 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
   dim3 block(64 * WV);
   if (NBI == 1 && NBO == 1) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
-    hipLaunchKernelGGL((k_gw_mfma<1, 1, 2, WV>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<1, 1, 2, WV, true>), grid, block, 0, st, a, NBO);
   } else if (NBI == 2 && NBO == 2) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
-    hipLaunchKernelGGL((k_gw_mfma<2, 2, 2, WV>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<2, 2, 2, WV, true>), grid, block, 0, st, a, NBO);
   } else if (NBI == 4 && NBO == 4) {
+#if NIF_GW_WIDE_KC2
+    // 128-wide: both planes of a pair in one workgroup (256 accumulator registers, single-buffered): the layer-input
+    // stash is read 2x and dL/da 1x instead of 4x and 2x
+    dim3 grid(rows, (a.r + 1 + 1) / 2, 2);
+    hipLaunchKernelGGL((k_gw_mfma<4, 2, 2, WV, false>), grid, block, 0, st, a, NBO);
+#else
     dim3 grid(rows, a.r + 1, 2);
-    hipLaunchKernelGGL((k_gw_mfma<4, 2, 1, WV>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<4, 2, 1, WV, true>), grid, block, 0, st, a, NBO);
+#endif
   }
 }
 
