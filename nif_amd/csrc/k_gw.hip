@@ -46,6 +46,24 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[(WV-1)*64]*/, 
   return v;
 }
 
+// the same for a whole 16-register accumulator block: 2 barriers per 16 values
+template <int WV>
+__device__ __forceinline__ f32x16 block_sum16(f32x16 v, float* red16 /*[(WV-1)*16*64]*/, int wid, int lane) {
+  if (wid > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red16[((wid - 1) * 16 + e) * 64 + lane] = v[e];
+  }
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int w = 0; w < WV - 1; ++w)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += red16[(w * 16 + e) * 64 + lane];
+  }
+  __syncthreads();
+  return v;
+}
+
 // WV waves per workgroup: with the bf16 path the kernel is a stream of loads + VALU splits + few MFMAs, and two
 // 256-register waves per SIMD overlap one wave's splitting with the other's loads
 template <int NBI, int OBC, int KC, int WV, bool DBUF>
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
 // so a tile costs 16 MFMAs per 32 output features instead of (r+1)(nd+1) VALU passes with LDS accumulators.
 template <int NBO, int WV>
 __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
-  __shared__ float red[(WV - 1) * 64];
+  __shared__ float red16[(WV - 1) * 16 * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const long nwaves = (long)gridDim.x * WV;
@@ -395,10 +413,11 @@ __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
   }
   float* prow = A.partial + (long)blockIdx.x * A.pstride;
 #pragma unroll
-  for (int ob = 0; ob < NBO; ++ob)
+  for (int ob = 0; ob < NBO; ++ob) {
+    const f32x16 vs = block_sum16<WV>(acc[ob], red16, wid, lane);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float v = block_sum<WV>(acc[ob][e], red, wid, lane);
+      const float v = vs[e];
       const int m = fmap(e, hf), f = 32 * ob + i;
       const int kk = m / nd1, dd = m - kk * nd1;
       if (wid == 0 && m < (A.r + 1) * nd1) {
@@ -406,6 +425,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
         else if (A.has_bias && f < A.Bv.nout) prow[matref_index(A.Bv, kk, 0, f)] = v;
       }
     }
+  }
 }
 
 // MFMA form of k_gw_out for (r+1) nc <= 32: the columns of ONE 32-column B operand are the planes x outputs
@@ -413,6 +433,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
 template <int NBI, int WV>
 __global__ __launch_bounds__(64 * WV) void k_gw_out_mfma(GwArgs A) {
   __shared__ float red[(WV - 1) * 64];
+  __shared__ float red16[(WV - 1) * 16 * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const long nwaves = (long)gridDim.x * WV;
@@ -460,13 +481,14 @@ __global__ __launch_bounds__(64 * WV) void k_gw_out_mfma(GwArgs A) {
   float* prow = A.partial + (long)blockIdx.x * A.pstride;
   if (need_w) {
 #pragma unroll
-    for (int ib = 0; ib < NBI; ++ib)
+    for (int ib = 0; ib < NBI; ++ib) {
+      const f32x16 vs = block_sum16<WV>(acc[ib], red16, wid, lane);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float v = block_sum<WV>(acc[ib][e], red, wid, lane);
         const int f = 32 * ib + fmap(e, hf);
-        if (wid == 0 && col_ok && f < A.W.nin) prow[matref_index(A.W, k, f, c)] = A.scale * v;
+        if (wid == 0 && col_ok && f < A.W.nin) prow[matref_index(A.W, k, f, c)] = A.scale * vs[e];
       }
+    }
   }
   {
     float v = bsum;

@@ -195,25 +195,45 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     __syncthreads();
     return v;
   };
+  // whole accumulator blocks per round; the per-wave layer tiles in LDS are dead by now and serve as scratch
+  __syncthreads();
+  auto sum16 = [&](f32x16 v) -> f32x16 {
+    if (wid > 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lds[((wid - 1) * 16 + e) * 64 + lane] = v[e];
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+      for (int w = 0; w < WV - 1; ++w)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += lds[(w * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+    return v;
+  };
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const long w_off = RES ? (m == 0 ? A.hid_w[0] : A.hid_w2[0]) : A.hid_w[m];
     const long b_off = RES ? (m == 0 ? A.hid_b[0] : A.hid_b2[0]) : A.hid_b[m];
+    {
+      const f32x16 vs = sum16(C[m]);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float v = sum8(C[m][e]);
-      const int in = fmap(e, hf), out = i;
-      if (wid == 0 && in < A.nst && out < A.nst) prow_out[w_off + (long)in * A.nst + out] = A.omega * v;
+      for (int e = 0; e < 16; ++e) {
+        const int in = fmap(e, hf), out = i;
+        if (wid == 0 && in < A.nst && out < A.nst) prow_out[w_off + (long)in * A.nst + out] = A.omega * vs[e];
+      }
     }
     float vb = gbh[m];
     vb += __shfl_xor(vb, 32);
     vb = sum8(vb);
     if (wid == 0 && hf == 0 && i < A.nst) prow_out[b_off + i] = vb;
   }
+  const f32x16 s1 = sum16(C1), sb = sum16(Cb);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const float v1 = sum8(C1[e]);
-    const float vb = sum8(Cb[e]);
+    const float v1 = s1[e];
+    const float vb = sb[e];
     const int row = fmap(e, hf);
     if (wid == 0) {
       if (row < A.pi && i < A.nst) prow_out[A.first_w + (long)row * A.nst + i] = A.omega * v1;
