@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256) void k_gw_first(GwArgs A) {
 template <int NBO, int WV>
 __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
   __shared__ float red16[(WV - 1) * 16 * 64];
+  extern __shared__ __attribute__((aligned(16))) float xs_all[];   // per wave: the tile's input columns [nd][32]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const long nwaves = (long)gridDim.x * WV;
@@ -385,24 +386,27 @@ __global__ __launch_bounds__(64 * WV) void k_gw_first_mfma(GwArgs A) {
       for (int q = 0; q < 4; ++q) bf[ob][q] = ld4(A.DA + t * FO + (long)(32 * ob + i) * 32 + 16 * hf + 4 * q);
     const int tz = A.zt_mod >= A.ntiles ? (int)t : (int)t % (int)A.zt_mod;
     const int pseudo = t < A.bias_ntiles ? -1 : A.seed[(int)t / (int)A.zt_mod - 1];
+    // the tile's input columns, transposed through the wave's private LDS rows (one coalesced pass instead of 16
+    // scalar loads per lane)
+    float* xs = xs_all + (long)wid * A.nd * 32;
+    if (pseudo < 0)
+      for (int e2 = lane; e2 < 32 * A.nd; e2 += 64) {
+        const int pp = e2 / A.nd, dd = e2 - pp * A.nd;
+        long pt = (long)tz * 32 + pp;
+        if (pt >= A.B) pt = A.B - 1;
+        xs[dd * 32 + pp] = A.xin[pt * A.ncol + A.col0 + dd];
+      }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 z = {1.f, 1.f, 1.f, 1.f};
       if (row_ok && k < A.r) z = ld4(A.Z + ((long)tz * A.r + k) * 32 + 16 * hf + 4 * q);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float xv = 0.f;
-        if (row_ok) {
-          if (pseudo >= 0) xv = d == pseudo ? 1.0f : 0.0f;        // tangent stream: one-hot input, no bias row
-          else if (d == A.nd) xv = 1.0f;
-          else {
-            long pt = (long)tz * 32 + 16 * hf + 4 * q + c;
-            if (pt >= A.B) pt = A.B - 1;
-            xv = A.xin[pt * A.ncol + A.col0 + d];
-          }
-        }
-        a[q][c] = xv * z[c];
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok) {
+        if (pseudo >= 0) { const float o = d == pseudo ? 1.0f : 0.0f; xv[0] = o; xv[1] = o; xv[2] = o; xv[3] = o; }   // one-hot, no bias row
+        else if (d == A.nd) { xv[0] = 1.f; xv[1] = 1.f; xv[2] = 1.f; xv[3] = 1.f; }
+        else xv = *reinterpret_cast<const f32x4*>(xs + d * 32 + 16 * hf + 4 * q);
       }
+      a[q] = xv * z;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -509,9 +513,10 @@ void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
   if (NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32) {
     constexpr int WV = NIF_GW_EDGE_WAVES;   // one workgroup per partial row: many waves hide the single-buffered loads
     dim3 grid(rows);
-    if (NBO == 1) hipLaunchKernelGGL((k_gw_first_mfma<1, WV>), grid, dim3(64 * WV), 0, st, a);
-    else if (NBO == 2) hipLaunchKernelGGL((k_gw_first_mfma<2, WV>), grid, dim3(64 * WV), 0, st, a);
-    else hipLaunchKernelGGL((k_gw_first_mfma<4, 4>), grid, dim3(256), 0, st, a);   // 128+ registers: 4 waves
+    const size_t shx = (size_t)WV * (a.nd > 0 ? a.nd : 1) * 32 * sizeof(float);
+    if (NBO == 1) hipLaunchKernelGGL((k_gw_first_mfma<1, WV>), grid, dim3(64 * WV), shx, st, a);
+    else if (NBO == 2) hipLaunchKernelGGL((k_gw_first_mfma<2, WV>), grid, dim3(64 * WV), shx, st, a);
+    else hipLaunchKernelGGL((k_gw_first_mfma<4, 4>), grid, dim3(256), shx, st, a);   // 128+ registers: 4 waves
     return;
   }
   dim3 grid(rows, a.r + 1), block(256);
