@@ -122,3 +122,73 @@ __device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)
   }
 }
 
+// ---- fp32 products as exact bf16 splits (k_snet4.hip has the derivation and the measured accuracy) ---------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NBL>
+__device__ __forceinline__ void split3(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2], bf16x8 (&s2)[NBL / 2]) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = h[2 * ks + (t >> 2)][t & 3];
+      const __bf16 x0 = (__bf16)x;
+      const float r1 = x - (float)x0;
+      const __bf16 x1 = (__bf16)r1;
+      s0[ks][t] = x0; s1[ks][t] = x1; s2[ks][t] = (__bf16)(r1 - (float)x1);
+    }
+}
+template <int NBL>
+__device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2]) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = h[2 * ks + (t >> 2)][t & 3];
+      const __bf16 x0 = (__bf16)x;
+      s0[ks][t] = x0; s1[ks][t] = (__bf16)(x - (float)x0);
+    }
+}
+// one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form.
+// Two output blocks at a time: their 6-MFMA chains interleave (a dependent v_mfma_f32_16x16x32_bf16 cannot issue
+// back to back) and one LDS round trip feeds 12 MFMAs
+template <int NBL>
+__device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ob = 0; ob < NBL; ob += 2) {
+    const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], a1 = cur[(ob * 3 + 1) * 64 + lane], a2 = cur[(ob * 3 + 2) * 64 + lane];
+    const bf16x8 c0 = cur[(ob * 3 + 3) * 64 + lane], c1 = cur[(ob * 3 + 4) * 64 + lane], c2 = cur[(ob * 3 + 5) * 64 + lane];
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b1, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b2, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c2, b0, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b0, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ob + 1], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+// one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
+template <int NBL>
+__device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ib = 0; ib < NBL; ib += 2) {
+    const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
+    const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, T[ib + 1], 0, 0, 0);
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b0, T[ib + 1], 0, 0, 0);
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+

@@ -24,14 +24,18 @@ struct SobArgs {
   float* JU;                    // optional outputs du/dx [B][so][ns] (predict) or null
 };
 
-template <int NBL, int MODE, bool TRAIN>
+// BF: n x n products as exact bf16 splits on v_mfma_f32_16x16x32_bf16 (forward 6-product, adjoint 3-product form, see
+// k_snet4.hip), whole bf16 planes per LDS step; otherwise the f32-input MFMA planes (odd block counts, n = 128)
+template <int NBL, int MODE, bool TRAIN, bool BF>
 __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
   constexpr int NT = 256, WAVES = 4, NS = NIF_SOB_MAXSEED, NQ = 1 + NS;
-  constexpr int PLANE = NBL * NBL * 256;
-  constexpr int PF4 = (PLANE / 4 + NT - 1) / NT;
-  constexpr bool PEXACT = (PLANE / 4) % NT == 0;
+  constexpr int NCH = NBL / 2, CF = NBL * 3 * 64, CB = NBL * 2 * 64;       // bf16 planes: K-step chunks, 16-B units
+  constexpr int PLANE = BF ? NCH * CF * 4 : NBL * NBL * 256;              // floats per LDS plane buffer
+  constexpr int UF = BF ? NCH * CF : PLANE / 4, UB = BF ? NCH * CB : PLANE / 4;   // 16-B units of a forward / adjoint plane
+  constexpr int PF4 = (UF + NT - 1) / NT;
+  constexpr bool PEXACT = false;
   constexpr int NP = 16 * NBL;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
@@ -51,11 +55,18 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
   const int NPL = nh * (r + 1);
   const int nplanes = TRAIN ? 2 * NPL : NPL;
   auto plane_src = [&](int i) -> const f32x4* {
+    if (BF) {
+      if (i < NPL) return reinterpret_cast<const f32x4*>(A.WF4) + (long)i * UF;
+      const int ii = i - NPL;
+      const int j = nh - 1 - ii / (r + 1), k = ii % (r + 1);
+      return reinterpret_cast<const f32x4*>(A.WB4) + ((long)j * (r + 1) + k) * UB;
+    }
     if (i < NPL) return A.WF + (long)i * (PLANE / 4);
     const int ii = i - NPL;
     const int j = nh - 1 - ii / (r + 1), k = ii % (r + 1);
     return A.WB + ((long)j * (r + 1) + k) * (PLANE / 4);
   };
+  auto plane_units = [&](int i) -> int { return i < NPL ? UF : UB; };
   {
     const long s_wl = (long)si * n + (long)nh * n * n;
     const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
       const f32x4* src = plane_src(0);
 #pragma unroll
       for (int q = 0; q < PF4; ++q)
-        if (PEXACT || tid + NT * q < PLANE / 4) planes[tid + NT * q] = src[tid + NT * q];
+        if (tid + NT * q < plane_units(0)) planes[tid + NT * q] = src[tid + NT * q];
     }
   }
   __syncthreads();
@@ -88,10 +99,12 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
 #define SOB_PLANE(...)                                                                        \
   {                                                                                           \
     if ((pl + 1 < nplanes) || !last_group) {                                                  \
-      const f32x4* src = plane_src(pl + 1 < nplanes ? pl + 1 : 0);                            \
+      const int nxt_ = pl + 1 < nplanes ? pl + 1 : 0;                                         \
+      const f32x4* src = plane_src(nxt_);                                                     \
+      const int nu_ = plane_units(nxt_);                                                      \
       f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);                                   \
       _Pragma("unroll") for (int q = 0; q < PF4; ++q)                                         \
-        if (PEXACT || wid * 64 + NT * q < PLANE / 4)                                          \
+        if (wid * 64 + NT * q < nu_)                                                          \
           __builtin_amdgcn_global_load_lds(                                                   \
               (const __attribute__((address_space(1))) void*)(src + tid + NT * q),            \
               (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);  \
@@ -175,7 +188,14 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
             if (q <= ns) {
               f32x4 hz[NBL];
               _Pragma("unroll") for (int b = 0; b < NBL; ++b) hz[b] = zt * hq[q][b];
-              mfma16<NBL, true>(cur, hz, aq[q], lane);
+              if constexpr (BF) {
+                bf16x8 b0[NCH], b1[NCH], b2[NCH];
+                split3<NBL>(hz, b0, b1, b2);
+                _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
+                  mfma_x6<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CF, b0[ks], b1[ks], b2[ks], aq[q], lane);
+              } else {
+                mfma16<NBL, true>(cur, hz, aq[q], lane);
+              }
             }
         })
       }
@@ -331,14 +351,29 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
               if (q <= ns) {
                 if (k < r) {
                   f32x4 U[NBL], hin[NBL];
-                  mfma16<NBL, false>(cur, vq[q], U, lane);
+                  if constexpr (BF) {
+                    bf16x8 b0[NCH], b1[NCH];
+                    split2<NBL>(vq[q], b0, b1);
+                    _Pragma("unroll") for (int b = 0; b < NBL; ++b) ZERO4(U[b]);
+                    _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
+                      mfma_x3<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], U, lane);
+                  } else {
+                    mfma16<NBL, false>(cur, vq[q], U, lane);
+                  }
                   st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0(q), hin, g);
                   _Pragma("unroll") for (int b = 0; b < NBL; ++b) {
                     lam[q][b] += zt * U[b];
                     dzk += (hin[b][0] * U[b][0] + hin[b][1] * U[b][1]) + (hin[b][2] * U[b][2] + hin[b][3] * U[b][3]);
                   }
                 } else {
-                  mfma16<NBL, true>(cur, vq[q], lam[q], lane);
+                  if constexpr (BF) {
+                    bf16x8 b0[NCH], b1[NCH];
+                    split2<NBL>(vq[q], b0, b1);
+                    _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
+                      mfma_x3<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], lam[q], lane);
+                  } else {
+                    mfma16<NBL, true>(cur, vq[q], lam[q], lane);
+                  }
                 }
               }
             if (k < r) {
@@ -426,26 +461,27 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   J.s = a; J.ns = ns; J.gt = gt; J.wj = wj; J.ring = ring; J.JU = ju;
   for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
   dim3 grid(nblk), block(256);
-  const size_t plane = (size_t)NBL * NBL * 256;
+  const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
+  const size_t plane = bf ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
-#define SBL(NBL_, MODE_, TR_)                                                                                   \
+#define SBL(NBL_, MODE_, TR_, BF_)                                                                              \
   {                                                                                                             \
     if (shm > 48 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)shm);                                                                      \
-    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_>), grid, block, shm, st, J);                                     \
+    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_>), grid, block, shm, st, J);                                \
   }
-#define SBK(NBL_)                                                                    \
-  if (a.res) { if (train) SBL(NBL_, 1, true) else SBL(NBL_, 1, false) }             \
-  else { if (train) SBL(NBL_, 0, true) else SBL(NBL_, 0, false) }
+#define SBK(NBL_, BF_)                                                               \
+  if (a.res) { if (train) SBL(NBL_, 1, true, BF_) else SBL(NBL_, 1, false, BF_) }   \
+  else { if (train) SBL(NBL_, 0, true, BF_) else SBL(NBL_, 0, false, BF_) }
   switch (NBL) {
-    case 1: SBK(1) break;
-    case 2: SBK(2) break;
-    case 3: SBK(3) break;
-    case 4: SBK(4) break;
-    case 6: SBK(6) break;
-    default: SBK(8) break;
+    case 1: SBK(1, false) break;
+    case 2: if (bf) { SBK(2, true) } else { SBK(2, false) } break;
+    case 3: SBK(3, false) break;
+    case 4: if (bf) { SBK(4, true) } else { SBK(4, false) } break;
+    case 6: if (bf) { SBK(6, true) } else { SBK(6, false) } break;
+    default: SBK(8, false) break;
   }
 #undef SBK
 #undef SBL

@@ -440,7 +440,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.Z = c->Z; a.WF = c->sWF; a.WB = c->sWB; a.stash = c->stash_s; a.slot_stride = c->slot_s;
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
-  a.WF4 = c->sWF4; a.WB4 = c->sWB4;
+  a.WF4 = c->use_snet4 ? c->sWF4 : nullptr; a.WB4 = c->use_snet4 ? c->sWB4 : nullptr;   // packed only then
   a.dring = c->dring;
   a.tl = c->tl;
 }
