@@ -431,6 +431,17 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
           }
         }
         if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
+        // <dL/da, b^(k)> now, so that dL/da is dead once it is split and stashed (16 registers less across the planes)
+        for (int k = 0; k < r; ++k) {
+          const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
+          float sbv = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+            sbv += (ga[b][0] * bb[0] + ga[b][1] * bb[1]) + (ga[b][2] * bb[2] + ga[b][3] * bb[3]);
+          }
+          dzs[k * 64 + lane] += sbv;
+        }
         bf16x8 b0[NCH], b1[NCH];
         split2<NBL>(ga, b0, b1);
         NIF_TL(50 + j);
@@ -446,19 +457,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
                 if (!SGN && ks == 0) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
               })
             const float zt = zt_base[k * 16];
-            const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
-            float s = 0.f, sbv = 0.f;
+            float s = 0.f;
 #pragma unroll
             for (int b = 0; b < NBL; ++b) {
               gh[b] += zt * U[b];
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                s = fmaf(hin[b][v], U[b][v], s);
-                sbv = fmaf(ga[b][v], bb[v], sbv);
-              }
+              for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
             }
-            dzs[k * 64 + lane] += fmaf(A.omega, s, sbv);
+            dzs[k * 64 + lane] = fmaf(A.omega, s, dzs[k * 64 + lane]);
           } else {
 #pragma unroll
             for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL>(cur, b0[ks], b1[ks], gh, lane); })
