@@ -121,14 +121,19 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
   float* sm = smem + 2 * CF * 4;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   const int rl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
-  const int pw = 2 * r * 64 + r * 16 + (LL ? (2 * rl + so + sou) * 16 : 0);   // per-wave LDS floats
+  // per-wave input rows [column][16 points] of the tile: coordinates, latent (ParameterNet output), targets, sample
+  // weight -- each group padded to 4 columns = one 64-lane LDS-DMA instruction; two sets: the NEXT tile's inputs are
+  // fetched by DMA while the current tile computes, so no global-load latency sits in the tile's critical path
+  const int nz = LL ? rl : r;
+  const int CX = (si + 3) & ~3, CZ = (nz + 3) & ~3, CY = (sou + 3) & ~3;
+  const int NI = (CX + CZ + CY + 4) * 16;
+  const int pw = 2 * r * 64 + (LL ? (rl + so + sou) * 16 : 0) + 2 * NI;   // per-wave LDS floats
   float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
-  float* zs = sks + r * 64;
-  float* zl = zs + r * 16;          // LL: a [rl][16], phi / dphi [so][16], dL/da [rl][16], du [sou][16]
-  float* phis = zl + rl * 16;
-  float* das = phis + so * 16;
+  float* phis = sks + r * 64;       // LL: phi / dphi [so][16], dL/da [rl][16], du [sou][16]
+  float* das = phis + (LL ? so * 16 : 0);
   float* dul = das + rl * 16;
+  float* inp = dul + (LL ? sou * 16 : 0);
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((rl * rl + 3) & ~3))) : 0;   // LL extras sit at the end of sm
   const int o_lw = o_llb + ((sou + 3) & ~3);
@@ -157,9 +162,39 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + NT * q),
                                          (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
   };
+  auto prefetch_inputs = [&](long tgn, int set) {
+    long t16n = tgn * WAVES + wid;
+    if (t16n >= nt16) t16n = nt16 - 1;
+    const long tile32n = t16n >> 1;
+    const int poffn = 16 * (int)(t16n & 1) + p;
+    long ptn = t16n * 16 + p;
+    if (ptn >= A.B) ptn = A.B - 1;
+    float* dst = inp + set * NI;
+    for (int i0 = 0; i0 < CX; i0 += 4) {
+      const int c = i0 + g < si ? i0 + g : si - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.xin + ptn * A.ncol + A.col0 + c),
+                                       (__attribute__((address_space(3))) void*)(dst + i0 * 16), 4, 0, 0);
+    }
+    for (int i0 = 0; i0 < CZ; i0 += 4) {
+      const int c = i0 + g < nz ? i0 + g : nz - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (tile32n * nz + c) * 32 + poffn),
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + i0) * 16), 4, 0, 0);
+    }
+    if (TRAIN) {
+      for (int i0 = 0; i0 < CY; i0 += 4) {
+        const int c = i0 + g < sou ? i0 + g : sou - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.y + ptn * sou + c),
+                                         (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
+      }
+      const float* swp = A.sw ? A.sw + ptn : A.y + ptn * sou;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
+    }
+  };
   {
     const long s_wl = (long)si * n + (long)nh * n * n;
     const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    prefetch_inputs(blockIdx.x, 0);
     for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
       const int k = idx / nsm, e = idx - k * nsm;
       float v = 0.f;
@@ -202,7 +237,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     ++gpar; ++cc;                                                             \
   }
 
-  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+  int iset = 0;
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
     const bool last_group = tg + gridDim.x >= ngroups;
     const long t16_raw = tg * WAVES + wid;
     const bool active = t16_raw < nt16;
@@ -212,11 +248,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     const long pt = t16 * 16 + p;
     const bool valid = active && pt < A.B;
     const long ptc = pt < A.B ? pt : A.B - 1;
-    const float* xrow = A.xin + ptc * A.ncol + A.col0;
-    if (g == 0)
-      for (int k = 0; k < r; ++k) zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
-    if (LL && g == 0)
-      for (int j = 0; j < rl; ++j) zl[j * 16 + p] = A.Z[(tile32 * rl + j) * 32 + poff];
+    const float* xs = inp + (iset & 1) * NI + p;        // x_d = xs[d*16], fetched during the previous tile
+    const float* zs = inp + (iset & 1) * NI + CX * 16;  // latent rows [k][16]
+    const float* zl = zs;
+    const float* ys = zs + CZ * 16 + p;                 // y_o = ys[o*16]
+    const float* wsp = zs + (CZ + CY) * 16 + p;
     const float* zt_base = zs + p;
     const long row0 = tile32 * (long)FP * 32 + poff;
     if (TRAIN)
@@ -233,7 +269,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int dd = 0; dd < si; ++dd) s += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
         acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
       }
     }
@@ -247,6 +283,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
       }
     }
     NIF_TL(2);
+    prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);   // lands behind the hidden-layer barriers of THIS tile
     // ---- hidden hyper-matrices -------------------------------------------------------------------
     int cc = 0;
     f32x4 ublk[MODE == 1 ? NBL : 1];
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
     if (TRAIN && active) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
     f32x4 gh[NBL];
     ZERO_T(gh)
-    const float wsamp = (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f);
+    const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
     float se = 0.f;
     if (LL) {
       // phi[o] = <h, Wl[:, o]> + bl[o] into the wave's LDS row, then per point u = Dot(phi, a) + bias
@@ -329,7 +366,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
         for (int j = 0; j < rl; ++j) uo = fmaf(phis[(s_ * rl + j) * 16 + p], zl[j * 16 + p], uo);
         if (valid && g == 0 && A.u_out) A.u_out[pt * sou + s_] = uo;
         if (TRAIN) {
-          const float e = uo - A.y[ptc * sou + s_];
+          const float e = uo - ys[s_ * 16];
           se = fmaf(e, e, se);
           const float du = 2.0f * wsamp * e * A.inv_bg / (float)sou;
           if (g == 0) {
@@ -387,7 +424,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
       const float uo = part + bias;
       if (valid && g == 0 && A.u_out) A.u_out[pt * so + o] = uo;
       if (TRAIN) {
-        const float e = uo - A.y[ptc * so + o];
+        const float e = uo - ys[o * 16];
         se = fmaf(e, e, se);
         const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
         if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
@@ -496,7 +533,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
 #pragma unroll
           for (int b = 0; b < NBL; ++b) {
             f32x4 xw = {0.f, 0.f, 0.f, 0.f};
-            for (int dd = 0; dd < si; ++dd) xw += xrow[dd] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+            for (int dd = 0; dd < si; ++dd) xw += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
             const f32x4 t = A.omega * xw + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
             s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
           }
@@ -520,7 +557,9 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNet
 // ---- host side ---------------------------------------------------------------------------------
 static size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  const size_t pw = 2 * a.r * 64 + a.r * 16 + (a.ll ? (size_t)(2 * a.rl + a.so + a.so_u) * 16 : 0);
+  const int nz = a.ll ? a.rl : a.r, sou = a.ll ? a.so_u : a.so;
+  const size_t ni = (size_t)(((a.si + 3) & ~3) + ((nz + 3) & ~3) + ((sou + 3) & ~3) + 4) * 16;
+  const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni;
   return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);
 }
 // floats per k of the LDS small-vector image (last-layer class: + last_layer_bias and the rl x rl map)
