@@ -23,6 +23,9 @@
 #ifndef NIF_S4_OCC
 #define NIF_S4_OCC 3
 #endif
+#ifndef NIF_S4_OCC_WIDE
+#define NIF_S4_OCC_WIDE 2   // workgroups per CU of the 96- and 128-wide instantiations: 2 x 256 registers with ~200 spilled beat 1 x 512 (cfg-3: 3.45 -> 2.79 ms)
+#endif
 
 // ---- packing ------------------------------------------------------------------------------------
 // K-slot (g, t), g = lane >> 4, t = 0..7 of K-step ks  <->  feature 16*(2ks + (t >> 2)) + 4g + (t & 3): exactly what a
@@ -104,7 +107,7 @@ __device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f
 // (r = 0, one plane per layer) whose last layer emits phi [so_u x rl]; u = Dot(phi, a) + bias with the ParameterNet
 // output a; the adjoint starts from dphi = du (x) a and also yields dL/da (and dL/dlatent through the rl x rl map).
 template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL>
-__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : 1)) void k_snet4(SNetArgs A) {
+__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
   constexpr int NCH = NBL / 2;                      // K-step chunks per plane
@@ -591,7 +594,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
-  const long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256;
+  const long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256 * NIF_S4_OCC_WIDE;
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   if (query_only) return nblk;
   dim3 grid(nblk), block(256);
