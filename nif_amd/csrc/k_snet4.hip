@@ -353,16 +353,25 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     float se = 0.f;
     if (LL) {
       // phi[o] = <h, Wl[:, o]> + bl[o] into the wave's LDS row, then per point u = Dot(phi, a) + bias
-      for (int o = 0; o < so; ++o) {
-        float part = 0.f;
+      // four outputs per pass: independent dot-product chains hide the LDS and cross-row shuffle latencies
+      for (int o0 = 0; o0 < so; o0 += 4) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
-          part += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+        for (int u4 = 0; u4 < 4; ++u4) {
+          const int o = o0 + u4 < so ? o0 + u4 : so - 1;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+            part[u4] += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          }
         }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (g == 0) phis[o * 16 + p] = part + sm[o_bl + o];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) part[u4] += __shfl_xor(part[u4], 16);
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) part[u4] += __shfl_xor(part[u4], 32);
+        // lane group g keeps output o0 + g
+        const float mine = g == 0 ? part[0] : (g == 1 ? part[1] : (g == 2 ? part[2] : part[3]));
+        if (o0 + g < so) phis[(o0 + g) * 16 + p] = mine + sm[o_bl + o0 + g];
       }
       for (int s_ = 0; s_ < sou; ++s_) {
         float uo = sm[o_llb + s_];
@@ -392,15 +401,24 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
           if (active) A.DZL[(tile32 * rl + k) * 32 + poff] = dz;
         }
         // dphi[o] = du[s] a[j] replaces phi in LDS; it is also the "dL/dout" stash of the phi layer's weight gradient
-        for (int o = g; o < so; o += 4) {
-          const float dq = dul[(o / rl) * 16 + p] * zl[(o % rl) * 16 + p];
-          phis[o * 16 + p] = dq;
-          if (active) A.DPHI[(tile32 * so + o) * 32 + poff] = dq;
+        for (int s_ = 0; s_ < sou; ++s_) {
+          const float du = dul[s_ * 16 + p];
+          for (int j = g; j < rl; j += 4) {
+            const int o = s_ * rl + j;
+            const float dq = du * zl[j * 16 + p];
+            phis[o * 16 + p] = dq;
+            if (active) A.DPHI[(tile32 * so + o) * 32 + poff] = dq;
+          }
         }
-        for (int o = 0; o < so; ++o) {
-          const float dq = phis[o * 16 + p];
+        for (int o0 = 0; o0 < so; o0 += 2) {       // two outputs per pass (independent LDS reads in flight)
+          const int o1 = o0 + 1 < so ? o0 + 1 : o0;
+          const float dq0 = phis[o0 * 16 + p], dq1 = o0 + 1 < so ? phis[o1 * 16 + p] : 0.f;
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) gh[b] += dq * *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + o_wl + o0 * NP + 16 * b + 4 * g);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + o_wl + o1 * NP + 16 * b + 4 * g);
+            gh[b] += dq0 * w0 + dq1 * w1;
+          }
         }
       }
     } else

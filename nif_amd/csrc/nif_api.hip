@@ -428,6 +428,7 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
   a.DU = c->DU; a.DZ = nullptr; a.dring = c->dring;
   a.ll = 1; a.rl = c->r; a.so_u = c->so; a.DPHI = c->DPHI; a.DA_ll = c->DA; a.DZL = c->DZL;
   a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
+  a.tl = c->tl;
 }
 static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
