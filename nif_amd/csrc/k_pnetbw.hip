@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
 
 bool pnet_bwg_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
-  return a.nst <= 32 && a.pi <= 6 && a.r <= 32 && !a.ll_kind && nm >= 1 && nm <= 2 && (!a.res || a.lst == 1);
+  // (last-layer class: DZ is then dL/dlatent in front of the rl x rl map, whose own gradient stays a k_gw_out launch)
+  return a.nst <= 32 && a.pi <= 6 && a.r <= 32 && nm >= 1 && nm <= 2 && (!a.res || a.lst == 1);
 }
 
 void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st) {

@@ -760,7 +760,9 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
   LLArgs la; fill_ll(c, la, B);
   la.y = y; la.sw = sw; la.inv_bg = 1.0f / (float)Bg;
-  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, true, c->st); }
+  static const bool force_stash_ll = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
+  const bool fused_p = !force_stash_ll && pnet_bwg_supported(pa);
+  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   int nloss = (int)((ntiles * 32 + 255) / 256);
   if (c->use_ll4) {
     SNetArgs sa; fill_snet_ll(c, sa, xin, ncol, c->pi, B);
@@ -780,10 +782,12 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     launch_ll_out(la, true, c->st);
     launch_pnet_bwd(ma, c->NB, c->st);
   }
-  { ProfScope p_(c, NIF_PROF_PNET_BWD); launch_pnet_bwd(pa, c->NSTB, c->st); }
   int rows = (int)((ntiles + 3) / 4);
   if (rows > c->rows_cap) rows = c->rows_cap;
   if (rows < 1) rows = 1;
+  { ProfScope p_(c, NIF_PROF_PNET_BWD);
+    if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st);
+    else launch_pnet_bwd(pa, c->NSTB, c->st); }
   {
     ProfScope p_(c, NIF_PROF_GW);
     GwArgs g;
@@ -813,6 +817,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     launch_gw_out(g, c->NB, rows, c->st);
     // ParameterNet: first, hidden matrices, bottleneck, last (r x r)
     float* pST = c->stash_p;
+    if (!fused_p) {
     base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.scale = pa.omega;
     g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
     launch_gw_first(g, c->NSTB, rows, c->st);
@@ -827,6 +832,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->DZL; g.nc = c->r;
     g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
     launch_gw_out(g, c->NSTB, rows, c->st);
+    }
     base(g); g.IN = c->ZL; g.SM = c->DA; g.nc = c->r;   // latent (padded rows) x dL/da
     g.W = dense_ref(c->last_w, c->r, c->r); g.Bv = vec_ref(c->last_b, c->r);
     launch_gw_out(g, c->RB, rows, c->st);
