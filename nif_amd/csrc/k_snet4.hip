@@ -66,6 +66,42 @@ void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void
   hipLaunchKernelGGL(k_pack16b, dim3(grid), dim3(256), 0, st, theta, m, NBL, (__bf16*)WF, (__bf16*)WB);
 }
 
+// phi layer of the last-layer class: dense W[n][sop], sop <= 32 (two 16-output blocks)
+__global__ void k_pack_phi(const float* __restrict__ theta, long w_off, int n, int sop, int NBL, __bf16* __restrict__ WPF,
+                           __bf16* __restrict__ WPB) {
+  const int NCH = NBL / 2;
+  const long total_f = (long)NCH * 2 * 3 * 64 * 8, total_b = (long)NBL * 2 * 64 * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
+    const bool fwd = idx < total_f;
+    long rem = fwd ? idx : idx - total_f;
+    const int t = rem & 7; rem >>= 3;
+    const int lane = rem & 63; rem >>= 6;
+    const int ns = fwd ? 3 : 2;
+    const int sp = (int)(rem % ns); rem /= ns;
+    int in, out;
+    if (fwd) {
+      const int ob = (int)(rem % 2), ks = (int)(rem / 2);
+      in = 16 * (2 * ks + (t >> 2)) + 4 * (lane >> 4) + (t & 3);
+      out = 16 * ob + (lane & 15);
+    } else {
+      const int ib = (int)rem;
+      in = 16 * ib + (lane & 15);
+      out = 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
+    }
+    const float x = (in < n && out < sop) ? theta[w_off + (long)in * sop + out] : 0.f;
+    const __bf16 x0 = (__bf16)x;
+    const float r1 = x - (float)x0;
+    const __bf16 x1 = (__bf16)r1;
+    const __bf16 x2 = (__bf16)(r1 - (float)x1);
+    (fwd ? WPF : WPB)[fwd ? idx : idx - total_f] = sp == 0 ? x0 : (sp == 1 ? x1 : x2);
+  }
+}
+long snet4_phi_fwd_elems(int n) { return (long)(snet3_nbl(n) / 2) * 2 * 3 * 64 * 8; }
+long snet4_phi_bwd_elems(int n) { return (long)snet3_nbl(n) * 2 * 64 * 8; }
+void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, void* WPB, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_phi, dim3(64), dim3(256), 0, st, theta, w_off, n, sop, snet3_nbl(n), (__bf16*)WPF, (__bf16*)WPB);
+}
+
 __device__ __forceinline__ void sgn_push(unsigned long long& lo, unsigned long long& hi, unsigned bits, int w) {
   hi = (hi << w) | (lo >> (64 - w));
   lo = (lo << w) | bits;
@@ -96,6 +132,7 @@ __device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f
       d[b][v] = __uint_as_float(__float_as_uint(c) | (((bits >> (4 * b + v)) & 1u) << 31));
     }
 }
+#define ZERO4_(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
 // MODE: 0 = plain (NIFMultiScale without resblock), 1 = SIREN resblock, 2 = NIF skip connection
@@ -145,12 +182,17 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 
   const int NPL = nh * (r + 1);
   const int nfwd = NPL * NCH;
-  const int nchunks = TRAIN ? 2 * nfwd : nfwd;
+  constexpr int PHF = 2 * 3 * 64;                       // units of a phi-layer forward chunk (LL)
+  const int nphi = LL ? NCH + (TRAIN ? 1 : 0) : 0;      // LL: phi forward chunks, then its adjoint chunk, sit between the sweeps
+  const int nchunks = (TRAIN ? 2 * nfwd : nfwd) + nphi;
   const bf16x8* WF = reinterpret_cast<const bf16x8*>(A.WF4);
   const bf16x8* WB = reinterpret_cast<const bf16x8*>(A.WB4);
+  auto chunk_units = [&](int i) -> int { return i < nfwd ? CF : ((LL && i < nfwd + NCH) ? PHF : CB); };
   auto chunk_src = [&](int i) -> const bf16x8* {
     if (i < nfwd) return WF + (long)i * CF;
-    const int ii = i - nfwd;
+    if (LL && i < nfwd + NCH) return reinterpret_cast<const bf16x8*>(A.WPF) + (long)(i - nfwd) * PHF;
+    if (LL && i == nfwd + NCH) return reinterpret_cast<const bf16x8*>(A.WPB);
+    const int ii = i - nfwd - nphi;
     const int pp = ii / NCH, ks = ii - pp * NCH;
     const int j = nh - 1 - pp / (r + 1), k = pp % (r + 1);
     return WB + (((long)j * (r + 1) + k) * NCH + ks) * CB;
@@ -158,10 +200,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   auto dma = [&](int i, int buf) {
     const bf16x8* src = chunk_src(i);
     bf16x8* dst = chunks + buf * CF;
-    const bool fwd = i < nfwd;
+    const int nun = chunk_units(i);
 #pragma unroll
     for (int q = 0; q < QF; ++q)
-      if (wid * 64 + NT * q < (fwd ? CF : CB))
+      if (wid * 64 + NT * q < nun)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + NT * q),
                                          (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
   };
@@ -353,25 +395,21 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     float se = 0.f;
     if (LL) {
       // phi[o] = <h, Wl[:, o]> + bl[o] into the wave's LDS row, then per point u = Dot(phi, a) + bias
-      // four outputs per pass: independent dot-product chains hide the LDS and cross-row shuffle latencies
-      for (int o0 = 0; o0 < so; o0 += 4) {
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
+      // phi = Wl^T h on the matrix cores (two 16-output blocks, the 6-product form), into the wave's LDS rows
+      {
+        bf16x8 b0[NCH], b1[NCH], b2[NCH];
+        split3<NBL>(h, b0, b1, b2);
+        f32x4 T2[2];
+        ZERO4_(T2[0]) ZERO4_(T2[1])
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-          const int o = o0 + u4 < so ? o0 + u4 : so - 1;
+        for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<2>(cur, b0[ks], b1[ks], b2[ks], T2, lane); })
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
-            part[u4] += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int o = 16 * b + 4 * g + v;
+            if (o < so) phis[o * 16 + p] = T2[b][v] + sm[o_bl + o];
           }
-        }
-#pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) part[u4] += __shfl_xor(part[u4], 16);
-#pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) part[u4] += __shfl_xor(part[u4], 32);
-        // lane group g keeps output o0 + g
-        const float mine = g == 0 ? part[0] : (g == 1 ? part[1] : (g == 2 ? part[2] : part[3]));
-        if (o0 + g < so) phis[(o0 + g) * 16 + p] = mine + sm[o_bl + o0 + g];
       }
       for (int s_ = 0; s_ < sou; ++s_) {
         float uo = sm[o_llb + s_];
@@ -410,15 +448,19 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             if (active) A.DPHI[(tile32 * so + o) * 32 + poff] = dq;
           }
         }
-        for (int o0 = 0; o0 < so; o0 += 2) {       // two outputs per pass (independent LDS reads in flight)
-          const int o1 = o0 + 1 < so ? o0 + 1 : o0;
-          const float dq0 = phis[o0 * 16 + p], dq1 = o0 + 1 < so ? phis[o1 * 16 + p] : 0.f;
+        // dL/dh = Wl dphi: one adjoint chunk (K = the 32 padded outputs), 3-product form
+        {
+          f32x4 dq2[2];
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + o_wl + o0 * NP + 16 * b + 4 * g);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + o_wl + o1 * NP + 16 * b + 4 * g);
-            gh[b] += dq0 * w0 + dq1 * w1;
-          }
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int o = 16 * b + 4 * g + v;
+              dq2[b][v] = o < so ? phis[o * 16 + p] : 0.f;
+            }
+          bf16x8 d0[1], d1[1];
+          split2<2>(dq2, d0, d1);
+          NIF_CHUNK({ mfma_x3<NBL>(cur, d0[0], d1[0], gh, lane); })
         }
       }
     } else
@@ -598,6 +640,7 @@ void launch_ll_slots(const float* theta, const LLSlotMap& m, float* slots, hipSt
 bool snet4_supported(const SNetArgs& a) {
   const int NBL = snet3_nbl(a.n);
   if (a.n > 128 || (NBL & 1) || a.nh < 1) return false;
+  if (a.ll && a.so > 32) return false;          // the phi layer runs as two 16-output MFMA blocks
   return snet4_shmem(a, NBL) <= 160u * 1024u;
 }
 // bf16 elements of the packed forward / adjoint planes of ONE hidden hyper-matrix (all r+1 planes)

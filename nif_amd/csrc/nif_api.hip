@@ -41,6 +41,7 @@ struct nif_ctx {
   void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
+  void *ll_wpf = nullptr, *ll_wpb = nullptr;   // phi layer as bf16-split MFMA operands (launch_pack_phi)
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -203,6 +204,8 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
     if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpf, (size_t)snet4_phi_fwd_elems(c->n) * 2);
+    if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpb, (size_t)snet4_phi_bwd_elems(c->n) * 2);
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess)
       e = hipMalloc(&c->ll_slots, sizeof(float) * (size_t)((long)c->si * c->n + (long)nh * c->n * c->n + (long)c->n * c->so * c->r +
                                                              c->n + (long)nh * c->n + c->so * c->r + c->so + c->r * c->r + 64));
@@ -224,7 +227,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -427,6 +430,7 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
   a.Z = c->Z; a.WF4 = c->sWF4; a.WB4 = c->sWB4; a.stash = c->stash_s; a.slot_stride = c->slot_s;
   a.DU = c->DU; a.DZ = nullptr; a.dring = c->dring;
   a.ll = 1; a.rl = c->r; a.so_u = c->so; a.DPHI = c->DPHI; a.DA_ll = c->DA; a.DZL = c->DZL;
+  a.WPF = c->ll_wpf; a.WPB = c->ll_wpb;
   a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
   a.tl = c->tl;
 }
@@ -489,7 +493,7 @@ static int ensure_packed(nif_ctx* c) {
     {
       SNetArgs probe; fill_snet_ll(c, probe, nullptr, 0, 0, 32);
       static const bool ll_old = [] { const char* e = getenv("NIF_LL_MLP"); return e && e[0] == '1'; }();
-      c->use_ll4 = c->sWF4 && c->ll_slots && !ll_old && snet4_supported(probe);
+      c->use_ll4 = c->sWF4 && c->ll_slots && c->ll_wpf && c->ll_wpb && !ll_old && snet4_supported(probe);
     }
     if (c->use_ll4) {
       const int n = c->n, nh = c->nh, sop = c->so * c->r;
@@ -511,6 +515,7 @@ static int ensure_packed(nif_ctx* c) {
       seg(c->ll_bias, s_bl + sop, c->so);
       seg(c->last_w, s_bl + sop + c->so, (long)c->r * c->r);
       launch_ll_slots(c->theta, m, c->ll_slots, c->st);
+      launch_pack_phi(c->theta, c->s_bott_w, n, sop, c->ll_wpf, c->ll_wpb, c->st);
     }
     HIPCHK(hipGetLastError());
     c->packed = true;

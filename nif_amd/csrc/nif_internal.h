@@ -86,6 +86,7 @@ struct SNetArgs {
   // last-layer-parameterised class on k_snet4 (r = 0: shared dense SIREN; theta = the slot-ordered copy built by
   // launch_ll_slots; so = so_u * rl outputs phi): u = Dot(phi, a) + bias, a = Z [tiles][rl][32]
   int ll, rl, so_u;
+  const void* WPF; const void* WPB;       // bf16-split planes of the phi layer [n][so <= 32] (launch_pack_phi)
   float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
@@ -95,6 +96,11 @@ struct SNetArgs {
 struct LLSlotSeg { long src, dst, len; };
 struct LLSlotMap { int nseg; LLSlotSeg seg[48]; };
 void launch_ll_slots(const float* theta, const LLSlotMap& m, float* slots, hipStream_t st);
+// phi layer (dense [n][sop], sop <= 32) as bf16-split MFMA operands: NBL/2 forward K-step chunks of 2*3*64 16-byte units
+// and one adjoint chunk of NBL*2*64 units
+long snet4_phi_fwd_elems(int n);
+long snet4_phi_bwd_elems(int n);
+void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, void* WPB, hipStream_t st);
 // slot offsets inside pnet_output (nif/model.py:253-300): computed on the fly
 __host__ __device__ inline long slot_w1(const SNetArgs& a) { return 0; }
 __host__ __device__ inline long slot_wh(const SNetArgs& a, int j) { return (long)a.si * a.n + (long)j * a.n * a.n; }
