@@ -192,3 +192,35 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 
+// ---- sign-of-cosine shift register (plain SIREN: cos(a) = +-sqrt(1 - sin^2(a)), sin(a) is the next layer's stashed
+// input; see k_snet4.hip) ------------------------------------------------------------------------------------
+__device__ __forceinline__ void sgn_push(unsigned long long& lo, unsigned long long& hi, unsigned bits, int w) {
+  hi = (hi << w) | (lo >> (64 - w));
+  lo = (lo << w) | bits;
+}
+__device__ __forceinline__ unsigned sgn_pop(unsigned long long& lo, unsigned long long& hi, int w) {
+  const unsigned bits = (unsigned)(lo & ((1ull << w) - 1ull));
+  lo = (lo >> w) | (hi << (64 - w));
+  hi >>= w;
+  return bits;
+}
+template <int NBL>
+__device__ __forceinline__ unsigned sgn_pack(const f32x4 (&d)[NBL]) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bits |= (__float_as_uint(d[b][v]) >> 31) << (4 * b + v);
+  return bits;
+}
+// cos(a) from sin(a) and the sign bit
+template <int NBL>
+__device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f32x4 (&d)[NBL]) {
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float c = __builtin_sqrtf(fmaxf(fmaf(-sn[b][v], sn[b][v], 1.0f), 0.0f));
+      d[b][v] = __uint_as_float(__float_as_uint(c) | (((bits >> (4 * b + v)) & 1u) << 31));
+    }
+}

@@ -102,36 +102,6 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
   hipLaunchKernelGGL(k_pack_phi, dim3(64), dim3(256), 0, st, theta, w_off, n, sop, snet3_nbl(n), (__bf16*)WPF, (__bf16*)WPB);
 }
 
-__device__ __forceinline__ void sgn_push(unsigned long long& lo, unsigned long long& hi, unsigned bits, int w) {
-  hi = (hi << w) | (lo >> (64 - w));
-  lo = (lo << w) | bits;
-}
-__device__ __forceinline__ unsigned sgn_pop(unsigned long long& lo, unsigned long long& hi, int w) {
-  const unsigned bits = (unsigned)(lo & ((1ull << w) - 1ull));
-  lo = (lo >> w) | (hi << (64 - w));
-  hi >>= w;
-  return bits;
-}
-template <int NBL>
-__device__ __forceinline__ unsigned sgn_pack(const f32x4 (&d)[NBL]) {
-  unsigned bits = 0;
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) bits |= (__float_as_uint(d[b][v]) >> 31) << (4 * b + v);
-  return bits;
-}
-// cos(a) from sin(a) and the sign bit
-template <int NBL>
-__device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f32x4 (&d)[NBL]) {
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float c = __builtin_sqrtf(fmaxf(fmaf(-sn[b][v], sn[b][v], 1.0f), 0.0f));
-      d[b][v] = __uint_as_float(__float_as_uint(c) | (((bits >> (4 * b + v)) & 1u) << 31));
-    }
-}
 #define ZERO4_(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 

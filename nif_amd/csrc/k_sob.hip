@@ -26,7 +26,10 @@ struct SobArgs {
 
 // BF: n x n products as exact bf16 splits on v_mfma_f32_16x16x32_bf16 (forward 6-product, adjoint 3-product form, see
 // k_snet4.hip), whole bf16 planes per LDS step; otherwise the f32-input MFMA planes (odd block counts, n = 128)
-template <int NBL, int MODE, bool TRAIN, bool BF>
+// SGN (plain SIREN, training): the ring keeps only the tangent pre-activations a'^d of the ACTIVE seeds; cos(a) is
+// rebuilt from the stashed sin(a) (the next layer's primal input) and its sign bit (k_snet4's shift register) --
+// the ring was 5 blocks written + 5 read per layer, now ns written + ns read and one stash read
+template <int NBL, int MODE, bool TRAIN, bool BF, bool SGN>
 __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
 
     // hq[0] = h, hq[1+d] = h'^d ; aq likewise for the pre-activation accumulators
     f32x4 hq[NQ][NBL], aq[NQ][NBL];
+    unsigned long long sg_lo = 0ull, sg_hi = 0ull;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -160,13 +164,14 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
       sine16<NBL>(aq[0], hq[0], c);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
-        if (TRAIN) { ring[0 * NBL * 64 + b * 64 + lane] = c[b]; ring[1 * NBL * 64 + b * 64 + lane] = hq[0][b]; }
+        if (TRAIN && !SGN) { ring[0 * NBL * 64 + b * 64 + lane] = c[b]; ring[1 * NBL * 64 + b * 64 + lane] = hq[0][b]; }
 #pragma unroll
         for (int d = 0; d < NS; ++d) {
-          if (TRAIN) ring[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
+          if (TRAIN && d < ns) ring[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
           hq[1 + d][b] = c[b] * aq[1 + d][b];
         }
       }
+      if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(c), 4 * NBL);
     }
     // ---- hidden hyper-matrices -------------------------------------------------------------------
     int pl = 0;
@@ -214,11 +219,12 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
       f32x4* rl = ring + (long)(j + 1) * (2 + NS) * NBL * 64;
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
-        if (TRAIN) { rl[0 * NBL * 64 + b * 64 + lane] = c[b]; rl[1 * NBL * 64 + b * 64 + lane] = sn[b]; }
+        if (TRAIN && !SGN) { rl[0 * NBL * 64 + b * 64 + lane] = c[b]; rl[1 * NBL * 64 + b * 64 + lane] = sn[b]; }
 #pragma unroll
         for (int d = 0; d < NS; ++d)
-          if (TRAIN) rl[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
+          if (TRAIN && d < ns) rl[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
       }
+      if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(c), 4 * NBL);
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -323,9 +329,22 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
 #pragma unroll
             for (int b = 0; b < NBL; ++b) { lam[q][b] *= 0.5f; skip[q][b] = lam[q][b]; }
         }
+        f32x4 cv[NBL], snv[NBL];
+        if (SGN) {
+          if (j == nh - 1) {
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) snv[b] = hq[0][b];                  // sin(a) of the top layer: still in registers
+          } else {
+            st_load16<NBL>(IN0 + (long)(j + 1) * A.slot_stride, row0(0), snv, g);   // = the next layer's primal input
+          }
+          sgn_cos<NBL>(snv, sgn_pop(sg_lo, sg_hi, 4 * NBL), cv);
+        } else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) { cv[b] = rl[0 * NBL * 64 + b * 64 + lane]; snv[b] = rl[1 * NBL * 64 + b * 64 + lane]; }
+        }
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
-          const f32x4 c = rl[0 * NBL * 64 + b * 64 + lane], sn = rl[1 * NBL * 64 + b * 64 + lane];
+          const f32x4 c = cv[b], sn = snv[b];
           f32x4 da = lam[0][b] * c;
 #pragma unroll
           for (int d = 0; d < NS; ++d) {
@@ -398,9 +417,17 @@ __global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
       // ---- first layer ---------------------------------------------------------------------------
       {
         f32x4 vq[NQ][NBL];
+        f32x4 cv[NBL], snv[NBL];
+        if (SGN) {
+          st_load16<NBL>(IN0, row0(0), snv, g);                               // h_0 = sin(a_0)
+          sgn_cos<NBL>(snv, sgn_pop(sg_lo, sg_hi, 4 * NBL), cv);
+        } else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) { cv[b] = ring[0 * NBL * 64 + b * 64 + lane]; snv[b] = ring[1 * NBL * 64 + b * 64 + lane]; }
+        }
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
-          const f32x4 c = ring[0 * NBL * 64 + b * 64 + lane], sn = ring[1 * NBL * 64 + b * 64 + lane];
+          const f32x4 c = cv[b], sn = snv[b];
           f32x4 da = lam[0][b] * c;
 #pragma unroll
           for (int d = 0; d < NS; ++d) {
@@ -462,19 +489,21 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
+  const bool sgn = !a.res && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register
   const size_t plane = bf ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
-#define SBL(NBL_, MODE_, TR_, BF_)                                                                              \
+#define SBL(NBL_, MODE_, TR_, BF_, SGN_)                                                                            \
   {                                                                                                             \
     if (shm > 48 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_, BF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_, BF_, SGN_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)shm);                                                                      \
-    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_>), grid, block, shm, st, J);                                \
+    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_>), grid, block, shm, st, J);                                \
   }
 #define SBK(NBL_, BF_)                                                               \
-  if (a.res) { if (train) SBL(NBL_, 1, true, BF_) else SBL(NBL_, 1, false, BF_) }   \
-  else { if (train) SBL(NBL_, 0, true, BF_) else SBL(NBL_, 0, false, BF_) }
+  if (a.res) { if (train) SBL(NBL_, 1, true, BF_, false) else SBL(NBL_, 1, false, BF_, false) }   \
+  else if (train) { if (sgn) SBL(NBL_, 0, true, BF_, true) else SBL(NBL_, 0, true, BF_, false) } \
+  else SBL(NBL_, 0, false, BF_, false)
   switch (NBL) {
     case 1: SBK(1, false) break;
     case 2: if (bf) { SBK(2, true) } else { SBK(2, false) } break;
