@@ -13,6 +13,9 @@
 #include "k_snet3_dev.h"
 
 #define NIF_SOB_MAXSEED 3
+#ifndef NIF_SOB_OCC
+#define NIF_SOB_OCC 1   // workgroups per CU for n <= 64 (2 = 256 registers each: 149 spills, 5.3 -> 8.3 ms)
+#endif
 
 struct SobArgs {
   SNetArgs s;
@@ -30,7 +33,7 @@ struct SobArgs {
 // rebuilt from the stashed sin(a) (the next layer's primal input) and its sign bit (k_snet4's shift register) --
 // the ring was 5 blocks written + 5 read per layer, now ns written + ns read and one stash read
 template <int NBL, int MODE, bool TRAIN, bool BF, bool SGN>
-__global__ __launch_bounds__(256, 1) void k_sob(SobArgs J) {
+__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
   constexpr int NT = 256, WAVES = 4, NS = NIF_SOB_MAXSEED, NQ = 1 + NS;
@@ -482,7 +485,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
-  const int nblk = (int)(ngroups < 256 ? ngroups : 256);
+  const long cap = NBL <= 4 ? 256 * NIF_SOB_OCC : 256;
+  const int nblk = (int)(ngroups < cap ? ngroups : cap);
   if (query_only) return nblk;
   SobArgs J;
   J.s = a; J.ns = ns; J.gt = gt; J.wj = wj; J.ring = ring; J.JU = ju;
