@@ -225,7 +225,7 @@ def main():
             "roofline_given_w": roofline_given_w,
             "kernel_ms": kern_ms,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle in the fence)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
         sys.stdout.flush()
