@@ -479,3 +479,44 @@ def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
     assert hist[-1] < 0.2 * hist[0], (hist[0], hist[-1])
     _, _, mse_u_plain, mse_j_plain = run(False)
     assert mse_j < mse_j_plain, (mse_j, mse_j_plain)
+
+
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ms_res_48x2_pres"])
+def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
+    """Two epochs of fit() (partial last batch) against the oracle's loss/grad + Keras-Adam trajectory for the
+    last-layer class (fused LL kernel) and a resblock model, then save_weights / load_weights into a fresh model:
+    identical predictions and identical continuation (optimizer slots travel with the checkpoint)."""
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make(name)
+    model.compile(nif_amd.Adam(1e-3), loss="mse")
+    bs = 100
+    hist = model.fit(x, y, epochs=2, batch_size=bs, shuffle=False, verbose=0)
+    th = O.flatten(ws); mm = np.zeros_like(th); vv = np.zeros_like(th)
+    t = 0
+    ep_losses = []
+    for ep in range(2):
+        tot = 0.0
+        for b0 in range(0, x.shape[0], bs):
+            xb, yb = x[b0:b0 + bs], y[b0:b0 + bs]
+            l, g = O.loss_and_grad(spec, O.unflatten(spec, th), xb.astype(np.float64), yb.astype(np.float64))
+            t += 1
+            th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t)
+            tot += l * xb.shape[0]
+        ep_losses.append(tot / x.shape[0])
+    assert np.allclose(hist.history["loss"], ep_losses, rtol=1e-3), (hist.history["loss"], ep_losses)
+    assert _rel(O.flatten(model.get_weights()), th) < 2e-4
+    ck = str(tmp_path / "ckpt")
+    model.save_weights(ck)
+    kind = type(m)
+    m2 = kind(m.cfg_shape_net, m.cfg_parameter_net) if hasattr(m, "cfg_shape_net") else None
+    if m2 is None:
+        (k_, cs, cp), _ = CONFIGS[name]
+        m2 = getattr(nif_amd, k_)(cs, cp)
+    model2 = m2.build()
+    model2.compile(nif_amd.Adam(1e-3), loss="mse")
+    model2.load_weights(ck)
+    assert np.array_equal(model2.predict(x), model.predict(x))
+    h1 = model.fit(x, y, epochs=1, batch_size=bs, shuffle=False, verbose=0)
+    h2 = model2.fit(x, y, epochs=1, batch_size=bs, shuffle=False, verbose=0)
+    assert np.allclose(h1.history["loss"], h2.history["loss"], rtol=1e-6)
+    assert np.array_equal(model2.predict(x), model.predict(x))
