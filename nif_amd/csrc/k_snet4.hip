@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   constexpr int NT = 256, WAVES = 4;
   constexpr int NCH = NBL / 2;                      // K-step chunks per plane
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
-  constexpr int QF = (CF + NT - 1) / NT, QB = (CB + NT - 1) / NT;
+  constexpr int QF = (CF + NT - 1) / NT;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
@@ -262,7 +262,6 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     const int poff = 16 * (int)(t16 & 1) + p;
     const long pt = t16 * 16 + p;
     const bool valid = active && pt < A.B;
-    const long ptc = pt < A.B ? pt : A.B - 1;
     const float* xs = inp + (iset & 1) * NI + p;        // x_d = xs[d*16], fetched during the previous tile
     const float* zs = inp + (iset & 1) * NI + CX * 16;  // latent rows [k][16]
     const float* zl = zs;

@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
   constexpr int PLANE = BF ? NCH * CF * 4 : NBL * NBL * 256;              // floats per LDS plane buffer
   constexpr int UF = BF ? NCH * CF : PLANE / 4, UB = BF ? NCH * CB : PLANE / 4;   // 16-B units of a forward / adjoint plane
   constexpr int PF4 = (UF + NT - 1) / NT;
-  constexpr bool PEXACT = false;
   constexpr int NP = 16 * NBL;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
