@@ -32,7 +32,11 @@
 // lane of the previous layer's C/D tile holds in blocks 2ks, 2ks+1 -- the activation tile is the B operand as is.
 //   fwd chunk (plane, ks): unit ((ob*3 + s)*64 + lane), 8 bf16: split s of M[in = slot(ks,g,t)][out = 16ob + (lane&15)]
 //   bwd chunk (plane, ks): unit ((ib*2 + s)*64 + lane), 8 bf16: split s of M[in = 16ib + (lane&15)][out = slot(ks,g,t)]
-__global__ void k_pack16b(const float* __restrict__ theta, MatRef m, int NBL, __bf16* __restrict__ WF, __bf16* __restrict__ WB) {
+// blockIdx.y = matrix j of a batch of equally shaped matrices `mstride` slots apart (the hidden hyper-matrices)
+__global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstride, int NBL, __bf16* __restrict__ WF,
+                          __bf16* __restrict__ WB, long fstride, long bstride) {
+  m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
+  WF += (long)blockIdx.y * fstride; WB += (long)blockIdx.y * bstride;
   const int NCH = NBL / 2;
   const long fwd_plane = (long)NCH * NBL * 3 * 64 * 8, bwd_plane = (long)NCH * NBL * 2 * 64 * 8;
   const long total_f = fwd_plane * (m.r + 1), total_b = bwd_plane * (m.r + 1);
@@ -60,10 +64,15 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, int NBL, __
   }
 }
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st) {
-  const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m.r + 1);
+  launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, st);
+}
+void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
+                          long fstride_elems, long bstride_elems, hipStream_t st) {
+  const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m0.r + 1);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_pack16b, dim3(grid), dim3(256), 0, st, theta, m, NBL, (__bf16*)WF, (__bf16*)WB);
+  hipLaunchKernelGGL(k_pack16b, dim3(grid, nmat), dim3(256), 0, st, theta, m0, mstride, NBL, (__bf16*)WF, (__bf16*)WB,
+                     fstride_elems, bstride_elems);
 }
 
 // phi layer of the last-layer class: dense W[n][sop], sop <= 32 (two 16-output blocks)

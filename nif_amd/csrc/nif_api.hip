@@ -527,13 +527,9 @@ static int ensure_packed(nif_ctx* c) {
   static const bool fp32_only = [] { const char* e = getenv("NIF_FP32_MFMA"); return e && e[0] == '1'; }();
   c->use_snet4 = c->use_snet3 && c->sWF4 && !fp32_only && snet4_supported(probe);
   c->packed32 = false;
-  for (int j = 0; j < c->nh; ++j) {
-    const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
-    if (c->use_snet4)
-      launch_pack16b(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n),
-                     (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(c->n, c->r) * 2,
-                     (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(c->n, c->r) * 2, c->st);
-  }
+  if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
+    launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
+                         c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), c->st);
   HIPCHK(hipGetLastError());
   c->packed = true;
   if (!c->use_snet4) return ensure_packed32(c);

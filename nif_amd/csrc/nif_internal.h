@@ -149,6 +149,8 @@ bool snet4_supported(const SNetArgs& a);
 long snet4_fwd_elems(int n, int r);
 long snet4_bwd_elems(int n, int r);
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st);
+void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
+                          long fstride_elems, long bstride_elems, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
