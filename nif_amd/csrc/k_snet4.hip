@@ -111,6 +111,44 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
   hipLaunchKernelGGL(k_pack_phi, dim3(64), dim3(256), 0, st, theta, w_off, n, sop, snet3_nbl(n), (__bf16*)WPF, (__bf16*)WPB);
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 points of a tile for one feature group); result in lane 15 of the row
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+// Edge-gradient accumulation  E[m][f] += sum_{p<16} W[m][p] * T[p][f]  for one 16-point tile:
+//   T   the wave's register tile (lane (p,g): features 16b+4g+v) -- transposed through 2 KB of private LDS, 32 features at
+//       a time, so that a lane (f&15, kk) reads 4 consecutive points of one feature: the B operand of v_mfma_f32_16x16x4_f32
+//       with the K order  step t <-> point 4*kk + t;
+//   W   at most 16 per-point weight rows m (built by the caller in the SAME K order): the A operand;
+//   E   rows m < nrows of the D tile (lanes with 4*(lane>>4)+v == m) added into the wave's LDS accumulators [m][NP].
+// ~45 instructions per 32 features instead of 8 DPP row reductions per value.
+template <int NBL>
+__device__ __forceinline__ void edge_accum(const f32x4 (&T)[NBL], const f32x4 wA /*A operand: rows m, k-steps t=0..3*/, int nrows,
+                                           float* __restrict__ eacc_rows, float* __restrict__ tT, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int half = 0; half < NBL; half += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) tT[(16 * b + 4 * g + v) * 16 + p] = T[half + b][v];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(tT + (16 * b + p) * 16 + 4 * g);   // feature 16b + (lane&15), points 4g..4g+3
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[t], bq[t], d, 0, 0, 0);
+      // d[v] = E[m = 4g + v][f = 16(half+b) + p]
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * g + v < nrows) eacc_rows[(4 * g + v) * (16 * NBL) + 16 * (half + b) + p] += d[v];
+    }
+  }
+}
 #define ZERO4_(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
@@ -122,7 +160,10 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
 // LL: last-layer-parameterised class (model.py:1044-1068, :1219-1269): the ShapeNet is a shared-weight dense SIREN
 // (r = 0, one plane per layer) whose last layer emits phi [so_u x rl]; u = Dot(phi, a) + bias with the ParameterNet
 // output a; the adjoint starts from dphi = du (x) a and also yields dL/da (and dL/dlatent through the rl x rl map).
-template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL>
+// EDGE: the first-/last-layer weight gradients are accumulated in the kernel (edge_accum) instead of being stashed for
+// k_gw_first / k_gw_out.  Measured on cfg-2: -0.15 ms in the gradient kernels, +0.07 ms here (72 spilled registers at
+// the 168-register budget): no net gain yet, so it is opt-in (NIF_FUSE_EDGE=1) and a separate instantiation.
+template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool EDGE = false>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
@@ -146,13 +187,22 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   const int nz = LL ? rl : r;
   const int CX = (si + 3) & ~3, CZ = (nz + 3) & ~3, CY = (sou + 3) & ~3;
   const int NI = (CX + CZ + CY + 4) * 16;
-  const int pw = 2 * r * 64 + (LL ? (rl + so + sou) * 16 : 0) + 2 * NI;   // per-wave LDS floats
+  constexpr bool edge = EDGE && TRAIN && !LL;            // first/last-layer weight gradients accumulated here
+  const int NE = edge ? A.edge_ne : 0;
+  const int pw = 2 * r * 64 + (LL ? (rl + so + sou) * 16 : 0) + 2 * NI + NE + (edge ? 512 + so * 16 : 0);   // per-wave LDS floats
   float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
   float* phis = sks + r * 64;       // LL: phi / dphi [so][16], dL/da [rl][16], du [sou][16]
   float* das = phis + (LL ? so * 16 : 0);
   float* dul = das + rl * 16;
   float* inp = dul + (LL ? sou * 16 : 0);
+  float* eacc = inp + 2 * NI;        // edge-gradient accumulators of this wave (whole kernel)
+  float* tT = eacc + NE;             // 32 x 16 transposition scratch
+  float* dus = tT + 512;             // dL/du of the tile [so][16]
+  if (edge)
+    for (int e = lane; e < NE; e += 64) eacc[e] = 0.f;
+  const int e_l = (r + 1) * (si + 1) * (16 * NBL);          // start of the last-layer part
+  const int e_b = e_l + (r + 1) * so * (16 * NBL);          // start of the last-layer bias part
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((rl * rl + 3) & ~3))) : 0;   // LL extras sit at the end of sm
   const int o_lw = o_llb + ((sou + 3) & ~3);
@@ -366,7 +416,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     }
     NIF_TL(3);
     // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
-    if (TRAIN && active) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
+    if (TRAIN && active && !edge) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
     f32x4 gh[NBL];
     ZERO_T(gh)
     const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
@@ -468,7 +518,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         const float e = uo - ys[o * 16];
         se = fmaf(e, e, se);
         const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
-        if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
+        if (!edge && active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
+        if (edge && g == 0) dus[o * 16 + p] = du;     // dL/du of this tile, for the edge accumulation below
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
         for (int k = 0; k < r; ++k) {
@@ -477,6 +528,22 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
           dzs[k * 64 + lane] += t;
         }
       }
+    }
+    if (edge) {
+      // dL/dWl^(k)[f][o] += sum_p zt_k du_o h[f] ,  dL/dbl^(k)[o] += sum_p zt_k du_o :  rows m = k*so + o
+      const int nrow = (r + 1) * so;
+      const int m = p, kk_ = g;                      // A operand: lane (row m, k-group): points 4kk..4kk+3
+      f32x4 wA = {0.f, 0.f, 0.f, 0.f};
+      if (m < nrow) {
+        const int k = m / so, o = m - k * so;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wA[t] = (k < r ? zs[k * 16 + 4 * kk_ + t] : 1.0f) * dus[o * 16 + 4 * kk_ + t];
+      }
+      edge_accum<NBL>(h, wA, nrow, eacc + e_l, tT, lane);
+      float sb_ = (wA[0] + wA[1]) + (wA[2] + wA[3]);
+      sb_ += __shfl_xor(sb_, 16);
+      sb_ += __shfl_xor(sb_, 32);
+      if (g == 0 && m < nrow) eacc[e_b + m] += sb_;
     }
     if (TRAIN) {
       if (g == 0) loss_lane += wsamp * se / (float)sou * A.inv_bg;
@@ -567,7 +634,21 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         }
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
-        if (active) st_store16<NBL>(DA0, row0, ga, g);
+        if (active && !edge) st_store16<NBL>(DA0, row0, ga, g);
+        if (edge) {
+          // dL/dW1^(k)[d][f] += sum_p zt_k x_d da0[f] (w0 is applied in k_reduce_edge); row d = si is the bias: m = k*(si+1) + d
+          const int nrow = (r + 1) * (si + 1);
+          const int m = p, kk_ = g;
+          f32x4 wA = {0.f, 0.f, 0.f, 0.f};
+          if (m < nrow && active) {
+            const int k = m / (si + 1), dd = m - k * (si + 1);
+            const float* xr = inp + (iset & 1) * NI;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              wA[t] = (k < r ? zs[k * 16 + 4 * kk_ + t] : 1.0f) * (dd < si ? xr[dd * 16 + 4 * kk_ + t] : 1.0f);
+          }
+          edge_accum<NBL>(ga, wA, nrow, eacc, tT, lane);
+        }
         for (int k = 0; k < r; ++k) {
           const float* s0 = sm + k * nsm + 4 * g;
           float s = 0.f;
@@ -591,6 +672,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
     if (lane == 0) lsum[wid] = loss_lane;
     __syncthreads();
+    if (edge) {   // the four waves' accumulators -> this workgroup's compact partial (fixed order)
+      const float* e0 = sm + sm_tot + (pw - NE - 512 - so * 16);
+      for (int e = tid; e < NE; e += NT)
+        A.EDGE[(long)blockIdx.x * NE + e] = (e0[e] + e0[pw + e]) + (e0[2 * pw + e] + e0[3 * pw + e]);
+    }
     if (tid == 0) A.loss_partial[blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
   }
 }
@@ -600,7 +686,7 @@ static size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const int nz = a.ll ? a.rl : a.r, sou = a.ll ? a.so_u : a.so;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((nz + 3) & ~3) + ((sou + 3) & ~3) + 4) * 16;
-  const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni;
+  const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni + (a.EDGE ? a.edge_ne + 512 + a.so * 16 : 0);
   return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);
 }
 // floats per k of the LDS small-vector image (last-layer class: + last_layer_bias and the rl x rl map)
@@ -625,6 +711,50 @@ bool snet4_supported(const SNetArgs& a) {
 long snet4_fwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 3 * 64 * 8 * (r + 1); }
 long snet4_bwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 2 * 64 * 8 * (r + 1); }
 
+bool snet4_sign_ring(const SNetArgs& a);
+int snet4_edge_ne(const SNetArgs& a) {
+  if (a.ll || !snet4_sign_ring(a)) return 0;     // built for the plain-SIREN training instantiation
+  const int NP = 16 * snet3_nbl(a.n);
+  const long ne = (long)(a.r + 1) * (a.si + 1) * NP + (long)(a.r + 1) * a.so * NP + (long)(a.r + 1) * a.so;
+  const long ne4 = (ne + 3) & ~3L;
+  if ((a.r + 1) * (a.si + 1) > 16 || (a.r + 1) * a.so > 16) return 0;   // rows of one 16-row MFMA operand
+  return ne4 <= 1024 ? (int)ne4 : 0;       // 4 waves x 4 KB of LDS at most
+}
+// edge partials [nblk][ne] -> the first-/last-layer entries of the flat gradient (fixed summation order)
+__global__ __launch_bounds__(256) void k_reduce_edge(SNetArgs A, const float* __restrict__ edge, int nblk, int ne, int NP,
+                                                     float* __restrict__ g) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (e < ne)
+    for (int b = rg; b < nblk; b += 4) s += edge[(long)b * ne + e];
+  red[rg][col] = s;
+  __syncthreads();
+  if (rg != 0 || e >= ne) return;
+  const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  const int r = A.r, si = A.si, so = A.so, n = A.n;
+  const long s_wl = (long)si * n + (long)A.nh * n * n, s_b1 = s_wl + (long)n * so, s_bl = s_b1 + n + (long)A.nh * n;
+  const int e_l = (r + 1) * (si + 1) * NP, e_b = e_l + (r + 1) * so * NP;
+  auto base = [&](int k) -> long { return k < r ? A.off_Wh + (long)k * A.po : A.off_bh; };
+  if (e < e_l) {
+    const int f = e % NP, kd = e / NP, k = kd / (si + 1), dd = kd % (si + 1);
+    if (f < n) {
+      if (dd < si) g[base(k) + (long)dd * n + f] = A.omega * v;
+      else g[base(k) + s_b1 + f] = v;
+    }
+  } else if (e < e_b) {
+    const int e2 = e - e_l, f = e2 % NP, ko = e2 / NP, k = ko / so, o = ko % so;
+    if (f < n) g[base(k) + s_wl + (long)f * so + o] = v;
+  } else if (e < e_b + (r + 1) * so) {
+    const int ko = e - e_b, k = ko / so, o = ko % so;
+    g[base(k) + s_bl + o] = v;
+  }
+}
+void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st) {
+  const int ne = a.edge_ne;
+  hipLaunchKernelGGL(k_reduce_edge, dim3((ne + 63) / 64), dim3(256), 0, st, a, edge, nblk, ne, 16 * snet3_nbl(a.n), grad);
+}
 // plain SIREN whose sign bits fit the 128-bit shift register: the act'(a) ring is not needed
 bool snet4_sign_ring(const SNetArgs& a) {
   return !a.nif_skip && !a.res && (long)(a.nh + 1) * 4 * snet3_nbl(a.n) <= 128;
@@ -645,6 +775,13 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
     hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>), grid, block, shm, st, a);                           \
   }
+#define S4LE(NBL_)                                                                                                  \
+  {                                                                                                                 \
+    if (shm > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, true, ACT_SINE, 0, true, false, true>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
+    hipLaunchKernelGGL((k_snet4<NBL_, true, ACT_SINE, 0, true, false, true>), grid, block, shm, st, a);             \
+  }
 #define S4(NBL_)                                                            \
   if (a.ll) {                                                               \
     if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, true) else S4L(NBL_, false, ACT_SINE, 1, false, true) } \
@@ -655,7 +792,8 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   } else if (a.res) {                                                       \
     if (train) S4L(NBL_, true, ACT_SINE, 1, false, false) else S4L(NBL_, false, ACT_SINE, 1, false, false) \
   } else if (train) {                                                       \
-    if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, false) else S4L(NBL_, true, ACT_SINE, 0, false, false) \
+    if (snet4_sign_ring(a)) { if (a.EDGE) S4LE(NBL_) else S4L(NBL_, true, ACT_SINE, 0, true, false) } \
+    else S4L(NBL_, true, ACT_SINE, 0, false, false) \
   } else {                                                                  \
     S4L(NBL_, false, ACT_SINE, 0, false, false)                             \
   }
@@ -666,6 +804,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
     default: S4(8) break;
   }
 #undef S4
+#undef S4LE
 #undef S4L
   return nblk;
 }

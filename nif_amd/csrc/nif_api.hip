@@ -42,6 +42,7 @@ struct nif_ctx {
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
   void *ll_wpf = nullptr, *ll_wpb = nullptr;   // phi layer as bf16-split MFMA operands (launch_pack_phi)
+  float* edge = nullptr; long edge_cap = 0;    // per-workgroup first/last-layer gradient partials of k_snet4
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -227,7 +228,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -873,6 +874,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
   int nloss = (int)((ntiles + 3) / 4);
+  bool fused_edge = false;
   if (ns > 0) {
     const int nblk = launch_sob(sa, true, ns, seeds, gt, wj, nullptr, nullptr, true, c->st);
     const long need = (long)nblk * 4 * sob_ring_floats_per_wave(c->n, c->nh);
@@ -885,7 +887,20 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
   } else if (c->use_snet3) {
     int waves = 4;
+    static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
+    if (c->use_snet4 && want_edge) {  // opt-in: first/last-layer weight gradients inside k_snet4 (no DA_0 / IN_nh / DU stashes)
+      sa.edge_ne = snet4_edge_ne(sa);
+      fused_edge = sa.edge_ne > 0;
+    }
     const int nblk = c->use_snet4 ? launch_snet4(sa, true, true, c->st) : launch_snet3(sa, true, true, &waves, c->st);
+    if (fused_edge) {
+      const long need_e = (long)nblk * sa.edge_ne;
+      if (need_e > c->edge_cap) {
+        HIPCHK(hipStreamSynchronize(c->st));
+        rc = grow(&c->edge, &c->edge_cap, need_e); if (rc) return rc;
+      }
+      sa.EDGE = c->edge;
+    }
     const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
@@ -924,7 +939,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = c->Z; g.r = c->r; g.scale = om_s;
   g.W = hyper_ref(c, 0, c->n, c->si, c->n);
   g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
-  launch_gw_first(g, c->NB, rows, c->st);
+  if (!fused_edge) launch_gw_first(g, c->NB, rows, c->st);
   // ShapeNet hidden matrices
   for (int j = 0; j < c->nh; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = c->Z; g.r = c->r; g.scale = om_s;
@@ -941,7 +956,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
     g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
     g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
-    launch_gw_out(g, c->NB, rows, c->st);
+    if (!fused_edge) launch_gw_out(g, c->NB, rows, c->st);
   }
   // ParameterNet: first, hidden matrices, bottleneck
   float* pST = c->stash_p;
@@ -965,6 +980,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   // rows -> flat gradient, loss
   ProfScope pr_(c, NIF_PROF_REDUCE);
   launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
+  if (fused_edge) launch_reduce_edge(sa, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }

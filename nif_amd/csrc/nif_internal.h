@@ -86,6 +86,9 @@ struct SNetArgs {
   // last-layer-parameterised class on k_snet4 (r = 0: shared dense SIREN; theta = the slot-ordered copy built by
   // launch_ll_slots; so = so_u * rl outputs phi): u = Dot(phi, a) + bias, a = Z [tiles][rl][32]
   int ll, rl, so_u;
+  // fused first-/last-layer weight gradients (k_snet4, hypernetwork classes): per-workgroup compact partials
+  //   [(k, d')][NP] first layer (d' = si: bias) | [(k, o)][NP] last layer | [(k, o)] last bias ;  NP = 16*NBL
+  float* EDGE; int edge_ne;               // [gridDim.x][edge_ne] or null (then the stashes feed k_gw_first / k_gw_out)
   const void* WPF; const void* WPB;       // bf16-split planes of the phi layer [n][so <= 32] (launch_pack_phi)
   float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
   float* DA_ll;                           // [tiles][rl][32]   dL/da
@@ -153,6 +156,8 @@ void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, in
                           long fstride_elems, long bstride_elems, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
+int snet4_edge_ne(const SNetArgs& a);    // floats of one workgroup's edge partial; 0 = not fusable (falls back to k_gw_first/out)
+void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,

@@ -51,8 +51,10 @@ def _rel(a, b):
 
 
 def test_bf16_split_and_fp32_mfma_paths_agree(tmp_path):
-    a = _run(tmp_path, "split", {"NIF_FP32_MFMA": "0", "NIF_PNET_STASH": "0"})
+    a = _run(tmp_path, "split", {"NIF_FP32_MFMA": "0", "NIF_PNET_STASH": "0", "NIF_FUSE_EDGE": "0"})
     b = _run(tmp_path, "fp32", {"NIF_FP32_MFMA": "1", "NIF_PNET_STASH": "1"})
+    c = _run(tmp_path, "edge", {"NIF_FUSE_EDGE": "1"})       # opt-in: first/last-layer gradients fused into k_snet4
+    assert _rel(c["u"], a["u"]) < 1e-7 and _rel(c["grad"], a["grad"]) < 2e-5, _rel(c["grad"], a["grad"])
     # the two GPU formulations against each other
     assert _rel(a["u"], b["u"]) < 2e-6, _rel(a["u"], b["u"])
     assert abs(float(a["loss"]) - float(b["loss"])) <= 2e-6 * abs(float(b["loss"]))
