@@ -520,3 +520,74 @@ def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
     h2 = model2.fit(x, y, epochs=1, batch_size=bs, shuffle=False, verbose=0)
     assert np.allclose(h1.history["loss"], h2.history["loss"], rtol=1e-6)
     assert np.array_equal(model2.predict(x), model.predict(x))
+
+
+@pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev"])
+def test_full_size_shard_sum_other_configs(which):
+    """The same size-independent properties at the per-GPU shard sizes of BASELINE configs 3-5: the sum over 8
+    contiguous shards of [grad | loss] equals the full-batch result, a repeated launch is bit-identical, and the
+    oracle on a sample pins the loss (it cannot run 10^5..10^6 points)."""
+    import nif_amd
+    from nif_amd.engine import DeviceArray
+    from nif_amd import distributed as dist
+    rng = np.random.default_rng(4)
+    xi = None
+    if which == "cfg3_ms_128":
+        kind, cs, cp = _cfg("NIFMultiScale", 128, 3, 64, 2, 1, 2, 1, 1, p_act="swish")
+        B = 1 << 17
+    elif which == "cfg4_last_layer":
+        kind, cs, cp = _cfg("LL", 128, 2, 32, 2, 10, 3, 3, 1, p_act="swish")
+        B = 1 << 18
+    else:
+        kind, cs, cp = _cfg("NIFMultiScale", 64, 4, 32, 2, 1, 2, 1, 1, p_act="swish")
+        B = 1 << 17
+        xi = [1, 2]
+    spec = O.Spec(kind, cs, cp)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    names = [nm for nm, _ in spec.param_shapes()]
+    ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * (30.0 if kind.endswith("Parameterized") else 2.0)).astype(np.float32)
+    m = getattr(nif_amd, kind)(cs, cp)
+    model = m.build(); model.set_weights(ws)
+    e = m._engine
+    ncol, so = spec.pi + spec.si, spec.so
+    x = rng.uniform(-1, 1, size=(B, ncol)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, so)).astype(np.float32)
+    gt = rng.uniform(-1, 1, size=(B, so * 2)).astype(np.float32) if xi else None
+    d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
+    d_x.upload(x); d_y.upload(y)
+    d_g = None
+    if xi:
+        d_g = DeviceArray(e, gt.size); d_g.upload(gt)
+
+    def grad_of(lo, hi, bg):
+        if xi:
+            e.sobolev_loss_grad_dev(d_x.at(lo * ncol), d_y.at(lo * so), d_g.at(lo * so * 2), None, hi - lo, bg, xi, 0.1)
+        else:
+            e.loss_grad_dev(d_x.at(lo * ncol), d_y.at(lo * so), None, hi - lo, bg)
+        buf = DeviceArray.__new__(DeviceArray)
+        buf.engine, buf.n, buf.ptr = e, e.n_params + 1, e.grad_dev_ptr()
+        out = buf.download()
+        buf.ptr = None
+        return out.astype(np.float64)
+
+    full = grad_of(0, B, B)
+    assert np.array_equal(full, grad_of(0, B, B))
+    acc = np.zeros_like(full)
+    for r_ in range(8):
+        lo, hi = dist.shard_bounds(B, 8, r_)
+        acc += grad_of(lo, hi, B)
+    assert abs(acc[-1] - full[-1]) < 2e-6 * abs(full[-1])
+    assert np.linalg.norm(acc[:-1] - full[:-1]) < 2e-5 * np.linalg.norm(full[:-1])
+    ws64 = [w.astype(np.float64) for w in ws]
+    n_s = 2048
+    if xi:
+        lref = O.sobolev_loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64),
+                                       gt[:n_s].astype(np.float64), xi, 0.1)[0]
+        got = grad_of(0, n_s, n_s)[-1]
+    else:
+        lref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))[0]
+        got = grad_of(0, n_s, n_s)[-1]
+    assert abs(got - lref) < 2e-5 * abs(lref), (got, lref)
+    d_x.free(); d_y.free()
+    if d_g is not None:
+        d_g.free()
