@@ -74,6 +74,25 @@ def all_reduce_scalar_sum(v):
     return int(round(t.item()))
 
 
+def all_reduce_ints(values, op="sum"):
+    """Element-wise SUM (or MAX) over ranks of a short list of integers: ONE collective and one host read-back.
+    fit() uses it once per call to learn every step's global batch size instead of syncing the host every step."""
+    import torch
+    td = _td()
+    dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX if op == "max" else td.ReduceOp.SUM)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def zero_grad(engine):
+    """A rank whose shard has no rows left for a step still takes part in the collective: with a zero buffer."""
+    import torch
+    t, stream = grad_tensor(engine)
+    with torch.cuda.stream(stream):
+        t.zero_()
+
+
 class _DevPtr(object):
     """Zero-copy view of a raw device buffer for torch.as_tensor (CUDA array interface v2)."""
 

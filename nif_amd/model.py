@@ -182,6 +182,15 @@ class Model(object):
         rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
         resident = False
         world = dist.world_size()
+        # every rank walks its own shard; the global size of every step's batch is agreed ONCE (one collective, one
+        # host read-back), ranks whose shard is a batch shorter join the last collective with a zero gradient
+        sizes = [min(bs, N - b0) for b0 in range(0, N, bs)]
+        if world > 1:
+            nb = dist.all_reduce_ints([len(sizes)], op="max")[0]
+            sizes = sizes + [0] * (nb - len(sizes))
+            gsizes = dist.all_reduce_ints(sizes, op="sum")
+        else:
+            gsizes = sizes
         try:
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
@@ -207,11 +216,13 @@ class Model(object):
                     resident = True
                 adam = self.optimizer.as_struct()
                 e.metric_read(reset=True)
-                for b0 in range(0, N, bs):
-                    b = min(bs, N - b0)
-                    bg = dist.all_reduce_scalar_sum(b) if world > 1 else b
-                    self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * t.shape[1]) for dt, t in zip(d_t, targets)],
-                                        d_sw.at(b0) if d_sw is not None else None, b, bg)
+                for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
+                    b0 = ib * bs
+                    if b > 0:
+                        self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * t.shape[1]) for dt, t in zip(d_t, targets)],
+                                            d_sw.at(b0) if d_sw is not None else None, b, bg)
+                    else:
+                        dist.zero_grad(e)
                     if world > 1:
                         dist.all_reduce_grad(e)
                     e.adam_step_dev(adam)

@@ -54,6 +54,22 @@ e.adam_step_dev(adam); e.sync()
 w1 = O.flatten(model.get_weights())
 th, _, _ = O.adam_step(w0.astype(np.float64), g.astype(np.float64), 0.0, 0.0, 1, lr=1e-3)
 assert np.abs(w1 - th).max() < 1e-6
+# fit() through its multi-rank code path (agreed batch sizes, all-reduce on the library stream every step): with one
+# real rank the sums are identities, so the history must equal the single-process one exactly
+nif_amd.set_seed(5)
+ma = nif_amd.NIFMultiScale(cs, cp); a = ma.build(); a.compile(nif_amd.Adam(1e-3), "mse")
+nif_amd.set_seed(5)
+mb = nif_amd.NIFMultiScale(cs, cp); b = mb.build(); b.compile(nif_amd.Adam(1e-3), "mse")
+ha = a.fit(x, y, epochs=2, batch_size=1000, shuffle=False, verbose=0)
+real_ws = dist.world_size
+dist.world_size = lambda: 2
+hb = b.fit(x, y, epochs=2, batch_size=1000, shuffle=False, verbose=0)
+dist.world_size = real_ws
+assert ha.history["loss"] == hb.history["loss"], (ha.history, hb.history)
+assert np.array_equal(O.flatten(a.get_weights()), O.flatten(b.get_weights()))
+dist.zero_grad(mb._engine); mb._engine.sync(); torch.cuda.synchronize()
+assert not dist.grad_tensor(mb._engine)[0].cpu().numpy().any()
+assert dist.all_reduce_ints([3, 4, 5]) == [3, 4, 5] and dist.all_reduce_ints([7], op="max") == [7]
 dist.shutdown()
 print("OK")
 '''
