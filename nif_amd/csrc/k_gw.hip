@@ -264,6 +264,9 @@ static GwArgs gw_fix(const GwArgs& in) {
   return a;
 }
 
+#ifndef NIF_GW_WIDE_DBUF
+#define NIF_GW_WIDE_DBUF false
+#endif
 #ifndef NIF_GW_WIDE_KC2
 #define NIF_GW_WIDE_KC2 1
 #endif
@@ -285,7 +288,7 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
     // 128-wide: both planes of a pair in one workgroup (256 accumulator registers, single-buffered): the layer-input
     // stash is read 2x and dL/da 1x instead of 4x and 2x
     dim3 grid(rows, (a.r + 1 + 1) / 2, 2);
-    hipLaunchKernelGGL((k_gw_mfma<4, 2, 2, WV, false>), grid, block, 0, st, a, NBO);
+    hipLaunchKernelGGL((k_gw_mfma<4, 2, 2, WV, NIF_GW_WIDE_DBUF>), grid, block, 0, st, a, NBO);
 #else
     dim3 grid(rows, a.r + 1, 2);
     hipLaunchKernelGGL((k_gw_mfma<4, 2, 1, WV, true>), grid, block, 0, st, a, NBO);
