@@ -20,15 +20,37 @@ struct PbwArgs {
 
 __device__ __forceinline__ f32x4 lds4(const float* q) { return *reinterpret_cast<const f32x4*>(q); }
 
-// C[in][out] += sum_p IN[p][in] * DA[p][out] over the 32 points of the tile; IN, DA are LDS tiles [feature][32]
+// C[in][out] += sum_p IN[p][in] * DA[p][out] over the 32 points of the tile; IN, DA are LDS tiles [feature][32].
+// Gradient path: bf16 hi/lo splits, three v_mfma_f32_32x32x16_bf16 per 16 points (k_gw.hip) instead of 8 f32-input MFMAs
+typedef __bf16 pbw_bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef NIF_PBW_BF16
+#define NIF_PBW_BF16 1
+#endif
 __device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x16& C, int i, int hf) {
   f32x4 a[4], b[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { a[q] = lds4(IN + i * 32 + 16 * hf + 4 * q); b[q] = lds4(DA + i * 32 + 16 * hf + 4 * q); }
+#if NIF_PBW_BF16
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    pbw_bf16x8 ah, al, bh, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = a[2 * hh + (e >> 2)][e & 3], y = b[2 * hh + (e >> 2)][e & 3];
+      const __bf16 x0 = (__bf16)x, y0 = (__bf16)y;
+      ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
+      bh[e] = y0; bl[e] = (__bf16)(y - (float)y0);
+    }
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, C, 0, 0, 0);
+  }
+#else
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int c = 0; c < 4; ++c) C = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], C, 0, 0, 0);
+#endif
 }
 // column sums of a DA tile: lane (i, hf) -> sum over its 16 points of feature i (other half via shfl)
 __device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
