@@ -76,7 +76,7 @@ __device__ __forceinline__ void pnet_first(const PNetArgs& A, long ptc, int hf, 
   act_tile<NB>(A.act, h, h, d, A.nst, hf);
 }
 
-template <int NB, bool TRAIN>
+template <int NB, bool TRAIN, int ACT>
 __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int p = lane & 31, hf = lane >> 5;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       for (int dd = 0; dd < A.pi; ++dd) acc += prow[dd] * psmall_get(S.fw + dd * NB * 32, b, hf);
       h[b] = A.omega * acc + psmall_get(S.fb, b, hf);
     }
-    act_tile<NB>(A.act, h, h, d, A.nst, hf);
+    act_tile_sel<NB, ACT>(A.act, h, h, d, A.nst, hf);
   }
   if (TRAIN) stash_store<NB>(A.stash + (long)(nm + 1) * A.slot_stride, tile, d, p, hf);
 
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       dense_mfma<NB, NB>(A.WF + (long)i * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
-      act_tile<NB>(A.act, T, T, d, A.nst, hf);
+      act_tile_sel<NB, ACT>(A.act, T, T, d, A.nst, hf);
 #pragma unroll
       for (int b = 0; b < NB; ++b) h[b] = A.siren ? T[b] : h[b] + T[b];
       if (TRAIN) stash_store<NB>(A.stash + (long)(nm + 2 + i) * A.slot_stride, tile, d, p, hf);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       dense_mfma<NB, NB>(A.WF + (long)(2 * i) * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
-      act_tile<NB>(A.act, T, t, d, A.nst, hf);
+      act_tile_sel<NB, ACT>(A.act, T, t, d, A.nst, hf);
       if (TRAIN) {
         stash_store<NB>(A.stash + (long)(nm + 2 + 2 * i) * A.slot_stride, tile, d, p, hf);
         stash_store<NB>(A.stash + (long)(2 * i + 1) * A.slot_stride, tile, t, p, hf);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
         const f32x16 lin = A.omega * T[b] + psmall_get(S.hb2 + i * NB * 32, b, hf);
         T[b] = A.siren ? lin : h[b] + lin;
       }
-      act_tile<NB>(A.act, T, T, d, A.nst, hf);
+      act_tile_sel<NB, ACT>(A.act, T, T, d, A.nst, hf);
 #pragma unroll
       for (int b = 0; b < NB; ++b) h[b] = A.siren ? 0.5f * (h[b] + T[b]) : T[b];
       if (TRAIN) stash_store<NB>(A.stash + (long)(nm + 2 + 2 * i + 1) * A.slot_stride, tile, d, p, hf);
@@ -243,11 +243,15 @@ void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st) {
   if (nblk > 2048) nblk = 2048;          // persistent: the small vectors are staged in LDS once per workgroup
   dim3 grid((unsigned)nblk), block(256);
   const size_t shm = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)psmall_floats(a, NSTB)) * sizeof(float);
+#define PNA(NB_, TR_)                                                                             \
+  if (a.act == ACT_SWISH) hipLaunchKernelGGL((k_pnet<NB_, TR_, ACT_SWISH>), grid, block, shm, st, a);  \
+  else if (a.act == ACT_SINE) hipLaunchKernelGGL((k_pnet<NB_, TR_, ACT_SINE>), grid, block, shm, st, a); \
+  else hipLaunchKernelGGL((k_pnet<NB_, TR_, -1>), grid, block, shm, st, a);
 #define PN(NB_) \
-  if (train) hipLaunchKernelGGL((k_pnet<NB_, true>), grid, block, shm, st, a); \
-  else hipLaunchKernelGGL((k_pnet<NB_, false>), grid, block, shm, st, a);
+  if (train) { PNA(NB_, true) } else { PNA(NB_, false) }
   if (NSTB == 1) { PN(1) } else if (NSTB == 2) { PN(2) } else { PN(4) }
 #undef PN
+#undef PNA
 }
 void launch_pnet_bwd(const PNetArgs& a, int NSTB, hipStream_t st) {
   const long ntiles = (a.B + 31) / 32;

@@ -63,7 +63,8 @@ __device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
 #ifndef NIF_PBW_WAVES
 #define NIF_PBW_WAVES 8   // 2 waves per SIMD (256 registers each, some spills) beat 1 wave with 478 registers: 0.27 -> 0.24 ms
 #endif
-template <int NM, bool RES>
+// ACT: ACT_SWISH / ACT_SINE fixed at compile time (the defaults of the reference's ParameterNets), -1 = runtime switch
+template <int NM, bool RES, int ACT>
 __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
   const PNetArgs& A = G.p;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       for (int dd = 0; dd < A.pi; ++dd) acc += prow[dd] * psmall_get(S.fw + dd * 32, 0, hf);
       h[0] = A.omega * acc + psmall_get(S.fb, 0, hf);
     }
-    act_tile<1>(A.act, h, h, d[0], A.nst, hf);
+    act_tile_sel<1, ACT>(A.act, h, h, d[0], A.nst, hf);
     if (hf == 0) {
       for (int dd = 0; dd < A.pi; ++dd) xT[dd * 32 + p] = prow[dd];
       xT[A.pi * 32 + p] = 1.0f;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
         stash_store<1>(hs + m * 1024, 0, h, p, hf);
         dense_mfma<1, 1>(A.WF + (long)m * plane, h, T, lane);
         T[0] = A.omega * T[0] + psmall_get(S.hb + m * 32, 0, hf);
-        act_tile<1>(A.act, T, T, d[m + 1], A.nst, hf);
+        act_tile_sel<1, ACT>(A.act, T, T, d[m + 1], A.nst, hf);
         h[0] = A.siren ? T[0] : h[0] + T[0];
       }
     } else {
@@ -124,14 +125,14 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       stash_store<1>(hs, 0, h, p, hf);
       dense_mfma<1, 1>(A.WF, h, T, lane);
       T[0] = A.omega * T[0] + psmall_get(S.hb, 0, hf);
-      act_tile<1>(A.act, T, t, d[1], A.nst, hf);
+      act_tile_sel<1, ACT>(A.act, T, t, d[1], A.nst, hf);
       stash_store<1>(hs + 1024, 0, t, p, hf);
       dense_mfma<1, 1>(A.WF + plane, t, T, lane);
       {
         const f32x16 lin = A.omega * T[0] + psmall_get(S.hb2, 0, hf);
         T[0] = A.siren ? lin : h[0] + lin;
       }
-      act_tile<1>(A.act, T, T, d[NM], A.nst, hf);
+      act_tile_sel<1, ACT>(A.act, T, T, d[NM], A.nst, hf);
       h[0] = A.siren ? 0.5f * (h[0] + T[0]) : T[0];
     }
     stash_store<1>(hs + NM * 1024, 0, h, p, hf);
@@ -283,13 +284,18 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
   const int nm = a.lst * (a.res ? 2 : 1);
   dim3 grid(rows), block(64 * NIF_PBW_WAVES);
   const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)psmall_floats(a, 1)) * sizeof(float);
-#define PBW(NM_, RES_)                                                                                              \
+#define PBW(NM_, RES_, ACT_)                                                                                        \
   {                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_pnet_bwg<NM_, RES_>), grid, block, shm, st, G);                                           \
+    (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_pnet_bwg<NM_, RES_, ACT_>), grid, block, shm, st, G);                                     \
   }
-  if (a.res) PBW(2, true)
-  else if (nm == 1) PBW(1, false)
-  else PBW(2, false)
+#define PBWA(NM_, RES_)                                                       \
+  if (a.act == ACT_SWISH) PBW(NM_, RES_, ACT_SWISH)                           \
+  else if (a.act == ACT_SINE) PBW(NM_, RES_, ACT_SINE)                        \
+  else PBW(NM_, RES_, -1)
+  if (a.res) { PBWA(2, true) }
+  else if (nm == 1) { PBWA(1, false) }
+  else { PBWA(2, false) }
+#undef PBWA
 #undef PBW
 }

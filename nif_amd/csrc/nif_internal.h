@@ -425,6 +425,7 @@ __device__ __forceinline__ PSmall psmall_stage(const PNetArgs& A, float* lds, in
 template <int NB, int ACT>
 __device__ __forceinline__ void act_tile_sel(int act, const f32x16 (&a)[NB], f32x16 (&h)[NB], f32x16 (&d)[NB], int n, int hf) {
   if (ACT == ACT_SINE) sine_tile<NB>(a, h, d, n, hf);
+  else if (ACT == ACT_SWISH) act_tile_t<NB, ACT_SWISH>(a, h, d, n, hf);
   else act_tile<NB>(act, a, h, d, n, hf);
 }
 
