@@ -91,6 +91,12 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
   }
   for (int q = lane; q < 256; q += 64) xT[q] = 0.f;
   const PSmall S = psmall_stage<1>(A, lds + (long)WV * WLDS, threadIdx.x, 64 * WV);
+  // the 2 NM packed 32x32 weight planes (forward, then adjoint) live in LDS for the whole kernel: the per-tile
+  // dense products read their A operands with ds_read_b128 instead of waiting on global loads four times a tile
+  f32x4* wpl = reinterpret_cast<f32x4*>(lds + (long)WV * WLDS + ((psmall_floats(A, 1) + 3) & ~3));
+  for (int e = threadIdx.x; e < NM * 256; e += 64 * WV) { wpl[e] = A.WF[e]; wpl[NM * 256 + e] = A.WB[e]; }
+  const f32x4* WFl = wpl;
+  const f32x4* WBl = wpl + NM * 256;
   __syncthreads();
 
   for (long tile = (long)blockIdx.x * WV + wid; tile < ntiles; tile += (long)gridDim.x * WV) {
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         stash_store<1>(hs + m * 1024, 0, h, p, hf);
-        dense_mfma<1, 1>(A.WF + (long)m * plane, h, T, lane);
+        dense_mfma_lds<1, 1, false>(WFl + (long)m * plane, h, T, lane);
         T[0] = A.omega * T[0] + psmall_get(S.hb + m * 32, 0, hf);
         act_tile_sel<1, ACT>(A.act, T, T, d[m + 1], A.nst, hf);
         h[0] = A.siren ? T[0] : h[0] + T[0];
@@ -123,11 +129,11 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     } else {
       f32x16 t[1];
       stash_store<1>(hs, 0, h, p, hf);
-      dense_mfma<1, 1>(A.WF, h, T, lane);
+      dense_mfma_lds<1, 1, false>(WFl, h, T, lane);
       T[0] = A.omega * T[0] + psmall_get(S.hb, 0, hf);
       act_tile_sel<1, ACT>(A.act, T, t, d[1], A.nst, hf);
       stash_store<1>(hs + 1024, 0, t, p, hf);
-      dense_mfma<1, 1>(A.WF + plane, t, T, lane);
+      dense_mfma_lds<1, 1, false>(WFl + plane, t, T, lane);
       {
         const f32x16 lin = A.omega * T[0] + psmall_get(S.hb2, 0, hf);
         T[0] = A.siren ? lin : h[0] + lin;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
         stash_store<1>(gaT, 0, ga, p, hf);
         grad_mfma(hs + m * 1024, gaT, C[m], i, hf);
         gbh[m] += col_sum(gaT, i, hf);
-        dense_mfma<1, 1>(A.WB + (long)m * plane, ga, U, lane);
+        dense_mfma_lds<1, 1, false>(WBl + (long)m * plane, ga, U, lane);
         gh[0] = A.siren ? A.omega * U[0] : gh[0] + A.omega * U[0];
       }
     } else {
@@ -178,14 +184,14 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       stash_store<1>(gaT, 0, ga, p, hf);
       grad_mfma(hs + 1024, gaT, C[NM - 1], i, hf);
       gbh[NM - 1] += col_sum(gaT, i, hf);
-      dense_mfma<1, 1>(A.WB + plane, ga, U, lane);
+      dense_mfma_lds<1, 1, false>(WBl + plane, ga, U, lane);
       f32x16 skip;
       skip = A.siren ? 0.5f * gh[0] : ga[0];
       ga[0] = A.omega * U[0] * d[1][0];
       stash_store<1>(gaT, 0, ga, p, hf);
       grad_mfma(hs, gaT, C[0], i, hf);
       gbh[0] += col_sum(gaT, i, hf);
-      dense_mfma<1, 1>(A.WB, ga, U, lane);
+      dense_mfma_lds<1, 1, false>(WBl, ga, U, lane);
       gh[0] = skip + A.omega * U[0];
     }
     // ---- first layer: dL/dW_1[d][f] = w0 sum_p x_d[p] da0[p][f] (rows of X^T), bias = column sums -----
@@ -283,7 +289,8 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
   PbwArgs G; G.p = a; G.partial = partial; G.pstride = pstride;
   const int nm = a.lst * (a.res ? 2 : 1);
   dim3 grid(rows), block(64 * NIF_PBW_WAVES);
-  const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)psmall_floats(a, 1)) * sizeof(float);
+  const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)((psmall_floats(a, 1) + 3) & ~3) +
+                      (size_t)2 * nm * 1024) * sizeof(float);
 #define PBW(NM_, RES_, ACT_)                                                                                        \
   {                                                                                                                 \
     (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
