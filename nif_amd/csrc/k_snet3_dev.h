@@ -220,7 +220,7 @@ __device__ __forceinline__ void sgn_cos(const f32x4 (&sn)[NBL], unsigned bits, f
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const float c = __builtin_sqrtf(fmaxf(fmaf(-sn[b][v], sn[b][v], 1.0f), 0.0f));
+      const float c = __builtin_amdgcn_sqrtf(fmaxf(fmaf(-sn[b][v], sn[b][v], 1.0f), 0.0f));   // v_sqrt_f32 (1 ulp), not the IEEE fix-up sequence
       d[b][v] = __uint_as_float(__float_as_uint(c) | (((bits >> (4 * b + v)) & 1u) << 31));
     }
 }
