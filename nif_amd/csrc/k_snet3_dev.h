@@ -102,6 +102,24 @@ __device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f
       h[b][v] = hv; d[b][v] = dv;
     }
 }
+// SIREN tile, training with the sign-bit cosine: h = sin(a) and d = a float carrying only the SIGN of cos(a)
+template <int NBL>
+__device__ __forceinline__ void sine16_sign(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
+  float mx = 0.f;
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
+  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) { sine16<NBL>(a, h, d); return; }
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float hv, dv;
+      nif_sin_cossign_core(a[b][v], &hv, &dv);
+      h[b][v] = hv; d[b][v] = dv;
+    }
+}
 template <int NBL, int ACT>
 __device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL], int n, int g) {
 #ifdef NIF_ABL_NOACT

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     }
     {
       f32x4 d[NBL];
-      act16<NBL, ACT>(A.act, acc, h, d, n, g);
+      if (TRAIN && SGN) sine16_sign<NBL>(acc, h, d);    // only the sign of cos(a) is kept: no v_cos_f32
+      else act16<NBL, ACT>(A.act, acc, h, d, n, g);
       if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(d), SW);
       if (TRAIN && !SGN) {
 #pragma unroll
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
       }
       {
         f32x4 d[NBL];
-        act16<NBL, ACT>(A.act, acc, acc, d, n, g);
+        if (TRAIN && SGN) sine16_sign<NBL>(acc, acc, d);
+        else act16<NBL, ACT>(A.act, acc, acc, d, n, g);
         if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(d), SW);
         if (TRAIN && !SGN) {
 #pragma unroll

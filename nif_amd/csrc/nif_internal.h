@@ -242,6 +242,15 @@ __device__ __forceinline__ void nif_sincosf_core(float x, float* sp, float* cp) 
   *sp = __builtin_amdgcn_sinf(f);
   *cp = __builtin_amdgcn_cosf(f);
 }
+// sine only, plus a float whose SIGN is the sign of the cosine: cos(2 pi f) < 0  <=>  |f| > 1/4 on the reduced revolution
+// fraction f in [-1/2, 1/2] -- saves the quarter-rate v_cos_f32 where only the sign of cos(a) is kept (k_snet4 SGN)
+__device__ __forceinline__ void nif_sin_cossign_core(float x, float* sp, float* csign) {
+  const float k = rintf(x * 0.15915493667125702f);
+  float f = fmaf(x, 0.15915493667125702f, -k);
+  f = fmaf(x, 6.420638326565253e-09f, f);
+  *sp = __builtin_amdgcn_sinf(f);
+  *csign = 0.25f - fabsf(f);
+}
 #else
 __device__ __forceinline__ void nif_sincosf_core(float x, float* sp, float* cp) {
   const float k = rintf(x * 0.63661977236758134308f);
