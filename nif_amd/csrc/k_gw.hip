@@ -256,6 +256,170 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_gw_lds: the same K = batch GEMM with the stash tiles brought in by LDS-DMA.
+//
+// k_gw_mfma's register loads give lane (i, hf) 16 bytes of row i: one load instruction touches 32 cache lines for
+// 32 bytes each, and the address path (not HBM) bounds the kernel at ~4 TB/s.  Here every load instruction is a
+// global_load_lds of ONE contiguous KiB (8 stash rows) and the (feature, points) operand shape is recovered by
+// ds_read_b128.  The DMA writes LDS lane-major, but WHICH 16-byte piece of the KiB a lane fetches is free: piece
+// c of row r of chunk j goes to slot 8 r + (c ^ r ^ (j & 1)), which makes the 16 lanes of a ds_read_b128 pass hit 16
+// distinct 4-bank groups.  Per tile: read tile t from LDS into registers, issue the DMA of tile t+1 into the other
+// buffer, then split + MFMA tile t while that DMA is in flight.  Wave-private buffers, no barriers in the loop.
+// ------------------------------------------------------------------------------------------
+// Measured and not kept: one buffer per wave + two workgroups per CU (256 registers: 51 spilled, 0.27 ms instead of 0.11).
+template <int NB>   // NBI = OBC = NB (1 or 2), KC = 2, 4 waves
+__global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
+  constexpr int NBUF = 2;
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  constexpr int KC = 2, WV = 4;
+  constexpr int TF = NB * 1024;            // floats per operand tile
+  constexpr int BUF = 2 * TF + 64;         // IN | DA | Z rows (2 x 32)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int k0 = blockIdx.y * KC;
+  const long nwaves = (long)gridDim.x * WV;
+  float* wbuf = gsm + (long)wid * NBUF * BUF;
+
+  f32x16 acc[KC][NB][NB];
+  float bacc[KC][NB];
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[kk][ib][ob][e] = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) bacc[kk][ob] = 0.f;
+  }
+  const int zt_mod = (int)A.zt_mod, nt_all = (int)A.ntiles;
+  // DMA source of this lane inside a 1-KiB chunk j: row r = lane>>3, piece c = (lane&7) ^ r ^ (j&1)
+  const int dr = lane >> 3, dx = lane & 7;
+  const int src0 = dr * 32 + ((dx ^ dr) & 7) * 4, src1 = dr * 32 + ((dx ^ dr ^ 1) & 7) * 4;
+  // latent rows k0, k0+1 (clamped to a valid row; k >= r is replaced by ones at use)
+  const int kz = (k0 + hf < A.r) ? k0 + hf : (A.r > 0 ? A.r - 1 : 0);
+  auto dma_tile = [&](long t, int set) {
+    float* dst = wbuf + set * BUF;
+    const float* in = A.IN + t * TF;
+    const float* da = A.DA + t * TF;
+#pragma unroll
+    for (int j = 0; j < NB * 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + j * 256 + ((j & 1) ? src1 : src0)),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB * 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + ((j & 1) ? src1 : src0)),
+                                       (__attribute__((address_space(3))) void*)(dst + TF + j * 256), 16, 0, 0);
+    const int ti = __builtin_amdgcn_readfirstlane((int)t);
+    const int tz = zt_mod >= nt_all ? ti : ti % zt_mod;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + ((long)tz * A.r + kz) * 32 + i),
+                                     (__attribute__((address_space(3))) void*)(dst + 2 * TF), 4, 0, 0);
+  };
+  // reader offset of lane (i, hf): chunk i>>3 of the block, row i&7, piece 4 hf + q
+  const int jr = i >> 3, rr = i & 7;
+  int roff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) roff[q] = jr * 256 + (rr * 8 + (((4 * hf + q) ^ rr ^ (jr & 1)) & 7)) * 4;
+
+  const long last = A.ntiles - 1;
+  long t = (long)blockIdx.x * WV + wid;
+  int set = 0;
+  if (t < A.ntiles) dma_tile(t, 0);
+  for (; t < A.ntiles; t += nwaves, set ^= (NBUF - 1)) {
+    const float* buf = wbuf + set * BUF;
+    f32x4 af[NB][4], bf[NB][4], zq[KC][4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TF + ob * 1024 + roff[q]);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zq[kk][q] = *reinterpret_cast<const f32x4*>(buf + 2 * TF + kk * 32 + 16 * hf + 4 * q);
+    const long t1 = t + nwaves;
+    dma_tile(t1 < last ? t1 : last, set ^ (NBUF - 1));   // unconditional (re-reads the last tile at the end)
+    const bool wbias = t < A.bias_ntiles;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      bf16x8 bh[NB], bl[NB];
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
+          const __bf16 x0 = (__bf16)x;
+          bh[ob][e] = x0; bl[ob][e] = (__bf16)(x - (float)x0);
+        }
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        if (k0 + kk > A.r) break;
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+          bf16x8 ah, al;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = af[ib][2 * hh + (e >> 2)][e & 3] * (k0 + kk < A.r ? zq[kk][2 * hh + (e >> 2)][e & 3] : 1.0f);
+            const __bf16 x0 = (__bf16)x;
+            ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
+          }
+#pragma unroll
+          for (int ob = 0; ob < NB; ++ob) {
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ob], acc[kk][ib][ob], 0, 0, 0);
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 2 * hh; q < 2 * hh + 2; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+              bacc[kk][ob] = fmaf(wbias ? (k0 + kk < A.r ? zq[kk][q][c] : 1.0f) : 0.f, bf[ob][q][c], bacc[kk][ob]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // the tile buffers become the reduction scratch
+
+  float* red = gsm;
+  float* red16 = gsm + (WV - 1) * 64;
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+    const int k = k0 + kk;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        f32x16 v = block_sum16<WV>(acc[kk][ib][ob], red16, wid, lane);
+        if (wid == 0) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int in = 32 * ib + fmap(e, hf), out = 32 * ob + i;
+            if (k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v[e];
+          }
+        }
+      }
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      float v = bacc[kk][ob];
+      v += __shfl_xor(v, 32);
+      v = block_sum<WV>(v, red, wid, lane);
+      const int out = 32 * ob + i;
+      if (A.has_bias && wid == 0 && hf == 0 && k <= A.r && out < A.Bv.nout) prow[matref_index(A.Bv, k, 0, out)] = v;
+    }
+  }
+}
+
 static GwArgs gw_fix(const GwArgs& in) {
   GwArgs a = in;
   if (a.zt_mod <= 0) a.zt_mod = a.ntiles > 0 ? a.ntiles : 1;
@@ -277,6 +441,19 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
   const GwArgs a = gw_fix(a_);
   constexpr int WV = NIF_GW_WAVES;
   dim3 block(64 * WV);
+  static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
+  if (use_lds && NBI == NBO && NBI <= 2) {
+    dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
+    const size_t shm = sizeof(float) * (size_t)(4 * 2 * (2 * NBI * 1024 + 64));
+    if (NBI == 1) {
+      (void)hipFuncSetAttribute((const void*)k_gw_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_gw_lds<1>), grid, dim3(256), shm, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_gw_lds<2>), grid, dim3(256), shm, st, a);
+    }
+    return;
+  }
   if (NBI == 1 && NBO == 1) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
     hipLaunchKernelGGL((k_gw_mfma<1, 1, 2, WV, true>), grid, block, 0, st, a, NBO);
