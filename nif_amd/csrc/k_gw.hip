@@ -769,6 +769,113 @@ __global__ __launch_bounds__(256) void k_gw_out(GwArgs A) {
     }
 }
 
+// LDS-DMA form of k_gw_out for (r+1) nc <= 8 (see k_gw_lds): the layer-input tile arrives as contiguous KiB chunks,
+// all r+1 planes are reduced by the same workgroup (the stash is read once, not r+1 times) and the (plane, column)
+// accumulators stay in registers.  grid = (rows)
+template <int NBI>
+__global__ __launch_bounds__(256) void k_gw_out_lds(GwArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  constexpr int WV = 4, TF = NBI * 1024, MAXKC = 8;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int r = A.r, nc = A.nc, nkc = (r + 1) * nc;
+  const int nzf = r * 32, nsf = nc * 32;                 // floats of the tile's latent / dL/dout rows
+  const int ZO = TF, SO = TF + ((nzf + 63) & ~63);       // buffer: IN | Z rows | SM rows
+  const int BUF = SO + ((nsf + 63) & ~63);
+  const long nwaves = (long)gridDim.x * WV;
+  float* wbuf = gsm + (long)wid * 2 * BUF;
+  float acc[MAXKC][NBI + 1];
+#pragma unroll
+  for (int kc = 0; kc < MAXKC; ++kc)
+#pragma unroll
+    for (int ib = 0; ib <= NBI; ++ib) acc[kc][ib] = 0.f;
+  const int zt_mod = (int)A.zt_mod, nt_all = (int)A.ntiles;
+  const int dr = lane >> 3, dx = lane & 7;
+  const int src0 = dr * 32 + ((dx ^ dr) & 7) * 4, src1 = dr * 32 + ((dx ^ dr ^ 1) & 7) * 4;
+  auto dma_tile = [&](long t, int set) {
+    float* dst = wbuf + set * BUF;
+    const float* in = A.IN + t * TF;
+#pragma unroll
+    for (int j = 0; j < NBI * 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + j * 256 + ((j & 1) ? src1 : src0)),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+    const int ti = __builtin_amdgcn_readfirstlane((int)t);
+    const int tz = zt_mod >= nt_all ? ti : ti % zt_mod;
+    for (int m = 0; m < nzf; m += 64) {
+      const int e = m + lane < nzf ? m + lane : nzf - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (long)tz * nzf + e),
+                                       (__attribute__((address_space(3))) void*)(dst + ZO + m), 4, 0, 0);
+    }
+    for (int m = 0; m < nsf; m += 64) {
+      const int e = m + lane < nsf ? m + lane : nsf - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.SM + t * nsf + e),
+                                       (__attribute__((address_space(3))) void*)(dst + SO + m), 4, 0, 0);
+    }
+  };
+  const int jr = i >> 3, rr = i & 7;
+  int roff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) roff[q] = jr * 256 + (rr * 8 + (((4 * hf + q) ^ rr ^ (jr & 1)) & 7)) * 4;
+
+  const long last = A.ntiles - 1;
+  long t = (long)blockIdx.x * WV + wid;
+  int set = 0;
+  if (t < A.ntiles) dma_tile(t, 0);
+  for (; t < A.ntiles; t += nwaves, set ^= 1) {
+    const float* buf = wbuf + set * BUF;
+    f32x4 af[NBI][4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ib = 0; ib < NBI; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
+    const long t1 = t + nwaves;
+    const bool wbias = t < A.bias_ntiles;
+    // the small rows are read per (plane, column) below, so the refill of the other buffer can start right away
+    dma_tile(t1 < last ? t1 : last, set ^ 1);
+#pragma unroll
+    for (int kc = 0; kc < MAXKC; ++kc) {
+      if (kc < nkc) {
+        const int k = kc / nc, c = kc - k * nc;
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 w = *reinterpret_cast<const f32x4*>(buf + SO + c * 32 + 16 * hf + 4 * q);
+          if (k < r) w *= *reinterpret_cast<const f32x4*>(buf + ZO + k * 32 + 16 * hf + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int ib = 0; ib < NBI; ++ib) acc[kc][ib] = fmaf(w[e], af[ib][q][e], acc[kc][ib]);
+            sb += w[e];
+          }
+        }
+        acc[kc][NBI] += wbias ? sb : 0.f;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* red = gsm;
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+#pragma unroll
+  for (int kc = 0; kc < MAXKC; ++kc) {
+    if (kc < nkc) {
+      const int k = kc / nc, c = kc - k * nc;
+#pragma unroll
+      for (int ib = 0; ib <= NBI; ++ib) {
+        float v = acc[kc][ib];
+        v += __shfl_xor(v, 32);
+        v = block_sum4(v, red, wid, lane);
+        if (wid == 0 && hf == 0) {
+          const int f = 32 * ib + i;
+          if (ib < NBI) { if (f < A.W.nin) prow[matref_index(A.W, k, f, c)] = A.scale * v; }
+          else if (A.has_bias && i == 0) prow[matref_index(A.Bv, k, 0, c)] = v;
+        }
+      }
+    }
+  }
+}
+
 void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
   // few columns (e.g. so = 1, r = 1): the VALU kernel below is as fast; from 8 columns on the MFMA form wins big
@@ -777,6 +884,19 @@ void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
     if (NBI == 1) hipLaunchKernelGGL((k_gw_out_mfma<1, 4>), grid, block, 0, st, a);
     else if (NBI == 2) hipLaunchKernelGGL((k_gw_out_mfma<2, 4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_gw_out_mfma<4, 4>), grid, block, 0, st, a);
+    return;
+  }
+  static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
+  if (use_lds && (a.r + 1) * a.nc <= 8 && NBI <= 2) {
+    const int buf = NBI * 1024 + ((a.r * 32 + 63) & ~63) + ((a.nc * 32 + 63) & ~63);
+    const size_t shl = sizeof(float) * (size_t)(4 * 2 * buf);
+    if (NBI == 1) {
+      (void)hipFuncSetAttribute((const void*)k_gw_out_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_out_lds<1>), dim3(rows), dim3(256), shl, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw_out_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_out_lds<2>), dim3(rows), dim3(256), shl, st, a);
+    }
     return;
   }
   dim3 grid(rows, a.r + 1), block(256);
