@@ -688,8 +688,157 @@ __global__ __launch_bounds__(64 * WV) void k_gw_out_mfma(GwArgs A) {
 #ifndef NIF_GW_EDGE_WAVES
 #define NIF_GW_EDGE_WAVES 16
 #endif
+// LDS-DMA form of k_gw_first_mfma (see k_gw_lds): the dL/da tile arrives as contiguous KiB chunks, the tile's input
+// rows [32 points][ncol] and latent rows by 4-byte DMA; the K = 32 points product runs as three bf16 products
+// (hi*lo + lo*hi + hi*hi, like the hidden layers) on v_mfma_f32_32x32x16_bf16.  grid = (rows)
+template <int NBO, int WV>
+__global__ __launch_bounds__(64 * WV) void k_gw_first_lds(GwArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  constexpr int TF = NBO * 1024;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, hf = lane >> 5;
+  const int r = A.r, ncol = A.ncol;
+  const int nzf = r * 32, nxf = ncol * 32;
+  const int ZO = TF, XO = TF + ((nzf + 63) & ~63);
+  const int BUF = XO + ((nxf + 63) & ~63);
+  const long nwaves = (long)gridDim.x * WV;
+  float* wbuf = gsm + (long)wid * 2 * BUF;
+  const int nd1 = A.nd + 1;
+  const int k = i / nd1, d = i - k * nd1;
+  const bool row_ok = i < (r + 1) * nd1;
+  f32x16 acc[NBO];
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ob][e] = 0.f;
+  const int zt_mod = (int)A.zt_mod, nt_all = (int)A.ntiles;
+  const long xmax = A.B * ncol - 1;
+  const int dr = lane >> 3, dx = lane & 7;
+  const int src0 = dr * 32 + ((dx ^ dr) & 7) * 4, src1 = dr * 32 + ((dx ^ dr ^ 1) & 7) * 4;
+  auto dma_tile = [&](long t, int set) {
+    float* dst = wbuf + set * BUF;
+    const float* da = A.DA + t * TF;
+#pragma unroll
+    for (int j = 0; j < NBO * 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + ((j & 1) ? src1 : src0)),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+    const int ti = __builtin_amdgcn_readfirstlane((int)t);
+    const int tz = zt_mod >= nt_all ? ti : ti % zt_mod;
+    for (int m = 0; m < nzf; m += 64) {
+      const int e = m + lane < nzf ? m + lane : nzf - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (long)tz * nzf + e),
+                                       (__attribute__((address_space(3))) void*)(dst + ZO + m), 4, 0, 0);
+    }
+    for (int m = 0; m < nxf; m += 64) {
+      long e = (long)tz * nxf + m + lane;     // rows beyond the batch: any valid element (their dL/da rows are zero)
+      e = e < xmax ? e : xmax;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.xin + e),
+                                       (__attribute__((address_space(3))) void*)(dst + XO + m), 4, 0, 0);
+    }
+  };
+  const int jr = i >> 3, rr = i & 7;
+  int roff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) roff[q] = jr * 256 + (rr * 8 + (((4 * hf + q) ^ rr ^ (jr & 1)) & 7)) * 4;
+
+  const long last = A.ntiles - 1;
+  long t = (long)blockIdx.x * WV + wid;
+  int set = 0;
+  if (t < A.ntiles) dma_tile(t, 0);
+  for (; t < A.ntiles; t += nwaves, set ^= 1) {
+    const float* buf = wbuf + set * BUF;
+    f32x4 bf[NBO][4], a[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // refill the OTHER buffer first (its reads ended with the previous tile): the whole tile's work overlaps the DMA
+      const long t1 = t + nwaves;
+      dma_tile(t1 < last ? t1 : last, set ^ 1);
+    }
+#pragma unroll
+    for (int ob = 0; ob < NBO; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + ob * 1024 + roff[q]);
+    // wave-uniform, and the seed picked by static index (a dynamic index into the kernel arguments is a vector load
+    // whose s_waitcnt vmcnt(0) would also drain the DMA just issued)
+    const int tu = __builtin_amdgcn_readfirstlane((int)t);
+    const int sidx = tu < (int)A.bias_ntiles ? -1 : tu / zt_mod - 1;
+    const int pseudo = sidx < 0 ? -1 : (sidx == 0 ? A.seed[0] : (sidx == 1 ? A.seed[1] : A.seed[2]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 z = {1.f, 1.f, 1.f, 1.f};
+      if (row_ok && k < r) z = *reinterpret_cast<const f32x4*>(buf + ZO + k * 32 + 16 * hf + 4 * q);
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok) {
+        if (pseudo >= 0) { const float o = d == pseudo ? 1.0f : 0.0f; xv[0] = o; xv[1] = o; xv[2] = o; xv[3] = o; }   // one-hot, no bias row
+        else if (d == A.nd) { xv[0] = 1.f; xv[1] = 1.f; xv[2] = 1.f; xv[3] = 1.f; }
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xv[c] = buf[XO + (16 * hf + 4 * q + c) * ncol + A.col0 + d];
+        }
+      }
+      a[q] = xv * z;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      bf16x8 ah, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = a[2 * hh + (e >> 2)][e & 3];
+        const __bf16 x0 = (__bf16)x;
+        ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
+      }
+#pragma unroll
+      for (int ob = 0; ob < NBO; ++ob) {
+        bf16x8 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
+          const __bf16 x0 = (__bf16)x;
+          bh[e] = x0; bl[e] = (__bf16)(x - (float)x0);
+        }
+        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ob], 0, 0, 0);
+        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ob], 0, 0, 0);
+        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ob], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* red16 = gsm;
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+#pragma unroll
+  for (int ob = 0; ob < NBO; ++ob) {
+    const f32x16 vs = block_sum16<WV>(acc[ob], red16, wid, lane);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = vs[e];
+      const int m = fmap(e, hf), f = 32 * ob + i;
+      const int kk = m / nd1, dd = m - kk * nd1;
+      if (wid == 0 && m < (r + 1) * nd1) {
+        if (dd < A.nd) { if (f < A.W.nout) prow[matref_index(A.W, kk, dd, f)] = A.scale * v; }
+        else if (A.has_bias && f < A.Bv.nout) prow[matref_index(A.Bv, kk, 0, f)] = v;
+      }
+    }
+  }
+}
+
 void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
+  if (use_lds && NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32 && NBO <= 2 && a.ncol <= 16) {
+    const int buf = NBO * 1024 + ((a.r * 32 + 63) & ~63) + ((a.ncol * 32 + 63) & ~63);
+    constexpr int WVL = 4;   // one wave per SIMD (two: 0.089 instead of 0.080 ms)
+    size_t shl = sizeof(float) * (size_t)(WVL * 2 * buf);
+    const size_t shr = sizeof(float) * (size_t)((WVL - 1) * 16 * 64);   // the block reduction reuses the tile buffers
+    if (shl < shr) shl = shr;
+    if (NBO == 1) {
+      (void)hipFuncSetAttribute((const void*)k_gw_first_lds<1, WVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_first_lds<1, WVL>), dim3(rows), dim3(64 * WVL), shl, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw_first_lds<2, WVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_first_lds<2, WVL>), dim3(rows), dim3(64 * WVL), shl, st, a);
+    }
+    return;
+  }
   if (NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32) {
     constexpr int WV = NIF_GW_EDGE_WAVES;   // one workgroup per partial row: many waves hide the single-buffered loads
     dim3 grid(rows);
