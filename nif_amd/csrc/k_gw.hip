@@ -269,31 +269,34 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 // buffer, then split + MFMA tile t while that DMA is in flight.  Wave-private buffers, no barriers in the loop.
 // ------------------------------------------------------------------------------------------
 // Measured and not kept: one buffer per wave + two workgroups per CU (256 registers: 51 spilled, 0.27 ms instead of 0.11).
-template <int NB>   // NBI = OBC = NB (1 or 2), KC = 2, 4 waves
-__global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
-  constexpr int NBUF = 2;
+// NBUF = 1 (128-wide layers: 256 accumulator registers and a 24-KiB tile per wave): one buffer, refilled as soon as the
+// tile sits in registers -- the DMA of tile t+1 still overlaps the whole split + MFMA phase of tile t.
+template <int NBI, int OBC, int NBUF>   // KC = 2, 4 waves; grid = (rows, planes / 2, NBO / OBC)
+__global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   constexpr int KC = 2, WV = 4;
-  constexpr int TF = NB * 1024;            // floats per operand tile
-  constexpr int BUF = 2 * TF + 64;         // IN | DA | Z rows (2 x 32)
+  constexpr int TFI = NBI * 1024, TFB = OBC * 1024;   // floats of the operand tiles held by this workgroup
+  constexpr int BUF = TFI + TFB + 64;                 // IN | DA | Z rows (2 x 32)
+  const int ob0 = blockIdx.z * OBC;
+  const long TFO = (long)NBO * 1024;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const int k0 = blockIdx.y * KC;
   const long nwaves = (long)gridDim.x * WV;
   float* wbuf = gsm + (long)wid * NBUF * BUF;
 
-  f32x16 acc[KC][NB][NB];
-  float bacc[KC][NB];
+  f32x16 acc[KC][NBI][OBC];
+  float bacc[KC][OBC];
 #pragma unroll
   for (int kk = 0; kk < KC; ++kk) {
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib)
+    for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob)
+      for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[kk][ib][ob][e] = 0.f;
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) bacc[kk][ob] = 0.f;
+    for (int ob = 0; ob < OBC; ++ob) bacc[kk][ob] = 0.f;
   }
   const int zt_mod = (int)A.zt_mod, nt_all = (int)A.ntiles;
   // DMA source of this lane inside a 1-KiB chunk j: row r = lane>>3, piece c = (lane&7) ^ r ^ (j&1)
@@ -303,20 +306,20 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
   const int kz = (k0 + hf < A.r) ? k0 + hf : (A.r > 0 ? A.r - 1 : 0);
   auto dma_tile = [&](long t, int set) {
     float* dst = wbuf + set * BUF;
-    const float* in = A.IN + t * TF;
-    const float* da = A.DA + t * TF;
+    const float* in = A.IN + t * TFI;
+    const float* da = A.DA + t * TFO + (long)ob0 * 1024;
 #pragma unroll
-    for (int j = 0; j < NB * 4; ++j)
+    for (int j = 0; j < NBI * 4; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + j * 256 + ((j & 1) ? src1 : src0)),
                                        (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NB * 4; ++j)
+    for (int j = 0; j < OBC * 4; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + ((j & 1) ? src1 : src0)),
-                                       (__attribute__((address_space(3))) void*)(dst + TF + j * 256), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + TFI + j * 256), 16, 0, 0);
     const int ti = __builtin_amdgcn_readfirstlane((int)t);
     const int tz = zt_mod >= nt_all ? ti : ti % zt_mod;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + ((long)tz * A.r + kz) * 32 + i),
-                                     (__attribute__((address_space(3))) void*)(dst + 2 * TF), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(dst + TFI + TFB), 4, 0, 0);
   };
   // reader offset of lane (i, hf): chunk i>>3 of the block, row i&7, piece 4 hf + q
   const int jr = i >> 3, rr = i & 7;
@@ -330,28 +333,29 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
   if (t < A.ntiles) dma_tile(t, 0);
   for (; t < A.ntiles; t += nwaves, set ^= (NBUF - 1)) {
     const float* buf = wbuf + set * BUF;
-    f32x4 af[NB][4], bf[NB][4], zq[KC][4];
+    f32x4 af[NBI][4], bf[OBC][4], zq[KC][4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib)
+    for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
       for (int q = 0; q < 4; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
+    for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TF + ob * 1024 + roff[q]);
+      for (int q = 0; q < 4; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TFI + ob * 1024 + roff[q]);
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) zq[kk][q] = *reinterpret_cast<const f32x4*>(buf + 2 * TF + kk * 32 + 16 * hf + 4 * q);
+      for (int q = 0; q < 4; ++q) zq[kk][q] = *reinterpret_cast<const f32x4*>(buf + TFI + TFB + kk * 32 + 16 * hf + 4 * q);
     const long t1 = t + nwaves;
+    if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is in registers before its buffer is refilled
     dma_tile(t1 < last ? t1 : last, set ^ (NBUF - 1));   // unconditional (re-reads the last tile at the end)
     const bool wbias = t < A.bias_ntiles;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      bf16x8 bh[NB], bl[NB];
+      bf16x8 bh[OBC], bl[OBC];
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob)
+      for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
       for (int kk = 0; kk < KC; ++kk) {
         if (k0 + kk > A.r) break;
 #pragma unroll
-        for (int ib = 0; ib < NB; ++ib) {
+        for (int ib = 0; ib < NBI; ++ib) {
           bf16x8 ah, al;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
             ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
           }
 #pragma unroll
-          for (int ob = 0; ob < NB; ++ob) {
+          for (int ob = 0; ob < OBC; ++ob) {
             acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ob], acc[kk][ib][ob], 0, 0, 0);
             acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ob], acc[kk][ib][ob], 0, 0, 0);
             acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ob], acc[kk][ib][ob], 0, 0, 0);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int ob = 0; ob < NB; ++ob)
+            for (int ob = 0; ob < OBC; ++ob)
               bacc[kk][ob] = fmaf(wbias ? (k0 + kk < A.r ? zq[kk][q][c] : 1.0f) : 0.f, bf[ob][q][c], bacc[kk][ob]);
       }
     }
@@ -397,24 +401,24 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A) {
   for (int kk = 0; kk < KC; ++kk) {
     const int k = k0 + kk;
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib)
+    for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
+      for (int ob = 0; ob < OBC; ++ob) {
         f32x16 v = block_sum16<WV>(acc[kk][ib][ob], red16, wid, lane);
         if (wid == 0) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int in = 32 * ib + fmap(e, hf), out = 32 * ob + i;
+            const int in = 32 * ib + fmap(e, hf), out = 32 * (ob0 + ob) + i;
             if (k <= A.r && in < A.W.nin && out < A.W.nout) prow[matref_index(A.W, k, in, out)] = A.scale * v[e];
           }
         }
       }
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
+    for (int ob = 0; ob < OBC; ++ob) {
       float v = bacc[kk][ob];
       v += __shfl_xor(v, 32);
       v = block_sum<WV>(v, red, wid, lane);
-      const int out = 32 * ob + i;
+      const int out = 32 * (ob0 + ob) + i;
       if (A.has_bias && wid == 0 && hf == 0 && k <= A.r && out < A.Bv.nout) prow[matref_index(A.Bv, k, 0, out)] = v;
     }
   }
@@ -442,16 +446,18 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
   constexpr int WV = NIF_GW_WAVES;
   dim3 block(64 * WV);
   static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
-  if (use_lds && NBI == NBO && NBI <= 2) {
-    dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
-    const size_t shm = sizeof(float) * (size_t)(4 * 2 * (2 * NBI * 1024 + 64));
-    if (NBI == 1) {
-      (void)hipFuncSetAttribute((const void*)k_gw_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      hipLaunchKernelGGL((k_gw_lds<1>), grid, dim3(256), shm, st, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)k_gw_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      hipLaunchKernelGGL((k_gw_lds<2>), grid, dim3(256), shm, st, a);
-    }
+  if (use_lds && NBI == NBO && (NBI <= 2 || NBI == 4)) {
+#define NIF_GWL(NBI_, OBC_, NBUF_)                                                                                         \
+  do {                                                                                                                     \
+    const size_t shm = sizeof(float) * (size_t)(4 * NBUF_ * ((NBI_ + OBC_) * 1024 + 64));                                  \
+    dim3 grid(rows, (a.r + 1 + 1) / 2, NBI_ / OBC_);                                                                       \
+    (void)hipFuncSetAttribute((const void*)k_gw_lds<NBI_, OBC_, NBUF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_gw_lds<NBI_, OBC_, NBUF_>), grid, dim3(256), shm, st, a, NBO);                                   \
+  } while (0)
+    if (NBI == 1) NIF_GWL(1, 1, 2);
+    else if (NBI == 2) NIF_GWL(2, 2, 2);
+    else NIF_GWL(4, 2, 1);
+#undef NIF_GWL
     return;
   }
   if (NBI == 1 && NBO == 1) {
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(64 * WV) void k_gw_first_lds(GwArgs A) {
 void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
   static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
-  if (use_lds && NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32 && NBO <= 2 && a.ncol <= 16) {
+  if (use_lds && NIF_GW_EDGE_MFMA && (a.r + 1) * (a.nd + 1) <= 32 && (NBO <= 2 || NBO == 4) && a.ncol <= 16) {
     const int buf = NBO * 1024 + ((a.r * 32 + 63) & ~63) + ((a.ncol * 32 + 63) & ~63);
     constexpr int WVL = 4;   // one wave per SIMD (two: 0.089 instead of 0.080 ms)
     size_t shl = sizeof(float) * (size_t)(WVL * 2 * buf);
@@ -833,9 +839,12 @@ void launch_gw_first(const GwArgs& a_, int NBO, int rows, hipStream_t st) {
     if (NBO == 1) {
       (void)hipFuncSetAttribute((const void*)k_gw_first_lds<1, WVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
       hipLaunchKernelGGL((k_gw_first_lds<1, WVL>), dim3(rows), dim3(64 * WVL), shl, st, a);
-    } else {
+    } else if (NBO == 2) {
       (void)hipFuncSetAttribute((const void*)k_gw_first_lds<2, WVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
       hipLaunchKernelGGL((k_gw_first_lds<2, WVL>), dim3(rows), dim3(64 * WVL), shl, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw_first_lds<4, WVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_first_lds<4, WVL>), dim3(rows), dim3(64 * WVL), shl, st, a);
     }
     return;
   }
@@ -1036,15 +1045,18 @@ void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
     return;
   }
   static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
-  if (use_lds && (a.r + 1) * a.nc <= 8 && NBI <= 2) {
+  if (use_lds && (a.r + 1) * a.nc <= 8 && (NBI <= 2 || NBI == 4)) {
     const int buf = NBI * 1024 + ((a.r * 32 + 63) & ~63) + ((a.nc * 32 + 63) & ~63);
     const size_t shl = sizeof(float) * (size_t)(4 * 2 * buf);
     if (NBI == 1) {
       (void)hipFuncSetAttribute((const void*)k_gw_out_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
       hipLaunchKernelGGL((k_gw_out_lds<1>), dim3(rows), dim3(256), shl, st, a);
-    } else {
+    } else if (NBI == 2) {
       (void)hipFuncSetAttribute((const void*)k_gw_out_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
       hipLaunchKernelGGL((k_gw_out_lds<2>), dim3(rows), dim3(256), shl, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw_out_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl);
+      hipLaunchKernelGGL((k_gw_out_lds<4>), dim3(rows), dim3(256), shl, st, a);
     }
     return;
   }
