@@ -4,11 +4,14 @@
 //
 // is the gradient of every hypernetwork slice (k < r -> row k of the hyper kernel, k = r -> the
 // hyper bias) and, with r = 0, of every shared-weight dense layer.  The sum over points is the K
-// dimension of v_mfma_f32_32x32x2_f32; both operands come straight from the [tile][feature][32]
-// stashes with 16-byte loads (lane (i,hf) reads 16 consecutive points of feature i, so the K order
-// is "hf picks the half-tile" for A and B alike) -- no LDS transpose.  Each workgroup reduces a
-// strided subset of tiles and writes one row of the partial buffer; k_reduce sums the rows in a
-// fixed order (deterministic, no atomics).
+// dimension of v_mfma_f32_32x32x16_bf16 (both operands split into bf16 hi + lo, three products); the
+// operands come from the [tile][feature][32 points] stashes: lane (i, hf) holds 16 consecutive points of
+// feature i, so the K order is "hf picks the half-tile" for A and B alike -- no transpose.  The default
+// kernels (k_gw_lds, k_gw_first_lds, k_gw_out_lds) bring the tiles in by LDS-DMA, one contiguous KiB per
+// load instruction; the k_gw_mfma / k_gw_first* / k_gw_out* register-load forms remain for the shapes the
+// DMA forms do not cover and for A/B runs (NIF_GW_LDS=0).  Each workgroup reduces a strided subset of
+// tiles and writes one row of the partial buffer; k_reduce sums the rows in a fixed order (deterministic,
+// no atomics).
 //
 // This replaces what GradientTape does for  tf.einsum('ai,aij->aj') / Dense / SIREN  weights
 // (nif/layers/mlp.py:219, nif/model.py:253-300 StridedSliceGrad + AddN; SURVEY a-10).

@@ -233,27 +233,36 @@ void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, lon
 // ============================================================================================
 // gradient rows -> flat gradient (fixed summation order), loss partials -> g[P]
 // ============================================================================================
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ partial, long pstride, int rows,
+__global__ __launch_bounds__(512) void k_reduce(const float* __restrict__ partial, long pstride, int rows,
                                                 const float* __restrict__ lossp, int nloss, float* __restrict__ g, long P) {
-  // block = 64 columns x 4 row groups; fixed summation order => deterministic
-  __shared__ float red[4][64];
+  // block = 64 columns x 8 row groups, four independent partial sums per thread (the kernel is a latency-bound
+  // stream of <= 256 rows: more loads in flight, not more bandwidth, is what it needs); fixed order => deterministic
+  __shared__ float red[8][64];
   const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (i < P)
-    for (int rrow = rg; rrow < rows; rrow += 4) s += partial[(long)rrow * pstride + i];
-  red[rg][col] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < P) {
+    const float* p = partial + i;
+    int rrow = rg;
+    for (; rrow + 24 < rows; rrow += 32) {
+      s0 += p[(long)rrow * pstride]; s1 += p[(long)(rrow + 8) * pstride];
+      s2 += p[(long)(rrow + 16) * pstride]; s3 += p[(long)(rrow + 24) * pstride];
+    }
+    for (; rrow < rows; rrow += 8) s0 += p[(long)rrow * pstride];
+  }
+  red[rg][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg == 0 && i < P) g[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (rg == 0 && i < P)
+    g[i] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
   if (blockIdx.x == gridDim.x - 1) {
     // the loss: every thread sums a strided subset in a fixed order, then a fixed tree
     __syncthreads();
     float ls = 0.f;
-    for (int b = threadIdx.x; b < nloss; b += 256) ls += lossp[b];
+    for (int b = threadIdx.x; b < nloss; b += 512) ls += lossp[b];
     red[rg][col] = ls;
     __syncthreads();
     if (threadIdx.x < 64) {
-      float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+      float v = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
       if (threadIdx.x == 0) g[P] = v;
     }
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ partia
 }
 void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss, float* g, long P,
                    hipStream_t st) {
-  dim3 grid((unsigned)((P + 63) / 64)), block(256);
+  dim3 grid((unsigned)((P + 63) / 64)), block(512);
   hipLaunchKernelGGL(k_reduce, grid, block, 0, st, partial, pstride, rows, loss_partial, nloss, g, P);
 }
 
