@@ -64,7 +64,10 @@ __device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
 #define NIF_PBW_WAVES 8   // 2 waves per SIMD (256 registers each, some spills) beat 1 wave with 478 registers: 0.27 -> 0.24 ms
 #endif
 // ACT: ACT_SWISH / ACT_SINE fixed at compile time (the defaults of the reference's ParameterNets), -1 = runtime switch
-template <int NM, bool RES, int ACT>
+// SMALL (pi == 1 and r == 1, every benchmark ParameterNet): the first-layer and bottleneck gradients are rank-one
+// per point, so they are accumulated per lane with 48 FMAs a tile (reduced over lanes once, at the end) instead of
+// 32 f32-input MFMAs (2 k matrix-pipe cycles) + an LDS round trip of the dL/da tile
+template <int NM, bool RES, int ACT, bool SMALL>
 __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
   const PNetArgs& A = G.p;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -79,10 +82,10 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
   float* xT = gaT + 1024;                          // [8 rows: the pi <= 6 inputs, then ones, rest zero][32]
   const long plane = 256;                           // f32x4 per packed 32x32 matrix
 
-  f32x16 C[NM], C1, Cb;
+  f32x16 C[NM], C1, Cb, CB1;   // SMALL: C1 = per-lane sum x da0, CB1 = per-lane sum da0, Cb = per-lane sum dz h
   float gbh[NM], gb0 = 0.f, gbb = 0.f;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { C1[e] = 0.f; Cb[e] = 0.f; }
+  for (int e = 0; e < 16; ++e) { C1[e] = 0.f; Cb[e] = 0.f; CB1[e] = 0.f; }
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     gbh[m] = 0.f;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       h[0] = A.omega * acc + psmall_get(S.fb, 0, hf);
     }
     act_tile_sel<1, ACT>(A.act, h, h, d[0], A.nst, hf);
-    if (hf == 0) {
+    if (!SMALL && hf == 0) {
       for (int dd = 0; dd < A.pi; ++dd) xT[dd * 32 + p] = prow[dd];
       xT[A.pi * 32 + p] = 1.0f;
     }
@@ -150,7 +153,11 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       const float dz = A.DZ[(tile * A.r + c) * 32 + p];
       gh[0] += dz * psmall_get(S.bw + c * 32, 0, hf);
     }
-    {
+    if (SMALL) {
+      const float dz = A.DZ[tile * 32 + p];
+      Cb += dz * h[0];
+      gbb += hf == 0 ? dz : 0.f;
+    } else {
       // the dz tile in the B-operand layout: lane (j = c, hf) holds dz_c of 16 consecutive points
       f32x4 a[4], b[4];
       float s = 0.f;
@@ -196,8 +203,11 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     }
     // ---- first layer: dL/dW_1[d][f] = w0 sum_p x_d[p] da0[p][f] (rows of X^T), bias = column sums -----
     ga[0] = gh[0] * d[0][0];
+    if (SMALL) {
+      C1 += prow[0] * ga[0];
+      CB1 += ga[0];
+    } else {
     stash_store<1>(gaT, 0, ga, p, hf);
-    {
       f32x4 a[4], b[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -258,6 +268,32 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     vb = sum8(vb);
     if (wid == 0 && hf == 0 && i < A.nst) prow_out[b_off + i] = vb;
   }
+  if (SMALL) {
+    // sum over the 32 point lanes of each half (the xor butterfly stays inside the half), then over the waves
+    auto lanes32 = [&](f32x16 v) -> f32x16 {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += __shfl_xor(v[e], off);
+      return v;
+    };
+    const f32x16 s1 = sum16(lanes32(C1)), s0 = sum16(lanes32(CB1)), sb = sum16(lanes32(Cb));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int f = fmap(e, hf);
+      if (wid == 0 && p == 0 && f < A.nst) {
+        prow_out[A.first_w + f] = A.omega * s1[e];
+        prow_out[A.first_b + f] = s0[e];
+        prow_out[A.bott_w + f] = sb[e];
+      }
+    }
+    float v = gbb;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    v = sum8(v);
+    if (wid == 0 && lane == 0) prow_out[A.bott_b] = v;
+    return;
+  }
   const f32x16 s1 = sum16(C1), sb = sum16(Cb);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -291,10 +327,14 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
   dim3 grid(rows), block(64 * NIF_PBW_WAVES);
   const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)((psmall_floats(a, 1) + 3) & ~3) +
                       (size_t)2 * nm * 1024) * sizeof(float);
+#define PBW1(NM_, RES_, ACT_, SM_)                                                                                  \
+  {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_, ACT_, SM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_pnet_bwg<NM_, RES_, ACT_, SM_>), grid, block, shm, st, G);                                \
+  }
 #define PBW(NM_, RES_, ACT_)                                                                                        \
   {                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_pnet_bwg<NM_, RES_, ACT_>), grid, block, shm, st, G);                                     \
+    if (a.pi == 1 && a.r == 1) PBW1(NM_, RES_, ACT_, true) else PBW1(NM_, RES_, ACT_, false)                        \
   }
 #define PBWA(NM_, RES_)                                                       \
   if (a.act == ACT_SWISH) PBW(NM_, RES_, ACT_SWISH)                           \
@@ -305,4 +345,5 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
   else { PBWA(2, false) }
 #undef PBWA
 #undef PBW
+#undef PBW1
 }
