@@ -12,6 +12,11 @@
 // one MLP_ResNet / SIREN_ResNet block); everything else takes the stash path (k_nets.hip + k_gw.hip).
 // Same math as k_pnet / k_pnet_bwd (reference nif/layers/mlp.py:62-79, :148-160, siren.py:256-281, :381-410).
 #include "nif_internal.h"
+#include "k_pnet_bf16.h"
+
+#ifndef NIF_PBW_DENSE_BF16
+#define NIF_PBW_DENSE_BF16 1   // 0: f32-input MFMAs for the dense products (A/B builds)
+#endif
 
 struct PbwArgs {
   PNetArgs p;
@@ -97,9 +102,24 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
   // the 2 NM packed 32x32 weight planes (forward, then adjoint) live in LDS for the whole kernel: the per-tile
   // dense products read their A operands with ds_read_b128 instead of waiting on global loads four times a tile
   f32x4* wpl = reinterpret_cast<f32x4*>(lds + (long)WV * WLDS + ((psmall_floats(A, 1) + 3) & ~3));
+#if NIF_PBW_DENSE_BF16
+  // bf16 split planes built here from theta (k_pnet_bf16.h): per matrix 6 KB forward + 4 KB adjoint
+  pbf16x8* bpl = reinterpret_cast<pbf16x8*>(wpl);
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const long w_off = RES ? (m == 0 ? A.hid_w[0] : A.hid_w2[0]) : A.hid_w[m];
+    pbf_build(bpl + m * (PBF_FWD_U4 + PBF_BWD_U4), bpl + m * (PBF_FWD_U4 + PBF_BWD_U4) + PBF_FWD_U4, A.theta, w_off, A.nst,
+              threadIdx.x, 64 * WV);
+  }
+  auto dense_f = [&](int m, const f32x16 (&x)[1], f32x16 (&y)[1]) { pbf_dense_fwd(bpl + m * (PBF_FWD_U4 + PBF_BWD_U4), x[0], y[0], lane); };
+  auto dense_b = [&](int m, const f32x16 (&x)[1], f32x16 (&y)[1]) { pbf_dense_bwd(bpl + m * (PBF_FWD_U4 + PBF_BWD_U4) + PBF_FWD_U4, x[0], y[0], lane); };
+#else
   for (int e = threadIdx.x; e < NM * 256; e += 64 * WV) { wpl[e] = A.WF[e]; wpl[NM * 256 + e] = A.WB[e]; }
   const f32x4* WFl = wpl;
   const f32x4* WBl = wpl + NM * 256;
+  auto dense_f = [&](int m, const f32x16 (&x)[1], f32x16 (&y)[1]) { dense_mfma_lds<1, 1, false>(WFl + (long)m * plane, x, y, lane); };
+  auto dense_b = [&](int m, const f32x16 (&x)[1], f32x16 (&y)[1]) { dense_mfma_lds<1, 1, false>(WBl + (long)m * plane, x, y, lane); };
+#endif
   __syncthreads();
 
   for (long tile = (long)blockIdx.x * WV + wid; tile < ntiles; tile += (long)gridDim.x * WV) {
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         stash_store<1>(hs + m * 1024, 0, h, p, hf);
-        dense_mfma_lds<1, 1, false>(WFl + (long)m * plane, h, T, lane);
+        dense_f(m, h, T);
         T[0] = A.omega * T[0] + psmall_get(S.hb + m * 32, 0, hf);
         act_tile_sel<1, ACT>(A.act, T, T, d[m + 1], A.nst, hf);
         h[0] = A.siren ? T[0] : h[0] + T[0];
@@ -132,11 +152,11 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     } else {
       f32x16 t[1];
       stash_store<1>(hs, 0, h, p, hf);
-      dense_mfma_lds<1, 1, false>(WFl, h, T, lane);
+      dense_f(0, h, T);
       T[0] = A.omega * T[0] + psmall_get(S.hb, 0, hf);
       act_tile_sel<1, ACT>(A.act, T, t, d[1], A.nst, hf);
       stash_store<1>(hs + 1024, 0, t, p, hf);
-      dense_mfma_lds<1, 1, false>(WFl + plane, t, T, lane);
+      dense_f(1, t, T);
       {
         const f32x16 lin = A.omega * T[0] + psmall_get(S.hb2, 0, hf);
         T[0] = A.siren ? lin : h[0] + lin;
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
         stash_store<1>(gaT, 0, ga, p, hf);
         grad_mfma(hs + m * 1024, gaT, C[m], i, hf);
         gbh[m] += col_sum(gaT, i, hf);
-        dense_mfma_lds<1, 1, false>(WBl + (long)m * plane, ga, U, lane);
+        dense_b(m, ga, U);
         gh[0] = A.siren ? A.omega * U[0] : gh[0] + A.omega * U[0];
       }
     } else {
@@ -191,14 +211,14 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       stash_store<1>(gaT, 0, ga, p, hf);
       grad_mfma(hs + 1024, gaT, C[NM - 1], i, hf);
       gbh[NM - 1] += col_sum(gaT, i, hf);
-      dense_mfma_lds<1, 1, false>(WBl + plane, ga, U, lane);
+      dense_b(1, ga, U);
       f32x16 skip;
       skip = A.siren ? 0.5f * gh[0] : ga[0];
       ga[0] = A.omega * U[0] * d[1][0];
       stash_store<1>(gaT, 0, ga, p, hf);
       grad_mfma(hs, gaT, C[0], i, hf);
       gbh[0] += col_sum(gaT, i, hf);
-      dense_mfma_lds<1, 1, false>(WBl, ga, U, lane);
+      dense_b(0, ga, U);
       gh[0] = skip + A.omega * U[0];
     }
     // ---- first layer: dL/dW_1[d][f] = w0 sum_p x_d[p] da0[p][f] (rows of X^T), bias = column sums -----
@@ -326,7 +346,7 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
   const int nm = a.lst * (a.res ? 2 : 1);
   dim3 grid(rows), block(64 * NIF_PBW_WAVES);
   const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)((psmall_floats(a, 1) + 3) & ~3) +
-                      (size_t)2 * nm * 1024) * sizeof(float);
+                      (size_t)nm * (NIF_PBW_DENSE_BF16 ? 2560 : 2048)) * sizeof(float);
 #define PBW1(NM_, RES_, ACT_, SM_)                                                                                  \
   {                                                                                                                 \
     (void)hipFuncSetAttribute((const void*)k_pnet_bwg<NM_, RES_, ACT_, SM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
