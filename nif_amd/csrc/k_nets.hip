@@ -13,6 +13,7 @@
 //   ShapeNet       NIF._call_shape_net model.py:233-324, NIFMultiScale._call_shape_net_mres :738-954
 //   loss           Keras 'mse' (README.md:33); adjoint hand-derived (SURVEY a-10)
 #include "nif_internal.h"
+#include "k_pnet_bf16.h"
 
 // (forcing a higher occupancy on the ParameterNet kernels with launch bounds was measured: 2-3x slower, spills)
 
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float pn_lds[];   // [LL kind: 4 waves x r x 32][small vectors]
   float* zl_lds = pn_lds;
   const PSmall S = psmall_stage<NB>(A, pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0), threadIdx.x, 256);
+  // one 32-feature block: the hidden products run as exact bf16 splits (k_pnet_bf16.h), forward planes built here
+  pbf16x8* bpl = reinterpret_cast<pbf16x8*>(pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0) + ((psmall_floats(A, NB) + 3) & ~3));
+  if constexpr (NB == 1) {
+    for (int m = 0; m < nm; ++m) {
+      const long w_off = A.res ? ((m & 1) ? A.hid_w2[m >> 1] : A.hid_w[m >> 1]) : A.hid_w[m];
+      pbf_build(bpl + m * PBF_FWD_U4, nullptr, A.theta, w_off, A.nst, threadIdx.x, 256);
+    }
+  }
   __syncthreads();
   for (long tile = (long)blockIdx.x * 4 + wid; tile < ntiles; tile += (long)gridDim.x * 4) {
   long pt = tile * 32 + p;
@@ -110,7 +119,8 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
     if (!A.res) {
       // MLP_SimpleShortCut: h + act(hK+b)   |   SIREN hidden: sin(w0 hW + b)
       if (TRAIN) stash_store<NB>(A.stash + (long)i * A.slot_stride, tile, h, p, hf);
-      dense_mfma<NB, NB>(A.WF + (long)i * plane, h, T, lane);
+      if constexpr (NB == 1) pbf_dense_fwd(bpl + i * PBF_FWD_U4, h[0], T[0], lane);
+      else dense_mfma<NB, NB>(A.WF + (long)i * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
       act_tile_sel<NB, ACT>(A.act, T, T, d, A.nst, hf);
@@ -121,7 +131,8 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       // MLP_ResNet: act(h + L2(act(L1 h)))   |   SIREN_ResNet: 0.5 (h + sin(w0 sin(w0 hW+b) W2 + b2))
       f32x16 t[NB];
       if (TRAIN) stash_store<NB>(A.stash + (long)(2 * i) * A.slot_stride, tile, h, p, hf);
-      dense_mfma<NB, NB>(A.WF + (long)(2 * i) * plane, h, T, lane);
+      if constexpr (NB == 1) pbf_dense_fwd(bpl + (2 * i) * PBF_FWD_U4, h[0], T[0], lane);
+      else dense_mfma<NB, NB>(A.WF + (long)(2 * i) * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
       act_tile_sel<NB, ACT>(A.act, T, t, d, A.nst, hf);
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
         stash_store<NB>(A.stash + (long)(nm + 2 + 2 * i) * A.slot_stride, tile, d, p, hf);
         stash_store<NB>(A.stash + (long)(2 * i + 1) * A.slot_stride, tile, t, p, hf);
       }
-      dense_mfma<NB, NB>(A.WF + (long)(2 * i + 1) * plane, t, T, lane);
+      if constexpr (NB == 1) pbf_dense_fwd(bpl + (2 * i + 1) * PBF_FWD_U4, t[0], T[0], lane);
+      else dense_mfma<NB, NB>(A.WF + (long)(2 * i + 1) * plane, t, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const f32x16 lin = A.omega * T[b] + psmall_get(S.hb2 + i * NB * 32, b, hf);
@@ -242,16 +254,25 @@ void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st) {
   long nblk = (ntiles + 3) / 4;
   if (nblk > 2048) nblk = 2048;          // persistent: the small vectors are staged in LDS once per workgroup
   dim3 grid((unsigned)nblk), block(256);
-  const size_t shm = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)psmall_floats(a, NSTB)) * sizeof(float);
-#define PNA(NB_, TR_)                                                                             \
-  if (a.act == ACT_SWISH) hipLaunchKernelGGL((k_pnet<NB_, TR_, ACT_SWISH>), grid, block, shm, st, a);  \
-  else if (a.act == ACT_SINE) hipLaunchKernelGGL((k_pnet<NB_, TR_, ACT_SINE>), grid, block, shm, st, a); \
-  else hipLaunchKernelGGL((k_pnet<NB_, TR_, -1>), grid, block, shm, st, a);
+  const int nmat = a.lst * (a.res ? 2 : 1);
+  const size_t shm = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)((psmall_floats(a, NSTB) + 3) & ~3) +
+                      (NSTB == 1 ? (size_t)nmat * PBF_FWD_U4 * 4 : 0)) * sizeof(float);
+#define PNL(NB_, TR_, ACT_)                                                                                             \
+  {                                                                                                                     \
+    if (shm > 48 * 1024)                                                                                                \
+      (void)hipFuncSetAttribute((const void*)k_pnet<NB_, TR_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_pnet<NB_, TR_, ACT_>), grid, block, shm, st, a);                                              \
+  }
+#define PNA(NB_, TR_)                              \
+  if (a.act == ACT_SWISH) PNL(NB_, TR_, ACT_SWISH) \
+  else if (a.act == ACT_SINE) PNL(NB_, TR_, ACT_SINE) \
+  else PNL(NB_, TR_, -1)
 #define PN(NB_) \
   if (train) { PNA(NB_, true) } else { PNA(NB_, false) }
   if (NSTB == 1) { PN(1) } else if (NSTB == 2) { PN(2) } else { PN(4) }
 #undef PN
 #undef PNA
+#undef PNL
 }
 void launch_pnet_bwd(const PNetArgs& a, int NSTB, hipStream_t st) {
   const long ntiles = (a.B + 31) / 32;

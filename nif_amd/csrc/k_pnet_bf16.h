@@ -17,7 +17,7 @@ typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int pbf_feat(int m, int hf, int t) { return 16 * m + 8 * (t >> 2) + 4 * hf + (t & 3); }
 
-// planes of ONE nst x nst matrix W[in][out] (row-major at theta + w_off): fwd [3][2][64] then bwd [2][2][64] bf16x8
+// planes of ONE nst x nst matrix W[in][out] (row-major at theta + w_off): fwd [3][2][64], bwd [2][2][64] bf16x8 (or null)
 __device__ __forceinline__ void pbf_build(pbf16x8* fwd, pbf16x8* bwd, const float* __restrict__ theta, long w_off, int nst,
                                           int tid, int nthreads) {
   __bf16* f16 = reinterpret_cast<__bf16*>(fwd);
@@ -34,7 +34,7 @@ __device__ __forceinline__ void pbf_build(pbf16x8* fwd, pbf16x8* bwd, const floa
       f16[((1 * 2 + m) * 64 + lane) * 8 + t] = w1;
       f16[((2 * 2 + m) * 64 + lane) * 8 + t] = (__bf16)(r1 - (float)w1);
     }
-    {  // adjoint: A[f = row][k = out feature kf] = W[row][kf]
+    if (bwd) {  // adjoint: A[f = row][k = out feature kf] = W[row][kf]
       const float w = (kf < nst && row < nst) ? theta[w_off + (long)row * nst + kf] : 0.f;
       const __bf16 w0 = (__bf16)w;
       b16[((0 * 2 + m) * 64 + lane) * 8 + t] = w0;
