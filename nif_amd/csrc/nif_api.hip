@@ -37,7 +37,7 @@ struct nif_ctx {
   // device state
   float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
   long step = 0;
-  bool have_params = false, packed = false, packed32 = false, use_snet3 = false, use_snet4 = false;
+  bool have_params = false, packed = false, packed32 = false, packed_p32 = false, use_snet3 = false, use_snet4 = false;
   void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
@@ -252,7 +252,7 @@ extern "C" int nif_set_params(nif_ctx* c, const float* host, int64_t n) {
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipMemcpyAsync(c->theta, host, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
-  c->have_params = true; c->packed = false; c->packed32 = false;
+  c->have_params = true; c->packed = false; c->packed32 = false; c->packed_p32 = false;
   return NIF_OK;
 }
 extern "C" int nif_get_params(nif_ctx* c, float* host, int64_t n) {
@@ -468,9 +468,11 @@ static int ensure_packed32(nif_ctx* c) {
   c->packed32 = true;
   return NIF_OK;
 }
-static int ensure_packed(nif_ctx* c) {
-  if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
-  if (c->packed) return NIF_OK;
+// fp32 MFMA planes of the ParameterNet's hidden matrices.  A 32-wide ParameterNet (k_pnet<1>, k_pnet_bwg) splits
+// its weights into bf16 operands itself, straight from theta -- the planes are then only needed by the stash-path
+// adjoint (k_pnet_bwd) and k_mlpjac, and packed on demand
+static int ensure_packed_p32(nif_ctx* c) {
+  if (c->packed_p32) return NIF_OK;
   ProfScope ps_(c, NIF_PROF_PACK);
   const long plane_p = (long)c->NSTB * c->NSTB * 256;
   for (int i = 0; i < c->lst; ++i) {
@@ -481,6 +483,16 @@ static int ensure_packed(nif_ctx* c) {
       launch_pack(c->theta, dense_ref(c->hid_w2[i], c->nst, c->nst), c->NSTB, c->NSTB, c->pWF + (2 * i + 1) * plane_p, c->pWB + (2 * i + 1) * plane_p, c->st);
     }
   }
+  HIPCHK(hipGetLastError());
+  c->packed_p32 = true;
+  return NIF_OK;
+}
+static int ensure_packed(nif_ctx* c) {
+  if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
+  if (c->packed) return NIF_OK;
+  c->packed_p32 = false;
+  if (c->NSTB > 1) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
+  ProfScope ps_(c, NIF_PROF_PACK);
   if (c->kind == NIF_KIND_LASTLAYER) {
     const long plane_l = (long)c->NB * c->NB * 256;
     for (int i = 0; i < c->L; ++i) {
@@ -602,6 +614,7 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
+  rc = ensure_packed_p32(c); if (rc) return rc;
   const bool ll = c->kind == NIF_KIND_LASTLAYER;
   if (!ll && !c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -764,6 +777,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   la.y = y; la.sw = sw; la.inv_bg = 1.0f / (float)Bg;
   static const bool force_stash_ll = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
   const bool fused_p = !force_stash_ll && pnet_bwg_supported(pa);
+  if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   int nloss = (int)((ntiles * 32 + 255) / 256);
   if (c->use_ll4) {
@@ -870,6 +884,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   // gradients itself (k_pnetbw.hip).  NIF_PNET_STASH=1 forces the stash path (A/B runs, tests)
   static const bool force_stash = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
   const bool fused_p = !force_stash && pnet_bwg_supported(pa);
+  if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
@@ -1068,7 +1083,7 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   { ProfScope p_(c, NIF_PROF_ADAM);
     launch_adam(c->theta, c->grad, c->m, c->v, c->P, (float)lr_t, opt->beta1, opt->beta2, opt->eps, c->st); }
   HIPCHK(hipGetLastError());
-  c->packed = false; c->packed32 = false;
+  c->packed = false; c->packed32 = false; c->packed_p32 = false;
   return NIF_OK;
 }
 

@@ -1,6 +1,7 @@
 """A/B of the alternative kernel paths on identical inputs, each in its own process (the switches are read once):
 bf16-split products (k_snet4, default) vs f32-input MFMAs (NIF_FP32_MFMA=1 -> k_snet3), and the stash-free
-ParameterNet adjoint (k_pnet_bwg, default) vs the stash path (NIF_PNET_STASH=1).  Both must agree with the fp64
+ParameterNet adjoint (k_pnet_bwg, default) vs the stash path (NIF_PNET_STASH=1), LDS-DMA vs register-load
+weight-gradient kernels (NIF_GW_LDS=0).  All must agree with the fp64
 oracle to the parity bar AND with each other far inside it -- the split products are an fp32-exact reformulation,
 not a lower-precision mode."""
 import os
@@ -55,6 +56,9 @@ def test_bf16_split_and_fp32_mfma_paths_agree(tmp_path):
     b = _run(tmp_path, "fp32", {"NIF_FP32_MFMA": "1", "NIF_PNET_STASH": "1"})
     c = _run(tmp_path, "edge", {"NIF_FUSE_EDGE": "1"})       # opt-in: first/last-layer gradients fused into k_snet4
     assert _rel(c["u"], a["u"]) < 1e-7 and _rel(c["grad"], a["grad"]) < 2e-5, _rel(c["grad"], a["grad"])
+    # weight-gradient kernels with register loads (k_gw_mfma / k_gw_first_mfma / k_gw_out) instead of the LDS-DMA forms
+    d = _run(tmp_path, "gwreg", {"NIF_GW_LDS": "0"})
+    assert _rel(d["u"], a["u"]) == 0.0 and _rel(d["grad"], a["grad"]) < 2e-5, _rel(d["grad"], a["grad"])
     # the two GPU formulations against each other
     assert _rel(a["u"], b["u"]) < 2e-6, _rel(a["u"], b["u"])
     assert abs(float(a["loss"]) - float(b["loss"])) <= 2e-6 * abs(float(b["loss"]))
