@@ -271,7 +271,9 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 // distinct 4-bank groups.  Per tile: read tile t from LDS into registers, issue the DMA of tile t+1 into the other
 // buffer, then split + MFMA tile t while that DMA is in flight.  Wave-private buffers, no barriers in the loop.
 // ------------------------------------------------------------------------------------------
-// Measured and not kept: one buffer per wave + two workgroups per CU (256 registers: 51 spilled, 0.27 ms instead of 0.11).
+// Measured and not kept: one buffer per wave + two workgroups per CU (256 registers: 51 spilled, 0.27 ms instead of 0.11);
+// two tiles in flight per wave (refill the buffer just read with tile t+2, s_waitcnt vmcnt(17)): 0.106 ms either way --
+// at 5 TB/s the kernel sits at the read bandwidth this access pattern reaches (k_gw_out_lds, no arithmetic: 5.3 TB/s).
 // NBUF = 1 (128-wide layers: 256 accumulator registers and a 24-KiB tile per wave): one buffer, refilled as soon as the
 // tile sits in registers -- the DMA of tile t+1 still overlaps the whole split + MFMA phase of tile t.
 template <int NBI, int OBC, int NBUF>   // KC = 2, 4 waves; grid = (rows, planes / 2, NBO / OBC)
