@@ -89,6 +89,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="join the process group and all-reduce even at world size 1")
     args = ap.parse_args()
 
+    # The contract is ONE line on stdout.  RCCL prints a version banner on the C-level stdout of rank 0 (buffered, so
+    # it would even land AFTER the JSON line at exit): keep the real stdout aside for the JSON and point fd 1 at
+    # stderr for everything else in the process (libraries, child threads).
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import nif_amd
     from nif_amd import distributed as dist
     from nif_amd.engine import DeviceArray
@@ -227,8 +234,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle in the fence)
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         fence()
         dist.shutdown()

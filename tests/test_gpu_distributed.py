@@ -89,10 +89,12 @@ def test_bench_runs_under_torchrun_single_rank():
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps",
            "2", "--warmup", "1", "--points", "65536", "--no-cpu-baseline", "--given-w-points", "4096",
            "--force-dist"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900,
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     import json
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    # the contract: ONE line on stdout (RCCL's version banner and everything else goes to stderr)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d
