@@ -96,6 +96,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's) and asks for
+    it by the unversioned file name, so the loader does NOT reuse a copy that libnif_hip.so pulled in from /opt/rocm
+    earlier: a process that builds a model first and joins the RCCL process group later would hold two runtimes and
+    the second one sees no GPU.  The other order is fine (libnif_hip.so needs `libamdhip64.so.7`, which matches
+    whatever is loaded).  So: when torch is installed but not imported yet, load ITS runtime first.  Locating the
+    package does not import it; NIF_NO_TORCH_HIP=1 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("NIF_NO_TORCH_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=getattr(os, "RTLD_GLOBAL", 0x100) | getattr(os, "RTLD_NOW", 2))
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load():
     """dlopen libnif_hip.so and bind every symbol of include/nif_hip.h.  Raises if it is absent."""
     global _lib
@@ -105,6 +127,7 @@ def load():
         raise NifError(
             "libnif_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  nif_amd has no CPU fallback." % LIB_PATH)
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
