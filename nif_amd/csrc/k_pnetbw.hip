@@ -21,6 +21,11 @@
 struct PbwArgs {
   PNetArgs p;
   float* partial; long pstride;   // partial[row * pstride + theta index], row = blockIdx.x
+  // Optional: a stash slot the NEXT kernel streams ([tiles][touch_floats]).  This kernel is compute-bound and leaves HBM
+  // idle, while the ≈256 MB of stash writes that k_snet4 left dirty in the Infinity Cache would otherwise be written
+  // back under the first streaming kernel after it (+35-50 us there).  Each wave touches one word per 64 bytes of its
+  // tile's slice: the lines are pulled in (evicting the dirty ones now) and the next kernel finds them cached.
+  const float* touch; long touch_floats;
 };
 
 __device__ __forceinline__ f32x4 lds4(const float* q) { return *reinterpret_cast<const f32x4*>(q); }
@@ -194,6 +199,14 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
         for (int c = 0; c < 4; ++c) Cb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], Cb, 0, 0, 0);
       gbb += s;
     }
+    // touch loads (see PbwArgs): issued once this tile's own global loads are consumed, waited for at the end of
+    // the tile -- everything in between runs out of registers and LDS
+    float tv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (G.touch) {
+      const float* tb = G.touch + tile * G.touch_floats + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tv[q] = tb[q * 1024 < G.touch_floats ? q * 1024 : 0];
+    }
     // ---- adjoint through the hidden matrices, gradient GEMMs on the way -----------------------------
     if (!RES) {
 #pragma unroll
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], C1, 0, 0, 0);
     }
+    asm volatile("" ::"v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]));
   }
 
   // ---- workgroup reduction (fixed order) and this workgroup's partial row --------------------------------
@@ -341,8 +355,9 @@ bool pnet_bwg_supported(const PNetArgs& a) {
   return a.nst <= 32 && a.pi <= 6 && a.r <= 32 && nm >= 1 && nm <= 2 && (!a.res || a.lst == 1);
 }
 
-void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st) {
-  PbwArgs G; G.p = a; G.partial = partial; G.pstride = pstride;
+void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st, const float* touch,
+                     long touch_floats) {
+  PbwArgs G; G.p = a; G.partial = partial; G.pstride = pstride; G.touch = touch; G.touch_floats = touch_floats;
   const int nm = a.lst * (a.res ? 2 : 1);
   dim3 grid(rows), block(64 * NIF_PBW_WAVES);
   const size_t shm = ((size_t)NIF_PBW_WAVES * ((nm + 2) * 1024 + 256) + (size_t)((psmall_floats(a, 1) + 3) & ~3) +

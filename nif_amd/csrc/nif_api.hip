@@ -935,7 +935,11 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   if (rows > c->rows_cap) rows = c->rows_cap;
   if (rows < 1) rows = 1;
   { ProfScope p_(c, NIF_PROF_PNET_BWD);
-    if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st);
+    // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
+    // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
+    static const bool touch_on = [] { const char* e = getenv("NIF_PBW_TOUCH"); return !(e && e[0] == '0'); }();
+    const float* touch = (touch_on && !fused_edge) ? c->stash_s + (long)(c->nh + 1) * c->slot_s : nullptr;
+    if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st, touch, (long)c->NB * 1024);
     else launch_pnet_bwd(pa, c->NSTB, c->st); }
   ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
   GwArgs g;

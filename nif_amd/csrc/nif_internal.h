@@ -146,7 +146,8 @@ int launch_snet3(const SNetArgs& a, bool train, bool query_only, int* waves_out,
 // ParameterNet adjoint + weight gradients without a stash (k_pnetbw.hip); writes the ParameterNet columns of
 // `rows` partial-gradient rows
 bool pnet_bwg_supported(const PNetArgs& a);
-void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st);
+void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, hipStream_t st, const float* touch = nullptr,
+                     long touch_floats = 0);
 // bf16-split variant of k_snet3 (k_snet4.hip): fp32-exact 6-product forward, 3-product adjoint on the bf16 MFMA
 bool snet4_supported(const SNetArgs& a);
 long snet4_fwd_elems(int n, int r);
