@@ -200,7 +200,9 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       gbb += s;
     }
     // touch loads (see PbwArgs): issued once this tile's own global loads are consumed, waited for at the end of
-    // the tile -- everything in between runs out of registers and LDS
+    // the tile at the latest.  In practice earlier: the kernel spills a few registers, scratch reloads count in
+    // vmcnt and the queue completes in order, so the first reload after this point waits for the touch loads too
+    // (that is the +22 us; fetching the next tile's inputs ahead did not help for the same reason)
     float tv[4] = {0.f, 0.f, 0.f, 0.f};
     if (G.touch) {
       const float* tb = G.touch + tile * G.touch_floats + lane * 16;
