@@ -141,6 +141,13 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       h[0] = A.omega * acc + psmall_get(S.fb, 0, hf);
     }
     act_tile_sel<1, ACT>(A.act, h, h, d[0], A.nst, hf);
+    // SMALL: the last layer-input tile is not needed in LDS (the bottleneck gradient is taken from registers), so
+    // the first layer's act'(a) -- live from here to the very end of the tile otherwise -- is parked there
+    float* park = hs + NM * 1024;
+    if (SMALL) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) park[v * 64 + lane] = d[0][0][v];
+    }
     if (!SMALL && hf == 0) {
       for (int dd = 0; dd < A.pi; ++dd) xT[dd * 32 + p] = prow[dd];
       xT[A.pi * 32 + p] = 1.0f;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       act_tile_sel<1, ACT>(A.act, T, T, d[NM], A.nst, hf);
       h[0] = A.siren ? 0.5f * (h[0] + T[0]) : T[0];
     }
-    stash_store<1>(hs + NM * 1024, 0, h, p, hf);
+    if (!SMALL) stash_store<1>(hs + NM * 1024, 0, h, p, hf);
     // ---- bottleneck: dL/dW_b[f][c] = sum_p h[p][f] dz_c[p]; gh[f] = sum_c dz_c W_b[f][c] -------------
     f32x16 gh[1], ga[1], U[1];
 #pragma unroll
@@ -200,9 +207,9 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       gbb += s;
     }
     // touch loads (see PbwArgs): issued once this tile's own global loads are consumed, waited for at the end of
-    // the tile at the latest.  In practice earlier: the kernel spills a few registers, scratch reloads count in
-    // vmcnt and the queue completes in order, so the first reload after this point waits for the touch loads too
-    // (that is the +22 us; fetching the next tile's inputs ahead did not help for the same reason)
+    // the tile.  This needs a spill-free kernel: scratch reloads count in vmcnt and the queue completes in order, so
+    // with the 5-8 spilled registers this kernel used to have, the first reload after this point waited for the touch
+    // loads too (+22 us instead of +12)
     float tv[4] = {0.f, 0.f, 0.f, 0.f};
     if (G.touch) {
       const float* tb = G.touch + tile * G.touch_floats + lane * 16;
@@ -237,7 +244,12 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       gh[0] = skip + A.omega * U[0];
     }
     // ---- first layer: dL/dW_1[d][f] = w0 sum_p x_d[p] da0[p][f] (rows of X^T), bias = column sums -----
-    ga[0] = gh[0] * d[0][0];
+    if (SMALL) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) ga[0][v] = gh[0][v] * park[v * 64 + lane];
+    } else {
+      ga[0] = gh[0] * d[0][0];
+    }
     if (SMALL) {
       C1 += prow[0] * ga[0];
       CB1 += ga[0];
