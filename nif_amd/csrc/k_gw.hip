@@ -340,24 +340,39 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
     const float* buf = wbuf + set * BUF;
     f32x4 af[NBI][4], bf[OBC][4], zq[KC][4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // operands of the tile's quads [q0, q1) from LDS into registers
+    auto read_quads = [&](int q0, int q1) {
 #pragma unroll
-    for (int ib = 0; ib < NBI; ++ib)
+      for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
+        for (int q = q0; q < q1; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
 #pragma unroll
-    for (int ob = 0; ob < OBC; ++ob)
+      for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TFI + ob * 1024 + roff[q]);
+        for (int q = q0; q < q1; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TFI + ob * 1024 + roff[q]);
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk)
+      for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) zq[kk][q] = *reinterpret_cast<const f32x4*>(buf + TFI + TFB + kk * 32 + 16 * hf + 4 * q);
+        for (int q = q0; q < q1; ++q) zq[kk][q] = *reinterpret_cast<const f32x4*>(buf + TFI + TFB + kk * 32 + 16 * hf + 4 * q);
+    };
     const long t1 = t + nwaves;
-    if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is in registers before its buffer is refilled
-    dma_tile(t1 < last ? t1 : last, set ^ (NBUF - 1));   // unconditional (re-reads the last tile at the end)
+    if (NBUF == 2) {
+      read_quads(0, 4);
+      dma_tile(t1 < last ? t1 : last, set ^ 1);   // unconditional (re-reads the last tile at the end)
+    }
     const bool wbias = t < A.bias_ntiles;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
+      if (NBUF == 1) {
+        // one buffer (256 accumulator registers): only half a tile of operands is live at a time (the whole tile in
+        // registers spilled 65 of them, and scratch reloads share the in-order vmcnt queue with the DMA); the buffer is
+        // refilled once its second half has been read, so the DMA overlaps the second half's split + MFMA phase
+        read_quads(2 * hh, 2 * hh + 2);
+        if (hh == 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_tile(t1 < last ? t1 : last, set);
+        }
+      }
       bf16x8 bh[OBC], bl[OBC];
 #pragma unroll
       for (int ob = 0; ob < OBC; ++ob)
