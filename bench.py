@@ -133,6 +133,9 @@ def main():
             td.barrier()
             torch.cuda.synchronize()
 
+    if use_dist:
+        fence()   # the first barrier builds RCCL's communicator (≈11 ms of idle GPU): pay that before the warm-up, not
+                  # between the warm-up and the timed region, where the idle gap lets the clocks drop
     for _ in range(args.warmup):
         step()
     fence()
