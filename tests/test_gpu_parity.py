@@ -37,6 +37,12 @@ CONFIGS = {
     "ms_cfg3_128x3": (_cfg("NIFMultiScale", 128, 3, 64, 2, 1, 2, 1, 1), 160),
     "ms_res_128x1_nst128": (_cfg("NIFMultiScale", 128, 1, 128, 1, 1, 2, 1, 1, s_res=True), 96),
     "ms_tiny_b1": (_cfg("NIFMultiScale", 8, 1, 6, 1, 1, 1, 1, 1), 1),
+    # boundaries of the LDS-DMA gradient kernels: (r+1) so = 8 (last of k_gw_out_lds), = 10 (register-load form),
+    # (r+1)(si+1) = 32 rows of the first-layer MFMA operand, a batch smaller than one wave's share of tiles
+    "ms_64x2_r1_so4": (_cfg("NIFMultiScale", 64, 2, 32, 2, 1, 2, 4, 1), 1031),
+    "ms_64x2_r1_so5": (_cfg("NIFMultiScale", 64, 2, 32, 2, 1, 2, 5, 1), 333),
+    "ms_32x2_r7_si3": (_cfg("NIFMultiScale", 32, 2, 32, 1, 7, 3, 1, 1), 4097),
+    "ms_64x3_r3_so2_b33": (_cfg("NIFMultiScale", 64, 3, 24, 2, 3, 1, 2, 2), 33),
     # last-layer-parameterised class (config 4 family)
     "ll_plain_32x2_r3": (_cfg("LL", 32, 2, 32, 1, 3, 2, 2, 1), 257),
     "ll_res_48x2_r4": (_cfg("LL", 48, 2, 40, 2, 4, 3, 1, 2, s_res=True, p_res=True, p_act="swish"), 130),
