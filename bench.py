@@ -1,14 +1,14 @@
 """bench.py -- train-step throughput of the NIF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launches its own N ranks, one process per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from the launcher)
 
 Workload (BASELINE.json configs[1]): 1D travelling wave, NIFMultiScale, ShapeNet 4x64 SIREN,
 ParameterNet 2x32, latent_dim 1, fp32, batch = 2^20 (t;x)->u points PER GPU (weak scaling),
 synthetic data from the closed form of the reference's bundled dataset, reference init.
 A step = loss+gradient of the local shard (HIP), ONE sum all-reduce of [grad|loss] over ranks
-(RCCL) when N > 1, Adam update.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line on rank 0."""
+(RCCL through the C-ABI: ncclAllReduce on the library's stream; no torch anywhere) when N > 1, Adam update.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -29,11 +29,16 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 HBM_PEAK_GBS = 8000.0        # spec; 6290 measured-achievable
 
 
-def cpu_baseline(sample_points=65536, micro=4096):
+def STASH_BYTES_PER_POINT(s):
+    """h and dL/da stash rows the fused kernel writes, h re-read in the adjoint"""
+    return 4.0 * 32 * ((s.n_sx + 31) // 32) * (2 * (s.n_hidden_mats + 1) + s.n_hidden_mats)
+
+
+def cpu_baseline(sample_points=1 << 20, micro=4096, probe_points=65536):
     """The reference FORMULATION restated in C/OpenMP (oracle/nif_ref_cpu.c: materialised pnet_output
     [b, po], per-sample einsum chain, reverse sweep with a materialised [b, po] gradient, Adam) timed on this
-    box's host cores, all of them, on a bounded sample of the same workload: train steps of `sample_points`
-    points executed as micro-batches of `micro` (fp32).  It stands in for the reference's tf.distribute CPU
+    box's host cores on a bounded sample of the same workload: whole train steps of the benchmark's `sample_points`
+    points (the same batch the GPU steps over) executed as micro-batches of `micro` (fp32), ~10-25 s in total.  It stands in for the reference's tf.distribute CPU
     path, which cannot run here (TensorFlow 2.11.1 is not installed and the reference's Python cannot travel)."""
     from oracle import nif_oracle as O
     from oracle import ref_cpu as R
@@ -41,19 +46,21 @@ def cpu_baseline(sample_points=65536, micro=4096):
     spec = O.Spec("NIFMultiScale", CFG_SHAPE, CFG_PARAM)
     rng = np.random.default_rng(1)
     th = O.flatten(O.init_weights(spec, rng, dtype=np.float32)).astype(np.float32)
-    x, y = O.synthetic_wave_batch(sample_points, seed=0)
+    x_all, y_all = O.synthetic_wave_batch(sample_points, seed=0)
     lib = R.load()
     cfg = R.make_cfg(spec)
     ncpu = min(os.cpu_count() or 1, lib.nifref_max_threads())
 
-    def run(cores, budget_s, max_rep):
+    def run(cores, budget_s, max_rep, npts):
         th_ = th.copy(); m = np.zeros_like(th_); v = np.zeros_like(th_)
+        x, y = x_all[:npts], y_all[:npts]
 
         def step(t):
             _, g = R.loss_and_grad(lib, cfg, th_, x, y, None, micro=micro, nthreads=cores)
             lib.nifref_adam(th_.ctypes.data, g.ctypes.data, m.ctypes.data, v.ctypes.data, th_.size, t, 1e-3, 0.9, 0.999, 1e-7)
 
-        step(1)  # warm-up
+        if npts <= probe_points:
+            step(1)  # warm-up
         t0 = time.perf_counter()
         nrep, t = 0, 2
         while True:
@@ -67,15 +74,33 @@ def cpu_baseline(sample_points=65536, micro=4096):
     # few counts briefly and time the best one
     best, best_rate = 1, 0.0
     for c in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
-        nrep, dt = run(c, 1.5, 4)
-        if nrep * sample_points / dt > best_rate:
-            best, best_rate = c, nrep * sample_points / dt
+        nrep, dt = run(c, 1.0, 3, probe_points)
+        if nrep * probe_points / dt > best_rate:
+            best, best_rate = c, nrep * probe_points / dt
     cores = best
-    nrep, dt = run(cores, 10.0, 200)
+    nrep, dt = run(cores, 10.0, 6, sample_points)
     return {"value": sample_points * nrep / dt, "unit": "points/s", "cores": int(cores), "kind": "port",
-            "sample": "%d train steps of %d points (micro-batches of %d) of the benchmark model; C/OpenMP fp32 "
+            "sample": "%d whole train steps of %d points (the benchmark batch; micro-batches of %d) of the benchmark model; C/OpenMP fp32 "
                       "restatement of the reference formulation (materialised [b,po] + per-sample einsum), "
                       "OMP threads = %d; not TensorFlow" % (nrep, sample_points, micro, cores)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one process per GPU), hand them
+    the torchrun-style environment, wait.  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NIF_RDZV_KEY="bench_%d_%d" % (os.getpid(), port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -85,9 +110,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1 << 20, help="points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the A/B and per-kernel legs after the timed region")
     ap.add_argument("--given-w-points", type=int, default=1 << 17)
-    ap.add_argument("--force-dist", action="store_true", help="join the process group and all-reduce even at world size 1")
+    ap.add_argument("--force-dist", action="store_true", help="build the RCCL communicator and all-reduce even at world size 1")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     # The contract is ONE line on stdout.  RCCL prints a version banner on the C-level stdout of rank 0 (buffered, so
     # it would even land AFTER the JSON line at exit): keep the real stdout aside for the JSON and point fd 1 at
@@ -102,11 +131,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_dist
+    rank = 0
+    comm = None
     if use_dist:
-        rank, world = dist.init("nccl")
-    else:
-        rank = 0
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus (got WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+        if args.force_dist:
+            os.environ["NIF_FORCE_RCCL"] = "1"
+        rank, world = dist.init()
+        comm = dist.get()
+    assert world == args.gpus, "launch with one rank per GPU: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
 
     nif_amd.set_seed(1)  # identical initial weights on every rank (mirrored variables)
     m = nif_amd.NIFMultiScale(CFG_SHAPE, CFG_PARAM)
@@ -118,23 +150,22 @@ def main():
     d_x.upload(x); d_y.upload(y)
     adam = nif_amd.Adam(1e-3).as_struct()
     Bg = B * world
+    e.reserve(B, 0)      # every workspace sized now: no hipMalloc inside a step
 
     def step():
         e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
         if use_dist:
-            dist.all_reduce_grad(e)
+            comm.all_reduce_grad(e)       # ONE ncclAllReduce(sum, f32, P+1) on the library's stream
         e.adam_step_dev(adam)
 
     def fence():
-        e.sync()
         if use_dist:
-            import torch
-            import torch.distributed as td
-            td.barrier()
-            torch.cuda.synchronize()
+            comm.barrier(e)               # all ranks here + this rank's stream drained
+        else:
+            e.sync()
 
     if use_dist:
-        fence()   # the first barrier builds RCCL's communicator (≈11 ms of idle GPU): pay that before the warm-up, not
+        fence()   # the first collective builds RCCL's channels (~10 ms of idle GPU): pay that before the warm-up, not
                   # between the warm-up and the timed region, where the idle gap lets the clocks drop
     for _ in range(args.warmup):
         step()
@@ -145,12 +176,21 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
-        import torch
-        import torch.distributed as td
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = comm.all_reduce_float(e, dt, op="max")
     loss = e.last_loss()
+
+    # SURVEY 8d's statistic next to the contract's: median of host-synchronised single steps (all ranks in lock step)
+    per = []
+    if not args.no_extras:
+        for _ in range(max(5, min(args.steps, 20))):
+            fence()
+            t1 = time.perf_counter()
+            step()
+            e.sync()
+            per.append(time.perf_counter() - t1)
+    med_ms = float(np.median(per)) * 1e3 if per else None
+    if use_dist and med_ms is not None:
+        med_ms = comm.all_reduce_float(e, med_ms, op="max")
 
     out = None
     if rank == 0:
@@ -182,7 +222,7 @@ def main():
         # flops actually executed and the stash traffic are given next to it
         nbl_even = (((s.n_sx + 15) // 16) % 2) == 0
         exec_bf16 = (6.0 + 3.0) * 2.0 * (s.pi_hidden + 1) * (s.n_hidden_mats * s.n_sx ** 2) * B if nbl_even else 0.0
-        stash_bytes = 4.0 * 32 * ((s.n_sx + 31) // 32) * (2 * (s.n_hidden_mats + 1) + s.n_hidden_mats) * B   # h, dL/da written; h re-read
+        stash_bytes = STASH_BYTES_PER_POINT(s) * B
         sn_s = kern_ms["snet"] * 1e-3
         roofline = {"kernel": "k_snet4<4,true,SINE,0> (ShapeNet fwd + MSE + data adjoint; fp32 products as bf16 splits on "
                               "v_mfma_f32_16x16x32_bf16)" if nbl_even else "k_snet3 (16x16x4 fp32 MFMA)",
@@ -193,6 +233,19 @@ def main():
                     "frac_of_bf16_mfma_peak_2500": exec_bf16 / sn_s / 1e12 / 2500.0 if sn_s > 0 else 0.0,
                     "stash_GBs": stash_bytes / sn_s / 1e9 if sn_s > 0 else 0.0,
                     "stash_frac_of_hbm_8000": stash_bytes / sn_s / 1e9 / HBM_PEAK_GBS if sn_s > 0 else 0.0}
+        # ---- A/B: the same step with every ShapeNet product on the f32-input MFMAs (no bf16 splits) -----------
+        fp32_ms = None
+        if not args.no_extras:
+            e.set_option("fp32_mfma", 1)
+            for _ in range(2):
+                e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg); e.adam_step_dev(adam)
+            e.sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg); e.adam_step_dev(adam)
+            e.sync()
+            fp32_ms = (time.perf_counter() - t1) / 5 * 1e3
+            e.set_option("fp32_mfma", 0)
         # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
         Bw = args.given_w_points
         rng = np.random.default_rng(7)
@@ -230,13 +283,19 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 1D travelling wave, NIFMultiScale ShapeNet 4x64 SIREN (omega_0=30), "
                                    "ParameterNet 2x32 swish, latent_dim 1, P=%d, %d points/GPU" % (e.n_params, B),
-                       "global_batch": Bg, "parallelism": "dp%d" % world, "final_loss": loss},
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "final_loss": loss,
+                       "collective": "RCCL ncclAllReduce(sum, f32, P+1) on the library stream, one per step" if use_dist else "none (1 GPU)"},
+            "median_ms_per_step_host_synced": med_ms,
+            "value_from_median": (Bg / (med_ms * 1e-3)) if med_ms else None,
+            "grad_products": "forward: fp32-exact 6-product bf16 split; data adjoint: 3-product bf16 split; weight gradients: "
+                             "2-way hi/lo bf16 split; fp32 accumulation everywhere",
+            "ms_per_step_fp32_mfma": fp32_ms,
             "roofline": roofline,
             "roofline_given_w": roofline_given_w,
             "kernel_ms": kern_ms,
         }
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle in the fence)
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(sample_points=B)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         fence()

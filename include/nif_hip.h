@@ -27,14 +27,15 @@
 extern "C" {
 #endif
 
-#define NIF_ABI_VERSION 1
+#define NIF_ABI_VERSION 2
 
 typedef enum {
   NIF_OK = 0,
   NIF_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
   NIF_ERR_HIP = -2,       /* HIP runtime error (message has hipGetErrorString) */
   NIF_ERR_NODEVICE = -3,  /* no gfx950 device */
-  NIF_ERR_STATE = -4      /* call order (e.g. train step before params are set) */
+  NIF_ERR_STATE = -4,     /* call order (e.g. train step before params are set) */
+  NIF_ERR_COMM = -5       /* RCCL error (message has ncclGetErrorString) */
 } nif_status;
 
 /* model classes of nif/model.py */
@@ -162,6 +163,12 @@ int nif_sobolev_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, const
                             float* dudx_dev);
 /* optimizer.apply_gradients with Adam on the (already all-reduced) nif_grad_dev() buffer */
 int nif_adam_step_dev(nif_ctx* ctx, const nif_adam* opt);
+/* zero [grad | loss]: what a rank contributes to the step's all-reduce when its shard has no rows left (uneven shards of
+ * Model.fit under data parallelism); the weight-regulariser term is still added by the following nif_adam_step_dev */
+int nif_zero_grad(nif_ctx* ctx);
+/* size every workspace of a training step over up to B_max points now (n_tangents = Sobolev seeds, 0 for the plain
+ * step), so that later steps never hipMalloc / synchronise (TensorFlow's allocator owned this in the reference) */
+int nif_reserve(nif_ctx* ctx, int64_t B_max, int32_t n_tangents);
 /* host-pointer conveniences */
 int nif_loss_and_grad(nif_ctx* ctx, const float* xin_host, const float* y_host, const float* sw_host_or_null,
                       int64_t B, float* loss_out, float* grad_host);        /* lbfgs.py:66-74 */
@@ -176,6 +183,42 @@ int nif_metric_accumulate(nif_ctx* ctx, float weight);
 int nif_metric_read(nif_ctx* ctx, double* sum_out, double* count_out, int reset);
 /* reads grad[P] (the loss of the last nif_loss_grad_dev) */
 int nif_last_loss(nif_ctx* ctx, float* loss_out);
+/* read-out half of nif_loss_and_grad for a resident dataset (lbfgs.py:66-74 closure): adds the weight-regulariser term
+ * once, copies loss and/or the flat gradient to the host, synchronises.  Either pointer may be NULL. */
+int nif_grad_read(nif_ctx* ctx, float* loss_out_or_null, float* grad_host_or_null);
+/* A/B switches for measurement and tests (no reference counterpart).  "fp32_mfma" = 1: every product of the
+ * ShapeNet on the f32-input MFMAs instead of the exact bf16 splits (default 0, or NIF_FP32_MFMA=1 in the environment) */
+int nif_set_option(nif_ctx* ctx, const char* key, int32_t value);
+
+/* ---- multi-GPU: RCCL over xGMI, called directly (replaces `tf.distribute.MirroredStrategy().scope()`, reference
+ * README.md:39-49: data parallelism over the GPUs of one node).  One nif_ctx per GPU.  The point batch is sharded
+ * over ranks; nif_loss_grad_dev pre-scales by 1/B_global; ONE sum all-reduce of the flat float buffer
+ * nif_grad_dev() = [grad(P) | loss] per step, enqueued on the context's stream (no host sync, no copy); every rank
+ * then applies the identical Adam update (replicated optimizer state, as MirroredStrategy does). */
+#define NIF_COMM_ID_BYTES 128
+typedef enum { NIF_DT_F32 = 0, NIF_DT_F64 = 1, NIF_DT_I64 = 2 } nif_dtype;
+typedef enum { NIF_OP_SUM = 0, NIF_OP_MAX = 1, NIF_OP_MIN = 2 } nif_redop;
+/* one process per GPU: rank 0 creates the id (ncclGetUniqueId), the host side carries the 128 bytes to the other
+ * processes, every rank joins (ncclCommInitRank on ctx's device; collective: returns when all `world` ranks called) */
+int nif_comm_unique_id(void* id_out_128_bytes);
+int nif_comm_init_rank(nif_ctx* ctx, const void* id_128_bytes, int32_t rank, int32_t world);
+/* one process driving n GPUs: ncclCommInitAll over the contexts' devices (rank i = ctxs[i]) */
+int nif_comm_init_all(nif_ctx** ctxs, int32_t n);
+int nif_comm_destroy(nif_ctx* ctx);                       /* also done by nif_destroy */
+int nif_comm_info(nif_ctx* ctx, int32_t* rank_out, int32_t* world_out);   /* (0, 1) without a communicator */
+/* THE collective of the training step: ncclAllReduce(sum, f32, P+1) in place on nif_grad_dev(), on ctx's stream.
+ * No-op for a context without communicator (world size 1). */
+int nif_allreduce_grad(nif_ctx* ctx);
+int nif_allreduce_grad_multi(nif_ctx** ctxs, int32_t n);  /* the n contexts of nif_comm_init_all, one RCCL group call */
+/* plumbing: in-place all-reduce of a caller-owned device buffer on ctx's stream (Model.fit: every step's global
+ * batch size, agreed once per call; bench.py: max-over-ranks wall time) */
+int nif_comm_allreduce(nif_ctx* ctx, void* dev_buf, int64_t count, int32_t dtype /* nif_dtype */, int32_t op /* nif_redop */);
+/* every rank reached this call and ctx's stream has drained (one-word all-reduce + stream synchronise) */
+int nif_comm_barrier(nif_ctx* ctx);
+/* Model.fit's train_step on n GPUs from ONE process: rows split contiguously and evenly over the
+ * contexts, per-shard loss/gradient, one grouped all-reduce, identical Adam update everywhere.  Host pointers. */
+int nif_train_step_multi(nif_ctx** ctxs, int32_t n, const float* xin_host, const float* y_host,
+                         const float* sw_host_or_null, int64_t B, const nif_adam* opt, float* loss_out);
 
 /* ---- measurement (HIP events on the context's stream; no reference counterpart) ------- */
 /* kernel groups timed when profiling is on */

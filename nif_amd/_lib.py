@@ -1,4 +1,4 @@
-"""ctypes binding of libnif_hip.so (include/nif_hip.h).  No torch, no numpy-side compute: every
+"""ctypes binding of libnif_hip.so (include/nif_hip.h).  No tensor framework, no numpy-side compute: every
 numeric result of the package comes out of the HIP library.  There is deliberately no fallback:
 if the shared object is missing or no gfx950 device is visible, we raise."""
 import ctypes as C
@@ -7,8 +7,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnif_hip.so")
 
-NIF_ABI_VERSION = 1
+NIF_ABI_VERSION = 2
 KIND_NIF, KIND_MULTISCALE, KIND_LASTLAYER = 0, 1, 2
+COMM_ID_BYTES = 128
+DT_F32, DT_F64, DT_I64 = 0, 1, 2
+OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 PROF_NAMES = ["pack", "pnet_fwd", "snet", "pnet_bwd", "gw", "reduce", "adam", "given_w", "latent_to_w", "snet_fwd"]
 
@@ -80,12 +83,26 @@ SIGNATURES = {
                                             C.c_float]),
     "nif_sobolev_forward_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
+    "nif_zero_grad": (C.c_int, [_CTX]),
+    "nif_reserve": (C.c_int, [_CTX, C.c_int64, C.c_int32]),
+    "nif_comm_unique_id": (C.c_int, [_VP]),
+    "nif_comm_init_rank": (C.c_int, [_CTX, _VP, C.c_int32, C.c_int32]),
+    "nif_comm_init_all": (C.c_int, [C.POINTER(_CTX), C.c_int32]),
+    "nif_comm_destroy": (C.c_int, [_CTX]),
+    "nif_comm_info": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "nif_allreduce_grad": (C.c_int, [_CTX]),
+    "nif_allreduce_grad_multi": (C.c_int, [C.POINTER(_CTX), C.c_int32]),
+    "nif_comm_allreduce": (C.c_int, [_CTX, _VP, C.c_int64, C.c_int32, C.c_int32]),
+    "nif_comm_barrier": (C.c_int, [_CTX]),
+    "nif_train_step_multi": (C.c_int, [C.POINTER(_CTX), C.c_int32, _VP, _VP, _VP, C.c_int64, C.POINTER(nif_adam), _FP]),
     "nif_loss_and_grad": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, _FP, _VP]),
     "nif_train_step": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.POINTER(nif_adam), _FP]),
     "nif_set_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float, C.c_int64, C.c_int64]),
     "nif_metric_accumulate": (C.c_int, [_CTX, C.c_float]),
     "nif_metric_read": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "nif_last_loss": (C.c_int, [_CTX, _FP]),
+    "nif_grad_read": (C.c_int, [_CTX, _FP, _VP]),
+    "nif_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int32]),
     "nif_profile_enable": (C.c_int, [_CTX, C.c_int]),
     "nif_profile_read": (C.c_int, [_CTX, _FP, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "nif_debug_timeline": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),
@@ -94,28 +111,6 @@ SIGNATURES = {
 }
 
 _lib = None
-
-
-def _one_hip_runtime():
-    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's) and asks for
-    it by the unversioned file name, so the loader does NOT reuse a copy that libnif_hip.so pulled in from /opt/rocm
-    earlier: a process that builds a model first and joins the RCCL process group later would hold two runtimes and
-    the second one sees no GPU.  The other order is fine (libnif_hip.so needs `libamdhip64.so.7`, which matches
-    whatever is loaded).  So: when torch is installed but not imported yet, load ITS runtime first.  Locating the
-    package does not import it; NIF_NO_TORCH_HIP=1 skips this."""
-    import sys
-    if "torch" in sys.modules or os.environ.get("NIF_NO_TORCH_HIP") == "1":
-        return
-    try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.origin:
-            return
-        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=getattr(os, "RTLD_GLOBAL", 0x100) | getattr(os, "RTLD_NOW", 2))
-    except (ImportError, OSError, ValueError):
-        pass
 
 
 def load():
@@ -127,7 +122,6 @@ def load():
         raise NifError(
             "libnif_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  nif_amd has no CPU fallback." % LIB_PATH)
-    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -7,82 +7,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include "nif_ctx.h"
+
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
-#define HIPCHK(expr)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess)                                                                         \
-      return fail(NIF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
-  } while (0)
-
-struct nif_ctx {
-  nif_cfg cfg;
-  int dev = 0;
-  hipStream_t st = nullptr;
-  // derived sizes
-  int kind, pi, si, so, n, L, nst, lst, r, nh, nm, NB, NSTB;
-  long po, P;
-  std::vector<nif_tensor_desc> layout;
-  // theta offsets
-  long first_w, first_b, hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
-  long bott_w, bott_b, last_w, last_b;
-  // last-layer class: shared-weight SIREN ShapeNet (model.py:1147-1217) + last_layer_bias
-  long s_first_w = 0, s_first_b = 0, s_hid_w[NIF_MAX_HID], s_hid_b[NIF_MAX_HID], s_hid_w2[NIF_MAX_HID], s_hid_b2[NIF_MAX_HID];
-  long s_bott_w = 0, s_bott_b = 0, ll_bias = 0;
-  int RB = 1;   // ZL rows per tile = 32*RB
-  // device state
-  float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
-  long step = 0;
-  bool have_params = false, packed = false, packed32 = false, packed_p32 = false, use_snet3 = false, use_snet4 = false;
-  void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
-  bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
-  float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
-  void *ll_wpf = nullptr, *ll_wpb = nullptr;   // phi layer as bf16-split MFMA operands (launch_pack_phi)
-  float* edge = nullptr; long edge_cap = 0;    // per-workgroup first/last-layer gradient partials of k_snet4
-  f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
-  // workspaces (capacity in points)
-  long cap = 0;
-  float *stash_s = nullptr, *stash_p = nullptr, *Z = nullptr, *DZ = nullptr, *DU = nullptr, *ZL = nullptr;
-  long slot_s = 0, slot_p = 0;
-  float* partial = nullptr; int rows_cap = 0; long pstride = 0;
-  float* loss_partial = nullptr; long nloss_cap = 0;
-  float* dring = nullptr; long dring_cap = 0;
-  long long* tl = nullptr;   // timeline stamps (measurement builds)
-  float reg_l1 = 0.f, reg_l2 = 0.f; long reg_lo = 0, reg_hi = 0; bool reg_applied = false;
-  double* metric = nullptr;  // device {sum, count}
-  float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
-  // profiling: (group id, start, stop) event triples recorded on st
-  bool prof_on = false;
-  std::vector<hipEvent_t> ev_pool;
-  struct Rec { int id; hipEvent_t a, b; };
-  std::vector<Rec> recs;
-  double prof_ms[NIF_PROF_N] = {0};
-  long prof_cnt[NIF_PROF_N] = {0};
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  // staging for the host-pointer API
-  float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
-  long cap_a = 0, cap_b = 0, cap_c = 0, cap_d = 0;
-};
-
-// RAII-ish helper: records an event pair around a kernel group when profiling is on
-struct ProfScope {
-  nif_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(nif_ctx* c_, int id_) : c(c_), id(id_) {
-    if (!c->prof_on) return;
-    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
-    a = get(); b = get();
-    (void)hipEventRecord(a, c->st);
-  }
-  ~ProfScope() {
-    if (!a) return;
-    (void)hipEventRecord(b, c->st);
-    c->recs.push_back({id, a, b});
-  }
-};
+int nif_fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 extern "C" const char* nif_last_error(void) { return g_err.c_str(); }
 extern "C" int nif_abi_version(void) { return NIF_ABI_VERSION; }
@@ -171,6 +103,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
 
   nif_ctx* c = new nif_ctx();
   c->cfg = *cfg;
+  { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
   c->dev = device_id;
   c->kind = cfg->kind; c->pi = cfg->pi_dim; c->si = cfg->si_dim; c->so = cfg->so_dim;
   c->n = cfg->n_sx; c->L = cfg->l_sx; c->nst = cfg->n_st; c->lst = cfg->l_st; c->r = cfg->latent_dim;
@@ -227,7 +160,8 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (!c) return NIF_OK;
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
-  void* ptrs[] = {c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  if (c->comm) (void)nif_comm_destroy(c);
+  void* ptrs[] = {c->comm_scratch, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -537,7 +471,7 @@ static int ensure_packed(nif_ctx* c) {
   SNetArgs probe; fill_snet(c, probe, nullptr, 0, 0, 32);
   c->use_snet3 = snet3_supported(probe);
   // NIF_FP32_MFMA=1 in the environment keeps every product on the f32-input MFMAs (k_snet3) for A/B runs
-  static const bool fp32_only = [] { const char* e = getenv("NIF_FP32_MFMA"); return e && e[0] == '1'; }();
+  const bool fp32_only = c->opt_fp32_mfma;
   c->use_snet4 = c->use_snet3 && c->sWF4 && !fp32_only && snet4_supported(probe);
   c->packed32 = false;
   if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
@@ -861,6 +795,47 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   return NIF_OK;
 }
 
+// Workspace sizing of the fused ShapeNet kernel the step will launch (no launch): number of workgroups (= loss partials),
+// the act'(a) ring, the optional edge-gradient partials.  Grows buffers when needed (stream sync + hipMalloc): call
+// nif_reserve() once up front to keep that out of the timed steps.
+static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nloss, bool* fused_edge) {
+  int rc;
+  *fused_edge = false;
+  if (ns > 0) {
+    const int nblk = launch_sob(sa, true, ns, seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
+    const long need = (long)nblk * 4 * sob_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    *nloss = nblk;
+  } else if (c->use_snet3) {
+    int waves = 4;
+    static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
+    if (c->use_snet4 && want_edge) {  // opt-in: first/last-layer weight gradients inside k_snet4 (no DA_0 / IN_nh / DU stashes)
+      sa.edge_ne = snet4_edge_ne(sa);
+      *fused_edge = sa.edge_ne > 0;
+    }
+    const int nblk = c->use_snet4 ? launch_snet4(sa, true, true, c->st) : launch_snet3(sa, true, true, &waves, c->st);
+    if (*fused_edge) {
+      const long need_e = (long)nblk * sa.edge_ne;
+      if (need_e > c->edge_cap) {
+        HIPCHK(hipStreamSynchronize(c->st));
+        rc = grow(&c->edge, &c->edge_cap, need_e); if (rc) return rc;
+      }
+      sa.EDGE = c->edge;
+    }
+    const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    *nloss = nblk;
+  }
+  sa.dring = c->dring;
+  return NIF_OK;
+}
+
 // ns = 0: loss = mse(u, y).  ns > 0 (Sobolev): + wj * mse(du/dx_seed, gt), k_sob instead of k_snet3; the
 // ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
@@ -890,45 +865,13 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
   int nloss = (int)((ntiles + 3) / 4);
   bool fused_edge = false;
-  if (ns > 0) {
-    const int nblk = launch_sob(sa, true, ns, seeds, gt, wj, nullptr, nullptr, true, c->st);
-    const long need = (long)nblk * 4 * sob_ring_floats_per_wave(c->n, c->nh);
-    if (need > c->dring_cap) {
-      HIPCHK(hipStreamSynchronize(c->st));
-      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
-    }
-    nloss = nblk;
+  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge); if (rc) return rc;
+  {
     ProfScope p_(c, NIF_PROF_SNET);
-    launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
-  } else if (c->use_snet3) {
-    int waves = 4;
-    static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
-    if (c->use_snet4 && want_edge) {  // opt-in: first/last-layer weight gradients inside k_snet4 (no DA_0 / IN_nh / DU stashes)
-      sa.edge_ne = snet4_edge_ne(sa);
-      fused_edge = sa.edge_ne > 0;
-    }
-    const int nblk = c->use_snet4 ? launch_snet4(sa, true, true, c->st) : launch_snet3(sa, true, true, &waves, c->st);
-    if (fused_edge) {
-      const long need_e = (long)nblk * sa.edge_ne;
-      if (need_e > c->edge_cap) {
-        HIPCHK(hipStreamSynchronize(c->st));
-        rc = grow(&c->edge, &c->edge_cap, need_e); if (rc) return rc;
-      }
-      sa.EDGE = c->edge;
-    }
-    const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
-    if (need > c->dring_cap) {
-      HIPCHK(hipStreamSynchronize(c->st));
-      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
-    }
-    sa.dring = c->dring;
-    nloss = nblk;
-    ProfScope p_(c, NIF_PROF_SNET);
-    if (c->use_snet4) launch_snet4(sa, true, false, c->st);
-    else launch_snet3(sa, true, false, nullptr, c->st);
-  } else {
-    ProfScope p_(c, NIF_PROF_SNET);
-    launch_snet(sa, c->NB, true, c->st);
+    if (ns > 0) launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
+    else if (c->use_snet4) launch_snet4(sa, true, false, c->st);
+    else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, c->st);
+    else launch_snet(sa, c->NB, true, c->st);
   }
   // weight gradients -> partial rows
   int rows = (int)((ntiles + 3) / 4);
@@ -941,7 +884,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     const float* touch = (touch_on && !fused_edge) ? c->stash_s + (long)(c->nh + 1) * c->slot_s : nullptr;
     if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st, touch, (long)c->NB * 1024);
     else launch_pnet_bwd(pa, c->NSTB, c->st); }
-  ProfScope* pgw = new ProfScope(c, NIF_PROF_GW);
+  std::unique_ptr<ProfScope> pgw(new ProfScope(c, NIF_PROF_GW));   // closed (event recorded) on every return path
   GwArgs g;
   auto base = [&](GwArgs& q) {
     memset(&q, 0, sizeof(q));
@@ -995,7 +938,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
   launch_gw_out(g, c->NSTB, rows, c->st);
   }
-  delete pgw;
+  pgw.reset();
   // rows -> flat gradient, loss
   ProfScope pr_(c, NIF_PROF_REDUCE);
   launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
@@ -1007,6 +950,29 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
 extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg) {
   if (!c || !xin || !y || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
   return loss_grad_core(c, xin, y, sw, B, Bg, 0, nullptr, nullptr, 0.f);
+}
+
+// Size every workspace of a training step over up to B_max points (n_tangents Sobolev seeds, 0 = plain step) now, so
+// that no hipMalloc / stream synchronisation happens inside a later (timed) step.
+extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
+  if (!c || B_max <= 0 || n_tangents < 0 || n_tangents > 3) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_packed(c); if (rc) return rc;
+  const long ntiles = (B_max + 31) / 32;
+  rc = ensure_capacity(c, ntiles * 32 * (1 + n_tangents), true); if (rc) return rc;
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    if (c->use_ll4) {
+      SNetArgs sa; fill_snet_ll(c, sa, nullptr, c->pi + c->si, c->pi, B_max);
+      const int nblk = launch_snet4(sa, true, true, c->st);
+      const long need = (long)nblk * 4 * snet3_ring_floats_per_wave(c->n, c->nh);
+      if (need > c->dring_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc; }
+    }
+    return NIF_OK;
+  }
+  SNetArgs sa; fill_snet(c, sa, nullptr, c->pi + c->si, c->pi, B_max);
+  int nloss = 0; bool fe = false;
+  const int seeds[3] = {0, 0, 0};
+  return snet_plan(c, sa, n_tangents, seeds, &nloss, &fe);
 }
 
 static int sobolev_seeds(nif_ctx* c, const int32_t* x_idx, int32_t nx, int* seeds) {
@@ -1088,6 +1054,41 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
     launch_adam(c->theta, c->grad, c->m, c->v, c->P, (float)lr_t, opt->beta1, opt->beta2, opt->eps, c->st); }
   HIPCHK(hipGetLastError());
   c->packed = false; c->packed32 = false; c->packed_p32 = false;
+  // the regulariser term belongs to ONE gradient: a following step that skips nif_loss_grad_dev (nif_zero_grad on a rank
+  // whose shard ran out of rows) must add it again, like the ranks that did compute a gradient
+  c->reg_applied = false;
+  return NIF_OK;
+}
+
+// A rank whose shard has no rows left for a step still joins the collective: with a zero [grad | loss] buffer.
+extern "C" int nif_zero_grad(nif_ctx* c) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemsetAsync(c->grad, 0, sizeof(float) * (size_t)(c->P + 1), c->st));
+  c->reg_applied = false;
+  return NIF_OK;
+}
+
+// A/B switches (measurement and tests; the defaults are the product path)
+extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
+  if (!c || !key) return fail(NIF_ERR_INVALID, "null");
+  if (strcmp(key, "fp32_mfma") == 0) {      // 1: every product on the f32-input MFMAs (k_snet3) instead of the bf16 splits
+    c->opt_fp32_mfma = value != 0;
+    c->packed = false; c->packed32 = false; c->packed_p32 = false;
+    return NIF_OK;
+  }
+  return fail(NIF_ERR_INVALID, std::string("unknown option ") + key);
+}
+
+// The weight-regulariser term is added (once) and [grad | loss] copied to the host: the read-out half of
+// nif_loss_and_grad for callers that keep the dataset resident (L-BFGS closure).  Either pointer may be NULL.
+extern "C" int nif_grad_read(nif_ctx* c, float* loss, float* grad) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  apply_reg(c);
+  if (grad) HIPCHK(hipMemcpyAsync(grad, c->grad, sizeof(float) * (size_t)c->P, hipMemcpyDeviceToHost, c->st));
+  if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
 }
 
@@ -1104,6 +1105,12 @@ static int stage_batch(nif_ctx* c, const float* xin, const float* y, const float
   int rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, y, B * c->so); if (rc) return rc;
   if (sw) { rc = stage(c, &c->d_c, &c->cap_c, sw, B); if (rc) return rc; }
+  return NIF_OK;
+}
+int nif_stage_batch(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, float** dx, float** dy, float** dsw) {
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
+  *dx = c->d_a; *dy = c->d_b; *dsw = sw ? c->d_c : nullptr;
   return NIF_OK;
 }
 

@@ -1,0 +1,88 @@
+// nif_ctx.h -- the context object behind the opaque nif_ctx* of include/nif_hip.h, shared by the translation units
+// that implement the C-ABI (nif_api.hip: orchestration; nif_comm.hip: RCCL).
+#pragma once
+#include "../../include/nif_hip.h"
+#include "nif_internal.h"
+#include <string>
+#include <vector>
+
+int nif_fail(int code, const std::string& msg);   // sets the thread-local message behind nif_last_error()
+static inline int fail(int code, const std::string& msg) { return nif_fail(code, msg); }
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(NIF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+struct nif_ctx {
+  nif_cfg cfg;
+  int dev = 0;
+  hipStream_t st = nullptr;
+  // derived sizes
+  int kind, pi, si, so, n, L, nst, lst, r, nh, nm, NB, NSTB;
+  long po, P;
+  std::vector<nif_tensor_desc> layout;
+  // theta offsets
+  long first_w, first_b, hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
+  long bott_w, bott_b, last_w, last_b;
+  // last-layer class: shared-weight SIREN ShapeNet (model.py:1147-1217) + last_layer_bias
+  long s_first_w = 0, s_first_b = 0, s_hid_w[NIF_MAX_HID], s_hid_b[NIF_MAX_HID], s_hid_w2[NIF_MAX_HID], s_hid_b2[NIF_MAX_HID];
+  long s_bott_w = 0, s_bott_b = 0, ll_bias = 0;
+  int RB = 1;   // ZL rows per tile = 32*RB
+  // device state
+  float *theta = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
+  long step = 0;
+  bool have_params = false, packed = false, packed32 = false, packed_p32 = false, use_snet3 = false, use_snet4 = false;
+  void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
+  bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
+  float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
+  void *ll_wpf = nullptr, *ll_wpb = nullptr;   // phi layer as bf16-split MFMA operands (launch_pack_phi)
+  float* edge = nullptr; long edge_cap = 0;    // per-workgroup first/last-layer gradient partials of k_snet4
+  f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
+  // workspaces (capacity in points)
+  long cap = 0;
+  float *stash_s = nullptr, *stash_p = nullptr, *Z = nullptr, *DZ = nullptr, *DU = nullptr, *ZL = nullptr;
+  long slot_s = 0, slot_p = 0;
+  float* partial = nullptr; int rows_cap = 0; long pstride = 0;
+  float* loss_partial = nullptr; long nloss_cap = 0;
+  float* dring = nullptr; long dring_cap = 0;
+  long long* tl = nullptr;   // timeline stamps (measurement builds)
+  float reg_l1 = 0.f, reg_l2 = 0.f; long reg_lo = 0, reg_hi = 0; bool reg_applied = false;
+  double* metric = nullptr;  // device {sum, count}
+  float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
+  // profiling: (group id, start, stop) event triples recorded on st
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  double prof_ms[NIF_PROF_N] = {0};
+  long prof_cnt[NIF_PROF_N] = {0};
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // staging for the host-pointer API
+  float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
+  long cap_a = 0, cap_b = 0, cap_c = 0, cap_d = 0;
+  // RCCL communicator of this context (nif_comm.hip): one rank = one ctx = one GPU
+  void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+  float* comm_scratch = nullptr;   // 64 B device scratch for barrier()
+  bool opt_fp32_mfma = false;      // nif_set_option("fp32_mfma"): A/B switch, default from NIF_FP32_MFMA
+};
+
+// RAII-ish helper: records an event pair around a kernel group when profiling is on
+struct ProfScope {
+  nif_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(nif_ctx* c_, int id_) : c(c_), id(id_) {
+    if (!c->prof_on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, c->st);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->st);
+    c->recs.push_back({id, a, b});
+  }
+};
+
+// host batch -> this context's staging buffers (asynchronous H2D on c->st); used by the host-pointer entry points
+int nif_stage_batch(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, float** dx, float** dy, float** dsw);

@@ -1,61 +1,172 @@
-"""Data parallelism over the point batch: one process per GPU, `torch.distributed` as plumbing
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  Replaces the reference's
-`tf.distribute.MirroredStrategy().scope()` recipe (README.md:39-49): rows (points) are independent, so
-every rank computes loss and gradient of its shard, pre-scaled by 1/B_global inside the HIP kernels, and
-ONE sum all-reduce of the flat float32 buffer [grad(P) | loss] per step makes every rank hold the
-global-batch gradient; each rank then applies the identical Adam update (replicated state).
+"""Data parallelism over the point batch: one process per GPU, RCCL over xGMI called directly through the C-ABI
+(include/nif_hip.h, "multi-GPU" section; nif_amd/csrc/nif_comm.hip).  Replaces the reference's
+`tf.distribute.MirroredStrategy().scope()` recipe (reference README.md:39-49): rows (points) are independent, so
+every rank computes loss and gradient of its shard, pre-scaled by 1/B_global inside the HIP kernels, and ONE
+ncclAllReduce(sum) of the flat float32 buffer [grad(P) | loss] per step makes every rank hold the global-batch
+gradient; each rank then applies the identical Adam update (replicated state).  The collective is enqueued on the
+context's own HIP stream on the library's own buffer: no host synchronisation, no copy, no tensor framework.
 
-torch is imported lazily and only here; the compute path (libnif_hip.so) never sees it.  The
-all-reduce runs on the context's own HIP stream (torch.cuda.ExternalStream) on a tensor aliasing the
-library's gradient buffer (__cuda_array_interface__), so there is no host synchronisation."""
+Process model: RANK / WORLD_SIZE / LOCAL_RANK from the environment (what the usual one-process-per-GPU launchers export; `bench.py
+--gpus N` launches its own ranks the same way).  The only thing that has to travel between the processes on
+the host is RCCL's 128-byte unique id: rank 0 publishes it in a file, the others read it (single node, like the
+reference's MirroredStrategy).  The file is named after NIF_RDZV_KEY, else MASTER_ADDR / MASTER_PORT and the launcher's
+pid, which all ranks of one launch share and no other launch does.
+
+The communicator object is pluggable (`install`): the CPU tests put a gloo-backed double with the same methods here to
+run `Model.fit`'s real sharding logic on two processes without a GPU."""
+import ctypes as C
 import os
+import tempfile
+import time
 
-_state = {"pg": False, "grad_alias": {}}
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+_comm = [None]
 
 
-def _td():
-    import torch.distributed as td
-    return td
+class RcclComm(object):
+    """One rank of the job.  Every Engine (= one nif_ctx, one HIP stream) joins its own RCCL communicator the first
+    time it takes part in a collective; all ranks create their engines in the same order (SPMD), so the n-th
+    communicator of every rank is the same one."""
+
+    def __init__(self, rank, world, local_rank, key=None, directory=None, timeout=300.0):
+        self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
+        self._key = key or os.environ.get("NIF_RDZV_KEY") or "%s_%s_%d" % (
+            os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+        self._dir = directory or os.environ.get("NIF_RDZV_DIR") or tempfile.gettempdir()
+        self._timeout = float(timeout)
+        self._seq = 0
+
+    # ---- host-side rendezvous of the 128-byte id -------------------------------------------------
+    def _id_path(self, seq):
+        safe = "".join(ch if ch.isalnum() or ch in "._-" else "_" for ch in self._key)
+        return os.path.join(self._dir, "nif_rccl_id_%s_%d" % (safe, seq))
+
+    def _exchange_id(self, lib):
+        path = self._id_path(self._seq)
+        self._seq += 1
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            check(lib.nif_comm_unique_id(buf))
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                f.write(buf.raw)
+            os.replace(tmp, path)     # atomic: a reader sees either nothing or all 128 bytes
+            return buf.raw, path
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    raw = f.read()
+                if len(raw) == _lib.COMM_ID_BYTES:
+                    return raw, None
+            except OSError:
+                pass
+            if time.time() - t0 > self._timeout:
+                raise _lib.NifError("rank %d: no RCCL id from rank 0 at %s after %.0f s" % (self.rank, path, self._timeout))
+            time.sleep(0.005)
+
+    def attach(self, engine):
+        """Join `engine`'s context to a fresh communicator of all ranks (collective)."""
+        if getattr(engine, "_comm_joined", False):
+            return
+        if self.world > 1 or os.environ.get("NIF_FORCE_RCCL") == "1":
+            raw, path = self._exchange_id(engine.lib)
+            check(engine.lib.nif_comm_init_rank(engine.ctx, raw, self.rank, self.world))
+            if path is not None:      # ncclCommInitRank returned on rank 0: every rank has read the id
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+        engine._comm_joined = True
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def all_reduce_grad(self, engine):
+        """THE collective of the training step: SUM over ranks of [grad | loss], in place, on the engine's stream."""
+        self.attach(engine)
+        check(engine.lib.nif_allreduce_grad(engine.ctx))
+
+    def zero_grad(self, engine):
+        check(engine.lib.nif_zero_grad(engine.ctx))
+
+    def _reduce_host(self, engine, arr, dtype, op):
+        self.attach(engine)
+        p = C.c_void_p()
+        check(engine.lib.nif_dev_alloc(engine.ctx, arr.nbytes, C.byref(p)))
+        try:
+            check(engine.lib.nif_h2d(engine.ctx, p, _lib.ptr(arr), arr.nbytes))
+            check(engine.lib.nif_comm_allreduce(engine.ctx, p, arr.size, dtype, op))
+            check(engine.lib.nif_d2h(engine.ctx, _lib.ptr(arr), p, arr.nbytes))
+        finally:
+            engine.lib.nif_dev_free(engine.ctx, p)
+        return arr
+
+    def all_reduce_ints(self, engine, values, op="sum"):
+        """Element-wise SUM (or MAX) over ranks of a short list of integers: ONE collective, one host read-back."""
+        a = np.ascontiguousarray([int(v) for v in values], dtype=np.int64)
+        self._reduce_host(engine, a, _lib.DT_I64, _lib.OP_MAX if op == "max" else _lib.OP_SUM)
+        return [int(v) for v in a]
+
+    def all_reduce_float(self, engine, value, op="max"):
+        a = np.ascontiguousarray([float(value)], dtype=np.float64)
+        self._reduce_host(engine, a, _lib.DT_F64, {"max": _lib.OP_MAX, "min": _lib.OP_MIN, "sum": _lib.OP_SUM}[op])
+        return float(a[0])
+
+    def barrier(self, engine):
+        """all ranks are here and the engine's stream has drained"""
+        self.attach(engine)
+        check(engine.lib.nif_comm_barrier(engine.ctx))
+
+    def shutdown(self):
+        pass
+
+
+def install(comm):
+    """Make `comm` (an object with RcclComm's methods) the process's communicator; None = single process."""
+    _comm[0] = comm
+    return comm
+
+
+def get():
+    return _comm[0]
+
+
+def init(rank=None, world=None, local_rank=None):
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK (the launcher's environment).  Returns (rank, world)."""
+    if _comm[0] is None:
+        rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if local_rank is None else int(local_rank)
+        if not 0 <= rank < world:
+            raise ValueError("RANK=%d outside WORLD_SIZE=%d" % (rank, world))
+        install(RcclComm(rank, world, local_rank))
+    return _comm[0].rank, _comm[0].world
 
 
 def is_initialized():
-    if not _state["pg"]:
-        return False
-    return _td().is_initialized()
+    return _comm[0] is not None
 
 
 def world_size():
-    return _td().get_world_size() if is_initialized() else 1
+    return _comm[0].world if _comm[0] is not None else 1
 
 
 def rank():
-    return _td().get_rank() if is_initialized() else 0
+    return _comm[0].rank if _comm[0] is not None else 0
 
 
 def local_device():
-    """HIP device of this process: LOCAL_RANK under torchrun, else 0."""
-    return int(os.environ.get("LOCAL_RANK", "0")) if is_initialized() else 0
-
-
-def init(backend=None):
-    """Join the process group described by RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT (torchrun env)."""
-    import torch
-    td = _td()
-    if not td.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        td.init_process_group(backend=backend)
-    _state["pg"] = True
-    return td.get_rank(), td.get_world_size()
+    """HIP device of this process: LOCAL_RANK of the job, else 0."""
+    return _comm[0].local_rank if _comm[0] is not None else 0
 
 
 def shutdown():
-    if _state["pg"] and _td().is_initialized():
-        _td().destroy_process_group()
-    _state["pg"] = False
-    _state["grad_alias"].clear()
+    if _comm[0] is not None:
+        _comm[0].shutdown()
+    _comm[0] = None
 
 
 def shard_bounds(n, world, r):
@@ -65,68 +176,14 @@ def shard_bounds(n, world, r):
     return lo, lo + base + (1 if r < rem else 0)
 
 
-def all_reduce_scalar_sum(v):
-    import torch
-    td = _td()
-    dev = "cuda" if td.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
-    td.all_reduce(t, op=td.ReduceOp.SUM)
-    return int(round(t.item()))
-
-
-def all_reduce_ints(values, op="sum"):
-    """Element-wise SUM (or MAX) over ranks of a short list of integers: ONE collective and one host read-back.
-    fit() uses it once per call to learn every step's global batch size instead of syncing the host every step."""
-    import torch
-    td = _td()
-    dev = "cuda" if td.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
-    td.all_reduce(t, op=td.ReduceOp.MAX if op == "max" else td.ReduceOp.SUM)
-    return [int(v) for v in t.cpu().tolist()]
-
-
-def zero_grad(engine):
-    """A rank whose shard has no rows left for a step still takes part in the collective: with a zero buffer."""
-    import torch
-    t, stream = grad_tensor(engine)
-    with torch.cuda.stream(stream):
-        t.zero_()
-
-
-class _DevPtr(object):
-    """Zero-copy view of a raw device buffer for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def grad_tensor(engine):
-    """torch float32 tensor [P+1] aliasing engine's flat gradient||loss buffer (device memory)."""
-    import torch
-    key = id(engine)
-    if key not in _state["grad_alias"]:
-        dev = torch.device("cuda", torch.cuda.current_device())
-        t = torch.as_tensor(_DevPtr(engine.grad_dev_ptr(), engine.n_params + 1), device=dev)
-        stream = torch.cuda.ExternalStream(engine.stream_ptr(), device=dev)
-        _state["grad_alias"][key] = (t, stream)
-    return _state["grad_alias"][key]
-
-
-def all_reduce_grad(engine):
-    """The one collective of the training step: SUM over ranks of [grad | loss], in place, enqueued on
-    the engine's HIP stream."""
-    import torch
-    td = _td()
-    t, stream = grad_tensor(engine)
-    with torch.cuda.stream(stream):
-        td.all_reduce(t, op=td.ReduceOp.SUM)
-
-
-def all_reduce_host(arr):
-    """SUM all-reduce of a host float32 array (gloo path used by the CPU tests)."""
-    import torch
-    td = _td()
-    t = torch.from_numpy(arr)
-    td.all_reduce(t, op=td.ReduceOp.SUM)
-    return arr
+def plan_steps(n_local, batch_size, comm=None, engine=None):
+    """Per-step (local, global) batch sizes of one epoch of `Model.fit` over a shard of n_local rows.  Every rank
+    walks its own shard in batches of `batch_size` (last one partial); the global size of every step's batch is
+    agreed ONCE per fit call (two small collectives, no host sync per step); a rank whose shard is a batch shorter
+    than another's gets a trailing 0 and joins that step's all-reduce with a zero gradient."""
+    sizes = [min(batch_size, n_local - b0) for b0 in range(0, n_local, batch_size)]
+    if comm is None or comm.world == 1:
+        return sizes, list(sizes)
+    nb = comm.all_reduce_ints(engine, [len(sizes)], op="max")[0]
+    sizes = sizes + [0] * (nb - len(sizes))
+    return sizes, comm.all_reduce_ints(engine, sizes, op="sum")

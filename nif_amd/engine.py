@@ -75,6 +75,10 @@ class Engine(object):
         except Exception:
             pass
 
+    def alloc(self, n_floats):
+        """float32 device buffer on this context's GPU"""
+        return DeviceArray(self, n_floats)
+
     # ---- parameters -----------------------------------------------------------------------------
     def layout(self):
         n = C.c_int32(0)
@@ -124,27 +128,38 @@ class Engine(object):
         check(self.lib.nif_set_opt_state(self.ctx, ptr(m), ptr(v), m.size, int(step)))
 
     # ---- inference ------------------------------------------------------------------------------
+    @staticmethod
+    def _rows(a, ncol, what, allow_extra=False):
+        """float32 C-contiguous [B, ncol] view of a caller array.  The C side copies B*ncol floats unconditionally, so
+        the column count is checked here.  allow_extra: full-model inputs may carry more columns, the model reads the
+        first pi+si (reference model.py:142-143 slices `inputs[:, :pi+si]`)."""
+        x = np.asarray(a, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] < ncol or (x.shape[1] != ncol and not allow_extra):
+            raise ValueError("%s: expected shape (batch, %d), got %s" % (what, ncol, x.shape))
+        if x.shape[1] != ncol:
+            x = x[:, :ncol]
+        return np.ascontiguousarray(x)
+
+    def _inputs(self, a):
+        return self._rows(a, self.spec.pi_dim + self.spec.si_dim, "inputs", allow_extra=True)
+
     def forward(self, inputs):
-        x = _f32(inputs)
+        x = self._inputs(inputs)
         s = self.spec
-        if x.ndim != 2 or x.shape[1] < s.pi_dim + s.si_dim:
-            raise ValueError("expected inputs of shape (batch, %d), got %s" % (s.pi_dim + s.si_dim, x.shape))
-        if x.shape[1] != s.pi_dim + s.si_dim:
-            x = _f32(x[:, :s.pi_dim + s.si_dim])  # model.py:142-143 slices the first pi+si columns
         out = np.empty((x.shape[0], s.so_dim), dtype=np.float32)
         if x.shape[0]:
             check(self.lib.nif_forward(self.ctx, ptr(x), x.shape[0], ptr(out)))
         return out
 
     def p_to_lr(self, p):
-        p = _f32(p)
+        p = self._rows(p, self.spec.pi_dim, "parameter inputs")
         out = np.empty((p.shape[0], self.spec.pi_hidden), dtype=np.float32)
         if p.shape[0]:
             check(self.lib.nif_pnet_latent(self.ctx, ptr(p), p.shape[0], ptr(out)))
         return out
 
     def jacobian(self, inputs, y_index, x_index):
-        x = _f32(inputs)
+        x = self._inputs(inputs)
         s = self.spec
         yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
         xi = np.ascontiguousarray(list(x_index), dtype=np.int32)
@@ -155,7 +170,7 @@ class Engine(object):
         return y, d
 
     def x_to_phi(self, x):
-        x = _f32(x)
+        x = self._rows(x, self.spec.si_dim, "coordinates")
         s = self.spec
         out = np.empty((x.shape[0], s.so_dim, s.pi_hidden), dtype=np.float32)
         if x.shape[0]:
@@ -163,14 +178,14 @@ class Engine(object):
         return out
 
     def lr_to_w(self, lr):
-        lr = _f32(lr)
+        lr = self._rows(lr, self.spec.pi_hidden, "latent")
         out = np.empty((lr.shape[0], self.spec.po_dim), dtype=np.float32)
         if lr.shape[0]:
             check(self.lib.nif_latent_to_w(self.ctx, ptr(lr), lr.shape[0], ptr(out)))
         return out
 
     def x_to_u_given_w(self, x, w):
-        x, w = _f32(x), _f32(w)
+        x, w = self._rows(x, self.spec.si_dim, "coordinates"), _f32(w)
         if w.shape != (x.shape[0], self.spec.po_dim):
             raise ValueError("expected w of shape (%d, %d), got %s" % (x.shape[0], self.spec.po_dim, w.shape))
         out = np.empty((x.shape[0], self.spec.so_dim), dtype=np.float32)
@@ -179,17 +194,35 @@ class Engine(object):
         return out
 
     # ---- training -------------------------------------------------------------------------------
+    def _targets(self, y, n_rows):
+        y = _f32(y)
+        if y.ndim == 1:
+            y = y[:, None]
+        if y.shape != (n_rows, self.spec.so_dim):
+            raise ValueError("targets: expected shape (%d, %d), got %s" % (n_rows, self.spec.so_dim, y.shape))
+        return y
+
+    def _weights(self, sw, n_rows):
+        if sw is None:
+            return None
+        sw = _f32(sw).reshape(-1)
+        if sw.shape != (n_rows,):
+            raise ValueError("sample_weight: expected shape (%d,), got %s" % (n_rows, sw.shape))
+        return sw
+
     def loss_and_grad(self, inputs, y, sample_weight=None):
-        x, y = _f32(inputs), _f32(y)
-        sw = None if sample_weight is None else _f32(sample_weight)
+        x = self._inputs(inputs)
+        y = self._targets(y, x.shape[0])
+        sw = self._weights(sample_weight, x.shape[0])
         g = np.empty((self.n_params,), dtype=np.float32)
         loss = C.c_float()
         check(self.lib.nif_loss_and_grad(self.ctx, ptr(x), ptr(y), ptr(sw), x.shape[0], C.byref(loss), ptr(g)))
         return float(loss.value), g
 
     def train_step(self, inputs, y, sample_weight, adam):
-        x, y = _f32(inputs), _f32(y)
-        sw = None if sample_weight is None else _f32(sample_weight)
+        x = self._inputs(inputs)
+        y = self._targets(y, x.shape[0])
+        sw = self._weights(sample_weight, x.shape[0])
         loss = C.c_float()
         check(self.lib.nif_train_step(self.ctx, ptr(x), ptr(y), ptr(sw), x.shape[0], C.byref(adam), C.byref(loss)))
         return float(loss.value)
@@ -205,7 +238,7 @@ class Engine(object):
                                                  float(w_jac)))
 
     def sobolev_forward(self, inputs, x_index):
-        x = _f32(inputs)
+        x = self._inputs(inputs)
         B, nx, so = x.shape[0], len(x_index), self.spec.so_dim
         xi = (C.c_int32 * nx)(*[int(i) for i in x_index])
         d_x, d_u, d_j = DeviceArray(self, x.size), DeviceArray(self, B * so), DeviceArray(self, B * so * nx)
@@ -219,8 +252,12 @@ class Engine(object):
         return u, j
 
     def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None):
-        x, y, g = _f32(inputs), _f32(y), _f32(dydx)
+        x = self._inputs(inputs)
         B = x.shape[0]
+        y, g = self._targets(y, B), _f32(dydx)
+        if g.size != B * self.spec.so_dim * len(x_index):
+            raise ValueError("dydx: expected %d x %d x %d values, got shape %s" % (B, self.spec.so_dim, len(x_index), g.shape))
+        sample_weight = self._weights(sample_weight, B)
         d_x, d_y, d_g = DeviceArray(self, x.size), DeviceArray(self, y.size), DeviceArray(self, g.size)
         d_sw = DeviceArray(self, B) if sample_weight is not None else None
         try:
@@ -240,6 +277,15 @@ class Engine(object):
     def adam_step_dev(self, adam):
         check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
 
+    def zero_grad(self):
+        check(self.lib.nif_zero_grad(self.ctx))
+
+    def reserve(self, b_max, n_tangents=0):
+        check(self.lib.nif_reserve(self.ctx, int(b_max), int(n_tangents)))
+
+    def allreduce_grad(self):
+        check(self.lib.nif_allreduce_grad(self.ctx))
+
     def set_regularizer(self, l1, l2, lo, hi):
         check(self.lib.nif_set_regularizer(self.ctx, float(l1), float(l2), int(lo), int(hi)))
 
@@ -250,6 +296,16 @@ class Engine(object):
         s, n = C.c_double(), C.c_double()
         check(self.lib.nif_metric_read(self.ctx, C.byref(s), C.byref(n), 1 if reset else 0))
         return float(s.value), float(n.value)
+
+    def set_option(self, key, value):
+        check(self.lib.nif_set_option(self.ctx, key.encode(), int(value)))
+
+    def grad_read(self):
+        """(loss, flat gradient) of the last loss_grad_dev, weight regulariser included"""
+        g = np.empty((self.n_params,), dtype=np.float32)
+        loss = C.c_float()
+        check(self.lib.nif_grad_read(self.ctx, C.byref(loss), ptr(g)))
+        return float(loss.value), g
 
     def last_loss(self):
         loss = C.c_float()

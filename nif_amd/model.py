@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 from . import distributed as dist
-from .engine import DeviceArray, Engine
+from .engine import Engine
 from .optimizers import Adam, get as get_optimizer
 from .spec import Spec
 
@@ -92,6 +92,7 @@ class Model(object):
         self.set_weights([d["w%03d" % i] for i in range(n)])
         if "adam_m" in d:
             self._engine.set_opt_state(d["adam_m"], d["adam_v"], int(d["adam_step"]))
+            self._fresh_slots = False
 
     # ---- inference -------------------------------------------------------------------------------
     def _run(self, x):
@@ -101,6 +102,8 @@ class Model(object):
         if self._role == "p_to_lr":
             return e.p_to_lr(x)
         if self._role == "p_to_w":
+            if self._owner._spec.connectivity == "last_layer":   # pnet output IS the last-layer weight vector (model.py:583-585)
+                return e.p_to_lr(x)
             return e.lr_to_w(e.p_to_lr(x))
         if self._role == "lr_to_w":
             return e.lr_to_w(x)
@@ -112,9 +115,23 @@ class Model(object):
             return e.x_to_phi(x)
         raise NotImplementedError(self._role)
 
+    _PREDICT_CHUNK = 1 << 21
+
     def predict(self, x, batch_size=None, verbose=0, **kwargs):
-        # Keras' default predict batch_size=32 is a host-loop artefact; the result does not depend on it.
-        return self._run(x)
+        """Keras Model.predict: the result does not depend on batch_size; rows are staged through the device in chunks
+        of max(batch_size, 2^21) so that an input table larger than the staging buffers never has to fit at once."""
+        chunk = max(int(batch_size or 0), self._PREDICT_CHUNK)
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        n = int(np.shape(xs[0])[0])
+        if n <= chunk:
+            return self._run(x)
+        outs = []
+        for lo in range(0, n, chunk):
+            part = [np.asarray(a)[lo:lo + chunk] for a in xs]
+            outs.append(self._run(part if isinstance(x, (list, tuple)) else part[0]))
+        if isinstance(outs[0], (list, tuple)):
+            return [np.concatenate([o[i] for o in outs], axis=0) for i in range(len(outs[0]))]
+        return np.concatenate(outs, axis=0)
 
     def __call__(self, x, training=False):
         return self._run(x)
@@ -126,7 +143,12 @@ class Model(object):
         name = loss if isinstance(loss, str) else getattr(loss, "name", None)
         if name not in ("mse", "mean_squared_error", "MSE"):
             raise NotImplementedError("only loss='mse' is built (README.md:33)")
-        self.optimizer = get_optimizer(optimizer)
+        if kwargs:
+            raise NotImplementedError("compile(%s): not on the built hot path" % ", ".join(sorted(kwargs)))
+        new = get_optimizer(optimizer)
+        if new is not self.optimizer:
+            self._fresh_slots = True     # Keras: a newly compiled optimizer starts with zero slots and iteration 0
+        self.optimizer = new
         self.loss = "mse"
 
     def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
@@ -148,6 +170,9 @@ class Model(object):
     def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
         e.loss_grad_dev(d_x, d_targets[0], d_sw, b, bg)
 
+    def _n_tangents(self):
+        return 0
+
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
             sample_weight=None, initial_epoch=0, **kwargs):
         """Keras Model.fit semantics for in-memory arrays: per epoch optionally shuffle, walk batches of
@@ -158,8 +183,16 @@ class Model(object):
         (tf.distribute.MirroredStrategy, README.md:39-49)."""
         if self.optimizer is None:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+        if kwargs:
+            raise NotImplementedError("fit(%s): not on the built hot path (in-memory x, y, sample_weight only)"
+                                      % ", ".join(sorted(kwargs)))
         s = self._owner._spec
         e = self._engine
+        self.stop_training = False
+        if getattr(self, "_fresh_slots", False):
+            z = np.zeros((e.n_params,), dtype=np.float32)
+            e.set_opt_state(z, z, 0)
+            self._fresh_slots = False
         x = np.ascontiguousarray(x, dtype=np.float32)
         targets = self._targets(y, x.shape[0])   # list of [N, width] tables that travel with x
         ncol = s.pi_dim + s.si_dim
@@ -176,21 +209,17 @@ class Model(object):
         for cb in callbacks:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
-        d_x = DeviceArray(e, N * ncol)
-        d_t = [DeviceArray(e, t.size) for t in targets]
-        d_sw = DeviceArray(e, N) if sw is not None else None
+        d_x = e.alloc(N * ncol)
+        d_t = [e.alloc(t.size) for t in targets]
+        d_sw = e.alloc(N) if sw is not None else None
         rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
         resident = False
-        world = dist.world_size()
-        # every rank walks its own shard; the global size of every step's batch is agreed ONCE (one collective, one
-        # host read-back), ranks whose shard is a batch shorter join the last collective with a zero gradient
-        sizes = [min(bs, N - b0) for b0 in range(0, N, bs)]
-        if world > 1:
-            nb = dist.all_reduce_ints([len(sizes)], op="max")[0]
-            sizes = sizes + [0] * (nb - len(sizes))
-            gsizes = dist.all_reduce_ints(sizes, op="sum")
-        else:
-            gsizes = sizes
+        comm = dist.get()
+        world = comm.world if comm is not None else 1
+        # every rank walks its own shard; the global size of every step's batch is agreed ONCE per call, ranks whose
+        # shard is a batch shorter join the last collective with a zero gradient (distributed.plan_steps)
+        sizes, gsizes = dist.plan_steps(N, bs, comm, e)
+        e.reserve(max(sizes) if sizes else 1, self._n_tangents())
         try:
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
@@ -222,19 +251,19 @@ class Model(object):
                         self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * t.shape[1]) for dt, t in zip(d_t, targets)],
                                             d_sw.at(b0) if d_sw is not None else None, b, bg)
                     else:
-                        dist.zero_grad(e)
+                        e.zero_grad()
                     if world > 1:
-                        dist.all_reduce_grad(e)
+                        comm.all_reduce_grad(e)
                     e.adam_step_dev(adam)
                     e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
                 tot, cnt = e.metric_read(reset=True)   # accumulated on the device: one host sync per epoch
                 logs = {"loss": tot / max(cnt, 1.0)}
-                hist.epoch.append(epoch)
-                for k, v in logs.items():
-                    hist.history.setdefault(k, []).append(v)
                 for cb in callbacks:
                     if hasattr(cb, "on_epoch_end"):
                         cb.on_epoch_end(epoch, logs)
+                hist.epoch.append(epoch)          # Keras' History runs after the user callbacks: it records what they
+                for k, v in logs.items():         # added to `logs` (LearningRateScheduler's 'lr')
+                    hist.history.setdefault(k, []).append(v)
                 if verbose:
                     print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
         finally:
@@ -321,6 +350,9 @@ class SobolevModel(Model):
         ty = Model._targets(self, y[0], n_rows)[0]
         tj = np.ascontiguousarray(y[1], dtype=np.float32).reshape(n_rows, so * nx)
         return [ty, tj]
+
+    def _n_tangents(self):
+        return len(self.x_index)
 
     def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
         # Keras total loss = w0*mse(u) + w1*mse(dudx); the kernel computes mse(u) + wj*mse(dudx) and the flat

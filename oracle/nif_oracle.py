@@ -399,8 +399,14 @@ def pnet_backward(spec, ws, tape_h, g_out, g_z_extra=None):
 
 
 def _ein(u, w):
-    """EinsumLayer('ai,aij->aj') (mlp.py:209-219)."""
-    return np.einsum("ai,aij->aj", u, w)
+    """EinsumLayer('ai,aij->aj') (mlp.py:209-219): one vector-matrix product per sample (batched matmul: the same
+    sums as the einsum, BLAS speed)."""
+    return np.matmul(u[:, None, :], w)[:, 0, :]
+
+
+def _ein_t(w, g):
+    """its adjoint w.r.t. the vector: 'aij,aj->ai'"""
+    return np.matmul(w, g[:, :, None])[:, :, 0]
 
 
 def shapenet_given_w(spec, x, w, keep=False):
@@ -461,7 +467,7 @@ def shapenet_given_w_backward(spec, tape, g_u):
     hL = tape["hL"]
     gw[:, sl["wl"][0]:sl["wl"][1]] = (hL[:, :, None] * g_u[:, None, :]).reshape(B, -1)
     gw[:, sl["bl"][0]:sl["bl"][1]] = g_u
-    gh = np.einsum("aij,aj->ai", tape["Wl"], g_u)
+    gh = _ein_t(tape["Wl"], g_u)
     acts = tape["acts"]
     Wh = tape["Wh"]
     if spec.kind == KIND_NIF:
@@ -471,7 +477,7 @@ def shapenet_given_w_backward(spec, tape, g_u):
             ga = gh * df(a)
             gw[:, sl["wh"][i][0]:sl["wh"][i][1]] = (hin[:, :, None] * ga[:, None, :]).reshape(B, -1)
             gw[:, sl["bh"][i][0]:sl["bh"][i][1]] = ga
-            gh = np.einsum("aij,aj->ai", Wh[i], ga) + gh
+            gh = _ein_t(Wh[i], ga) + gh
         a0 = acts[0][1]
         ga0 = gh * df(a0)
         om = 1.0
@@ -484,19 +490,19 @@ def shapenet_given_w_backward(spec, tape, g_u):
                 s2 = sl["wh"][2 * i + 1]
                 gw[:, s2[0]:s2[1]] = (om * t[:, :, None] * ga2[:, None, :]).reshape(B, -1)
                 gw[:, sl["bh"][2 * i + 1][0]:sl["bh"][2 * i + 1][1]] = ga2
-                gt = om * np.einsum("aij,aj->ai", Wh[2 * i + 1], ga2)
+                gt = om * _ein_t(Wh[2 * i + 1], ga2)
                 ga1 = gt * np.cos(a1)
                 s1 = sl["wh"][2 * i]
                 gw[:, s1[0]:s1[1]] = (om * hin[:, :, None] * ga1[:, None, :]).reshape(B, -1)
                 gw[:, sl["bh"][2 * i][0]:sl["bh"][2 * i][1]] = ga1
-                gh = 0.5 * gh + om * np.einsum("aij,aj->ai", Wh[2 * i], ga1)
+                gh = 0.5 * gh + om * _ein_t(Wh[2 * i], ga1)
         else:
             for i in reversed(range(spec.L)):
                 hin, a = acts[i + 1]
                 ga = gh * np.cos(a)
                 gw[:, sl["wh"][i][0]:sl["wh"][i][1]] = (om * hin[:, :, None] * ga[:, None, :]).reshape(B, -1)
                 gw[:, sl["bh"][i][0]:sl["bh"][i][1]] = ga
-                gh = om * np.einsum("aij,aj->ai", Wh[i], ga)
+                gh = om * _ein_t(Wh[i], ga)
         a0 = acts[0][1]
         ga0 = gh * np.cos(a0)
     x = tape["x"]
@@ -719,8 +725,8 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
         gWl = gWl + v[:, :, None] * g[:, None, :]
     gw[:, sl["wl"][0]:sl["wl"][1]] = gWl.reshape(B, -1)
     gw[:, sl["bl"][0]:sl["bl"][1]] = g_u
-    lam = np.einsum("aij,aj->ai", Wl, g_u)
-    mu = [np.einsum("aij,aj->ai", Wl, g) for g in g_ud]
+    lam = _ein_t(Wl, g_u)
+    mu = [_ein_t(Wl, g) for g in g_ud]
     wslices = [sl["w1"]] + list(sl["wh"])
     bslices = [sl["b1"]] + list(sl["bh"])
     skip = None
@@ -740,8 +746,8 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
         gw[:, wslices[l][0]:wslices[l][1]] = (om * gW).reshape(B, -1)
         gw[:, bslices[l][0]:bslices[l][1]] = da
         if l > 0:
-            lam = om * np.einsum("aij,aj->ai", W[l], da)
-            mu = [om * np.einsum("aij,aj->ai", W[l], g) for g in nu]
+            lam = om * _ein_t(W[l], da)
+            mu = [om * _ein_t(W[l], g) for g in nu]
             if spec.s_res and (l - 1) % 2 == 0:                  # first layer of a block: add the skip path
                 lam = lam + skip[0]
                 mu = [m + s_ for m, s_ in zip(mu, skip[1])]

@@ -1,9 +1,11 @@
-"""N>1 path on CPU: world_size-2 gloo process group exercising nif_amd.distributed (shard bounds, the
-scalar and buffer all-reduces) with the oracle standing in for the per-shard HIP compute: the SUM of the
-per-shard [grad | loss] buffers, each pre-scaled by 1/B_global, must equal the full-batch gradient and loss
-(this is exactly what the GPU path all-reduces over RCCL)."""
+"""N>1 path on CPU: two real processes (gloo) run the REAL `nif_amd.model.Model.fit` -- shard walking, the once-per-call
+agreement of every step's global batch size (`distributed.plan_steps`), the zero-gradient step of the rank whose shard
+is a batch shorter, one gradient all-reduce per step, replicated Adam -- with the oracle standing in for the per-shard
+HIP compute (tests/doubles.py) and a gloo communicator with RcclComm's interface installed in nif_amd.distributed.
+What the GPU path all-reduces over RCCL is exactly this buffer: [grad | loss], pre-scaled by 1/B_global."""
 import os
 import socket
+import types
 
 import numpy as np
 import pytest
@@ -20,53 +22,96 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, outdir):
-    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
-                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
-    from nif_amd import distributed as dist
-    r, w = dist.init("gloo")
-    assert (r, w) == (rank, world) and dist.is_initialized() and dist.world_size() == world and dist.rank() == rank
-    kind, cs, cp = ALL_SMALL[name]
-    spec = O.Spec(kind, cs, cp)
-    rng = np.random.default_rng(0)  # same data and weights on every rank
-    ws = O.init_weights(spec, rng)
-    B = 37  # not divisible by the world size: shards are 19 / 18
-    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si))
-    y = rng.uniform(-1, 1, size=(B, spec.so))
-    sw = rng.uniform(0.5, 1.5, size=(B,))
-    lo, hi = dist.shard_bounds(B, world, rank)
-    bg = dist.all_reduce_scalar_sum(hi - lo)
-    assert bg == B
-    loss, grads = O.loss_and_grad(spec, ws, x[lo:hi], y[lo:hi], sw[lo:hi], batch_global=bg)
-    buf = np.concatenate([O.flatten(grads), [loss]]).astype(np.float32)   # the [grad | loss] buffer
-    dist.all_reduce_host(buf)
-    np.save(os.path.join(outdir, "rank%d.npy" % rank), buf)
-    dist.shutdown()
+N_LOCAL = (40, 25)      # rows per rank: batches 16,16,8 on rank 0 and 16,9,- on rank 1 -> rank 1 joins step 3 with zeros
+BS = 16
+EPOCHS = 2
+L2 = 1e-3
 
 
-@pytest.mark.parametrize("name", ["ms_plain", "nif_swish"])
-def test_two_rank_gradient_allreduce_equals_full_batch(name, tmp_path):
-    torch = pytest.importorskip("torch")
-    import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
-    b0 = np.load(tmp_path / "rank0.npy")
-    b1 = np.load(tmp_path / "rank1.npy")
-    assert np.array_equal(b0, b1)  # every rank ends with the same buffer -> identical Adam update
+def _problem(name):
     kind, cs, cp = ALL_SMALL[name]
     spec = O.Spec(kind, cs, cp)
     rng = np.random.default_rng(0)
     ws = O.init_weights(spec, rng)
-    x = rng.uniform(-1, 1, size=(37, spec.pi + spec.si))
-    y = rng.uniform(-1, 1, size=(37, spec.so))
-    sw = rng.uniform(0.5, 1.5, size=(37,))
-    loss, grads = O.loss_and_grad(spec, ws, x, y, sw)
-    ref = np.concatenate([O.flatten(grads), [loss]])
-    assert np.allclose(b0, ref, rtol=2e-6, atol=1e-7)
+    n = sum(N_LOCAL)
+    x = rng.uniform(-1, 1, size=(n, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(n, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+    n_pnet = sum(int(np.prod(s)) for nm, s in spec.param_shapes() if nm.startswith("pnet_"))
+    return kind, cs, cp, spec, ws, x, y, sw, (0.0, L2, 0, n_pnet)
 
 
-def test_shard_bounds_partition_rows():
+def _worker(rank, world, port, name, outdir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    import torch.distributed as td
+    td.init_process_group("gloo")
+    import nif_amd
     from nif_amd import distributed as dist
+    from nif_amd.model import Model
+    from nif_amd.spec import Spec
+    from tests.doubles import GlooComm, OracleEngine
+    comm = dist.install(GlooComm())
+    assert dist.is_initialized() and dist.world_size() == world and dist.rank() == rank and dist.local_device() == rank
+    kind, cs, cp, spec, ws, x, y, sw, reg = _problem(name)
+    eng = OracleEngine(spec, ws, reg)
+    owner = types.SimpleNamespace(_spec=Spec(kind, cs, cp), _engine=eng)
+    model = Model(owner, "full")
+    model.compile(nif_amd.Adam(1e-2), "mse")
+    lo = sum(N_LOCAL[:rank]); hi = lo + N_LOCAL[rank]
+    h = model.fit(x[lo:hi], y[lo:hi], sample_weight=sw[lo:hi], batch_size=BS, epochs=EPOCHS, shuffle=False, verbose=0)
+    steps = [c for c in eng.calls if c[0] in ("loss_grad", "zero_grad")]
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), theta=eng.theta, loss=np.array(h.history["loss"]),
+             steps=np.array([c[1] if c[0] == "loss_grad" else 0 for c in steps]),
+             gsizes=np.array([c[2] if c[0] == "loss_grad" else -1 for c in steps]), nred=comm.n_grad_reduces)
+    dist.shutdown()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ms_plain", "nif_swish"])
+def test_two_rank_fit_equals_global_batch_training(name, tmp_path):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # both ranks took the same number of steps, one all-reduce each, and ended with IDENTICAL replicated weights
+    assert int(r0["nred"]) == int(r1["nred"]) == 3 * EPOCHS
+    assert np.array_equal(r0["theta"], r1["theta"])
+    assert np.array_equal(r0["loss"], r1["loss"])
+    # the agreed global sizes: 32, 25, 8; rank 1 contributed zeros to the third step
+    assert list(r0["steps"]) == [16, 16, 8] * EPOCHS and list(r1["steps"]) == [16, 9, 0] * EPOCHS
+    assert list(r0["gsizes"]) == [32, 25, 8] * EPOCHS and list(r1["gsizes"]) == [32, 25, -1] * EPOCHS
+    # serial emulation: every step sees the union of the ranks' rows of that step as ONE batch (+ L2 on the pnet)
+    kind, cs, cp, spec, ws, x, y, sw, reg = _problem(name)
+    theta = O.flatten(ws); m = np.zeros_like(theta); v = np.zeros_like(theta); t = 0
+    losses = []
+    for _ in range(EPOCHS):
+        tot, cnt = 0.0, 0.0
+        for ib in range(3):
+            rows = []
+            for r in range(2):
+                lo = sum(N_LOCAL[:r]) + ib * BS
+                rows += list(range(lo, min(lo + BS, sum(N_LOCAL[:r + 1]))))
+            rows = np.array(rows)
+            loss, grads = O.loss_and_grad(spec, O.unflatten(spec, theta), x[rows].astype(np.float64), y[rows].astype(np.float64),
+                                          sw[rows].astype(np.float64))
+            g = O.flatten(grads)
+            w = theta[reg[2]:reg[3]]
+            g[reg[2]:reg[3]] += 2 * L2 * w
+            loss += L2 * np.sum(w * w)
+            t += 1
+            f32 = lambda a: float(np.float32(a))     # nif_adam carries float32 hyper-parameters
+            theta, m, v = O.adam_step(theta, g, m, v, t, lr=f32(1e-2), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+            tot += loss * len(rows); cnt += len(rows)
+        losses.append(tot / cnt)
+    assert np.allclose(r0["theta"], theta, rtol=1e-9, atol=1e-12)
+    assert np.allclose(r0["loss"], losses, rtol=1e-9)
+
+
+def test_plan_steps_single_process_and_shard_bounds():
+    from nif_amd import distributed as dist
+    assert dist.plan_steps(37, 16) == ([16, 16, 5], [16, 16, 5])
+    assert dist.plan_steps(32, 16) == ([16, 16], [16, 16])
     for n in (1, 7, 64, 1000003):
         for world in (1, 2, 3, 8):
             cuts = [dist.shard_bounds(n, world, r) for r in range(world)]
@@ -78,4 +123,29 @@ def test_shard_bounds_partition_rows():
 
 def test_single_process_defaults():
     from nif_amd import distributed as dist
-    assert dist.world_size() == 1 and dist.rank() == 0 and dist.local_device() == 0
+    assert dist.get() is None and dist.world_size() == 1 and dist.rank() == 0 and dist.local_device() == 0
+
+
+def test_rccl_id_rendezvous_through_files(tmp_path, monkeypatch):
+    """the only host-side exchange of the RCCL path: rank 0 publishes the 128-byte id, the others read it"""
+    import threading
+    from nif_amd import _lib
+    from nif_amd.distributed import RcclComm
+
+    class FakeLib(object):
+        def nif_comm_unique_id(self, buf):
+            buf.raw = bytes(range(128))
+            return 0
+
+    a = RcclComm(0, 2, 0, key="k/ey 1", directory=str(tmp_path))
+    b = RcclComm(1, 2, 1, key="k/ey 1", directory=str(tmp_path), timeout=20)
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault("b", b._exchange_id(FakeLib())))
+    th.start()
+    raw, path = a._exchange_id(FakeLib())
+    th.join()
+    assert raw == bytes(range(128)) and got["b"][0] == raw and os.path.dirname(path) == str(tmp_path)
+    assert a._id_path(1) != a._id_path(0)          # one file per communicator
+    c = RcclComm(1, 2, 1, key="nobody", directory=str(tmp_path), timeout=0.05)
+    with pytest.raises(_lib.NifError):
+        c._exchange_id(FakeLib())

@@ -1,6 +1,9 @@
-"""GPU-side mechanics of the one collective of the step, exercised at world_size 1 over the RCCL backend:
-torch tensor aliasing the library's [grad | loss] buffer (__cuda_array_interface__), all-reduce issued on the
-library's own HIP stream (ExternalStream), bench.py's distributed code path."""
+"""GPU-side mechanics of the one collective of the step, exercised with one real rank over RCCL called through the
+C-ABI (nif_comm.hip): the communicator built from a rendezvoused unique id (one process per GPU) and by
+ncclCommInitAll (one process, n GPUs), the all-reduce on the library's own stream and buffer, Model.fit through its
+multi-rank code path, the zero-gradient step, bench.py launched the way the driver does and launching itself."""
+import ctypes as C
+import json
 import os
 import socket
 import subprocess
@@ -29,8 +32,10 @@ from nif_amd import distributed as dist
 from nif_amd.engine import DeviceArray
 from oracle import nif_oracle as O
 from tests.test_gpu_parity import _cfg
-rank, world = dist.init("nccl")
-assert world == 1
+assert "torch" not in sys.modules
+rank, world = dist.init()
+comm = dist.get()
+assert (rank, world) == (0, 1) and dist.local_device() == 0
 kind, cs, cp = _cfg("NIFMultiScale", 64, 2, 32, 2, 1, 1, 1, 1)
 nif_amd.set_seed(3)
 m = nif_amd.NIFMultiScale(cs, cp); model = m.build(); e = m._engine
@@ -39,15 +44,16 @@ loss, g = e.loss_and_grad(x, y)
 d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
 d_x.upload(x); d_y.upload(y)
 e.loss_grad_dev(d_x.at(0), d_y.at(0), None, 4096, 4096)
-t, stream = dist.grad_tensor(e)
-dist.all_reduce_grad(e)          # SUM over 1 rank: must leave the buffer unchanged
-e.sync()
-import torch
-torch.cuda.synchronize()
-alias = t.cpu().numpy()
-assert alias.shape == (e.n_params + 1,)
-assert np.array_equal(alias[:-1], g) and abs(alias[-1] - loss) < 1e-12, (alias[-1], loss)
-# the alias really is the library buffer: Adam consumes what the all-reduce left there
+comm.all_reduce_grad(e)          # builds the RCCL communicator (NIF_FORCE_RCCL=1); SUM over 1 rank: buffer unchanged
+import ctypes as C
+r_, w_ = C.c_int32(-1), C.c_int32(-1)
+assert e.lib.nif_comm_info(e.ctx, C.byref(r_), C.byref(w_)) == 0 and (r_.value, w_.value) == (0, 1)
+loss2, g2 = e.grad_read()
+assert np.array_equal(g2, g) and loss2 == loss, (loss2, loss)
+comm.barrier(e)
+assert comm.all_reduce_ints(e, [3, 4, 5]) == [3, 4, 5] and comm.all_reduce_ints(e, [7], op="max") == [7]
+assert comm.all_reduce_float(e, 1.25, op="max") == 1.25
+# the all-reduced buffer is what Adam consumes
 adam = nif_amd.Adam(1e-3).as_struct()
 w0 = O.flatten(model.get_weights())
 e.adam_step_dev(adam); e.sync()
@@ -60,31 +66,99 @@ nif_amd.set_seed(5)
 ma = nif_amd.NIFMultiScale(cs, cp); a = ma.build(); a.compile(nif_amd.Adam(1e-3), "mse")
 nif_amd.set_seed(5)
 mb = nif_amd.NIFMultiScale(cs, cp); b = mb.build(); b.compile(nif_amd.Adam(1e-3), "mse")
+dist.install(None)
 ha = a.fit(x, y, epochs=2, batch_size=1000, shuffle=False, verbose=0)
-real_ws = dist.world_size
-dist.world_size = lambda: 2
+dist.install(comm)
+comm.world = 2                    # take the N > 1 branches with one real rank
 hb = b.fit(x, y, epochs=2, batch_size=1000, shuffle=False, verbose=0)
-dist.world_size = real_ws
+comm.world = 1
 assert ha.history["loss"] == hb.history["loss"], (ha.history, hb.history)
 assert np.array_equal(O.flatten(a.get_weights()), O.flatten(b.get_weights()))
-dist.zero_grad(mb._engine); mb._engine.sync(); torch.cuda.synchronize()
-assert not dist.grad_tensor(mb._engine)[0].cpu().numpy().any()
-assert dist.all_reduce_ints([3, 4, 5]) == [3, 4, 5] and dist.all_reduce_ints([7], op="max") == [7]
+assert getattr(mb._engine, "_comm_joined", False)      # second engine, second communicator (its own id file)
 dist.shutdown()
 print("OK")
 '''
 
 
-def test_allreduce_aliases_library_buffer_world1():
+def test_rccl_allreduce_on_library_buffer_world1():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", NIF_FORCE_RCCL="1")
     r = subprocess.run([sys.executable, "-c", _SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-3000:]
 
 
-def test_bench_runs_under_torchrun_single_rank():
-    """bench.py's N>1 code path (process group, barrier, max-over-ranks) launched the way the driver does."""
+def _model(seed=3, l2=None):
+    import nif_amd
+    from tests.test_gpu_parity import _cfg
+    kind, cs, cp = _cfg("NIFMultiScale", 64, 2, 32, 2, 1, 1, 1, 1)
+    if l2 is not None:
+        cp = dict(cp, l2_reg=l2)
+    nif_amd.set_seed(seed)
+    m = nif_amd.NIFMultiScale(cs, cp)
+    return m, m.build()
+
+
+def test_zero_grad_step_still_applies_the_regulariser():
+    """ADVICE r1: a rank that joins a step with a zero gradient (shard ran out of rows) must add the same
+    weight-regulariser term as the ranks that computed one -- also right after an ordinary step."""
+    import nif_amd
+    from oracle import nif_oracle as O
+    l2 = 1e-2
+    m, model = _model(l2=l2)
+    e = m._engine
+    x, y = nif_amd.data.synthetic_wave_batch(2048, seed=1)
+    adam = nif_amd.Adam(1e-3).as_struct()
+    d_x, d_y = e.alloc(x.size), e.alloc(y.size)
+    d_x.upload(x); d_y.upload(y)
+    e.loss_grad_dev(d_x.at(0), d_y.at(0), None, 2048, 2048)
+    e.adam_step_dev(adam)                                    # ordinary step: leaves no stale "already applied" state
+    w0 = O.flatten(model.get_weights()).astype(np.float64)
+    mom, var, step = e.get_opt_state()
+    e.zero_grad()
+    e.adam_step_dev(adam)
+    w1 = O.flatten(model.get_weights()).astype(np.float64)
+    n_pnet = sum(int(np.prod(s)) for nm, s in m._spec.param_shapes() if nm.startswith("pnet_"))
+    g = np.zeros_like(w0); g[:n_pnet] = 2 * l2 * w0[:n_pnet]
+    th, _, _ = O.adam_step(w0, g, mom.astype(np.float64), var.astype(np.float64), step + 1, lr=1e-3)
+    assert np.abs(w1 - th).max() < 2e-6
+    assert np.abs(w1[:n_pnet] - w0[:n_pnet]).max() > 1e-5     # the regulariser did move the ParameterNet
+
+
+def test_single_process_group_and_sharding_train_step():
+    """ncclCommInitAll over the contexts of ONE process (n = 1 here) and nif_train_step_multi = nif_train_step"""
+    import nif_amd
+    from nif_amd._lib import check, ptr
+    from oracle import nif_oracle as O
+    ma, a = _model(seed=7)
+    mb, b = _model(seed=7)
+    ea, eb = ma._engine, mb._engine
+    x, y = nif_amd.data.synthetic_wave_batch(3000, seed=2)
+    sw = np.random.default_rng(0).uniform(0.5, 1.5, 3000).astype(np.float32)
+    adam = nif_amd.Adam(2e-3).as_struct()
+    arr = (C.c_void_p * 1)(eb.ctx)
+    check(eb.lib.nif_comm_init_all(arr, 1))
+    r_, w_ = C.c_int32(-1), C.c_int32(-1)
+    check(eb.lib.nif_comm_info(eb.ctx, C.byref(r_), C.byref(w_)))
+    assert (r_.value, w_.value) == (0, 1)
+    for _ in range(3):
+        la = ea.train_step(x, y, sw, adam)
+        lb = C.c_float()
+        check(eb.lib.nif_train_step_multi(arr, 1, ptr(x), ptr(y), ptr(sw), 3000, C.byref(adam), C.byref(lb)))
+        assert la == lb.value
+    check(eb.lib.nif_allreduce_grad_multi(arr, 1))
+    assert np.array_equal(O.flatten(a.get_weights()), O.flatten(b.get_weights()))
+    check(eb.lib.nif_comm_destroy(eb.ctx))
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_the_drivers_launcher_single_rank():
+    """bench.py's N>1 code path (RCCL communicator, barrier, max-over-ranks) launched the way the driver does"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps",
            "2", "--warmup", "1", "--points", "65536", "--no-cpu-baseline", "--given-w-points", "4096",
@@ -92,9 +166,16 @@ def test_bench_runs_under_torchrun_single_rank():
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    import json
-    # the contract: ONE line on stdout (RCCL's version banner and everything else goes to stderr)
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d
+    d = _one_json_line(r.stdout)      # the contract: ONE line on stdout
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d and "RCCL" in d["config"]["collective"]
+
+
+def test_bench_plain_invocation():
+    """`python bench.py` with no launcher around it"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--points",
+           "65536", "--no-cpu-baseline", "--given-w-points", "4096"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["median_ms_per_step_host_synced"] > 0 and d["ms_per_step_fp32_mfma"] > 0

@@ -47,6 +47,16 @@ CONFIGS = {
     "ll_plain_32x2_r3": (_cfg("LL", 32, 2, 32, 1, 3, 2, 2, 1), 257),
     "ll_res_48x2_r4": (_cfg("LL", 48, 2, 40, 2, 4, 3, 1, 2, s_res=True, p_res=True, p_act="swish"), 130),
     "ll_cfg4_128x2_r10_so3": (_cfg("LL", 128, 2, 32, 2, 10, 3, 3, 1), 96),
+    # BASELINE.json's own shapes / the kernel instantiations they select: plain SIREN nets whose (nh+1)*4*NBL sign bits
+    # do not fit the 128-bit ring run k_snet4<NBL,true,SINE,0,SGN=false> (act'(a) ring instead of the sign-bit cosine):
+    # configs[2] = 6x128 (NBL 8), a 128-wide net with 4 layers, a 64-wide one with 8 (NBL 4); configs[3] = last-layer class
+    # at 128x6 (and x4); configs[4] = 64x4 with two coordinates
+    "ms_cfg3_128x6": (_cfg("NIFMultiScale", 128, 6, 32, 2, 1, 2, 1, 1, p_act="swish"), 200),
+    "ms_128x4_r2": (_cfg("NIFMultiScale", 128, 4, 32, 2, 2, 2, 1, 1), 97),
+    "ms_64x8": (_cfg("NIFMultiScale", 64, 8, 32, 2, 1, 1, 1, 1, p_act="swish"), 150),
+    "ms_cfg5_64x4_si2": (_cfg("NIFMultiScale", 64, 4, 32, 2, 1, 2, 1, 1, p_act="swish"), 300),
+    "ll_cfg4_128x6_r10_so3": (_cfg("LL", 128, 6, 32, 2, 10, 3, 3, 1, p_act="swish"), 160),
+    "ll_128x4_r4": (_cfg("LL", 128, 4, 32, 2, 4, 2, 1, 1), 70),
 }
 
 
@@ -118,7 +128,7 @@ def test_three_stage_factorisation(name):
     assert _rel(w2, w.astype(np.float64)) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3"])
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3", "ll_cfg4_128x6_r10_so3"])
 def test_last_layer_class_submodels(name):
     """model.py:1070-1145: p -> lr (= pnet output), x -> phi, u = Dot(phi, lr) + bias; lr_to_w raises."""
     m, model, spec, ws, x, y, sw = _make(name)
@@ -138,7 +148,7 @@ def test_last_layer_class_submodels(name):
 
 
 @pytest.mark.parametrize("name", ["nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3",
-                                  "ms_res_48x2_pres", "ms_cfg3_128x3"])
+                                  "ms_res_48x2_pres", "ms_cfg3_128x3", "ms_cfg5_64x4_si2", "ms_cfg3_128x6"])
 def test_jacobian_layer_matches_oracle(name):
     """gradient.py:36-49: (y, dy/dx) w.r.t. the coordinate columns; oracle = analytic tangent in fp64 (itself
     pinned by central differences and torch autograd in tests/test_oracle.py)."""
@@ -167,7 +177,7 @@ def test_jacobian_layer_matches_oracle(name):
     assert _rel(Ja[:, :, :spec.pi], Jp.astype(np.float64)) < 2e-5 and _rel(Ja[:, :, spec.pi:], J.astype(np.float64)) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3"])
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3", "ll_cfg4_128x6_r10_so3"])
 def test_jacobian_layer_last_layer_class(name):
     import nif_amd
     m, model, spec, ws, x, y, sw = _make(name)
@@ -387,11 +397,14 @@ def test_lbfgs_fine_tuning_reduces_loss():
     tuner = nif_amd.optimizers.TFPLBFGS(model, "mse", x, y, display_epoch=10)
     hist = tuner.minimize(rounds=3, max_iter=20)
     l1 = model.evaluate(x, y)
-    assert l1 < l0 and len(hist) > 5 and abs(hist[-1] - l1) < 1e-4 * max(l1, 1e-8) + 1e-7
+    # lbfgs.py:123-126: history = {"iteration", "loss"} with one entry per closure evaluation
+    assert l1 < l0 and len(hist["loss"]) > 5 and len(hist["iteration"]) == len(hist["loss"])
+    assert min(hist["loss"]) <= hist["loss"][0] and abs(min(hist["loss"]) - l1) < 1e-4 * max(l1, 1e-8) + 1e-7
 
 
 # ---- Sobolev training (BASELINE config 5): JacobianLayer as a trained output -----------------------------
-SOB = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1"]
+SOB = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1",
+       "ms_cfg5_64x4_si2", "ms_cfg3_128x6", "ms_64x8"]
 
 
 @pytest.mark.parametrize("name", SOB)
@@ -530,7 +543,7 @@ def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
 
 @pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev"])
 def test_full_size_shard_sum_other_configs(which):
-    """The same size-independent properties at the per-GPU shard sizes of BASELINE configs 3-5: the sum over 8
+    """The same size-independent properties at the TRUE per-GPU shard sizes and shapes of BASELINE configs[2..4]: the sum over 8
     contiguous shards of [grad | loss] equals the full-batch result, a repeated launch is bit-identical, and the
     oracle on a sample pins the loss (it cannot run 10^5..10^6 points)."""
     import nif_amd
@@ -538,15 +551,15 @@ def test_full_size_shard_sum_other_configs(which):
     from nif_amd import distributed as dist
     rng = np.random.default_rng(4)
     xi = None
-    if which == "cfg3_ms_128":
-        kind, cs, cp = _cfg("NIFMultiScale", 128, 3, 64, 2, 1, 2, 1, 1, p_act="swish")
-        B = 1 << 17
-    elif which == "cfg4_last_layer":
-        kind, cs, cp = _cfg("LL", 128, 2, 32, 2, 10, 3, 3, 1, p_act="swish")
-        B = 1 << 18
-    else:
+    if which == "cfg3_ms_128":          # configs[2]: NIFMultiScale 6x128, 4M points / 8 GPUs
+        kind, cs, cp = _cfg("NIFMultiScale", 128, 6, 32, 2, 1, 2, 1, 1, p_act="swish")
+        B = 1 << 19
+    elif which == "cfg4_last_layer":    # configs[3]: last-layer class 128x6, 16M points / 8 GPUs
+        kind, cs, cp = _cfg("LL", 128, 6, 32, 2, 10, 3, 3, 1, p_act="swish")
+        B = 1 << 21
+    else:                               # configs[4]: Sobolev, 64x4 with two coordinates, 8M points / 8 GPUs
         kind, cs, cp = _cfg("NIFMultiScale", 64, 4, 32, 2, 1, 2, 1, 1, p_act="swish")
-        B = 1 << 17
+        B = 1 << 20
         xi = [1, 2]
     spec = O.Spec(kind, cs, cp)
     ws = O.init_weights(spec, rng, dtype=np.float32)
@@ -615,3 +628,99 @@ def test_ragged_tiny_batches_on_the_16_point_tile_kernels(name, B):
     rl, rg = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
     assert abs(loss - rl) <= 1e-5 * abs(rl)
     assert _rel(grad, O.flatten(rg)) < 2e-4
+
+
+# ---- the gradient-precision story: bf16-split products vs the f32-input MFMA path vs the oracle ----------
+def _per_tensor_rel(spec, g, gref):
+    out, off = {}, 0
+    gn = np.linalg.norm(gref)
+    for nm, shp in spec.param_shapes():
+        k = int(np.prod(shp))
+        a, b = g[off:off + k].astype(np.float64), gref[off:off + k].astype(np.float64)
+        out[nm] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-6 * gn))
+        off += k
+    return out
+
+
+def _oracle_grad_chunked(spec, ws, x, y, chunk=2048):
+    """full-batch oracle loss/gradient as a sum over chunks (the oracle materialises [chunk, po] tensors in fp64)"""
+    B = x.shape[0]
+    loss, g = 0.0, None
+    for lo in range(0, B, chunk):
+        l, gr = O.loss_and_grad(spec, ws, x[lo:lo + chunk].astype(np.float64), y[lo:lo + chunk].astype(np.float64), batch_global=B)
+        loss += l
+        g = O.flatten(gr) if g is None else g + O.flatten(gr)
+    return loss, g
+
+
+def test_full_size_gradient_split_path_vs_fp32_mfma_vs_oracle():
+    """The training step's gradient products run as bf16 splits (data adjoint: 3 products, weight gradients: hi/lo).  At the
+    benchmark size (2^20 points, 4x64): every tensor of the flat gradient against the same step on the f32-input MFMAs
+    (`fp32_mfma` option: fmaf-exact products), and both against the fp64 oracle on a 65 536-point sub-batch."""
+    m, model, x, y = _full_size_setup()
+    e = m._engine
+    spec = O.Spec("NIFMultiScale", m.cfg_shape_net, m.cfg_parameter_net)
+    ws = [w.astype(np.float64) for w in model.get_weights()]
+    ls, gs = e.loss_and_grad(x, y)
+    e.set_option("fp32_mfma", 1)
+    lf, gf = e.loss_and_grad(x, y)
+    e.set_option("fp32_mfma", 0)
+    assert abs(ls - lf) <= 2e-6 * abs(lf), (ls, lf)
+    rel = _per_tensor_rel(spec, gs, gf)
+    assert max(rel.values()) < 2e-4, rel
+    assert _rel(gs, gf.astype(np.float64)) < 5e-5
+    n_s = 1 << 16
+    lo_, go_ = _oracle_grad_chunked(spec, ws, x[:n_s], y[:n_s])
+    for fp32 in (0, 1):
+        e.set_option("fp32_mfma", fp32)
+        l_, g_ = e.loss_and_grad(x[:n_s], y[:n_s])
+        assert abs(l_ - lo_) <= 1e-5 * abs(lo_), (fp32, l_, lo_)
+        rel = _per_tensor_rel(spec, g_, go_)
+        assert max(rel.values()) < 2e-4, (fp32, rel)
+        assert _rel(g_, go_) < (1e-4 if fp32 == 0 else 5e-5), (fp32, _rel(g_, go_))
+    e.set_option("fp32_mfma", 0)
+
+
+def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
+    """200 full-batch Adam steps on the reference's bundled travelling-wave dataset with the benchmark model: the loss
+    curves of the bf16-split path, the f32-input MFMA path and the fp64 oracle agree to 1e-3 at every step."""
+    import os
+    import nif_amd
+    import bench
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "traveling_wave.npz"))["data"]
+    data, _, _ = O.standard_normalize(d.astype(np.float64))
+    x, y = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
+    steps, lr = 200, 1e-3
+    curves = {}
+    ws0 = None
+    for mode in ("split", "fp32"):
+        nif_amd.set_seed(21)
+        m = nif_amd.NIFMultiScale(bench.CFG_SHAPE, bench.CFG_PARAM)
+        model = m.build()
+        ws0 = [w.astype(np.float64) for w in model.get_weights()]
+        e = m._engine
+        e.set_option("fp32_mfma", 1 if mode == "fp32" else 0)
+        adam = nif_amd.Adam(lr).as_struct()
+        d_x, d_y = e.alloc(x.size), e.alloc(y.size)
+        d_x.upload(x); d_y.upload(y)
+        losses = []
+        for _ in range(steps):
+            e.loss_grad_dev(d_x.at(0), d_y.at(0), None, x.shape[0], x.shape[0])
+            losses.append(e.last_loss())
+            e.adam_step_dev(adam)
+        curves[mode] = np.array(losses)
+    spec = O.Spec("NIFMultiScale", bench.CFG_SHAPE, bench.CFG_PARAM)
+    th = O.flatten(ws0); mm = np.zeros_like(th); vv = np.zeros_like(th)
+    f32 = lambda a: float(np.float32(a))
+    ref = []
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    for t in range(1, steps + 1):
+        l, g = O.loss_and_grad(spec, O.unflatten(spec, th), x64, y64)
+        ref.append(l)
+        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=f32(lr), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+    ref = np.array(ref)
+    assert ref[-1] < 0.9 * ref[0]                  # it does train
+    for mode in ("split", "fp32"):
+        dev = np.abs(curves[mode] - ref) / ref
+        assert dev.max() < 1e-3, (mode, float(dev.max()), int(dev.argmax()))
+    assert (np.abs(curves["split"] - curves["fp32"]) / ref).max() < 1e-3
