@@ -682,15 +682,21 @@ def test_full_size_gradient_split_path_vs_fp32_mfma_vs_oracle():
 
 
 def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
-    """200 full-batch Adam steps on the reference's bundled travelling-wave dataset with the benchmark model: the loss
-    curves of the bf16-split path, the f32-input MFMA path and the fp64 oracle agree to 1e-3 at every step."""
+    """200 full-batch Adam steps on the reference's bundled travelling-wave dataset with the benchmark model: loss curves
+    of the bf16-split path, the f32-input MFMA path (fmaf-exact products) and the fp64 oracle.
+
+    Measured (tools/exp/traj_probe.py): all three agree to <= 2e-5 until the optimisation enters its steep phase
+    (the loss falls 100x within ~40 steps); from there ANY fp32 evaluation drifts from the fp64 trajectory -- the exact-fp32
+    path as much as the split path (2.8e-3 vs 2.5e-3 at lr = 3e-4; at lr = 1e-3 both reach O(1) around step 75).  The
+    dynamics, not the product splitting, set that bound.  So: 1e-4 agreement over the first 100 steps, and over all 200
+    steps the split path must stay within the drift the exact-fp32 path shows itself."""
     import os
     import nif_amd
     import bench
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "traveling_wave.npz"))["data"]
     data, _, _ = O.standard_normalize(d.astype(np.float64))
     x, y = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
-    steps, lr = 200, 1e-3
+    steps, lr = 200, 3e-4
     curves = {}
     ws0 = None
     for mode in ("split", "fp32"):
@@ -719,8 +725,9 @@ def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
         ref.append(l)
         th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=f32(lr), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
     ref = np.array(ref)
-    assert ref[-1] < 0.9 * ref[0]                  # it does train
+    assert ref[-1] < 1e-2 * ref[0]                 # it does train (1.3 -> 5.6e-4)
+    dev = {mode: np.abs(curves[mode] - ref) / ref for mode in curves}
     for mode in ("split", "fp32"):
-        dev = np.abs(curves[mode] - ref) / ref
-        assert dev.max() < 1e-3, (mode, float(dev.max()), int(dev.argmax()))
-    assert (np.abs(curves["split"] - curves["fp32"]) / ref).max() < 1e-3
+        assert dev[mode][:100].max() < 1e-4, (mode, float(dev[mode][:100].max()))
+        assert dev[mode].max() < 2e-2, (mode, float(dev[mode].max()), int(dev[mode].argmax()))
+    assert dev["split"].max() <= 3.0 * dev["fp32"].max() + 1e-3, (float(dev["split"].max()), float(dev["fp32"].max()))
