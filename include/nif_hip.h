@@ -113,6 +113,20 @@ int nif_dev_free(nif_ctx* ctx, void* dptr);
 int nif_h2d(nif_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 int nif_d2h(nif_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 int nif_sync(nif_ctx* ctx);
+/* shard streaming for tables larger than HBM (replaces the TFRecord meta-dataset of nif/data/tfr_dataset.py:85-163, whose
+ * tf.data pipeline prefetches the next file while the current one trains): pinned host staging buffers, asynchronous
+ * H2D on a copy stream, two staging slots.  nif_h2d_async(slot) first waits (on the device) until the steps that read
+ * the slot's device buffers have finished (nif_copy_release), then copies; nif_copy_acquire makes the compute stream
+ * wait for the slot's copies; nif_copy_wait_host blocks the host until the slot's pinned buffers may be refilled. */
+int nif_host_alloc(nif_ctx* ctx, int64_t bytes, void** hptr);
+int nif_host_free(nif_ctx* ctx, void* hptr);
+int nif_h2d_async(nif_ctx* ctx, void* dst_dev, const void* src_pinned, int64_t bytes, int32_t slot);
+int nif_copy_acquire(nif_ctx* ctx, int32_t slot);
+int nif_copy_release(nif_ctx* ctx, int32_t slot);
+int nif_copy_wait_host(nif_ctx* ctx, int32_t slot);
+/* device-side shuffle of a resident table (Keras fit(shuffle=True) / tf.data .shuffle, tfr_dataset.py:104-108):
+ * dst[i][:] = src[perm[i]][:] for n rows of ncol floats; perm is a device int32 array */
+int nif_gather_rows_dev(nif_ctx* ctx, const float* src_dev, const int32_t* perm_dev, int64_t n, int32_t ncol, float* dst_dev);
 void* nif_stream(nif_ctx* ctx);          /* hipStream_t of the context */
 void* nif_grad_dev(nif_ctx* ctx);        /* device float[P+1]: flat gradient || loss  (the RCCL all-reduce buffer) */
 void* nif_params_dev(nif_ctx* ctx);      /* device float[P] */

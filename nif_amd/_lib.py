@@ -66,6 +66,13 @@ SIGNATURES = {
     "nif_h2d": (C.c_int, [_CTX, _VP, _VP, C.c_int64]),
     "nif_d2h": (C.c_int, [_CTX, _VP, _VP, C.c_int64]),
     "nif_sync": (C.c_int, [_CTX]),
+    "nif_host_alloc": (C.c_int, [_CTX, C.c_int64, C.POINTER(_VP)]),
+    "nif_host_free": (C.c_int, [_CTX, _VP]),
+    "nif_h2d_async": (C.c_int, [_CTX, _VP, _VP, C.c_int64, C.c_int32]),
+    "nif_copy_acquire": (C.c_int, [_CTX, C.c_int32]),
+    "nif_copy_release": (C.c_int, [_CTX, C.c_int32]),
+    "nif_copy_wait_host": (C.c_int, [_CTX, C.c_int32]),
+    "nif_gather_rows_dev": (C.c_int, [_CTX, _VP, _VP, C.c_int64, C.c_int32, _VP]),
     "nif_stream": (_VP, [_CTX]),
     "nif_grad_dev": (_VP, [_CTX]),
     "nif_params_dev": (_VP, [_CTX]),

@@ -415,3 +415,23 @@ __global__ void k_metric(const float* __restrict__ g, long P, float weight, doub
 void launch_metric(const float* g, long P, float weight, double* acc, hipStream_t st) {
   hipLaunchKernelGGL(k_metric, dim3(1), dim3(1), 0, st, g, P, weight, acc);
 }
+
+// ============================================================================================
+// device-side shuffle of a resident point table: dst[i][:] = src[perm[i]][:]  (rows of ncol floats).  Model.fit keeps
+// the table in HBM and uploads only the epoch's permutation (4 bytes per row) instead of re-gathering and re-uploading
+// the table on the host every epoch.  One thread per output element: consecutive threads write consecutive floats.
+// ============================================================================================
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ perm, long n, int ncol,
+                              float* __restrict__ dst) {
+  const long total = n * ncol;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long i = idx / ncol;
+    const int c = (int)(idx - i * ncol);
+    dst[idx] = src[(long)perm[i] * ncol + c];
+  }
+}
+void launch_gather_rows(const float* src, const int* perm, long n, int ncol, float* dst, hipStream_t st) {
+  const long total = n * ncol;
+  long grid = (total + 255) / 256; if (grid > 16384) grid = 16384; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)grid), dim3(256), 0, st, src, perm, n, ncol, dst);
+}

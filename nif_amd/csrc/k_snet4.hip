@@ -765,7 +765,8 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
-  const long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256 * NIF_S4_OCC_WIDE;
+  long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256 * NIF_S4_OCC_WIDE;
+  if (a.wg_cap > 0 && a.wg_cap < cap) cap = a.wg_cap;
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   if (query_only) return nblk;
   dim3 grid(nblk), block(256);

@@ -13,6 +13,10 @@
 
 #include "nif_ctx.h"
 
+#ifndef NIF_PIPE_CHUNK_DEFAULT
+#define NIF_PIPE_CHUNK_DEFAULT 131072L
+#endif
+
 static thread_local std::string g_err;
 int nif_fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -104,6 +108,9 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   nif_ctx* c = new nif_ctx();
   c->cfg = *cfg;
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
+  { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
+  { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
+  { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
   c->dev = device_id;
   c->kind = cfg->kind; c->pi = cfg->pi_dim; c->si = cfg->si_dim; c->so = cfg->so_dim;
   c->n = cfg->n_sx; c->L = cfg->l_sx; c->nst = cfg->n_st; c->lst = cfg->l_st; c->r = cfg->latent_dim;
@@ -116,7 +123,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   build_layout(c);
   hipError_t e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
-  const size_t pb = (size_t)(c->P + 1) * sizeof(float);
+  const size_t pb = (size_t)(c->P + 2) * sizeof(float);   // [grad | loss | one scratch word of the two-level row reduction]
   if (e == hipSuccess) e = hipMalloc(&c->theta, pb);
   if (e == hipSuccess) e = hipMalloc(&c->grad, pb);
   if (e == hipSuccess) e = hipMalloc(&c->m, pb);
@@ -161,7 +168,13 @@ extern "C" int nif_destroy(nif_ctx* c) {
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
   if (c->comm) (void)nif_comm_destroy(c);
-  void* ptrs[] = {c->comm_scratch, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  if (c->st2) { hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }
+  if (c->st_copy) { hipStreamSynchronize(c->st_copy); hipStreamDestroy(c->st_copy); }
+  for (int s_ = 0; s_ < 2; ++s_) { if (c->ev_copied[s_]) hipEventDestroy(c->ev_copied[s_]); if (c->ev_consumed[s_]) hipEventDestroy(c->ev_consumed[s_]); }
+  if (c->ev_start) hipEventDestroy(c->ev_start);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
+  for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
+  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -251,6 +264,69 @@ extern "C" int nif_sync(nif_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
 }
+// ---- shard streaming: pinned host staging + asynchronous H2D on a copy stream, double buffered -----------------------
+extern "C" int nif_host_alloc(nif_ctx* c, int64_t bytes, void** hptr) {
+  if (!c || !hptr || bytes < 0) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipHostMalloc(hptr, bytes > 0 ? (size_t)bytes : 4, hipHostMallocDefault));
+  return NIF_OK;
+}
+extern "C" int nif_host_free(nif_ctx* c, void* hptr) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->dev));
+  if (c->st_copy) HIPCHK(hipStreamSynchronize(c->st_copy));
+  if (hptr) HIPCHK(hipHostFree(hptr));
+  return NIF_OK;
+}
+static int ensure_copy_stream(nif_ctx* c) {
+  if (c->st_copy) return NIF_OK;
+  HIPCHK(hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
+  for (int s = 0; s < 2; ++s) {
+    HIPCHK(hipEventCreateWithFlags(&c->ev_copied[s], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_consumed[s], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_copied[s], c->st_copy));       // both start out signalled
+    HIPCHK(hipEventRecord(c->ev_consumed[s], c->st));
+  }
+  return NIF_OK;
+}
+extern "C" int nif_h2d_async(nif_ctx* c, void* dst_dev, const void* src_pinned, int64_t bytes, int32_t slot) {
+  if (!c || !dst_dev || !src_pinned || bytes < 0 || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_copy_stream(c); if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(c->st_copy, c->ev_consumed[slot], 0));   // the steps that read this slot's device buffer are done
+  HIPCHK(hipMemcpyAsync(dst_dev, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, c->st_copy));
+  HIPCHK(hipEventRecord(c->ev_copied[slot], c->st_copy));
+  return NIF_OK;
+}
+extern "C" int nif_copy_acquire(nif_ctx* c, int32_t slot) {       // compute stream: wait until the slot's copies have landed
+  if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_copy_stream(c); if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(c->st, c->ev_copied[slot], 0));
+  return NIF_OK;
+}
+extern "C" int nif_copy_release(nif_ctx* c, int32_t slot) {       // compute stream: everything enqueued so far has consumed the slot
+  if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_copy_stream(c); if (rc) return rc;
+  HIPCHK(hipEventRecord(c->ev_consumed[slot], c->st));
+  return NIF_OK;
+}
+extern "C" int nif_copy_wait_host(nif_ctx* c, int32_t slot) {     // host: the slot's pinned staging buffer may be overwritten
+  if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_copy_stream(c); if (rc) return rc;
+  HIPCHK(hipEventSynchronize(c->ev_copied[slot]));
+  return NIF_OK;
+}
+extern "C" int nif_gather_rows_dev(nif_ctx* c, const float* src_dev, const int32_t* perm_dev, int64_t n, int32_t ncol, float* dst_dev) {
+  if (!c || !src_dev || !perm_dev || !dst_dev || n < 0 || ncol < 1) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->dev));
+  if (n > 0) launch_gather_rows(src_dev, perm_dev, n, ncol, dst_dev, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
 extern "C" void* nif_stream(nif_ctx* c) { return c ? (void*)c->st : nullptr; }
 extern "C" void* nif_grad_dev(nif_ctx* c) { return c ? (void*)c->grad : nullptr; }
 extern "C" void* nif_params_dev(nif_ctx* c) { return c ? (void*)c->theta : nullptr; }
@@ -836,8 +912,157 @@ static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nl
   return NIF_OK;
 }
 
-// ns = 0: loss = mse(u, y).  ns > 0 (Sobolev): + wj * mse(du/dx_seed, gt), k_sob instead of k_snet3; the
-// ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
+static int rows_for(const nif_ctx* c, long ntiles) {
+  int rows = (int)((ntiles + 3) / 4);
+  if (rows > c->rows_cap) rows = c->rows_cap;
+  return rows < 1 ? 1 : rows;
+}
+
+// chunk size (points) of the two-stream pipeline, 0 = off.  nif_set_option("pipe_chunk", points) / NIF_PIPE_CHUNK;
+// default: on for batches of at least four chunks of 2^17 points
+static long pipe_chunk_points(const nif_ctx* c, long B) {
+  long ch = c->opt_pipe_chunk;
+  if (ch < 0) ch = 0;     // measured slower than the single-stream step: off unless asked for
+  if (ch <= 0) return 0;
+  ch = (ch + 2047) / 2048 * 2048;          // whole groups of 4 x 16-point tiles x 32 (and 32-point stash tiles)
+  return ch;
+}
+
+static int ensure_pipe(nif_ctx* c, int nchunk) {
+  if (!c->st2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  }
+  while ((int)c->ev_chunk.size() < nchunk) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_chunk.push_back(e);
+  }
+  if (nchunk > c->chunk_cap) {
+    HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipStreamSynchronize(c->st2));
+    if (c->chunk_grad) HIPCHK(hipFree(c->chunk_grad));
+    c->chunk_grad = nullptr; c->chunk_cap = 0;
+    HIPCHK(hipMalloc(&c->chunk_grad, sizeof(float) * (size_t)nchunk * c->pstride));
+    c->chunk_cap = nchunk;
+  }
+  return NIF_OK;
+}
+
+// Forward + adjoint + weight-gradient partial rows of the points [off, off + Bc) of a batch (NIF / NIFMultiScale).
+// The ParameterNet forward and the fused ShapeNet kernel go to stream sa_st, everything that consumes their output (the
+// ParameterNet adjoint, the weight-gradient reductions) to sb_st, ordered behind them by an event when the streams differ.
+// ns = 0: loss = mse(u, y).  ns > 0 (Sobolev, whole batch only): + wj * mse(du/dx_seed, gt), k_sob instead of k_snet3/4;
+// the ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
+static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const float* sw0, long off, long B, long Bg, int ns,
+                      const int* seeds, const float* gt, float wj, hipStream_t sa_st, hipStream_t sb_st, hipStream_t pb_st,
+                      float* partial, float* loss_partial, int* nloss_out, int chunk_idx, bool whole, SNetArgs* sa_edge = nullptr) {
+  int rc;
+  const int ncol = c->pi + c->si;
+  const long ntiles = (B + 31) / 32, t0 = off / 32;       // off is a multiple of 32 points
+  const float* xin = xin0 + off * ncol;
+  const float* y = y0 + off * c->so;
+  const float* sw = sw0 ? sw0 + off : nullptr;
+  // forward + adjoint
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  pa.Z = c->Z + t0 * 32 * c->r; pa.DZ = c->DZ + t0 * 32 * c->r;
+  if (pa.stash) pa.stash += t0 * 32 * 32 * c->NSTB;
+  // small ParameterNets: no stash -- the adjoint kernel recomputes the forward pass and reduces the weight
+  // gradients itself (k_pnetbw.hip).  NIF_PNET_STASH=1 forces the stash path (A/B runs, tests)
+  static const bool force_stash = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
+  const bool fused_p = !force_stash && pnet_bwg_supported(pa);
+  if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
+  { ProfScope p_(c, NIF_PROF_PNET_FWD, sa_st); launch_pnet(pa, c->NSTB, !fused_p, sa_st); }
+  SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
+  sa.Z = pa.Z; sa.DZ = pa.DZ; sa.DU = c->DU + t0 * 32 * c->so;
+  sa.stash = c->stash_s + t0 * 32 * 32 * c->NB;
+  sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+  if (!whole) sa.wg_cap = c->opt_pipe_wgs;        // leave room on every CU for the reductions of the previous chunk
+  int nloss = (int)((ntiles + 3) / 4);
+  bool fused_edge = false;
+  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge); if (rc) return rc;
+  if (!whole && fused_edge) { fused_edge = false; sa.EDGE = nullptr; sa.edge_ne = 0; }
+  *nloss_out = nloss;
+  {
+    ProfScope p_(c, NIF_PROF_SNET, sa_st);
+    if (ns > 0) launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st);
+    else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
+    else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
+    else launch_snet(sa, c->NB, true, sa_st);
+  }
+  if (sb_st != sa_st || pb_st != sa_st) {
+    HIPCHK(hipEventRecord(c->ev_chunk[chunk_idx], sa_st));
+    if (sb_st != sa_st) HIPCHK(hipStreamWaitEvent(sb_st, c->ev_chunk[chunk_idx], 0));
+    if (pb_st != sa_st && pb_st != sb_st) HIPCHK(hipStreamWaitEvent(pb_st, c->ev_chunk[chunk_idx], 0));
+  }
+  // weight gradients -> partial rows
+  const int rows = rows_for(c, ntiles);
+  { ProfScope p_(c, NIF_PROF_PNET_BWD, pb_st);
+    // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
+    // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
+    static const bool touch_on = [] { const char* e = getenv("NIF_PBW_TOUCH"); return !(e && e[0] == '0'); }();
+    const float* touch = (touch_on && !fused_edge && whole && pb_st == sb_st) ? sa.stash + (long)(c->nh + 1) * c->slot_s : nullptr;
+    if (fused_p) launch_pnet_bwg(pa, partial, c->pstride, rows, pb_st, touch, (long)c->NB * 1024);
+    else launch_pnet_bwd(pa, c->NSTB, pb_st); }
+  ProfScope pgw(c, NIF_PROF_GW, sb_st);
+  GwArgs g;
+  auto base = [&](GwArgs& q) {
+    memset(&q, 0, sizeof(q));
+    q.ntiles = ntiles; q.B = B; q.partial = partial; q.pstride = c->pstride; q.has_bias = 1; q.scale = 1.0f;
+  };
+  auto sbase = [&](GwArgs& q) {   // ShapeNet reductions also run over the tangent pseudo-tiles
+    base(q);
+    q.ntiles = ntiles * (1 + ns); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
+    for (int d = 0; d < 3; ++d) q.seed[d] = (seeds && d < ns) ? seeds[d] : 0;
+  };
+  const float om_s = sa.omega, om_p = pa.omega;
+  float* sIN = sa.stash; float* sDA = sa.stash + (long)(c->nh + 1) * c->slot_s;
+  // ShapeNet first layer
+  sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
+  g.W = hyper_ref(c, 0, c->n, c->si, c->n);
+  g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
+  if (!fused_edge) launch_gw_first(g, c->NB, rows, sb_st);
+  // ShapeNet hidden matrices
+  for (int j = 0; j < c->nh; ++j) {
+    sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
+    const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
+    const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
+    g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
+    g.Bv = hyper_ref(c, bslot, 0, 1, c->n);
+    launch_gw_mfma(g, c->NB, c->NB, rows, sb_st);
+  }
+  // ShapeNet last layer
+  {
+    sbase(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = sa.DU; g.nc = c->so; g.Z = sa.Z; g.r = c->r; g.scale = 1.0f;
+    const long wslot = (long)c->si * c->n + (long)c->nh * c->n * c->n;
+    const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
+    g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
+    g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
+    if (!fused_edge) launch_gw_out(g, c->NB, rows, sb_st);
+  }
+  // ParameterNet: first, hidden matrices, bottleneck
+  float* pST = pa.stash;
+  if (!fused_p) {
+  base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.r = 0; g.scale = om_p;
+  g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
+  launch_gw_first(g, c->NSTB, rows, pb_st);
+  for (int mi = 0; mi < c->nm; ++mi) {
+    base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.r = 0; g.scale = om_p;
+    long w_off, b_off;
+    if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
+    else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
+    g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
+    launch_gw_mfma(g, c->NSTB, c->NSTB, rows, pb_st);
+  }
+  base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = pa.DZ; g.nc = c->r; g.r = 0; g.scale = 1.0f;
+  g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
+  launch_gw_out(g, c->NSTB, rows, pb_st);
+  }
+  if (sa_edge) { *sa_edge = sa; if (!fused_edge) sa_edge->EDGE = nullptr; }   // whole batch: the kernel's own first/last-layer partials
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
                           const int* seeds, const float* gt, float wj) {
   HIPCHK(hipSetDevice(c->dev));
@@ -852,97 +1077,54 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
   c->reg_applied = false;
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
-  const int ncol = c->pi + c->si;
-  // forward + adjoint
-  PNetArgs pa; fill_pnet(c, pa, xin, B);
-  // small ParameterNets: no stash -- the adjoint kernel recomputes the forward pass and reduces the weight
-  // gradients itself (k_pnetbw.hip).  NIF_PNET_STASH=1 forces the stash path (A/B runs, tests)
-  static const bool force_stash = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();
-  const bool fused_p = !force_stash && pnet_bwg_supported(pa);
-  if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
-  { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
-  SNetArgs sa; fill_snet(c, sa, xin, ncol, c->pi, B);
-  sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
-  int nloss = (int)((ntiles + 3) / 4);
-  bool fused_edge = false;
-  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge); if (rc) return rc;
+  // Two-stream pipeline over chunks of the batch (plain step on the 16-point-tile kernels): the fused ShapeNet kernel of
+  // chunk i+1 (VALU / latency bound, 2 workgroups per CU) overlaps the HBM-bound weight-gradient reductions of chunk i
+  const long chunk = (ns == 0 && c->use_snet3) ? pipe_chunk_points(c, B) : 0;
+  if (chunk <= 0 || chunk >= B) {
+    int nloss = 0;
+    SNetArgs sae;
+    // the compute-bound ParameterNet adjoint runs on a second stream NEXT TO the HBM-bound weight-gradient reductions of
+    // the ShapeNet (both only need the fused kernel's outputs); joined in front of the row reduction
+    const bool side = c->opt_side_pnet && B >= 65536;
+    if (side) { rc = ensure_pipe(c, 1); if (rc) return rc; }
+    rc = step_chunk(c, xin, y, sw, 0, B, Bg, ns, seeds, gt, wj, c->st, c->st, side ? c->st2 : c->st, c->partial, c->loss_partial,
+                    &nloss, 0, true, &sae);
+    if (rc) return rc;
+    if (side) {
+      HIPCHK(hipEventRecord(c->ev_done, c->st2));
+      HIPCHK(hipStreamWaitEvent(c->st, c->ev_done, 0));
+    }
+    const int rows = rows_for(c, ntiles);
+    ProfScope pr_(c, NIF_PROF_REDUCE);
+    launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
+    if (sae.EDGE) launch_reduce_edge(sae, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
+    HIPCHK(hipGetLastError());
+    return NIF_OK;
+  }
+  const int nchunk = (int)((B + chunk - 1) / chunk);
+  rc = ensure_pipe(c, nchunk); if (rc) return rc;
+  HIPCHK(hipEventRecord(c->ev_start, c->st));             // stream B starts behind whatever st has queued (packing, Adam)
+  HIPCHK(hipStreamWaitEvent(c->st2, c->ev_start, 0));
+  const long lp_stride = c->nloss_cap / nchunk;            // loss partials of chunk i at i * lp_stride
+  for (int i = 0; i < nchunk; ++i) {
+    const long off = (long)i * chunk;
+    const long Bc = B - off < chunk ? B - off : chunk;
+    int nloss = 0;
+    rc = step_chunk(c, xin, y, sw, off, Bc, Bg, 0, nullptr, nullptr, 0.f, c->st, c->st2, c->st2, c->partial,
+                    c->loss_partial + i * lp_stride, &nloss, i, false);
+    if (rc) return rc;
+    if (nloss > lp_stride) return fail(NIF_ERR_STATE, "loss partial buffer too small for the chunk pipeline");
+    // this chunk's partial rows -> row i of the second-level buffer (loss in column P); stream B is in order, so the
+    // next chunk's reductions may overwrite the partial rows afterwards
+    const int rows = rows_for(c, (Bc + 31) / 32);
+    launch_reduce(c->partial, c->pstride, rows, c->loss_partial + i * lp_stride, nloss, c->chunk_grad + (long)i * c->pstride, c->P, c->st2);
+  }
+  HIPCHK(hipEventRecord(c->ev_done, c->st2));
+  HIPCHK(hipStreamWaitEvent(c->st, c->ev_done, 0));
   {
-    ProfScope p_(c, NIF_PROF_SNET);
-    if (ns > 0) launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, c->st);
-    else if (c->use_snet4) launch_snet4(sa, true, false, c->st);
-    else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, c->st);
-    else launch_snet(sa, c->NB, true, c->st);
+    ProfScope pr_(c, NIF_PROF_REDUCE);   // rows of the chunks -> flat gradient | loss (column P rides along as a regular column)
+    launch_reduce(c->chunk_grad, c->pstride, nchunk, nullptr, 0, c->grad, c->P + 1, c->st);
   }
-  // weight gradients -> partial rows
-  int rows = (int)((ntiles + 3) / 4);
-  if (rows > c->rows_cap) rows = c->rows_cap;
-  if (rows < 1) rows = 1;
-  { ProfScope p_(c, NIF_PROF_PNET_BWD);
-    // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
-    // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
-    static const bool touch_on = [] { const char* e = getenv("NIF_PBW_TOUCH"); return !(e && e[0] == '0'); }();
-    const float* touch = (touch_on && !fused_edge) ? c->stash_s + (long)(c->nh + 1) * c->slot_s : nullptr;
-    if (fused_p) launch_pnet_bwg(pa, c->partial, c->pstride, rows, c->st, touch, (long)c->NB * 1024);
-    else launch_pnet_bwd(pa, c->NSTB, c->st); }
-  std::unique_ptr<ProfScope> pgw(new ProfScope(c, NIF_PROF_GW));   // closed (event recorded) on every return path
-  GwArgs g;
-  auto base = [&](GwArgs& q) {
-    memset(&q, 0, sizeof(q));
-    q.ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride; q.has_bias = 1; q.scale = 1.0f;
-  };
-  auto sbase = [&](GwArgs& q) {   // ShapeNet reductions also run over the tangent pseudo-tiles
-    base(q);
-    q.ntiles = ntiles * (1 + ns); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
-    for (int d = 0; d < 3; ++d) q.seed[d] = (seeds && d < ns) ? seeds[d] : 0;
-  };
-  const float om_s = sa.omega, om_p = pa.omega;
-  float* sIN = c->stash_s; float* sDA = c->stash_s + (long)(c->nh + 1) * c->slot_s;
-  // ShapeNet first layer
-  sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = c->Z; g.r = c->r; g.scale = om_s;
-  g.W = hyper_ref(c, 0, c->n, c->si, c->n);
-  g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
-  if (!fused_edge) launch_gw_first(g, c->NB, rows, c->st);
-  // ShapeNet hidden matrices
-  for (int j = 0; j < c->nh; ++j) {
-    sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = c->Z; g.r = c->r; g.scale = om_s;
-    const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
-    const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
-    g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
-    g.Bv = hyper_ref(c, bslot, 0, 1, c->n);
-    launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
-  }
-  // ShapeNet last layer
-  {
-    sbase(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = c->DU; g.nc = c->so; g.Z = c->Z; g.r = c->r; g.scale = 1.0f;
-    const long wslot = (long)c->si * c->n + (long)c->nh * c->n * c->n;
-    const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
-    g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
-    g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
-    if (!fused_edge) launch_gw_out(g, c->NB, rows, c->st);
-  }
-  // ParameterNet: first, hidden matrices, bottleneck
-  float* pST = c->stash_p;
-  if (!fused_p) {
-  base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = c->pi; g.r = 0; g.scale = om_p;
-  g.W = dense_ref(c->first_w, c->pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
-  launch_gw_first(g, c->NSTB, rows, c->st);
-  for (int mi = 0; mi < c->nm; ++mi) {
-    base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.r = 0; g.scale = om_p;
-    long w_off, b_off;
-    if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
-    else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
-    g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
-    launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
-  }
-  base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->DZ; g.nc = c->r; g.r = 0; g.scale = 1.0f;
-  g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
-  launch_gw_out(g, c->NSTB, rows, c->st);
-  }
-  pgw.reset();
-  // rows -> flat gradient, loss
-  ProfScope pr_(c, NIF_PROF_REDUCE);
-  launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
-  if (fused_edge) launch_reduce_edge(sa, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
@@ -972,7 +1154,10 @@ extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
   SNetArgs sa; fill_snet(c, sa, nullptr, c->pi + c->si, c->pi, B_max);
   int nloss = 0; bool fe = false;
   const int seeds[3] = {0, 0, 0};
-  return snet_plan(c, sa, n_tangents, seeds, &nloss, &fe);
+  rc = snet_plan(c, sa, n_tangents, seeds, &nloss, &fe); if (rc) return rc;
+  const long chunk = (n_tangents == 0 && c->use_snet3) ? pipe_chunk_points(c, B_max) : 0;
+  if (chunk > 0 && chunk < B_max) { rc = ensure_pipe(c, (int)((B_max + chunk - 1) / chunk)); if (rc) return rc; }
+  return NIF_OK;
 }
 
 static int sobolev_seeds(nif_ctx* c, const int32_t* x_idx, int32_t nx, int* seeds) {
@@ -1077,6 +1262,9 @@ extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
     c->packed = false; c->packed32 = false; c->packed_p32 = false;
     return NIF_OK;
   }
+  if (strcmp(key, "side_pnet") == 0) { c->opt_side_pnet = value != 0; return NIF_OK; }   // ParameterNet adjoint on the second stream
+  if (strcmp(key, "pipe_chunk") == 0) { c->opt_pipe_chunk = value; return NIF_OK; }   // points per chunk, 0 = off, -1 = default
+  if (strcmp(key, "pipe_wgs") == 0) { c->opt_pipe_wgs = value; return NIF_OK; }       // workgroups of the fused kernel per chunk
   return fail(NIF_ERR_INVALID, std::string("unknown option ") + key);
 }
 

@@ -65,21 +65,29 @@ struct nif_ctx {
   // RCCL communicator of this context (nif_comm.hip): one rank = one ctx = one GPU
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   float* comm_scratch = nullptr;   // 64 B device scratch for barrier()
+  // two-stream chunk pipeline of the training step (nif_api.hip: loss_grad_core)
+  hipStream_t st2 = nullptr; hipEvent_t ev_start = nullptr, ev_done = nullptr; std::vector<hipEvent_t> ev_chunk;
+  float* chunk_grad = nullptr; int chunk_cap = 0;      // [chunks][pstride]: per-chunk gradient | loss rows
+  bool opt_side_pnet = false;                          // whole-batch step: ParameterNet adjoint on st2 next to the gradient reductions
+  long opt_pipe_chunk = -1; int opt_pipe_wgs = 512;    // points per chunk (-1 default, 0 off); fused-kernel workgroups per chunk
+  // shard streaming (nif_h2d_async): a copy stream and, per staging slot, 'copy landed' / 'slot consumed' events
+  hipStream_t st_copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   bool opt_fp32_mfma = false;      // nif_set_option("fp32_mfma"): A/B switch, default from NIF_FP32_MFMA
 };
 
 // RAII-ish helper: records an event pair around a kernel group when profiling is on
 struct ProfScope {
   nif_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(nif_ctx* c_, int id_) : c(c_), id(id_) {
+  hipStream_t s;
+  ProfScope(nif_ctx* c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->st) {
     if (!c->prof_on) return;
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
-    (void)hipEventRecord(a, c->st);
+    (void)hipEventRecord(a, s);
   }
   ~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, c->st);
+    (void)hipEventRecord(b, s);
     c->recs.push_back({id, a, b});
   }
 };

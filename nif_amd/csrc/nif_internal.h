@@ -93,6 +93,7 @@ struct SNetArgs {
   float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
+  int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
 // last_layer_bias | pnet last W (rl x rl)] -- the order k_snet4's prologue indexes (hyp3 with r = 0)
@@ -202,6 +203,7 @@ struct LLArgs {
   float* loss_partial;  // [gridDim.x]
 };
 void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
+void launch_gather_rows(const float* src, const int* perm, long n, int ncol, float* dst, hipStream_t st);
 void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st);
 void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st);
 

@@ -48,6 +48,30 @@ class DeviceArray(object):
             pass
 
 
+class PinnedArray(object):
+    """page-locked host staging buffer (hipHostMalloc through the C-ABI), exposed as a float32 NumPy view"""
+
+    def __init__(self, engine, n_floats):
+        self.engine = engine
+        self.n = int(n_floats)
+        p = C.c_void_p()
+        check(engine.lib.nif_host_alloc(engine.ctx, self.n * 4, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_float * max(self.n, 1)).from_address(self.ptr))[:self.n]
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.engine.lib.nif_host_free(self.engine.ctx, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine(object):
     def __init__(self, spec, device_id=0):
         self.spec = spec
@@ -78,6 +102,26 @@ class Engine(object):
     def alloc(self, n_floats):
         """float32 device buffer on this context's GPU"""
         return DeviceArray(self, n_floats)
+
+    def alloc_pinned(self, n_floats):
+        return PinnedArray(self, n_floats)
+
+    def gather_rows(self, src, d_perm, n, ncol, dst):
+        """dst[i][:] = src[perm[i]][:] on the device (perm: int32 bit patterns in a DeviceArray)"""
+        check(self.lib.nif_gather_rows_dev(self.ctx, src.at(0), d_perm.at(0), int(n), int(ncol), dst.at(0)))
+
+    # shard streaming (include/nif_hip.h: nif_h2d_async / nif_copy_*)
+    def h2d_async(self, dst, pinned, n_floats, slot):
+        check(self.lib.nif_h2d_async(self.ctx, dst.at(0), C.c_void_p(pinned.ptr), int(n_floats) * 4, int(slot)))
+
+    def copy_acquire(self, slot):
+        check(self.lib.nif_copy_acquire(self.ctx, int(slot)))
+
+    def copy_release(self, slot):
+        check(self.lib.nif_copy_release(self.ctx, int(slot)))
+
+    def copy_wait_host(self, slot):
+        check(self.lib.nif_copy_wait_host(self.ctx, int(slot)))
 
     # ---- parameters -----------------------------------------------------------------------------
     def layout(self):

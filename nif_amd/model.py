@@ -9,6 +9,7 @@ import numpy as np
 
 from . import _lib
 from . import distributed as dist
+from .data import ShardBatches
 from .engine import Engine
 from .optimizers import Adam, get as get_optimizer
 from .spec import Spec
@@ -175,10 +176,10 @@ class Model(object):
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
             sample_weight=None, initial_epoch=0, **kwargs):
-        """Keras Model.fit semantics for in-memory arrays: per epoch optionally shuffle, walk batches of
-        `batch_size` (default 32, last one partial), one Adam step per batch; the epoch 'loss' is the
-        sample-weighted mean of the batch losses.  The epoch's (shuffled) table is made resident in HBM
-        once; batches are device-pointer slices.  Under `nif_amd.distributed` every rank walks its own
+        """Keras Model.fit semantics for in-memory arrays (or one file of a shard dataset, nif_amd.data): per epoch
+        optionally shuffle, walk batches of `batch_size` (default 32, last one partial), one Adam step per batch; the
+        epoch 'loss' is the sample-weighted mean of the batch losses.  The table is made resident in HBM once; a
+        shuffled epoch uploads only its permutation and gathers on the device; batches are device-pointer slices.  Under `nif_amd.distributed` every rank walks its own
         shard and the flat gradient is SUM-all-reduced (RCCL) before the identical Adam update
         (tf.distribute.MirroredStrategy, README.md:39-49)."""
         if self.optimizer is None:
@@ -193,13 +194,39 @@ class Model(object):
             z = np.zeros((e.n_params,), dtype=np.float32)
             e.set_opt_state(z, z, 0)
             self._fresh_slots = False
-        x = np.ascontiguousarray(x, dtype=np.float32)
-        targets = self._targets(y, x.shape[0])   # list of [N, width] tables that travel with x
         ncol = s.pi_dim + s.si_dim
-        if x.shape[1] != ncol:
-            x = np.ascontiguousarray(x[:, :ncol])
-        N = x.shape[0]
-        sw = None if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float32)
+        shard = x if isinstance(x, ShardBatches) else None
+        if shard is not None:
+            # one file of a sharded dataset (nif_amd.data.NPZShardDataset, the TFRDataset replacement): its columns are
+            # already on their way to (or in) HBM through the double-buffered copy stream; fit() trains on the slot
+            if y is not None or sample_weight is not None:
+                raise ValueError("a shard dataset carries its own targets and weights")
+            if batch_size is not None and int(batch_size) != shard.batch_size:
+                raise ValueError("the batch size was fixed by gen_dataset_from_batch_file")
+            batch_size = shard.batch_size
+            shuffle = shard.shuffle
+            N = shard.n_rows
+            widths = shard.widths(self)
+            src_x, src_t, src_sw = shard.device_tables(e, self)
+            has_sw = src_sw is not None
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            targets = self._targets(y, x.shape[0])   # list of [N, width] tables that travel with x
+            if x.shape[1] != ncol:
+                x = np.ascontiguousarray(x[:, :ncol])
+            N = x.shape[0]
+            sw = None if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float32)
+            widths = [t.shape[1] for t in targets]
+            has_sw = sw is not None
+            # the table is made resident in HBM ONCE; a shuffled epoch uploads its permutation (4 bytes per row) and
+            # gathers on the device
+            src_x = e.alloc(N * ncol); src_x.upload(x)
+            src_t = []
+            for t in targets:
+                dt = e.alloc(t.size); dt.upload(t); src_t.append(dt)
+            src_sw = None
+            if has_sw:
+                src_sw = e.alloc(N); src_sw.upload(sw)
         bs = 32 if batch_size is None else int(batch_size)
         callbacks = list(callbacks or [])
         hist = History()
@@ -209,11 +236,16 @@ class Model(object):
         for cb in callbacks:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
-        d_x = e.alloc(N * ncol)
-        d_t = [e.alloc(t.size) for t in targets]
-        d_sw = e.alloc(N) if sw is not None else None
+        owned = [] if shard is not None else [src_x] + src_t + ([src_sw] if has_sw else [])
+        if shuffle:
+            d_x = e.alloc(N * ncol)
+            d_t = [e.alloc(N * w) for w in widths]
+            d_sw = e.alloc(N) if has_sw else None
+            d_perm = e.alloc(N)
+            owned += [d_x] + d_t + ([d_sw] if has_sw else []) + [d_perm]
+        else:
+            d_x, d_t, d_sw = src_x, src_t, src_sw
         rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
-        resident = False
         comm = dist.get()
         world = comm.world if comm is not None else 1
         # every rank walks its own shard; the global size of every step's batch is agreed ONCE per call, ranks whose
@@ -228,27 +260,20 @@ class Model(object):
                     if hasattr(cb, "on_epoch_begin"):
                         cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
-                if shuffle or not resident:
-                    if shuffle:
-                        perm = rng.permutation(N)
-                        d_x.upload(x[perm])
-                        for dt, t in zip(d_t, targets):
-                            dt.upload(t[perm])
-                        if sw is not None:
-                            d_sw.upload(sw[perm])
-                    else:
-                        d_x.upload(x)
-                        for dt, t in zip(d_t, targets):
-                            dt.upload(t)
-                        if sw is not None:
-                            d_sw.upload(sw)
-                    resident = True
+                if shuffle:
+                    perm = rng.permutation(N).astype(np.int32)
+                    d_perm.upload(perm.view(np.float32))
+                    e.gather_rows(src_x, d_perm, N, ncol, d_x)
+                    for st_, dt, w in zip(src_t, d_t, widths):
+                        e.gather_rows(st_, d_perm, N, w, dt)
+                    if has_sw:
+                        e.gather_rows(src_sw, d_perm, N, 1, d_sw)
                 adam = self.optimizer.as_struct()
                 e.metric_read(reset=True)
                 for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
                     b0 = ib * bs
                     if b > 0:
-                        self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * t.shape[1]) for dt, t in zip(d_t, targets)],
+                        self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * w) for dt, w in zip(d_t, widths)],
                                             d_sw.at(b0) if d_sw is not None else None, b, bg)
                     else:
                         e.zero_grad()
@@ -267,12 +292,11 @@ class Model(object):
                 if verbose:
                     print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
         finally:
+            if shard is not None:
+                shard.release(e)          # the slot's device buffers may be refilled once these steps have run
             e.sync()
-            d_x.free()
-            for dt in d_t:
-                dt.free()
-            if d_sw is not None:
-                d_sw.free()
+            for arr in owned:
+                arr.free()
         for cb in callbacks:
             if hasattr(cb, "on_train_end"):
                 cb.on_train_end({})

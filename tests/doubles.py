@@ -39,10 +39,38 @@ class OracleEngine(object):
         self.reg_applied = False
         self._metric = [0.0, 0.0]
         self.calls = []
+        self._slot_free = [True, True]
 
     # ---- what Model.fit uses ------------------------------------------------------------------------
     def alloc(self, n):
         return _HostArray(n)
+
+    def alloc_pinned(self, n):
+        a = _HostArray(n)
+        a.array = a.buf
+        return a
+
+    def gather_rows(self, src, d_perm, n, ncol, dst):
+        perm = d_perm.buf[:n].view(np.int32)
+        dst.buf[:n * ncol] = src.buf[:src.buf.size // ncol * ncol].reshape(-1, ncol)[perm].ravel()
+        self.calls.append(("gather", int(n), int(ncol)))
+
+    # shard streaming: the double copies at once and records the protocol
+    def h2d_async(self, dst, pinned, n_floats, slot):
+        assert self._slot_free[slot], "H2D into a slot whose steps were not released"
+        dst.buf[:n_floats] = pinned.buf[:n_floats]
+        self.calls.append(("h2d", int(slot), int(n_floats)))
+
+    def copy_acquire(self, slot):
+        self._slot_free[slot] = False
+        self.calls.append(("acquire", int(slot)))
+
+    def copy_release(self, slot):
+        self._slot_free[slot] = True
+        self.calls.append(("release", int(slot)))
+
+    def copy_wait_host(self, slot):
+        pass
 
     def reserve(self, b_max, n_tangents=0):
         self.calls.append(("reserve", int(b_max)))

@@ -1,0 +1,90 @@
+"""GPU tests of the data path around the training step: resident table + device-side shuffle in
+Model.fit, the sharded dataset streamed through the double-buffered copy stream, chunked predict."""
+import numpy as np
+import pytest
+
+from oracle import nif_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed=2):
+    import nif_amd
+    from tests.test_gpu_parity import _cfg
+    kind, cs, cp = _cfg("NIFMultiScale", 64, 2, 32, 2, 1, 1, 1, 1, p_act="swish")
+    nif_amd.set_seed(seed)
+    m = nif_amd.NIFMultiScale(cs, cp)
+    model = m.build()
+    model.compile(nif_amd.Adam(1e-3), "mse")
+    return nif_amd, m, model, O.Spec(kind, cs, cp)
+
+
+def test_fit_device_shuffle_follows_the_oracle_with_the_same_permutations():
+    nif_amd, m, model, spec = _model()
+    x, y = nif_amd.data.synthetic_wave_batch(700, seed=4)
+    sw = np.random.default_rng(1).uniform(0.5, 1.5, 700).astype(np.float32)
+    ws = [w.astype(np.float64) for w in model.get_weights()]
+    model._shuffle_seed = 13
+    h = model.fit(x, y, sample_weight=sw, epochs=3, batch_size=256, shuffle=True, verbose=0)
+    rng = np.random.default_rng(13)
+    th = O.flatten(ws); mm = np.zeros_like(th); vv = np.zeros_like(th); t = 0
+    f32 = lambda a: float(np.float32(a))
+    losses = []
+    for _ in range(3):
+        perm = rng.permutation(700)
+        xs, ys, ss = x[perm].astype(np.float64), y[perm].astype(np.float64), sw[perm].astype(np.float64)
+        tot = 0.0
+        for b0 in range(0, 700, 256):
+            l, g = O.loss_and_grad(spec, O.unflatten(spec, th), xs[b0:b0 + 256], ys[b0:b0 + 256], ss[b0:b0 + 256])
+            t += 1
+            th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+            tot += l * min(256, 700 - b0)
+        losses.append(tot / 700)
+    assert np.allclose(h.history["loss"], losses, rtol=2e-4), (h.history["loss"], losses)
+    assert np.abs(O.flatten(model.get_weights()) - th).max() < 0.05 * 1e-3 * t
+
+
+def test_streamed_shard_dataset_trains_like_the_host_staged_one(tmp_path):
+    """README.md:155-178 workflow on .npz shards; files i+1 streams to HBM (pinned staging, copy stream) while file i trains"""
+    from nif_amd.data import NPZShardDataset
+    nif_amd, m, model, spec = _model(seed=6)
+    x, y = nif_amd.data.synthetic_wave_batch(21000, seed=8)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (21000, 1)).astype(np.float32)
+    np.savez(tmp_path / "big.npz", data=np.hstack([x, y, w]))
+    fh = NPZShardDataset(n_feature=2, n_target=1, area_weight=True)
+    assert fh.create_from_npz(4096, str(tmp_path / "big.npz"), "data", str(tmp_path / "shards"), "wave", seed=0) == 6
+    model._shuffle_seed = 3
+    n = 0
+    for batch_file in fh.get_tfr_meta_dataset(str(tmp_path / "shards"), epoch=2, model=model):
+        h = model.fit(fh.gen_dataset_from_batch_file(batch_file, 512), epochs=1, verbose=0)
+        assert np.isfinite(h.history["loss"][0])
+        n += 1
+    assert n == 12
+    _, m2, model2, _ = _model(seed=6)
+    model2._shuffle_seed = 3
+    for batch_file in fh.get_meta_dataset(str(tmp_path / "shards"), epoch=2):
+        model2.fit(fh.gen_dataset_from_batch_file(batch_file, 512), epochs=1, verbose=0)
+    assert np.array_equal(O.flatten(model.get_weights()), O.flatten(model2.get_weights()))
+    # and the same as fitting the concatenated file tables in memory, file by file
+    _, m3, model3, _ = _model(seed=6)
+    model3._shuffle_seed = 3
+    for _ in range(2):
+        for sh in fh.get_meta_dataset(str(tmp_path / "shards"), epoch=1):
+            xs, ys, ws_ = sh.load_host()
+            model3.fit(xs, ys, sample_weight=ws_, batch_size=512, epochs=1, verbose=0)
+    assert np.array_equal(O.flatten(model.get_weights()), O.flatten(model3.get_weights()))
+    assert model.evaluate(x, y) < 1.3
+
+
+def test_predict_is_chunked_through_the_staging_buffers():
+    nif_amd, m, model, spec = _model()
+    x, _ = nif_amd.data.synthetic_wave_batch(5000, seed=1)
+    u = model.predict(x)
+    model._PREDICT_CHUNK = 1024
+    assert np.array_equal(model.predict(x), u)
+    assert np.array_equal(model.predict(x, batch_size=2048), u)
+    lr = m.model_p_to_lr().predict(x[:, :1])
+    w = m.model_lr_to_w().predict(lr[:600])
+    sub = m.model_x_to_u_given_w()
+    sub._PREDICT_CHUNK = 256
+    assert np.array_equal(sub.predict([x[:600, 1:], w]), m.model_x_to_u_given_w()._run([x[:600, 1:], w]))
