@@ -51,6 +51,13 @@ typedef enum {
   NIF_ACT_SIGMOID = 5, NIF_ACT_ELU = 6, NIF_ACT_SOFTPLUS = 7, NIF_ACT_GELU = 8
 } nif_act;
 
+/* `mixed_policy` of the model constructors (tf.keras.mixed_precision.Policy, model.py:101-105).  Variables are fp32 under
+ * both.  NIF_POLICY_MIXED_BF16: the operands of the ShapeNet's hidden n x n products (activations, hyper-planes, dL/da in
+ * the data adjoint) are rounded to bfloat16, accumulation in fp32; biases, activations, first/last layer, loss, the
+ * ParameterNet and the weight-gradient sums stay fp32 (strictly more accurate than Keras' policy, which also stores
+ * every layer output in bf16).  Kernels without a bf16 path (odd 16-feature block counts, 128-wide Sobolev) keep fp32. */
+typedef enum { NIF_POLICY_FLOAT32 = 0, NIF_POLICY_MIXED_BF16 = 1 } nif_policy;
+
 /* What NIF.__init__ (model.py:73-128) / NIFMultiScale._initialize_pnet (model.py:541-736)
  * derive from cfg_shape_net / cfg_parameter_net. */
 typedef struct {
@@ -70,7 +77,8 @@ typedef struct {
   int32_t p_act;         /* cfg_parameter_net["activation"]; NIF_ACT_SINE => SIREN pnet (model.py:591) */
   int32_t p_resblock;    /* cfg_parameter_net["use_resblock"] model.py:609,681 */
   float   p_omega0;      /* cfg_parameter_net["omega_0"]     model.py:599 */
-  int32_t reserved[8];   /* must be zero */
+  int32_t mixed_policy;  /* nif_policy: the `mixed_policy` argument of NIF(...)           model.py:73,101-105 */
+  int32_t reserved[7];   /* must be zero */
 } nif_cfg;
 
 /* One trainable tensor in Keras variable order. */

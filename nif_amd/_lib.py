@@ -11,6 +11,7 @@ NIF_ABI_VERSION = 2
 KIND_NIF, KIND_MULTISCALE, KIND_LASTLAYER = 0, 1, 2
 COMM_ID_BYTES = 128
 DT_F32, DT_F64, DT_I64 = 0, 1, 2
+POLICY_IDS = {"float32": 0, "mixed_bfloat16": 1}
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 PROF_NAMES = ["pack", "pnet_fwd", "snet", "pnet_bwd", "gw", "reduce", "adam", "given_w", "latent_to_w", "snet_fwd"]
@@ -31,7 +32,7 @@ class nif_cfg(C.Structure):
         ("so_dim", C.c_int32), ("n_sx", C.c_int32), ("l_sx", C.c_int32), ("n_st", C.c_int32),
         ("l_st", C.c_int32), ("latent_dim", C.c_int32), ("s_act", C.c_int32), ("s_resblock", C.c_int32),
         ("s_omega0", C.c_float), ("p_act", C.c_int32), ("p_resblock", C.c_int32), ("p_omega0", C.c_float),
-        ("reserved", C.c_int32 * 8),
+        ("mixed_policy", C.c_int32), ("reserved", C.c_int32 * 7),
     ]
 
 

@@ -170,11 +170,18 @@ __device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL /
 // one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form.
 // Two output blocks at a time: their 6-MFMA chains interleave (a dependent v_mfma_f32_16x16x32_bf16 cannot issue
 // back to back) and one LDS round trip feeds 12 MFMAs
-template <int NBL>
+// PR (the mixed_bfloat16 policy of the build): operands rounded to bf16, ONE product a0*b0 instead of the exact split
+template <int NBL, bool PR = false>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ob = 0; ob < NBL; ob += 2) {
+    if (PR) {
+      const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
+      T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
+      T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ob + 1], 0, 0, 0);
+      continue;
+    }
     const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], a1 = cur[(ob * 3 + 1) * 64 + lane], a2 = cur[(ob * 3 + 2) * 64 + lane];
     const bf16x8 c0 = cur[(ob * 3 + 3) * 64 + lane], c1 = cur[(ob * 3 + 4) * 64 + lane], c2 = cur[(ob * 3 + 5) * 64 + lane];
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, T[ob], 0, 0, 0);
@@ -193,11 +200,17 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
-template <int NBL>
+template <int NBL, bool PR = false>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ib = 0; ib < NBL; ib += 2) {
+    if (PR) {
+      const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
+      T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
+      T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
+      continue;
+    }
     const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
     const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ib], 0, 0, 0);

@@ -163,7 +163,7 @@ __device__ __forceinline__ void edge_accum(const f32x4 (&T)[NBL], const f32x4 wA
 // EDGE: the first-/last-layer weight gradients are accumulated in the kernel (edge_accum) instead of being stashed for
 // k_gw_first / k_gw_out.  Measured on cfg-2: -0.15 ms in the gradient kernels, +0.07 ms here (72 spilled registers at
 // the 168-register budget): no net gain yet, so it is opt-in (NIF_FUSE_EDGE=1) and a separate instantiation.
-template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool EDGE = false>
+template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool EDGE = false, bool PR = false>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
@@ -372,13 +372,13 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
           f32x4 T[NBL];
           ZERO_T(T)
 #pragma unroll
-          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
+          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
           const float zt = zt_base[k * 16];
 #pragma unroll
           for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
         } else {
 #pragma unroll
-          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
         }
       }
       NIF_TL(30 + j);
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 #pragma unroll
             for (int ks = 0; ks < NCH; ++ks)
               NIF_CHUNK({
-                mfma_x3<NBL>(cur, b0[ks], b1[ks], U, lane);
+                mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane);
                 if (!SGN && ks == 0) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
               })
             const float zt = zt_base[k * 16];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             dzs[k * 64 + lane] = fmaf(A.omega, s, dzs[k * 64 + lane]);
           } else {
 #pragma unroll
-            for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL>(cur, b0[ks], b1[ks], gh, lane); })
+            for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
           }
         }
         NIF_TL(70 + j);
@@ -778,6 +778,13 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
     hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>), grid, block, shm, st, a);                           \
   }
+#define S4P(NBL_, TR_, ACT_, MODE_, SGN_)   /* mixed_bfloat16 policy: single bf16 product per n x n operand pair */        \
+  {                                                                                                                 \
+    if (shm > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, false, false, true>,                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, false, false, true>), grid, block, shm, st, a);            \
+  }
 #define S4LE(NBL_)                                                                                                  \
   {                                                                                                                 \
     if (shm > 48 * 1024)                                                                                            \
@@ -790,6 +797,11 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
     if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, true) else S4L(NBL_, false, ACT_SINE, 1, false, true) } \
     else if (train) { if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, true) else S4L(NBL_, true, ACT_SINE, 0, false, true) } \
     else S4L(NBL_, false, ACT_SINE, 0, false, true)                         \
+  } else if (a.prec == 1) {                                                 \
+    if (a.nif_skip) { if (train) S4P(NBL_, true, -1, 2, false) else S4P(NBL_, false, -1, 2, false) } \
+    else if (a.res) { if (train) S4P(NBL_, true, ACT_SINE, 1, false) else S4P(NBL_, false, ACT_SINE, 1, false) } \
+    else if (train) { if (snet4_sign_ring(a)) S4P(NBL_, true, ACT_SINE, 0, true) else S4P(NBL_, true, ACT_SINE, 0, false) } \
+    else S4P(NBL_, false, ACT_SINE, 0, false)                               \
   } else if (a.nif_skip) {                                                  \
     if (train) S4L(NBL_, true, -1, 2, false, false) else S4L(NBL_, false, -1, 2, false, false) \
   } else if (a.res) {                                                       \
@@ -808,6 +820,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   }
 #undef S4
 #undef S4LE
+#undef S4P
 #undef S4L
   return nblk;
 }

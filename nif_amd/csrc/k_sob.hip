@@ -32,7 +32,8 @@ struct SobArgs {
 // SGN (plain SIREN, training): the ring keeps only the tangent pre-activations a'^d of the ACTIVE seeds; cos(a) is
 // rebuilt from the stashed sin(a) (the next layer's primal input) and its sign bit (k_snet4's shift register) --
 // the ring was 5 blocks written + 5 read per layer, now ns written + ns read and one stash read
-template <int NBL, int MODE, bool TRAIN, bool BF, bool SGN>
+// BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
+template <int NBL, int MODE, bool TRAIN, int BF, bool SGN>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
                 bf16x8 b0[NCH], b1[NCH], b2[NCH];
                 split3<NBL>(hz, b0, b1, b2);
                 _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
-                  mfma_x6<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CF, b0[ks], b1[ks], b2[ks], aq[q], lane);
+                  mfma_x6<NBL, BF == 2>(reinterpret_cast<const bf16x8*>(cur) + ks * CF, b0[ks], b1[ks], b2[ks], aq[q], lane);
               } else {
                 mfma16<NBL, true>(cur, hz, aq[q], lane);
               }
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
                     split2<NBL>(vq[q], b0, b1);
                     _Pragma("unroll") for (int b = 0; b < NBL; ++b) ZERO4(U[b]);
                     _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
-                      mfma_x3<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], U, lane);
+                      mfma_x3<NBL, BF == 2>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], U, lane);
                   } else {
                     mfma16<NBL, false>(cur, vq[q], U, lane);
                   }
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
                     bf16x8 b0[NCH], b1[NCH];
                     split2<NBL>(vq[q], b0, b1);
                     _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks)
-                      mfma_x3<NBL>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], lam[q], lane);
+                      mfma_x3<NBL, BF == 2>(reinterpret_cast<const bf16x8*>(cur) + ks * CB, b0[ks], b1[ks], lam[q], lane);
                   } else {
                     mfma16<NBL, true>(cur, vq[q], lam[q], lane);
                   }
@@ -508,12 +509,12 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   else if (train) { if (sgn) SBL(NBL_, 0, true, BF_, true) else SBL(NBL_, 0, true, BF_, false) } \
   else SBL(NBL_, 0, false, BF_, false)
   switch (NBL) {
-    case 1: SBK(1, false) break;
-    case 2: if (bf) { SBK(2, true) } else { SBK(2, false) } break;
-    case 3: SBK(3, false) break;
-    case 4: if (bf) { SBK(4, true) } else { SBK(4, false) } break;
-    case 6: if (bf) { SBK(6, true) } else { SBK(6, false) } break;
-    default: SBK(8, false) break;
+    case 1: SBK(1, 0) break;
+    case 2: if (bf && a.prec == 1) { SBK(2, 2) } else if (bf) { SBK(2, 1) } else { SBK(2, 0) } break;
+    case 3: SBK(3, 0) break;
+    case 4: if (bf && a.prec == 1) { SBK(4, 2) } else if (bf) { SBK(4, 1) } else { SBK(4, 0) } break;
+    case 6: if (bf && a.prec == 1) { SBK(6, 2) } else if (bf) { SBK(6, 1) } else { SBK(6, 0) } break;
+    default: SBK(8, 0) break;
   }
 #undef SBK
 #undef SBL

@@ -88,6 +88,11 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     return fail(NIF_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", libnif_hip is built for gfx950 only");
   if (cfg->kind != NIF_KIND_NIF && cfg->kind != NIF_KIND_MULTISCALE && cfg->kind != NIF_KIND_LASTLAYER)
     return fail(NIF_ERR_INVALID, "unknown model kind");
+  if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->mixed_policy != NIF_POLICY_MIXED_BF16)
+    return fail(NIF_ERR_INVALID, "unknown mixed_policy");
+  if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->kind == NIF_KIND_LASTLAYER)
+    return fail(NIF_ERR_INVALID, "mixed_bfloat16 is built for NIF / NIFMultiScale");
+  for (int i = 0; i < 7; ++i) if (cfg->reserved[i] != 0) return fail(NIF_ERR_INVALID, "reserved fields must be zero");
   if (cfg->kind == NIF_KIND_LASTLAYER && cfg->latent_dim * cfg->so_dim > 64)
     return fail(NIF_ERR_INVALID, "last-layer class: latent_dim * output_dim must be <= 64");
   if (cfg->pi_dim < 1 || cfg->si_dim < 1 || cfg->so_dim < 1 || cfg->latent_dim < 1)
@@ -457,6 +462,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
   a.WF4 = c->use_snet4 ? c->sWF4 : nullptr; a.WB4 = c->use_snet4 ? c->sWB4 : nullptr;   // packed only then
+  a.prec = (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 && !c->opt_fp32_mfma) ? 1 : 0;
   a.dring = c->dring;
   a.tl = c->tl;
 }

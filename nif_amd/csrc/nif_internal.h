@@ -93,6 +93,7 @@ struct SNetArgs {
   float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
+  int prec;                               // 0: fp32-exact products; 1: mixed_bfloat16 policy (operands of the n x n products rounded to bf16)
   int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |

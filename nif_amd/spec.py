@@ -18,8 +18,11 @@ class Spec(object):
             raise TypeError("cfg_parameter_net must be a dictionary")
         if not isinstance(cfg_shape_net, dict):
             raise TypeError("cfg_shape_net must be a dictionary")
-        if mixed_policy != "float32":
-            raise NotImplementedError("mixed_policy %r: only 'float32' is built so far" % (mixed_policy,))
+        if mixed_policy not in _lib.POLICY_IDS:
+            raise NotImplementedError("mixed_policy %r: 'float32' and 'mixed_bfloat16' are built (float16 needs loss scaling, "
+                                      "which the reference does not set up either)" % (mixed_policy,))
+        if mixed_policy != "float32" and kind == "NIFMultiScaleLastLayerParameterized":
+            raise NotImplementedError("mixed_bfloat16 is built for NIF / NIFMultiScale")
         self.kind = kind
         self.cfg_shape_net = cfg_shape_net
         self.cfg_parameter_net = cfg_parameter_net
@@ -84,6 +87,7 @@ class Spec(object):
         c.p_act = _lib.ACT_IDS[self.p_activation]
         c.p_resblock = int(self.p_resblock)
         c.p_omega0 = self.p_omega0
+        c.mixed_policy = _lib.POLICY_IDS[self.mixed_policy]
         return c
 
     # ---- trainable variables, Keras order ---------------------------------------------------

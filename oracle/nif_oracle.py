@@ -333,17 +333,21 @@ def pnet_forward(spec, ws, p, keep=False):
     return out, z
 
 
-def pnet_backward(spec, ws, tape_h, g_out, g_z_extra=None):
+def pnet_backward(spec, ws, tape_h, g_out, g_z_extra=None, g_last=None):
     """Reverse sweep of pnet_forward.  g_out = dLoss/d pnet_out [B,po].  Returns list of grads
-    for the pnet variables (Keras order)."""
+    for the pnet variables (Keras order).  (g_out None: the last layer's gradients `g_last` = [gW, gb] and the
+    latent gradient `g_z_extra` come from the plane formulation below.)"""
     first, hidden, bott, last, _ = _pnet_split(spec, ws)
     tape, h_last = tape_h
     # last layer: out = z@Wl + bl
     z = h_last @ bott[0] + bott[1]
-    g_last = [z.T @ g_out, g_out.sum(0)]
-    gz = g_out @ last[0].T
-    if g_z_extra is not None:
-        gz = gz + g_z_extra
+    if g_out is None:
+        gz = g_z_extra
+    else:
+        g_last = [z.T @ g_out, g_out.sum(0)]
+        gz = g_out @ last[0].T
+        if g_z_extra is not None:
+            gz = gz + g_z_extra
     g_bott = [h_last.T @ gz, gz.sum(0)]
     gh = gz @ bott[0].T
     g_hidden = []
@@ -509,6 +513,129 @@ def shapenet_given_w_backward(spec, tape, g_u):
     gw[:, sl["w1"][0]:sl["w1"][1]] = (om * x[:, :, None] * ga0[:, None, :]).reshape(B, -1)
     gw[:, sl["b1"][0]:sl["b1"][1]] = ga0
     return gw
+
+
+# ----------------------------------------------------------------------------------------------
+# The same ShapeNet in its PLANE formulation (what the HIP kernels execute): with zt = (z_1..z_r, 1) and
+# M^(k) the k-th plane of pnet_output's affine map (k < r: row k of the hyper kernel, k = r: the hyper bias),
+#     h . W(a) = sum_k zt_k(a) (h . M^(k))
+# so nothing of size [B, po] exists.  Algebraically identical to shapenet_given_w (tests pin 1e-12 agreement); used
+# (a) as a second, independent restatement and (b) to EMULATE the mixed_bfloat16 policy of the build, whose rounding
+# points are those of the plane formulation: the operands of every hidden n x n product (activations and planes in
+# the forward sweep, dL/da and planes in the data adjoint) are rounded to bfloat16 (`rnd`), accumulation, biases,
+# activations, first/last layer, loss and the weight-gradient sums stay in full precision.
+# ----------------------------------------------------------------------------------------------
+def bf16_round(a):
+    """round-to-nearest-even to bfloat16 of the float32 value of `a` (what v_cvt_pk_bf16_f32 does), as float64"""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).astype(np.float64).reshape(a32.shape)
+
+
+def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None):
+    """loss, grads (Keras order) and predictions of NIF / NIFMultiScale in the plane formulation.
+    rnd=None: exact; rnd=bf16_round: the build's mixed_bfloat16 policy."""
+    assert spec.kind in (KIND_NIF, KIND_MS)
+    R = (lambda a: a) if rnd is None else rnd
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    _, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    first, hidden, bott, last, _ = _pnet_split(spec, ws)
+    M = np.vstack([last[0], last[1][None, :]])          # [(r+1), po]
+    zt = np.hstack([z, np.ones((B, 1), dtype=z.dtype)])   # [B, r+1]
+    K = spec.r + 1
+    si, so, n = spec.si, spec.so, spec.n
+    sl = spec.slices()
+    nif = spec.kind == KIND_NIF
+    om = 1.0 if nif else spec.omega_s
+    f, df = act_fn(spec.s_act) if nif else (np.sin, np.cos)
+    mat = lambda k, ab, shape: M[k, ab[0]:ab[1]].reshape(shape)
+    vec = lambda k, ab: M[k, ab[0]:ab[1]]
+
+    def prod(u, ab, shape, rounded):      # sum_k zt_k (u . M_k) and the per-plane products
+        T = [(R(u) if rounded else u) @ (R(mat(k, ab, shape)) if rounded else mat(k, ab, shape)) for k in range(K)]
+        return sum(zt[:, k:k + 1] * T[k] for k in range(K)), T
+
+    def bias(ab):
+        return sum(zt[:, k:k + 1] * vec(k, ab)[None, :] for k in range(K))
+
+    # ---- forward
+    s0, T0 = prod(x, sl["w1"], (si, n), False)
+    a0 = om * s0 + bias(sl["b1"])
+    u = f(a0)
+    acts = []
+    nh = spec.n_hidden_mats
+    if nif:
+        for i in range(nh):
+            a = prod(u, sl["wh"][i], (n, n), True)[0] + bias(sl["bh"][i])
+            acts.append((u, a)); u = f(a) + u
+    elif spec.s_res:
+        for i in range(spec.L):
+            a1 = om * prod(u, sl["wh"][2 * i], (n, n), True)[0] + bias(sl["bh"][2 * i])
+            t = np.sin(a1)
+            a2 = om * prod(t, sl["wh"][2 * i + 1], (n, n), True)[0] + bias(sl["bh"][2 * i + 1])
+            acts.append((u, a1, t, a2)); u = 0.5 * (u + np.sin(a2))
+    else:
+        for i in range(nh):
+            a = om * prod(u, sl["wh"][i], (n, n), True)[0] + bias(sl["bh"][i])
+            acts.append((u, a)); u = np.sin(a)
+    sL, TL = prod(u, sl["wl"], (n, so), False)
+    out = sL + bias(sl["bl"])
+    # ---- loss
+    e = out - y
+    w_a = np.ones((B,), dtype=out.dtype) if sample_weight is None else sample_weight
+    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
+    # ---- adjoint
+    gM = np.zeros_like(M)
+    gzt = np.zeros_like(zt)
+
+    def wgrad(ab, hin, ga, scale):        # dL/dM_k[slot] += scale * sum_a zt_k h (x) ga   (full precision)
+        for k in range(K):
+            gM[k, ab[0]:ab[1]] += scale * ((zt[:, k:k + 1] * hin).T @ ga).ravel()
+
+    def bgrad(ab, ga):
+        for k in range(K):
+            gM[k, ab[0]:ab[1]] += (zt[:, k:k + 1] * ga).sum(0)
+            gzt[:, k] += ga @ vec(k, ab)
+
+    def back(ab, shape, ga, hin, scale, rounded):     # dL/dh_in and the latent part through the matrix
+        U = [(R(ga) if rounded else ga) @ (R(mat(k, ab, shape)) if rounded else mat(k, ab, shape)).T for k in range(K)]
+        for k in range(K):
+            gzt[:, k] += scale * (hin * U[k]).sum(1)
+        return scale * sum(zt[:, k:k + 1] * U[k] for k in range(K))
+
+    wgrad(sl["wl"], u, g_u, 1.0); bgrad(sl["bl"], g_u)
+    gh = back(sl["wl"], (n, so), g_u, u, 1.0, False)
+    if nif:
+        for i in reversed(range(nh)):
+            hin, a = acts[i]
+            ga = gh * df(a)
+            wgrad(sl["wh"][i], hin, ga, 1.0); bgrad(sl["bh"][i], ga)
+            gh = back(sl["wh"][i], (n, n), ga, hin, 1.0, True) + gh
+    elif spec.s_res:
+        for i in reversed(range(spec.L)):
+            hin, a1, t, a2 = acts[i]
+            ga2 = 0.5 * gh * np.cos(a2)
+            wgrad(sl["wh"][2 * i + 1], t, ga2, om); bgrad(sl["bh"][2 * i + 1], ga2)
+            gt = back(sl["wh"][2 * i + 1], (n, n), ga2, t, om, True)
+            ga1 = gt * np.cos(a1)
+            wgrad(sl["wh"][2 * i], hin, ga1, om); bgrad(sl["bh"][2 * i], ga1)
+            gh = 0.5 * gh + back(sl["wh"][2 * i], (n, n), ga1, hin, om, True)
+    else:
+        for i in reversed(range(nh)):
+            hin, a = acts[i]
+            ga = gh * np.cos(a)
+            wgrad(sl["wh"][i], hin, ga, om); bgrad(sl["bh"][i], ga)
+            gh = back(sl["wh"][i], (n, n), ga, hin, om, True)
+    ga0 = gh * df(a0)
+    wgrad(sl["w1"], x, ga0, om); bgrad(sl["b1"], ga0)
+    back(sl["w1"], (si, n), ga0, x, om, False)
+    grads = pnet_backward(spec, ws, ptape, None, g_z_extra=gzt[:, :spec.r], g_last=[gM[:spec.r], gM[spec.r]])
+    return loss, grads, out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -731,3 +731,84 @@ def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
         assert dev[mode][:100].max() < 1e-4, (mode, float(dev[mode][:100].max()))
         assert dev[mode].max() < 2e-2, (mode, float(dev[mode].max()), int(dev[mode].argmax()))
     assert dev["split"].max() <= 3.0 * dev["fp32"].max() + 1e-3, (float(dev["split"].max()), float(dev["fp32"].max()))
+
+
+# ---- mixed_bfloat16 policy (BASELINE configs[4] names bf16; reference model.py:73,101-105) ----------------------------------
+BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_so2_b33", "nif_cfg1_32x2", "ms_64x8"]
+
+
+def _make_policy(name, policy, boost=1.0):
+    import nif_amd
+    (kind, cs, cp), B = CONFIGS[name]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    if kind == "NIFMultiScale":
+        names = [nm for nm, _ in spec.param_shapes()]
+        ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * boost).astype(np.float32)
+    m = getattr(nif_amd, kind)(cs, cp, mixed_policy=policy)
+    model = m.build(); model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    return m, model, spec, [w.astype(np.float64) for w in ws], x, y, sw
+
+
+@pytest.mark.parametrize("name", BF16)
+def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
+    """Policy of the build (include/nif_hip.h nif_policy): operands of the hidden n x n products rounded to bf16, fp32
+    accumulation, everything else fp32.  The oracle's plane formulation with bf16 rounding at the same points
+    (oracle/nif_oracle.py planes_loss_and_grad(rnd=bf16_round)) pins it: predictions and loss to 1e-4 (a 1e-7
+    difference of an fp32 activation flips a bf16 rounding now and then), gradients to 2e-3 per tensor; against the
+    exact fp64 oracle the policy itself costs ~1e-3..1e-2, reported by the looser second bar."""
+    m, model, spec, ws, x, y, sw = _make_policy(name, "mixed_bfloat16")
+    assert m.compute_Dtype == "bfloat16" and m.variable_Dtype == "float32" and m.mixed_policy_name == "mixed_bfloat16"
+    x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+    rl, rg, ru = O.planes_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round)
+    u = model.predict(x)
+    assert _rel(u, ru) < 1e-4, _rel(u, ru)
+    loss, g = m._engine.loss_and_grad(x, y, sw)
+    assert abs(loss - rl) <= 1e-4 * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, g, O.flatten(rg))
+    assert max(rel.values()) < 2e-3, rel
+    # distance of the policy from exact arithmetic: present (it IS a different computation) but bounded
+    el, eg = O.loss_and_grad(spec, ws, x64, y64, s64)
+    d_u = _rel(u, O.forward(spec, ws, x64))
+    assert 1e-6 < d_u < 5e-2, d_u
+    assert _rel(g, O.flatten(eg)) < 0.2
+    # the fp32 model on the same weights is unaffected by the other one's policy
+    m32, model32, *_ = _make_policy(name, "float32")
+    assert _rel(model32.predict(x), O.forward(spec, ws, x64)) < 1e-5
+
+
+def test_mixed_bfloat16_training_and_sobolev_step():
+    """fit() under the policy follows the emulating oracle's Adam trajectory; the Sobolev step (configs[4]) runs on the
+    single-product planes and stays within the policy's distance of the exact oracle"""
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make_policy("ms_cfg5_64x4_si2", "mixed_bfloat16")
+    model.compile(nif_amd.Adam(1e-3), "mse")
+    h = model.fit(x, y, epochs=3, batch_size=x.shape[0], shuffle=False, verbose=0)
+    th = O.flatten(ws); mm = np.zeros_like(th); vv = np.zeros_like(th)
+    f32 = lambda a: float(np.float32(a))
+    losses = []
+    for t in range(1, 4):
+        l, g, _ = O.planes_loss_and_grad(spec, O.unflatten(spec, th), x.astype(np.float64), y.astype(np.float64), rnd=O.bf16_round)
+        losses.append(l)
+        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+    assert np.allclose(h.history["loss"], losses, rtol=5e-4), (h.history["loss"], losses)
+    # Sobolev under the policy
+    m, model, spec, ws, x, y, sw = _make_policy("ms_cfg5_64x4_si2", "mixed_bfloat16")
+    xi = [1, 2]
+    gt = np.random.default_rng(3).uniform(-1, 1, size=(x.shape[0], 1, 2)).astype(np.float32)
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.05, sw)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), gt.astype(np.float64), xi, 0.05,
+                                             sw.astype(np.float64))
+    assert abs(loss - rl) < 2e-2 * abs(rl), (loss, rl)
+    assert _rel(grad, O.flatten(rg)) < 0.2
+    m32, model32, *_ = _make_policy("ms_cfg5_64x4_si2", "float32")
+    l32, g32 = m32._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.05, sw)
+    assert abs(l32 - rl) < 2e-5 * abs(rl) and loss != l32          # the policy really changes the arithmetic
+    with pytest.raises(NotImplementedError):
+        nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
+    with pytest.raises(NotImplementedError):
+        nif_amd.NIFMultiScaleLastLayerParameterized(*CONFIGS["ll_plain_32x2_r3"][0][1:], mixed_policy="mixed_bfloat16")

@@ -170,3 +170,21 @@ def test_normalisers_match_reference_golden():
     assert np.array_equal(d, g["std_data"]) and np.array_equal(m, g["std_mean"]) and np.array_equal(s, g["std_std"])
     d, m, s = O.minmax_normalize(raw.copy(), 1, 1, 1)
     assert np.array_equal(d, g["mm_data"]) and np.array_equal(m, g["mm_mean"]) and np.array_equal(s, g["mm_std"])
+
+
+@pytest.mark.parametrize("name", ["nif_swish", "nif_tanh_r2_so2", "ms_plain", "ms_plain_r3_si2", "ms_res", "ms_res_pres", "ms_mlp_pres"])
+def test_plane_formulation_equals_the_materialised_reference_formulation(name):
+    """h.W(a) = sum_k zt_k (h.M^(k)): the oracle's second restatement, which never forms [B, po], against the
+    reference formulation (materialised pnet_output + per-sample einsum chain); and its bf16 emulation is a rounding"""
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name)
+    for sample_weight, bg in ((None, None), (sw, 13)):
+        l, g = O.loss_and_grad(spec, ws, inputs, y, sample_weight, batch_global=bg)
+        l2, g2, u2 = O.planes_loss_and_grad(spec, ws, inputs, y, sample_weight, batch_global=bg)
+        assert abs(l - l2) <= 1e-12 * max(1.0, abs(l))
+        assert np.allclose(u2, O.forward(spec, ws, inputs), rtol=1e-12, atol=1e-12)
+        for (nm, _), a, b in zip(spec.param_shapes(), g, g2):
+            assert np.abs(a - b).max() <= 1e-10 * max(np.abs(a).max(), 1e-30), nm
+    lb, gb, ub = O.planes_loss_and_grad(spec, ws, inputs, y, sw, rnd=O.bf16_round)
+    assert np.isfinite(lb) and lb != l
+    r = O.bf16_round(np.array([1.0, 1.00390625, 1.005859375, 1.01171875, -3.14159265, 0.0]))
+    assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.0078125, -3.140625, 0.0]))     # ties to even, 8-bit significand

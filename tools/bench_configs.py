@@ -31,6 +31,10 @@ WORK = {
     "cfg4_linear_nif_3d": ("NIFMultiScaleLastLayerParameterized", ms(128, 2, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
     "cfg5_sobolev_2d_4x64": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1, 2]),
     "cfg5_sobolev_2d_dx_only": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1]),
+    # configs[4] names bf16: the mixed_bfloat16 policy of the build (single bf16 product per n x n operand pair)
+    "cfg5_sobolev_2d_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1, 2], "mixed_bfloat16"),
+    "cfg2_wave_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 1, 1, 1), 1 << 20, None, "mixed_bfloat16"),
+    "cfg4_linear_nif_3d_128x6": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
     "cfg1_nif_swish_2x32": ("NIF", ({"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"},
                                     {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}), 1 << 20, None),
 }
@@ -45,11 +49,13 @@ def main():
     import nif_amd
     from nif_amd.engine import DeviceArray
     out = {}
-    for name, (cls, (cs, cp), B, xi) in WORK.items():
+    for name, work in WORK.items():
+        cls, (cs, cp), B, xi = work[:4]
+        policy = work[4] if len(work) > 4 else "float32"
         if a.only and a.only not in name:
             continue
         nif_amd.set_seed(0)
-        m = getattr(nif_amd, cls)(cs, cp)
+        m = getattr(nif_amd, cls)(cs, cp, mixed_policy=policy)
         m.build()
         e = m._engine
         ncol = cp["input_dim"] + cs["input_dim"]
