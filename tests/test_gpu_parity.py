@@ -758,7 +758,7 @@ def _make_policy(name, policy, boost=1.0):
 def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
     """Policy of the build (include/nif_hip.h nif_policy): operands of the hidden n x n products rounded to bf16, fp32
     accumulation, everything else fp32.  The oracle's plane formulation with bf16 rounding at the same points
-    (oracle/nif_oracle.py planes_loss_and_grad(rnd=bf16_round)) pins it: predictions and loss to 1e-4 (a 1e-7
+    (oracle/nif_oracle.py planes_loss_and_grad(rnd=bf16_round)) pins it: predictions and loss to 5e-4 (a 1e-7
     difference of an fp32 activation flips a bf16 rounding now and then), gradients to 2e-3 per tensor; against the
     exact fp64 oracle the policy itself costs ~1e-3..1e-2, reported by the looser second bar."""
     m, model, spec, ws, x, y, sw = _make_policy(name, "mixed_bfloat16")
@@ -766,9 +766,9 @@ def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
     x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
     rl, rg, ru = O.planes_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round)
     u = model.predict(x)
-    assert _rel(u, ru) < 1e-4, _rel(u, ru)
+    assert _rel(u, ru) < 5e-4, _rel(u, ru)
     loss, g = m._engine.loss_and_grad(x, y, sw)
-    assert abs(loss - rl) <= 1e-4 * abs(rl), (loss, rl)
+    assert abs(loss - rl) <= 5e-4 * abs(rl), (loss, rl)
     rel = _per_tensor_rel(spec, g, O.flatten(rg))
     assert max(rel.values()) < 2e-3, rel
     # distance of the policy from exact arithmetic: present (it IS a different computation) but bounded

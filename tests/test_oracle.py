@@ -187,4 +187,4 @@ def test_plane_formulation_equals_the_materialised_reference_formulation(name):
     lb, gb, ub = O.planes_loss_and_grad(spec, ws, inputs, y, sw, rnd=O.bf16_round)
     assert np.isfinite(lb) and lb != l
     r = O.bf16_round(np.array([1.0, 1.00390625, 1.005859375, 1.01171875, -3.14159265, 0.0]))
-    assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.0078125, -3.140625, 0.0]))     # ties to even, 8-bit significand
+    assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.015625, -3.140625, 0.0]))      # ties to even, 8-bit significand
