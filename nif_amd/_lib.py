@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnif_hip.so")
+LIB_PATH = os.environ.get("NIF_LIB") or os.path.join(_HERE, "libnif_hip.so")   # NIF_LIB: measurement builds
 
 NIF_ABI_VERSION = 2
 KIND_NIF, KIND_MULTISCALE, KIND_LASTLAYER = 0, 1, 2

@@ -113,6 +113,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   nif_ctx* c = new nif_ctx();
   c->cfg = *cfg;
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
+  { const char* e = getenv("NIF_FUSED_GW"); if (e && e[0]) c->opt_fused_gw = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
   { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
@@ -891,6 +892,15 @@ static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nl
       rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
     }
     *nloss = nblk;
+  } else if (c->use_snet4 && c->opt_fused_gw && sa.wg_cap == 0 && snet5_supported(sa)) {
+    const int nblk = launch_snet5(sa, nullptr, 0, true, c->st);
+    const long need = (long)nblk * 8 * snet5_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) {
+      HIPCHK(hipStreamSynchronize(c->st));
+      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
+    }
+    *nloss = nblk;
+    sa.fused_gw = 1;
   } else if (c->use_snet3) {
     int waves = 4;
     static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
@@ -992,6 +1002,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st);
+    else if (sa.fused_gw) launch_snet5(sa, partial, c->pstride, false, sa_st);
     else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
     else launch_snet(sa, c->NB, true, sa_st);
@@ -1001,8 +1012,8 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     if (sb_st != sa_st) HIPCHK(hipStreamWaitEvent(sb_st, c->ev_chunk[chunk_idx], 0));
     if (pb_st != sa_st && pb_st != sb_st) HIPCHK(hipStreamWaitEvent(pb_st, c->ev_chunk[chunk_idx], 0));
   }
-  // weight gradients -> partial rows
-  const int rows = rows_for(c, ntiles);
+  // weight gradients -> partial rows (the fused kernel wrote the hidden matrices' columns of ITS rows: everybody uses as many)
+  const int rows = sa.fused_gw ? nloss : rows_for(c, ntiles);
   { ProfScope p_(c, NIF_PROF_PNET_BWD, pb_st);
     // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
     // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
@@ -1029,7 +1040,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
   if (!fused_edge) launch_gw_first(g, c->NB, rows, sb_st);
   // ShapeNet hidden matrices
-  for (int j = 0; j < c->nh; ++j) {
+  for (int j = 0; j < c->nh && !sa.fused_gw; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
@@ -1100,7 +1111,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
       HIPCHK(hipEventRecord(c->ev_done, c->st2));
       HIPCHK(hipStreamWaitEvent(c->st, c->ev_done, 0));
     }
-    const int rows = rows_for(c, ntiles);
+    const int rows = sae.fused_gw ? nloss : rows_for(c, ntiles);
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
     if (sae.EDGE) launch_reduce_edge(sae, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
@@ -1268,6 +1279,7 @@ extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
     c->packed = false; c->packed32 = false; c->packed_p32 = false;
     return NIF_OK;
   }
+  if (strcmp(key, "fused_gw") == 0) { c->opt_fused_gw = value != 0; return NIF_OK; }     // k_snet5 instead of k_snet4 + k_gw_lds
   if (strcmp(key, "side_pnet") == 0) { c->opt_side_pnet = value != 0; return NIF_OK; }   // ParameterNet adjoint on the second stream
   if (strcmp(key, "pipe_chunk") == 0) { c->opt_pipe_chunk = value; return NIF_OK; }   // points per chunk, 0 = off, -1 = default
   if (strcmp(key, "pipe_wgs") == 0) { c->opt_pipe_wgs = value; return NIF_OK; }       // workgroups of the fused kernel per chunk

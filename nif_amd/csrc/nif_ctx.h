@@ -72,6 +72,7 @@ struct nif_ctx {
   long opt_pipe_chunk = -1; int opt_pipe_wgs = 512;    // points per chunk (-1 default, 0 off); fused-kernel workgroups per chunk
   // shard streaming (nif_h2d_async): a copy stream and, per staging slot, 'copy landed' / 'slot consumed' events
   hipStream_t st_copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool opt_fused_gw = false;     // nif_set_option("fused_gw") / NIF_FUSED_GW: hidden-layer weight gradients inside the fused kernel (k_snet5)
   bool opt_fp32_mfma = false;      // nif_set_option("fp32_mfma"): A/B switch, default from NIF_FP32_MFMA
 };
 

@@ -94,6 +94,7 @@ struct SNetArgs {
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
   int prec;                               // 0: fp32-exact products; 1: mixed_bfloat16 policy (operands of the n x n products rounded to bf16)
+  int fused_gw;                           // set by the orchestration when k_snet5 runs the step (hidden-layer gradients in-kernel)
   int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
@@ -158,6 +159,11 @@ void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+// k_snet5.hip: the plain-SIREN training step with the hidden layers' weight gradients accumulated in the kernel; writes the
+// hidden hyper-matrices' columns of `nblk` partial-gradient rows (returns nblk; the other gradient kernels must use it as `rows`)
+bool snet5_supported(const SNetArgs& a);
+long snet5_ring_floats_per_wave(int n, int nh);
+int launch_snet5(const SNetArgs& a, float* partial, long pstride, bool query_only, hipStream_t st);
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
 int snet4_edge_ne(const SNetArgs& a);    // floats of one workgroup's edge partial; 0 = not fusable (falls back to k_gw_first/out)
 void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st);
