@@ -25,9 +25,30 @@ struct JacArgs {
   const float* ZD[NIF_JAC_MAXSEED];  // parameter seed: dz/dp_col of the latent, [tiles][r][32] (from k_mlp_jac)
   int nx_total, x0;           // dydx row stride (number of requested x columns) and first column of this launch
   float* dydx;                // [B][so][nx_total]
+  // HessianLayer launches (k_jac<..., HESS>): seeds 0, 1 = the coordinate pair at x positions (hj, hk); stream 2 -> d2[B][so][nx][nx]
+  int hj, hk; float* d2ydx2;
 };
 
-template <int NBL, int ACT, int MODE>
+// second derivative of the activation (HessianLayer): f''(a)
+template <int ACT>
+__device__ __forceinline__ float act_d2(int act, float a) {
+  const int id = ACT >= 0 ? ACT : act;
+  switch (id) {
+    case ACT_SINE: { float s, c; nif_sincosf(a, &s, &c); return -s; }
+    case ACT_SWISH: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (2.0f + a * (1.0f - 2.0f * s)); }
+    case ACT_TANH: { const float t = tanhf(a); return -2.0f * t * (1.0f - t * t); }
+    case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (1.0f - 2.0f * s); }
+    case ACT_ELU: return a > 0.f ? 0.f : expf(a);
+    case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s); }
+    case ACT_GELU: return 0.3989422804014327f * expf(-0.5f * a * a) * (2.0f - a * a);
+    default: return 0.f;   // linear, relu
+  }
+}
+
+// HESS (HessianLayer, gradient.py:130-180, :234-261): streams 0 and 1 are the first-order tangents of two coordinate seeds
+// (j, k), stream 2 is the SECOND-order tangent of the pair:  a'' = w0 W(a) h'' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k  (the
+// first layer is linear in x: a'' = 0); it leaves through the linear last layer like a first-order tangent
+template <int NBL, int ACT, int MODE, bool HESS = false>
 __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
@@ -115,19 +136,29 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
         acc[b] += zt * tk;
 #pragma unroll
         for (int d = 0; d < NS; ++d)
-          if (d < ns) {
+          if (d < ns && !(HESS && d == 2)) {
             if (J.seed[d] >= 0) accd[d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
             else if (k < r) accd[d][b] += zd_base[(d * r + k) * 16] * tk;
           }
       }
     }
     {
-      f32x4 dv[NBL];
+      f32x4 dv[NBL], d2[NBL];
+      if (HESS) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) d2[b][v] = act_d2<ACT>(A.act, acc[b][v]);
+      }
       act16<NBL, ACT>(A.act, acc, h, dv, n, g);
 #pragma unroll
       for (int d = 0; d < NS; ++d)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) hd[d][b] = dv[b] * accd[d][b];
+      if (HESS) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) hd[2][b] = d2[b] * accd[0][b] * accd[1][b];
+      }
     }
     // ---- hidden hyper-matrices -------------------------------------------------------------------
     int pl = 0;
@@ -207,13 +238,20 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
             for (int b = 0; b < NBL; ++b) accd[d][b] += zd * *reinterpret_cast<const f32x4*>(sb + 16 * b);
           }
       }
-      f32x4 dv[NBL];
+      f32x4 dv[NBL], d2[NBL];
+      if (HESS) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) d2[b][v] = act_d2<ACT>(A.act, acc[b][v]);
+      }
       act16<NBL, ACT>(A.act, acc, acc, dv, n, g);
 #pragma unroll
       for (int d = 0; d < NS; ++d)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
-          const f32x4 t = dv[b] * accd[d][b];
+          f32x4 t = dv[b] * accd[d][b];
+          if (HESS && d == 2) t += d2[b] * accd[0][b] * accd[1][b];
           if (MODE == 0) hd[d][b] = t;
           else if (MODE == 2) hd[d][b] += t;
           else {
@@ -274,19 +312,40 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
       for (int d = 0; d < NS; ++d) { pd[d] += __shfl_xor(pd[d], 16); pd[d] += __shfl_xor(pd[d], 32); }
       if (valid && g == 0) {
         if (A.u_out) A.u_out[pt * so + o] = part + bias;
+        if (HESS) {
+          J.dydx[(pt * so + o) * J.nx_total + J.hj] = pd[0];
+          J.dydx[(pt * so + o) * J.nx_total + J.hk] = pd[1];
+          J.d2ydx2[((pt * so + o) * J.nx_total + J.hj) * J.nx_total + J.hk] = pd[2];
+          J.d2ydx2[((pt * so + o) * J.nx_total + J.hk) * J.nx_total + J.hj] = pd[2];
+        } else {
 #pragma unroll
-        for (int d = 0; d < NS; ++d)
-          if (d < ns) J.dydx[(pt * so + o) * J.nx_total + J.x0 + d] = pd[d];
+          for (int d = 0; d < NS; ++d)
+            if (d < ns) J.dydx[(pt * so + o) * J.nx_total + J.x0 + d] = pd[d];
+        }
       }
     }
   }
 }
 
+static void launch_jac_impl(JacArgs& J, bool hess, hipStream_t st);
 void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
                 hipStream_t st) {
   JacArgs J;
-  J.s = a; J.ns = ns; J.nx_total = nx_total; J.x0 = x0; J.dydx = dydx;
+  J.s = a; J.ns = ns; J.nx_total = nx_total; J.x0 = x0; J.dydx = dydx; J.hj = J.hk = 0; J.d2ydx2 = nullptr;
   for (int d = 0; d < NIF_JAC_MAXSEED; ++d) { J.seed[d] = d < ns ? seeds[d] : 0; J.ZD[d] = d < ns ? zd[d] : nullptr; }
+  launch_jac_impl(J, false, st);
+}
+// one coordinate pair (seed_j at x position hj, seed_k at hk) of the Hessian: fills columns hj, hk of dydx and the entries
+// (hj, hk), (hk, hj) of d2ydx2 [B][so][nx][nx]
+void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st) {
+  JacArgs J;
+  J.s = a; J.ns = 3; J.nx_total = nx_total; J.x0 = 0; J.dydx = dydx; J.hj = hj; J.hk = hk; J.d2ydx2 = d2ydx2;
+  J.seed[0] = seed_j; J.seed[1] = seed_k; J.seed[2] = 0;
+  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) J.ZD[d] = nullptr;
+  launch_jac_impl(J, true, st);
+}
+static void launch_jac_impl(JacArgs& J, bool hess, hipStream_t st) {
+  const SNetArgs& a = J.s;
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
@@ -297,10 +356,17 @@ void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const*
   const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(1 + NIF_JAC_MAXSEED) * a.r * 16 + 8) * sizeof(float);
 #define JL(NBL_, ACT_, MODE_)                                                                                        \
   {                                                                                                                  \
-    if (shm > 48 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute((const void*)k_jac<NBL_, ACT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)shm);                                                                           \
-    hipLaunchKernelGGL((k_jac<NBL_, ACT_, MODE_>), grid, block, shm, st, J);                                         \
+    if (hess) {                                                                                                      \
+      if (shm > 48 * 1024)                                                                                           \
+        (void)hipFuncSetAttribute((const void*)k_jac<NBL_, ACT_, MODE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)shm);                                                                         \
+      hipLaunchKernelGGL((k_jac<NBL_, ACT_, MODE_, true>), grid, block, shm, st, J);                                 \
+    } else {                                                                                                         \
+      if (shm > 48 * 1024)                                                                                           \
+        (void)hipFuncSetAttribute((const void*)k_jac<NBL_, ACT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)shm);                                                                         \
+      hipLaunchKernelGGL((k_jac<NBL_, ACT_, MODE_>), grid, block, shm, st, J);                                       \
+    }                                                                                                                \
   }
 #define JK(NBL_)                                                      \
   if (a.nif_skip) JL(NBL_, -1, 2) else if (a.res) JL(NBL_, ACT_SINE, 1) else JL(NBL_, ACT_SINE, 0)

@@ -692,6 +692,55 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   return NIF_OK;
 }
 
+// HessianLayer (gradient.py:130-180, :234-261): y [B, so], dy/dx [B, ny, nx] and d2y/dx2 [B, ny, nx, nx] for COORDINATE
+// columns x_idx of NIF / NIFMultiScale: one launch of the second-order tangent kernel per coordinate pair (j <= k).
+extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
+                           int32_t nx, float* y_out, float* dydx_out, float* d2_out) {
+  if (!c || !xin || !y_idx || !x_idx || !y_out || !dydx_out || !d2_out || B <= 0 || ny <= 0 || nx <= 0)
+    return fail(NIF_ERR_INVALID, "bad argument");
+  for (int i = 0; i < ny; ++i)
+    if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
+  for (int j = 0; j < nx; ++j)
+    if (x_idx[j] < c->pi || x_idx[j] >= c->pi + c->si)
+      return fail(NIF_ERR_INVALID, "HessianLayer is built for coordinate columns (pi_dim <= x_index < pi_dim + si_dim): second-order "
+                                   "tangents through the ParameterNet are not");
+  if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "HessianLayer is built for NIF / NIFMultiScale");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_packed32(c); if (rc) return rc;
+  if (!c->use_snet3) return fail(NIF_ERR_INVALID, "HessianLayer needs the 16-point-tile path (units <= 128, small latent)");
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  const int ncol = c->pi + c->si;
+  rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
+  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
+  rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
+  rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * c->so * nx * nx); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+  launch_pnet(pa, c->NSTB, false, c->st);
+  SNetArgs sa; fill_snet(c, sa, c->d_a, ncol, c->pi, B);
+  for (int j = 0; j < nx; ++j)
+    for (int k = j; k < nx; ++k) {
+      sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
+      launch_hess(sa, x_idx[j] - c->pi, x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st);
+    }
+  HIPCHK(hipGetLastError());
+  std::vector<float> fj((size_t)B * c->so * nx), fh((size_t)B * c->so * nx * nx);
+  HIPCHK(hipMemcpyAsync(y_out, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(fj.data(), c->d_b, sizeof(float) * fj.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(fh.data(), c->d_c, sizeof(float) * fh.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (int64_t a_ = 0; a_ < B; ++a_)
+    for (int i = 0; i < ny; ++i) {
+      const size_t src = (size_t)a_ * c->so + y_idx[i];
+      for (int j = 0; j < nx; ++j) {
+        dydx_out[(a_ * ny + i) * nx + j] = fj[src * nx + j];
+        for (int k = 0; k < nx; ++k) d2_out[((a_ * ny + i) * nx + j) * nx + k] = fh[(src * nx + j) * nx + k];
+      }
+    }
+  return NIF_OK;
+}
+
 extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr) {
   if (!c || !p || !lr || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));

@@ -178,6 +178,7 @@ long snet3_plane_floats(int n);
 long snet3_ring_floats_per_wave(int n, int nh);
 void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
                 hipStream_t st);
+void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st);
 void launch_mlp_jac(const PNetArgs& a, int NB, int seed, float* ZD, hipStream_t st);
 void launch_ll_jac_out(const float* PHI, const float* Z, const float* PHID, const float* ZD, long B, int r, int so,
                        int nx_total, int xcol, float* dydx, hipStream_t st);

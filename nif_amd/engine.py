@@ -213,6 +213,18 @@ class Engine(object):
                                     xi.ctypes.data_as(C.POINTER(C.c_int32)), xi.size, ptr(y), ptr(d)))
         return y, d
 
+    def hessian(self, inputs, y_index, x_index):
+        x = self._inputs(inputs)
+        s = self.spec
+        yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
+        xi = np.ascontiguousarray(list(x_index), dtype=np.int32)
+        y = np.empty((x.shape[0], s.so_dim), dtype=np.float32)
+        d = np.empty((x.shape[0], yi.size, xi.size), dtype=np.float32)
+        h = np.empty((x.shape[0], yi.size, xi.size, xi.size), dtype=np.float32)
+        check(self.lib.nif_hessian(self.ctx, ptr(x), x.shape[0], yi.ctypes.data_as(C.POINTER(C.c_int32)), yi.size,
+                                   xi.ctypes.data_as(C.POINTER(C.c_int32)), xi.size, ptr(y), ptr(d), ptr(h)))
+        return y, d, h
+
     def x_to_phi(self, x):
         x = self._rows(x, self.spec.si_dim, "coordinates")
         s = self.spec

@@ -323,6 +323,25 @@ class JacobianLayer(object):
     __call__ = call
 
 
+class HessianLayer(object):
+    """reference nif/layers/gradient.py:130-180: `y, dys_dxs, dys2_dxs2 = HessianLayer(model, y_index, x_index)(x)` with
+    dys2_dxs2[a, i, j, k] = d^2 y[a, y_index[i]] / d x[a, x_index[j]] d x[a, x_index[k]].  Second-order forward-mode
+    tangents in one HIP kernel per coordinate pair (the reference nests two GradientTapes and batch_jacobian, :251-261);
+    built for the coordinate columns of NIF / NIFMultiScale."""
+
+    def __init__(self, model, y_index, x_index, **kwargs):
+        if not isinstance(model, Model) or model._role != "full":
+            raise TypeError("HessianLayer expects the model returned by NIF(...).build() / .model()")
+        self.model = model
+        self.y_index = [y_index] if isinstance(y_index, int) else list(y_index)
+        self.x_index = [x_index] if isinstance(x_index, int) else list(x_index)
+
+    def call(self, x, **kwargs):
+        return self.model._engine.hessian(x, self.y_index, self.x_index)
+
+    __call__ = call
+
+
 class SobolevModel(Model):
     """The Keras idiom  `tf.keras.Model(inp, JacobianLayer(nif_model, y_index, x_index)(inp))`  compiled with
     loss='mse' and loss_weights=[1, w]: a two-output model (u, du/dx) whose training differentiates through

@@ -964,6 +964,82 @@ def jacobian_analytic(spec, ws, inputs, y_index, x_index):
     return u, J
 
 
+def act_d2(name):
+    """f'' for a Keras activation name / 'sine'"""
+    if name in (None, "linear", "relu"):
+        return lambda a: np.zeros_like(a)
+    if name in ("swish", "silu"):
+        return lambda a: _sigmoid(a) * (1.0 - _sigmoid(a)) * (2.0 + a * (1.0 - 2.0 * _sigmoid(a)))
+    if name == "tanh":
+        return lambda a: -2.0 * np.tanh(a) * (1.0 - np.tanh(a) ** 2)
+    if name == "sigmoid":
+        return lambda a: _sigmoid(a) * (1.0 - _sigmoid(a)) * (1.0 - 2.0 * _sigmoid(a))
+    if name == "elu":
+        return lambda a: np.where(a > 0, 0.0, np.exp(np.minimum(a, 0.0)))
+    if name == "softplus":
+        return lambda a: _sigmoid(a) * (1.0 - _sigmoid(a))
+    if name == "gelu":
+        return lambda a: np.exp(-0.5 * a * a) / math.sqrt(2 * math.pi) * (2.0 - a * a)
+    if name == "sine":
+        return lambda a: -np.sin(a)
+    raise ValueError("unknown activation %r" % (name,))
+
+
+def hessian_analytic(spec, ws, inputs, y_index, x_index):
+    """HessianLayer (gradient.py:130-180, :234-261) for coordinate columns of the hypernetwork classes, by second-order
+    forward-mode tangents: returns (y [B, so], dy/dx [B, ny, nx], d2y/dx2 [B, ny, nx, nx]).  Per layer, with a' / a'' the
+    first / second-order tangents of the pre-activation:  h' = f'(a) a' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k ;  the
+    first layer is linear in x (a'' = 0).  Pinned by central differences of jacobian_analytic and by torch autograd."""
+    assert spec.kind in (KIND_NIF, KIND_MS)
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    pout, _ = pnet_forward(spec, ws, p)
+    u, tape = shapenet_given_w(spec, x, pout, keep=True)
+    B = x.shape[0]
+    nx = len(x_index)
+    J = np.zeros((B, len(y_index), nx), dtype=u.dtype)
+    H = np.zeros((B, len(y_index), nx, nx), dtype=u.dtype)
+    acts, Wh, W1, Wl = tape["acts"], tape["Wh"], tape["W1"], tape["Wl"]
+    nif = spec.kind == KIND_NIF
+    om = 1.0 if nif else spec.omega_s
+    name = spec.s_act if nif else "sine"
+    _, df = act_fn(name)
+    d2f = act_d2(name)
+    yi = list(y_index)
+    for jj in range(nx):
+        for kk in range(jj, nx):
+            dj, dk = x_index[jj] - spec.pi, x_index[kk] - spec.pi
+            assert dj >= 0 and dk >= 0, "analytic Hessian only for coordinate columns"
+            a0 = acts[0][1]
+            aj, ak = om * W1[:, dj, :], om * W1[:, dk, :]
+            hj, hk, hjk = df(a0) * aj, df(a0) * ak, d2f(a0) * aj * ak
+
+            def layer(a, W, sj, sk, sjk):
+                aj_, ak_, ajk_ = om * _ein(sj, W), om * _ein(sk, W), om * _ein(sjk, W)
+                return df(a) * aj_, df(a) * ak_, df(a) * ajk_ + d2f(a) * aj_ * ak_
+            if nif:
+                for i in range(spec.L):
+                    _, a = acts[i + 1]
+                    tj, tk, tjk = layer(a, Wh[i], hj, hk, hjk)
+                    hj, hk, hjk = tj + hj, tk + hk, tjk + hjk
+            elif spec.s_res:
+                for i in range(spec.L):
+                    _, a1, t, a2 = acts[i + 1]
+                    tj, tk, tjk = layer(a1, Wh[2 * i], hj, hk, hjk)
+                    vj, vk, vjk = layer(a2, Wh[2 * i + 1], tj, tk, tjk)
+                    hj, hk, hjk = 0.5 * (hj + vj), 0.5 * (hk + vk), 0.5 * (hjk + vjk)
+            else:
+                for i in range(spec.L):
+                    _, a = acts[i + 1]
+                    hj, hk, hjk = layer(a, Wh[i], hj, hk, hjk)
+            J[:, :, jj] = _ein(hj, Wl)[:, yi]
+            J[:, :, kk] = _ein(hk, Wl)[:, yi]
+            ujk = _ein(hjk, Wl)[:, yi]
+            H[:, :, jj, kk] = ujk
+            H[:, :, kk, jj] = ujk
+    return u, J, H
+
+
 # ----------------------------------------------------------------------------------------------
 # synthetic data = verified closed form of the bundled travelling-wave datasets
 # (nif/demo/dataset/*.npz; SURVEY section 4) + the reference normalisers

@@ -812,3 +812,30 @@ def test_mixed_bfloat16_training_and_sobolev_step():
         nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
     with pytest.raises(NotImplementedError):
         nif_amd.NIFMultiScaleLastLayerParameterized(*CONFIGS["ll_plain_32x2_r3"][0][1:], mixed_policy="mixed_bfloat16")
+
+
+# ---- HessianLayer (N3; reference gradient.py:130-180) ------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres",
+                                  "ms_cfg5_64x4_si2", "ms_cfg3_128x3", "ms_32x2_r7_si3"])
+def test_hessian_layer_matches_oracle(name):
+    """(y, dy/dx, d2y/dx2) for the coordinate columns: second-order forward-mode tangents in one kernel per coordinate pair
+    against the fp64 oracle (pinned by torch double-backward in tests/test_oracle.py).  With w0 = 30 the second derivatives
+    are O(w0^2) larger than the field: tolerance 1e-4 of the Hessian's own scale."""
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make(name, boost=1.0)
+    x = x[:200]
+    yi = list(range(spec.so))
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    yv, J, H = nif_amd.HessianLayer(model, yi, xi)(x)
+    ur, Jr, Hr = O.hessian_analytic(spec, ws, x.astype(np.float64), yi, xi)
+    assert yv.shape == (x.shape[0], spec.so) and J.shape == Jr.shape and H.shape == (x.shape[0], spec.so, spec.si, spec.si)
+    assert _rel(yv, ur) < 1e-5 and _rel(J, Jr) < 2e-5
+    assert _rel(H, Hr) < 1e-4, _rel(H, Hr)
+    assert np.array_equal(H, np.swapaxes(H, 2, 3))
+    # index selection like tf.gather: a single output / a single (repeated) column
+    y1, J1, H1 = nif_amd.HessianLayer(model, spec.so - 1, [xi[-1]])(x)
+    assert H1.shape == (x.shape[0], 1, 1, 1)
+    assert np.allclose(H1[:, 0, 0, 0], H[:, spec.so - 1, -1, -1], rtol=1e-5, atol=1e-6 * np.abs(H).max())
+    # parameter columns / the last-layer class are refused loudly
+    with pytest.raises(nif_amd._lib.NifError):
+        nif_amd.HessianLayer(model, yi, [0])(x)

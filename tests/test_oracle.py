@@ -188,3 +188,27 @@ def test_plane_formulation_equals_the_materialised_reference_formulation(name):
     assert np.isfinite(lb) and lb != l
     r = O.bf16_round(np.array([1.0, 1.00390625, 1.005859375, 1.01171875, -3.14159265, 0.0]))
     assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.015625, -3.140625, 0.0]))      # ties to even, 8-bit significand
+
+
+@pytest.mark.parametrize("name", ["nif_tanh_r2_so2", "nif_swish", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres"])
+def test_hessian_analytic_vs_fd_of_the_jacobian_and_torch(name):
+    """HessianLayer oracle: second-order forward mode against central differences of the analytic Jacobian and against
+    torch autograd (double backward) of the independent torch restatement"""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=5)
+    yi = list(range(spec.so))
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    u, J, H = O.hessian_analytic(spec, ws, inputs, yi, xi)
+    u2, J2 = O.jacobian_analytic(spec, ws, inputs, yi, xi)
+    assert np.allclose(u, u2) and np.allclose(J, J2, rtol=1e-12, atol=1e-14)
+    assert H.shape == (5, spec.so, spec.si, spec.si) and np.allclose(H, np.swapaxes(H, 2, 3))
+    eps = 1e-6
+    for kk, col in enumerate(xi):
+        d = np.zeros_like(inputs); d[:, col] = eps
+        _, Jp = O.jacobian_analytic(spec, ws, inputs + d, yi, xi)
+        _, Jm = O.jacobian_analytic(spec, ws, inputs - d, yi, xi)
+        fd = (Jp - Jm) / (2 * eps)
+        assert np.allclose(H[:, :, :, kk], fd, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(H).max())), (name, kk)   # FD truncation (w0 = 30)
+    tH = T.hessian(kind, cs, cp, ws, inputs)            # [B, so, ncol, ncol] over all input columns
+    assert np.allclose(H, tH[:, :, xi][:, :, :, xi], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(H).max()))

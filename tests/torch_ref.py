@@ -152,3 +152,20 @@ def sobolev_loss_and_grad(kind, cs, cp, ws_np, inputs_np, y_np, dydx_np, x_index
     loss = per.sum() / u.shape[0]
     grads = torch.autograd.grad(loss, ws, allow_unused=True)
     return (loss.item(), [g.numpy() if g is not None else None for g in grads], u.detach().numpy(), J.detach().numpy())
+
+
+def hessian(kind, cs, cp, ws_np, inputs_np):
+    """d^2 u_i / d input_j d input_k for every output and every pair of input columns: [B, so, ncol, ncol]
+    (what gradient.py:251-261 computes with two nested tapes and batch_jacobian)"""
+    ws = [torch.tensor(w, dtype=torch.float64) for w in ws_np]
+    inputs = torch.tensor(inputs_np, dtype=torch.float64, requires_grad=True)
+    u = forward(kind, cs, cp, ws, inputs)
+    B, so = u.shape
+    ncol = inputs.shape[1]
+    out = torch.zeros((B, so, ncol, ncol), dtype=torch.float64)
+    for i in range(so):
+        g, = torch.autograd.grad(u[:, i].sum(), inputs, create_graph=True)      # rows are independent: [B, ncol]
+        for j in range(ncol):
+            h, = torch.autograd.grad(g[:, j].sum(), inputs, retain_graph=True)
+            out[:, i, j, :] = h
+    return out.detach().numpy()
