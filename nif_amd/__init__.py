@@ -4,9 +4,9 @@ Drop-in for the point-wise training path of pswpswpsw/nif (`from nif import NIF`
 `from nif_amd import NIF`): same constructor cfg dicts, build/compile/fit/predict and the
 sub-model extractors, on hand-written HIP kernels behind a C-ABI (include/nif_hip.h)."""
 from .model import (NIF, NIFMultiScale, NIFMultiScaleLastLayerParameterized, Model, JacobianLayer,  # noqa: F401
-                    SobolevModel, set_seed)
+                    HessianLayer, SobolevModel, set_seed)
 from . import optimizers, callbacks, distributed, data  # noqa: F401
 from .optimizers import Adam  # noqa: F401
 
-__all__ = ["NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized", "Model", "JacobianLayer", "SobolevModel", "Adam", "set_seed",
-           "optimizers", "callbacks", "distributed"]
+__all__ = ["NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized", "Model", "JacobianLayer", "HessianLayer", "SobolevModel", "Adam", "set_seed",
+           "optimizers", "callbacks", "distributed", "data"]
