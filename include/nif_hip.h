@@ -207,6 +207,11 @@ int nif_train_step(nif_ctx* ctx, const float* xin_host, const float* y_host, con
  * every ParameterNet kernel and bias): loss += l2*sum(w^2) + l1*sum(|w|) over theta[lo, hi); the gradient
  * term is added once, after the cross-rank all-reduce, inside nif_adam_step_dev / nif_loss_and_grad. */
 int nif_set_regularizer(nif_ctx* ctx, float l1, float l2, int64_t lo, int64_t hi);
+/* Activity regulariser of cfg_parameter_net["act_l1_reg"/"act_l2_reg"] (nif/model.py:118-125: Keras activity_regularizer
+ * L2(l2) or else L1(l1) on the last ParameterNet layer, :226, :659, :731): loss += c / B * sum_a sum_i phi(pnet_out[a, i]),
+ * phi = (.)^2 or |.|, Keras dividing the activity loss by the batch size.  pnet_out [B, po] is never materialised: two
+ * passes recompute it on the fly (k_actreg_*).  NIF / NIFMultiScale, latent_dim <= 8. */
+int nif_set_activity_regularizer(nif_ctx* ctx, float l1, float l2);
 /* Keras' epoch loss metric without a host sync per batch: sum += weight * grad[P], count += weight (device side) */
 int nif_metric_accumulate(nif_ctx* ctx, float weight);
 int nif_metric_read(nif_ctx* ctx, double* sum_out, double* count_out, int reset);

@@ -435,3 +435,129 @@ void launch_gather_rows(const float* src, const int* perm, long n, int ncol, flo
   long grid = (total + 255) / 256; if (grid > 16384) grid = 16384; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)grid), dim3(256), 0, st, src, perm, n, ncol, dst);
 }
+
+// ============================================================================================
+// Activity regulariser of the ParameterNet output (reference nif/model.py:118-125, :226, :659, :731: Keras
+// `activity_regularizer=L1(l1)` or `L2(l2)` on the last ParameterNet layer): loss += c/B * sum_a sum_i phi(out_ai) with
+// out_ai = sum_k zt_k(a) M^(k)_i the NEVER MATERIALISED pnet_output, phi = |.| (L1) or (.)^2 (L2), Keras dividing the
+// activity loss by the batch size.  Two passes over the virtual [B, po] tensor, each recomputing out on the fly:
+//   k_actreg_points   one thread per point, loop over the po outputs (the plane rows are wave-uniform loads):
+//                     loss partial and dL/dz_k(a) += c/B sum_i phi'(out_ai) M^(k)_i        (before the ParameterNet adjoint)
+//   k_actreg_planes   one thread per output i, loop over a slab of points (their zt staged in LDS):
+//                     partial[slab][k][i] = sum_{a in slab} phi'(out_ai) zt_k(a)           (-> k_actreg_apply adds c/B * sum)
+// Cost 4 (r+1) po flop per point (67 kflop at 4x64): an optional regulariser, not the benchmark path.
+// ============================================================================================
+#define NIF_ACT_MAXR 8
+template <bool L1>
+__global__ __launch_bounds__(256) void k_actreg_points(const float* __restrict__ theta, long off_W, long off_b, int r, long po,
+                                                       const float* __restrict__ Z, long B, float coef, float* __restrict__ DZ,
+                                                       float* __restrict__ loss_partial) {
+  __shared__ float red[256];
+  const long a = (long)blockIdx.x * 256 + threadIdx.x;
+  float zt[NIF_ACT_MAXR], dz[NIF_ACT_MAXR];
+  const bool ok = a < B;
+  const long tile = a >> 5; const int pp = (int)(a & 31);
+#pragma unroll
+  for (int k = 0; k < NIF_ACT_MAXR; ++k) { zt[k] = (ok && k < r) ? Z[(tile * r + k) * 32 + pp] : 0.f; dz[k] = 0.f; }
+  float acc = 0.f;
+  for (long i = 0; i < po; ++i) {
+    float out = theta[off_b + i];
+#pragma unroll
+    for (int k = 0; k < NIF_ACT_MAXR; ++k)
+      if (k < r) out = fmaf(zt[k], theta[off_W + (long)k * po + i], out);
+    const float d = L1 ? (out > 0.f ? 1.f : (out < 0.f ? -1.f : 0.f)) : 2.0f * out;
+    acc += L1 ? fabsf(out) : out * out;
+#pragma unroll
+    for (int k = 0; k < NIF_ACT_MAXR; ++k)
+      if (k < r) dz[k] = fmaf(d, theta[off_W + (long)k * po + i], dz[k]);
+  }
+  if (ok)
+    for (int k = 0; k < r; ++k) DZ[(tile * r + k) * 32 + pp] += coef * dz[k];
+  red[threadIdx.x] = ok ? acc : 0.f;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_partial[blockIdx.x] = coef * red[0];
+}
+template <bool L1>
+__global__ __launch_bounds__(256) void k_actreg_planes(const float* __restrict__ theta, long off_W, long off_b, int r, long po,
+                                                       const float* __restrict__ Z, long B, long slab, float* __restrict__ part) {
+  __shared__ float zs[NIF_ACT_MAXR * 256];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long a0 = (long)blockIdx.y * slab, a1 = a0 + slab < B ? a0 + slab : B;
+  float m[NIF_ACT_MAXR + 1], g[NIF_ACT_MAXR + 1];
+#pragma unroll
+  for (int k = 0; k <= NIF_ACT_MAXR; ++k) { m[k] = 0.f; g[k] = 0.f; }
+  if (i < po) {
+#pragma unroll
+    for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) m[k] = theta[off_W + (long)k * po + i];
+    m[NIF_ACT_MAXR] = theta[off_b + i];
+  }
+  for (long c0 = a0; c0 < a1; c0 += 256) {
+    __syncthreads();
+    const long a = c0 + threadIdx.x;
+    for (int k = 0; k < r; ++k) zs[k * 256 + threadIdx.x] = a < a1 ? Z[((a >> 5) * r + k) * 32 + (a & 31)] : 0.f;
+    __syncthreads();
+    const int cnt = (int)(a1 - c0 < 256 ? a1 - c0 : 256);
+    for (int q = 0; q < cnt; ++q) {
+      float out = m[NIF_ACT_MAXR];
+#pragma unroll
+      for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) out = fmaf(zs[k * 256 + q], m[k], out);
+      const float d = L1 ? (out > 0.f ? 1.f : (out < 0.f ? -1.f : 0.f)) : 2.0f * out;
+#pragma unroll
+      for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) g[k] = fmaf(d, zs[k * 256 + q], g[k]);
+      g[NIF_ACT_MAXR] += d;
+    }
+  }
+  if (i < po) {
+    float* row = part + (long)blockIdx.y * (r + 1) * po;
+    for (int k = 0; k < r; ++k) row[(long)k * po + i] = g[k];
+    row[(long)r * po + i] = g[NIF_ACT_MAXR];
+  }
+}
+// g[hyper kernel rows | hyper bias] += coef * sum over slabs (fixed order); g[P] += sum of the loss partials
+__global__ __launch_bounds__(256) void k_actreg_apply(const float* __restrict__ part, int nslab, int r, long po, float coef,
+                                                      long off_W, long off_b, const float* __restrict__ loss_partial, int nloss,
+                                                      float* __restrict__ g, long P) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;       // element of [(r+1)][po]
+  if (e < (long)(r + 1) * po) {
+    float s = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) s += part[(long)sl * (r + 1) * po + e];
+    const long k = e / po, i = e - k * po;
+    g[(k < r ? off_W + k * po : off_b) + i] += coef * s;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float red[256];
+    float ls = 0.f;
+    for (int b = threadIdx.x; b < nloss; b += 256) ls += loss_partial[b];
+    red[threadIdx.x] = ls;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) g[P] += red[0];
+  }
+}
+int actreg_max_r() { return NIF_ACT_MAXR; }
+void launch_actreg_points(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, float coef,
+                          float* DZ, float* loss_partial, hipStream_t st) {
+  dim3 grid((unsigned)((B + 255) / 256)), block(256);
+  if (l1) hipLaunchKernelGGL(k_actreg_points<true>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+  else hipLaunchKernelGGL(k_actreg_points<false>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+}
+void launch_actreg_planes(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, int nslab,
+                          float* part, hipStream_t st) {
+  const long slab = ((B + nslab - 1) / nslab + 255) / 256 * 256;
+  dim3 grid((unsigned)((po + 255) / 256), (unsigned)nslab), block(256);
+  if (l1) hipLaunchKernelGGL(k_actreg_planes<true>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+  else hipLaunchKernelGGL(k_actreg_planes<false>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+}
+void launch_actreg_apply(const float* part, int nslab, int r, long po, float coef, long off_W, long off_b, const float* loss_partial,
+                         int nloss, float* g, long P, hipStream_t st) {
+  const long ne = (long)(r + 1) * po;
+  hipLaunchKernelGGL(k_actreg_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, part, nslab, r, po, coef, off_W, off_b,
+                     loss_partial, nloss, g, P);
+}

@@ -13,6 +13,9 @@
 
 #include "nif_ctx.h"
 
+#define NIF_ACT_SLABS 32   // point slabs of the activity regulariser's plane pass
+static inline bool act_on(const nif_ctx* c) { return c->act_l1 != 0.f || c->act_l2 != 0.f; }
+
 #ifndef NIF_PIPE_CHUNK_DEFAULT
 #define NIF_PIPE_CHUNK_DEFAULT 131072L
 #endif
@@ -180,7 +183,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -1056,6 +1059,13 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
     else launch_snet(sa, c->NB, true, sa_st);
   }
+  if (act_on(c)) {   // + c/Bg sum phi'(out) M^(k) into dL/dz, before the ParameterNet adjoint consumes it; its loss partials
+    const long nlp = (B + 255) / 256;
+    if (nlp > c->act_loss_cap) { HIPCHK(hipStreamSynchronize(sa_st)); rc = grow(&c->act_loss, &c->act_loss_cap, nlp); if (rc) return rc; }
+    const bool l1 = c->act_l2 == 0.f;
+    launch_actreg_points(l1, c->theta, c->last_w, c->last_b, c->r, c->po, sa.Z, B, (l1 ? c->act_l1 : c->act_l2) / (float)Bg, sa.DZ,
+                         c->act_loss, sa_st);
+  }
   if (sb_st != sa_st || pb_st != sa_st) {
     HIPCHK(hipEventRecord(c->ev_chunk[chunk_idx], sa_st));
     if (sb_st != sa_st) HIPCHK(hipStreamWaitEvent(sb_st, c->ev_chunk[chunk_idx], 0));
@@ -1145,7 +1155,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
   // Two-stream pipeline over chunks of the batch (plain step on the 16-point-tile kernels): the fused ShapeNet kernel of
   // chunk i+1 (VALU / latency bound, 2 workgroups per CU) overlaps the HBM-bound weight-gradient reductions of chunk i
-  const long chunk = (ns == 0 && c->use_snet3) ? pipe_chunk_points(c, B) : 0;
+  const long chunk = (ns == 0 && c->use_snet3 && !act_on(c)) ? pipe_chunk_points(c, B) : 0;
   if (chunk <= 0 || chunk >= B) {
     int nloss = 0;
     SNetArgs sae;
@@ -1164,6 +1174,14 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
     if (sae.EDGE) launch_reduce_edge(sae, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
+    if (act_on(c)) {   // the plane side of the activity regulariser and its loss, on top of the reduced gradient
+      const long need = (long)NIF_ACT_SLABS * (c->r + 1) * c->po;
+      if (need > c->act_part_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->act_part, &c->act_part_cap, need); if (rc) return rc; }
+      const bool l1 = c->act_l2 == 0.f;
+      launch_actreg_planes(l1, c->theta, c->last_w, c->last_b, c->r, c->po, c->Z, B, NIF_ACT_SLABS, c->act_part, c->st);
+      launch_actreg_apply(c->act_part, NIF_ACT_SLABS, c->r, c->po, (l1 ? c->act_l1 : c->act_l2) / (float)Bg, c->last_w, c->last_b,
+                          c->act_loss, (int)((B + 255) / 256), c->grad, c->P, c->st);
+    }
     HIPCHK(hipGetLastError());
     return NIF_OK;
   }
@@ -1271,6 +1289,15 @@ static void apply_reg(nif_ctx* c) {
 extern "C" int nif_set_regularizer(nif_ctx* c, float l1, float l2, int64_t lo, int64_t hi) {
   if (!c || lo < 0 || hi > c->P || lo > hi || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
   c->reg_l1 = l1; c->reg_l2 = l2; c->reg_lo = lo; c->reg_hi = hi;
+  return NIF_OK;
+}
+// Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)
+extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
+  if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
+  if ((l1 != 0.f || l2 != 0.f) && c->kind == NIF_KIND_LASTLAYER)
+    return fail(NIF_ERR_INVALID, "activity regularisers are built for NIF / NIFMultiScale");
+  if ((l1 != 0.f || l2 != 0.f) && c->r > actreg_max_r()) return fail(NIF_ERR_INVALID, "activity regularisers: latent_dim <= 8");
+  c->act_l1 = l2 != 0.f ? 0.f : l1; c->act_l2 = l2;
   return NIF_OK;
 }
 extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {

@@ -211,6 +211,14 @@ struct LLArgs {
   float* loss_partial;  // [gridDim.x]
 };
 void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
+// activity regulariser of the (virtual) pnet_output (k_misc.hip)
+int actreg_max_r();
+void launch_actreg_points(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, float coef,
+                          float* DZ, float* loss_partial, hipStream_t st);
+void launch_actreg_planes(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, int nslab,
+                          float* part, hipStream_t st);
+void launch_actreg_apply(const float* part, int nslab, int r, long po, float coef, long off_W, long off_b, const float* loss_partial,
+                         int nloss, float* g, long P, hipStream_t st);
 void launch_gather_rows(const float* src, const int* perm, long n, int ncol, float* dst, hipStream_t st);
 void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st);
 void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st);

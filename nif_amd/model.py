@@ -424,9 +424,14 @@ class NIF(object):
         self.p_l2_reg = cfg_parameter_net.get("l2_reg", None)
         self.p_act_l1_reg = cfg_parameter_net.get("act_l1_reg", None)
         self.p_act_l2_reg = cfg_parameter_net.get("act_l2_reg", None)
-        for nm in ("p_jac_reg", "p_act_l1_reg", "p_act_l2_reg"):
-            if isinstance(getattr(self, nm), (float, int)):
-                raise NotImplementedError("cfg_parameter_net regulariser %s is outside the built hot path" % nm)
+        if isinstance(self.p_jac_reg, (float, int)):
+            raise NotImplementedError("cfg_parameter_net['jac_reg'] (JacRegLatentLayer, gradient.py:52-127) is not built")
+        # activity regulariser of the ParameterNet output: L2 wins over L1 (model.py:118-125)
+        self._act_reg = (0.0, 0.0)
+        if isinstance(self.p_act_l2_reg, (float, int)):
+            self._act_reg = (0.0, float(self.p_act_l2_reg))
+        elif isinstance(self.p_act_l1_reg, (float, int)):
+            self._act_reg = (float(self.p_act_l1_reg), 0.0)
         # kernel/bias regularisers of every ParameterNet layer: L2 wins over L1 (model.py:109-117)
         self._reg = (0.0, 0.0)
         if isinstance(self.p_l2_reg, (float, int)):
@@ -451,6 +456,8 @@ class NIF(object):
             if self._reg != (0.0, 0.0):
                 n_pnet = sum(int(np.prod(s)) for nm, s in self._spec.param_shapes() if nm.startswith("pnet_"))
                 self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
+            if self._act_reg != (0.0, 0.0):
+                self.__engine.set_activity_regularizer(*self._act_reg)
         return self.__engine
 
     def call(self, inputs, training=None, mask=None):

@@ -760,10 +760,12 @@ def mse_loss(u, y, sample_weight=None):
     return per.sum() / u.shape[0]
 
 
-def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None):
+def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, act_reg=None):
     """MSE loss and gradient w.r.t. every variable (Keras order), hand-derived adjoint
     (SURVEY a-10).  `batch_global` lets a shard compute its share of a larger batch's
-    mean (loss and grads are scaled by 1/batch_global instead of 1/B)."""
+    mean (loss and grads are scaled by 1/batch_global instead of 1/B).
+    act_reg = (l1, l2): Keras activity_regularizer on the last ParameterNet layer (model.py:118-125, :226): L2 if l2 else L1
+    of the materialised pnet_output, divided by the batch size."""
     B = inputs.shape[0]
     Bg = B if batch_global is None else batch_global
     p = inputs[:, :spec.pi]
@@ -787,6 +789,14 @@ def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None):
         g_pnet = pnet_backward(spec, ws, ptape, g_pout)
         return loss, g_pnet + g_snet + [g_bias]
     g_pout = shapenet_given_w_backward(spec, tape, g_u)
+    if act_reg is not None and (act_reg[0] or act_reg[1]):
+        l1, l2 = act_reg
+        if l2:
+            loss = loss + l2 * (pout ** 2).sum() / Bg
+            g_pout = g_pout + 2.0 * l2 * pout / Bg
+        else:
+            loss = loss + l1 * np.abs(pout).sum() / Bg
+            g_pout = g_pout + l1 * np.sign(pout) / Bg
     return loss, pnet_backward(spec, ws, ptape, g_pout)
 
 

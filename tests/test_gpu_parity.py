@@ -839,3 +839,45 @@ def test_hessian_layer_matches_oracle(name):
     # parameter columns / the last-layer class are refused loudly
     with pytest.raises(nif_amd._lib.NifError):
         nif_amd.HessianLayer(model, yi, [0])(x)
+
+
+# ---- activity regularisers of the ParameterNet output (N3; reference model.py:118-125, :226, :659, :731) -----------------------
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_32x2_r7_si3"])
+@pytest.mark.parametrize("which", ["act_l2_reg", "act_l1_reg"])
+def test_activity_regularisers_match_oracle(name, which):
+    """loss += c/B sum phi(pnet_output) on the never materialised [B, po] tensor (two recompute passes, k_actreg_*) against
+    the oracle's materialised formulation; L2 wins over L1 when both are given; fit() trains with it"""
+    import nif_amd
+    (kind, cs, cp), B = CONFIGS[name]
+    B = min(B, 600)
+    val = 3e-3 if which == "act_l2_reg" else 2e-4
+    cp2 = dict(cp); cp2[which] = val
+    if which == "act_l2_reg":
+        cp2["act_l1_reg"] = 7.0      # ignored: L2 takes precedence (model.py:120-123)
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    m = getattr(nif_amd, kind)(cs, cp2)
+    model = m.build(); model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    act = (0.0, val) if which == "act_l2_reg" else (val, 0.0)
+    loss, g = m._engine.loss_and_grad(x, y, sw)
+    lr, gr = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64), act_reg=act)
+    l0, g0 = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
+    assert abs(lr - l0) > 1e-4 * abs(l0)                      # the term is visible
+    assert abs(loss - lr) <= 1e-5 * abs(lr), (loss, lr, l0)
+    rel = _per_tensor_rel(spec, g, O.flatten(gr))
+    assert max(rel.values()) < 3e-4, rel
+    # a shard of a larger batch (what a rank computes): scaled by 1/B_global
+    d_x, d_y = m._engine.alloc(x.size), m._engine.alloc(y.size)
+    d_x.upload(x); d_y.upload(y)
+    m._engine.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, 3 * B)
+    l3, g3 = m._engine.grad_read()
+    lr3, gr3 = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64), None, batch_global=3 * B, act_reg=act)
+    assert abs(l3 - lr3) <= 1e-5 * abs(lr3) and _rel(g3, O.flatten(gr3)) < 2e-4
+    model.compile(nif_amd.Adam(1e-3), "mse")
+    h = model.fit(x, y, epochs=2, batch_size=256, shuffle=False, verbose=0)
+    assert np.isfinite(h.history["loss"]).all()
