@@ -207,6 +207,11 @@ int nif_train_step(nif_ctx* ctx, const float* xin_host, const float* y_host, con
  * every ParameterNet kernel and bias): loss += l2*sum(w^2) + l1*sum(|w|) over theta[lo, hi); the gradient
  * term is added once, after the cross-rank all-reduce, inside nif_adam_step_dev / nif_loss_and_grad. */
 int nif_set_regularizer(nif_ctx* ctx, float l1, float l2, int64_t lo, int64_t hi);
+/* Latent Jacobian regulariser cfg_parameter_net["jac_reg"] (nif/model.py:353-375 wraps the model in JacRegLatentLayer,
+ * nif/layers/gradient.py:52-127): loss += l1 * mean_{a,c,d} (d latent_c / d parameter_d)^2, differentiated through the
+ * Jacobian: forward tangents of the ParameterNet + their adjoint (k_pjac), weight gradients by the batch GEMM kernels over
+ * tangent pseudo-tiles.  NIF / NIFMultiScale; units <= 64, <= 4 hidden matrices, <= 3 parameter inputs. */
+int nif_set_jac_regularizer(nif_ctx* ctx, float l1);
 /* Activity regulariser of cfg_parameter_net["act_l1_reg"/"act_l2_reg"] (nif/model.py:118-125: Keras activity_regularizer
  * L2(l2) or else L1(l1) on the last ParameterNet layer, :226, :659, :731): loss += c / B * sum_a sum_i phi(pnet_out[a, i]),
  * phi = (.)^2 or |.|, Keras dividing the activity loss by the batch size.  pnet_out [B, po] is never materialised: two

@@ -107,6 +107,7 @@ SIGNATURES = {
     "nif_loss_and_grad": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, _FP, _VP]),
     "nif_train_step": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.POINTER(nif_adam), _FP]),
     "nif_set_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float, C.c_int64, C.c_int64]),
+    "nif_set_jac_regularizer": (C.c_int, [_CTX, C.c_float]),
     "nif_set_activity_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float]),
     "nif_metric_accumulate": (C.c_int, [_CTX, C.c_float]),
     "nif_metric_read": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),

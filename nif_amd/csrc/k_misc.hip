@@ -561,3 +561,13 @@ void launch_actreg_apply(const float* part, int nslab, int r, long po, float coe
   hipLaunchKernelGGL(k_actreg_apply, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, part, nslab, r, po, coef, off_W, off_b,
                      loss_partial, nloss, g, P);
 }
+
+// g[0..ncols) += tmp[0..ncols) ,  g[P] += tmp[ncols]   (a side pass's reduced columns and loss on top of the main gradient)
+__global__ void k_axpy_cols(float* __restrict__ g, const float* __restrict__ tmp, long ncols, long P) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncols) g[i] += tmp[i];
+  else if (i == ncols) g[P] += tmp[ncols];
+}
+void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st) {
+  hipLaunchKernelGGL(k_axpy_cols, dim3((unsigned)((ncols + 1 + 255) / 256)), dim3(256), 0, st, g, tmp, ncols, P);
+}

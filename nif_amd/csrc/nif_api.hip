@@ -15,6 +15,7 @@
 
 #define NIF_ACT_SLABS 32   // point slabs of the activity regulariser's plane pass
 static inline bool act_on(const nif_ctx* c) { return c->act_l1 != 0.f || c->act_l2 != 0.f; }
+static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg);
 
 #ifndef NIF_PIPE_CHUNK_DEFAULT
 #define NIF_PIPE_CHUNK_DEFAULT 131072L
@@ -183,7 +184,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -1155,7 +1156,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
   // Two-stream pipeline over chunks of the batch (plain step on the 16-point-tile kernels): the fused ShapeNet kernel of
   // chunk i+1 (VALU / latency bound, 2 workgroups per CU) overlaps the HBM-bound weight-gradient reductions of chunk i
-  const long chunk = (ns == 0 && c->use_snet3 && !act_on(c)) ? pipe_chunk_points(c, B) : 0;
+  const long chunk = (ns == 0 && c->use_snet3 && !act_on(c) && c->jac_l1 == 0.f) ? pipe_chunk_points(c, B) : 0;
   if (chunk <= 0 || chunk >= B) {
     int nloss = 0;
     SNetArgs sae;
@@ -1182,6 +1183,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
       launch_actreg_apply(c->act_part, NIF_ACT_SLABS, c->r, c->po, (l1 ? c->act_l1 : c->act_l2) / (float)Bg, c->last_w, c->last_b,
                           c->act_loss, (int)((B + 255) / 256), c->grad, c->P, c->st);
     }
+    if (c->jac_l1 != 0.f) { rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
     HIPCHK(hipGetLastError());
     return NIF_OK;
   }
@@ -1291,6 +1293,63 @@ extern "C" int nif_set_regularizer(nif_ctx* c, float l1, float l2, int64_t lo, i
   c->reg_l1 = l1; c->reg_l2 = l2; c->reg_lo = lo; c->reg_hi = hi;
   return NIF_OK;
 }
+// cfg_parameter_net["jac_reg"] (nif/model.py:353-375 -> JacRegLatentLayer, nif/layers/gradient.py:52-127)
+extern "C" int nif_set_jac_regularizer(nif_ctx* c, float l1) {
+  if (!c || l1 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
+  if (l1 != 0.f) {
+    if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "jac_reg is built for NIF / NIFMultiScale");
+    PNetArgs pa; fill_pnet(c, pa, nullptr, 32);
+    if (!pjac_supported(pa)) return fail(NIF_ERR_INVALID, "jac_reg: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+  }
+  c->jac_l1 = l1;
+  return NIF_OK;
+}
+// The regulariser's own pass, on top of the reduced main gradient: loss += l1 mean (dz/dp)^2 and its gradient w.r.t. the
+// ParameterNet's first / hidden / bottleneck variables (the hyper layer is downstream of z and does not see it).
+static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg) {
+  const int pi = c->pi;
+  const long ntiles = (B + 31) / 32;
+  int rc = ensure_capacity(c, ntiles * 32 * (1 + pi), true); if (rc) return rc;
+  const long need_mu = (long)(1 + pi) * ntiles * 32 * c->r;
+  if (need_mu > c->jac_mu_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->jac_mu, &c->jac_mu_cap, need_mu); if (rc) return rc; }
+  if (!c->jac_tmp) HIPCHK(hipMalloc(&c->jac_tmp, sizeof(float) * (size_t)(c->P + 2)));
+  const long nlp = (B + 127) / 128;
+  if (nlp > c->act_loss_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->act_loss, &c->act_loss_cap, nlp); if (rc) return rc; }
+  PNetArgs pa; fill_pnet(c, pa, xin, B);
+  const float coef = c->jac_l1 / ((float)Bg * (float)c->r * (float)pi);
+  const int nloss = launch_pjac(pa, coef, c->jac_mu, c->act_loss, c->st);
+  const long nt_all = ntiles * (1 + pi);
+  const int rows = rows_for(c, nt_all);
+  GwArgs g;
+  auto base = [&](GwArgs& q) {
+    memset(&q, 0, sizeof(q));
+    q.ntiles = nt_all; q.zt_mod = ntiles; q.bias_ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride;
+    q.has_bias = 1; q.scale = 1.0f; q.r = 0;
+    for (int d = 0; d < 3; ++d) q.seed[d] = d < pi ? d : 0;
+  };
+  float* pST = c->stash_p;
+  const int ncol = c->pi + c->si;
+  base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = pi; g.scale = pa.omega;
+  g.W = dense_ref(c->first_w, pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
+  launch_gw_first(g, c->NSTB, rows, c->st);
+  for (int mi = 0; mi < c->nm; ++mi) {
+    base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.scale = pa.omega;
+    long w_off, b_off;
+    if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
+    else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
+    g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
+    launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
+  }
+  base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->jac_mu; g.nc = c->r; g.scale = 1.0f;
+  g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
+  launch_gw_out(g, c->NSTB, rows, c->st);
+  // the ParameterNet core variables are the first last_w columns of a partial row; column last_w of the result = the loss term
+  launch_reduce(c->partial, c->pstride, rows, c->act_loss, nloss, c->jac_tmp, c->last_w, c->st);
+  launch_axpy_cols(c->grad, c->jac_tmp, c->last_w, c->P, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+
 // Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)
 extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
   if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");

@@ -211,6 +211,10 @@ struct LLArgs {
   float* loss_partial;  // [gridDim.x]
 };
 void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
+// latent Jacobian regulariser (k_pjac.hip): tangents of the ParameterNet + their adjoint; operand pairs into the stash
+bool pjac_supported(const PNetArgs& a);
+int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st);
+void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st);
 // activity regulariser of the (virtual) pnet_output (k_misc.hip)
 int actreg_max_r();
 void launch_actreg_points(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, float coef,

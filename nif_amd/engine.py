@@ -345,6 +345,9 @@ class Engine(object):
     def set_regularizer(self, l1, l2, lo, hi):
         check(self.lib.nif_set_regularizer(self.ctx, float(l1), float(l2), int(lo), int(hi)))
 
+    def set_jac_regularizer(self, l1):
+        check(self.lib.nif_set_jac_regularizer(self.ctx, float(l1)))
+
     def set_activity_regularizer(self, l1, l2):
         check(self.lib.nif_set_activity_regularizer(self.ctx, float(l1), float(l2)))
 

@@ -424,8 +424,8 @@ class NIF(object):
         self.p_l2_reg = cfg_parameter_net.get("l2_reg", None)
         self.p_act_l1_reg = cfg_parameter_net.get("act_l1_reg", None)
         self.p_act_l2_reg = cfg_parameter_net.get("act_l2_reg", None)
-        if isinstance(self.p_jac_reg, (float, int)):
-            raise NotImplementedError("cfg_parameter_net['jac_reg'] (JacRegLatentLayer, gradient.py:52-127) is not built")
+        if isinstance(self.p_jac_reg, (float, int)) and self._KIND == "NIFMultiScaleLastLayerParameterized":
+            raise NotImplementedError("cfg_parameter_net['jac_reg'] is built for NIF / NIFMultiScale")
         # activity regulariser of the ParameterNet output: L2 wins over L1 (model.py:118-125)
         self._act_reg = (0.0, 0.0)
         if isinstance(self.p_act_l2_reg, (float, int)):
@@ -458,6 +458,8 @@ class NIF(object):
                 self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
             if self._act_reg != (0.0, 0.0):
                 self.__engine.set_activity_regularizer(*self._act_reg)
+            if isinstance(self.p_jac_reg, (float, int)) and self.p_jac_reg:
+                self.__engine.set_jac_regularizer(self.p_jac_reg)     # build() of the reference wraps the model (model.py:353-375)
         return self.__engine
 
     def call(self, inputs, training=None, mask=None):
@@ -465,7 +467,8 @@ class NIF(object):
         return self._engine.forward(inputs)
 
     def build(self):
-        """model.py:345-377 (the jac_reg branch is outside the hot path and rejected in __init__)."""
+        """model.py:345-377: with cfg_parameter_net['jac_reg'] the reference returns the model wrapped in JacRegLatentLayer
+        (same outputs, + l1 * mean((d latent / d parameter)^2) in the loss); here the engine carries the term."""
         return self.model()
 
     def model(self):

@@ -974,6 +974,94 @@ def jacobian_analytic(spec, ws, inputs, y_index, x_index):
     return u, J
 
 
+def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
+    """cfg_parameter_net["jac_reg"] (model.py:353-375 -> JacRegLatentLayer, gradient.py:52-127, :182-205):
+    loss = l1 * mean_{a,c,d} (d z_c / d p_d)^2 with z the latent, and its gradient w.r.t. every variable (Keras order; zero
+    for the layers downstream of z).  Forward-mode tangents of the ParameterNet + the hand-derived adjoint of the (primal,
+    tangent) program: nu_d = mu_d f'(a), da = lambda f'(a) + sum_d mu_d f''(a) a'_d, dW = s (h^T da + sum_d h'_d^T nu_d).
+    Pinned by torch double-backward in tests/test_oracle.py."""
+    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    B, pi = p.shape
+    Bg = B if batch_global is None else batch_global
+    siren = spec.p_siren
+    s = spec.omega_p if siren else 1.0
+    name = "sine" if siren else spec.p_act
+    f, df = act_fn(name)
+    d2f = act_d2(name)
+    D = range(pi)
+    # forward
+    a0 = s * (p @ first[0]) + first[1]
+    a0d = [np.broadcast_to(s * first[0][d], a0.shape) for d in D]
+    h = f(a0); hd = [df(a0) * a0d[d] for d in D]
+    tape = []
+    for lay in hidden:
+        if not spec.p_res:
+            a = s * (h @ lay[0]) + lay[1]; ad = [s * (hd[d] @ lay[0]) for d in D]
+            tape.append(("plain", h, hd, a, ad))
+            if siren:
+                h, hd = f(a), [df(a) * ad[d] for d in D]
+            else:
+                h, hd = h + f(a), [hd[d] + df(a) * ad[d] for d in D]
+        else:
+            a1 = s * (h @ lay[0]) + lay[1]; a1d = [s * (hd[d] @ lay[0]) for d in D]
+            t = f(a1); td = [df(a1) * a1d[d] for d in D]
+            a2 = s * (t @ lay[2]) + lay[3]; a2d = [s * (td[d] @ lay[2]) for d in D]
+            if not siren:
+                a2 = a2 + h; a2d = [a2d[d] + hd[d] for d in D]
+            tape.append(("res", h, hd, a1, a1d, t, td, a2, a2d))
+            if siren:
+                h, hd = 0.5 * (h + f(a2)), [0.5 * (hd[d] + df(a2) * a2d[d]) for d in D]
+            else:
+                h, hd = f(a2), [df(a2) * a2d[d] for d in D]
+    zd = [hd[d] @ bott[0] for d in D]                       # [B, r] each
+    coef = l1 / (Bg * spec.r * pi)
+    loss = coef * sum((zd[d] ** 2).sum() for d in D)
+    # adjoint
+    muz = [2.0 * coef * zd[d] for d in D]
+    g_bott = [sum(hd[d].T @ muz[d] for d in D), np.zeros_like(bott[1])]
+    lam = np.zeros_like(h); mu = [muz[d] @ bott[0].T for d in D]
+
+    def adj(a, ad, lam_, mu_, scale=1.0):
+        da = scale * lam_ * df(a)
+        for d in D:
+            da = da + scale * mu_[d] * d2f(a) * ad[d]
+        return da, [scale * mu_[d] * df(a) for d in D]
+    g_hidden = []
+    for lay, rec in zip(reversed(hidden), reversed(tape)):
+        if rec[0] == "plain":
+            _, hin, hind, a, ad = rec
+            da, nu = adj(a, ad, lam, mu)
+            gw = s * (hin.T @ da + sum(hind[d].T @ nu[d] for d in D))
+            g_hidden.append([gw, da.sum(0)])
+            keep = 0.0 if siren else 1.0
+            lam = keep * lam + s * (da @ lay[0].T)
+            mu = [keep * mu[d] + s * (nu[d] @ lay[0].T) for d in D]
+        else:
+            _, hin, hind, a1, a1d, t, td, a2, a2d = rec
+            if siren:
+                da2, nu2 = adj(a2, a2d, lam, mu, 0.5)
+                lam_h, mu_h = 0.5 * lam, [0.5 * mu[d] for d in D]
+            else:
+                da2, nu2 = adj(a2, a2d, lam, mu)
+                lam_h, mu_h = da2, list(nu2)
+            gw2 = s * (t.T @ da2 + sum(td[d].T @ nu2[d] for d in D))
+            lt = s * (da2 @ lay[2].T); mt = [s * (nu2[d] @ lay[2].T) for d in D]
+            da1, nu1 = adj(a1, a1d, lt, mt)
+            gw1 = s * (hin.T @ da1 + sum(hind[d].T @ nu1[d] for d in D))
+            g_hidden.append([gw1, da1.sum(0), gw2, da2.sum(0)])
+            lam = lam_h + s * (da1 @ lay[0].T)
+            mu = [mu_h[d] + s * (nu1[d] @ lay[0].T) for d in D]
+    da0, nu0 = adj(a0, a0d, lam, mu)
+    gw0 = s * (p.T @ da0)
+    for d in D:
+        gw0[d] = gw0[d] + s * nu0[d].sum(0)
+    grads = [gw0, da0.sum(0)]
+    for g in reversed(g_hidden):
+        grads += g
+    grads += g_bott + [np.zeros_like(last[0]), np.zeros_like(last[1])] + [np.zeros_like(w) for w in rest]
+    return loss, grads
+
+
 def act_d2(name):
     """f'' for a Keras activation name / 'sine'"""
     if name in (None, "linear", "relu"):

@@ -881,3 +881,54 @@ def test_activity_regularisers_match_oracle(name, which):
     model.compile(nif_amd.Adam(1e-3), "mse")
     h = model.fit(x, y, epochs=2, batch_size=256, shuffle=False, verbose=0)
     assert np.isfinite(h.history["loss"]).all()
+
+
+# ---- latent Jacobian regulariser (N3; reference model.py:353-375, gradient.py:52-127) ------------------------------------------
+JAC = {
+    "nif_swish_pi2": _cfg("NIF", 32, 2, 32, 2, 2, 1, 1, 2),
+    "ms_siren_pnet": _cfg("NIFMultiScale", 64, 2, 32, 2, 1, 1, 1, 1),
+    "ms_siren_res_pnet_r3": _cfg("NIFMultiScale", 32, 1, 40, 2, 3, 2, 1, 2, p_res=True),
+    "ms_mlp_res_pnet": _cfg("NIFMultiScale", 32, 1, 24, 1, 2, 1, 2, 3, p_act="tanh", p_res=True),
+    "ms_mlp_short_pnet_64": _cfg("NIFMultiScale", 32, 2, 64, 3, 2, 2, 1, 1, p_act="swish"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(JAC))
+def test_jac_reg_matches_oracle(name):
+    """cfg_parameter_net['jac_reg']: loss and every gradient tensor = main step + the oracle's regulariser term (itself
+    pinned by torch double-backward, tests/test_oracle.py); all four ParameterNet layer types; ragged batch"""
+    import nif_amd
+    kind, cs, cp = JAC[name]
+    l1 = 0.05
+    cp2 = dict(cp, jac_reg=l1)
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    m = getattr(nif_amd, kind)(cs, cp2)
+    model = m.build(); model.set_weights(ws)
+    ws64 = [w.astype(np.float64) for w in ws]
+    for B, bg in ((333, 333), (64, 200)):
+        x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+        y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+        d_x, d_y = m._engine.alloc(x.size), m._engine.alloc(y.size)
+        d_x.upload(x); d_y.upload(y)
+        m._engine.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, bg)
+        loss, g = m._engine.grad_read()
+        x64 = x.astype(np.float64)
+        l0, g0 = O.loss_and_grad(spec, ws64, x64, y.astype(np.float64), batch_global=bg)
+        lj, gj = O.jac_reg_loss_and_grad(spec, ws64, x64[:, :spec.pi], l1, batch_global=bg)
+        assert lj > 1e-6 * l0
+        assert abs(loss - (l0 + lj)) <= 1e-5 * (l0 + lj), (loss, l0, lj)
+        ref = O.flatten(g0) + O.flatten(gj)
+        rel = _per_tensor_rel(spec, g, ref)
+        assert max(rel.values()) < 3e-4, rel
+        # the regulariser's own part, isolated: gradient(with) - gradient(without) against the oracle's term
+        m._engine.set_jac_regularizer(0.0)
+        m._engine.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, bg)
+        lw, gw = m._engine.grad_read()
+        m._engine.set_jac_regularizer(l1)
+        dj = (g.astype(np.float64) - gw)[:spec.n_params()]
+        npn = sum(int(np.prod(s_)) for nm, s_ in spec.param_shapes() if nm.startswith("pnet_") and not nm.startswith("pnet_last"))
+        assert _rel(dj[:npn], O.flatten(gj)[:npn]) < 2e-3 and abs((loss - lw) - lj) < 2e-4 * lj + 1e-7 * l0
+    model.compile(nif_amd.Adam(1e-3), "mse")
+    assert np.isfinite(model.fit(x, y, epochs=2, batch_size=32, verbose=0).history["loss"]).all()

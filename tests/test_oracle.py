@@ -212,3 +212,23 @@ def test_hessian_analytic_vs_fd_of_the_jacobian_and_torch(name):
         assert np.allclose(H[:, :, :, kk], fd, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(H).max())), (name, kk)   # FD truncation (w0 = 30)
     tH = T.hessian(kind, cs, cp, ws, inputs)            # [B, so, ncol, ncol] over all input columns
     assert np.allclose(H, tH[:, :, xi][:, :, :, xi], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(H).max()))
+
+
+@pytest.mark.parametrize("name", ["nif_swish", "nif_tanh_r2_so2", "ms_plain", "ms_plain_r3_si2", "ms_res_pres", "ms_mlp_pnet", "ms_mlp_pres"])
+def test_jac_reg_matches_torch_double_backward(name):
+    """latent Jacobian regulariser: the oracle's tangent + adjoint program against torch autograd through the Jacobian,
+    for every ParameterNet layer type (Dense+shortcut, MLP_ResNet, SIREN, SIREN_ResNet)"""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=6)
+    p = inputs[:, :spec.pi]
+    loss, grads = O.jac_reg_loss_and_grad(spec, ws, p, 0.7)
+    tl, tg = T.jac_reg_loss_and_grad(kind, cs, cp, ws, p, 0.7)
+    assert abs(loss - tl) <= 1e-12 * max(1.0, abs(tl)) and loss > 0
+    for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
+        if t is None:
+            assert not np.any(g), nm          # downstream of the latent
+        else:
+            assert np.abs(g - t).max() <= 1e-9 * max(np.abs(t).max(), 1e-30), nm
+    l2, g2 = O.jac_reg_loss_and_grad(spec, ws, p, 0.7, batch_global=18)
+    assert abs(l2 - loss / 3) < 1e-15 * max(1.0, loss)

@@ -169,3 +169,53 @@ def hessian(kind, cs, cp, ws_np, inputs_np):
             h, = torch.autograd.grad(g[:, j].sum(), inputs, retain_graph=True)
             out[:, i, j, :] = h
     return out.detach().numpy()
+
+
+def latent(kind, cs, cp, ws, p):
+    """the ParameterNet up to the bottleneck: p [B, pi] -> z [B, r] (same tensor program as forward())"""
+    lst = cp["nlayers"]
+    it = iter(ws)
+    ms = kind != "NIF"
+    p_siren = ms and cp["activation"] == "sine"
+    p_res = ms and cp.get("use_resblock", False)
+    if p_siren:
+        om = cp["omega_0"]
+        w, b = next(it), next(it)
+        h = torch.sin(om * (p @ w) + b)
+        for _ in range(lst):
+            if p_res:
+                w, b, w2, b2 = next(it), next(it), next(it), next(it)
+                t = torch.sin(om * (h @ w) + b)
+                h = 0.5 * (h + torch.sin(om * (t @ w2) + b2))
+            else:
+                w, b = next(it), next(it)
+                h = torch.sin(om * (h @ w) + b)
+    else:
+        f = _act(cp["activation"])
+        w, b = next(it), next(it)
+        h = f(p @ w + b)
+        for _ in range(lst):
+            if p_res:
+                w, b, w2, b2 = next(it), next(it), next(it), next(it)
+                h = f(h + (f(h @ w + b) @ w2 + b2))
+            else:
+                w, b = next(it), next(it)
+                h = h + f(h @ w + b)
+    w, b = next(it), next(it)
+    return h @ w + b
+
+
+def jac_reg_loss_and_grad(kind, cs, cp, ws_np, p_np, l1):
+    """JacRegLatentLayer (gradient.py:52-127): l1 * reduce_mean(square(d latent / d p)), differentiated through the inner
+    Jacobian like Keras does"""
+    ws = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws_np]
+    p = torch.tensor(p_np, dtype=torch.float64, requires_grad=True)
+    z = latent(kind, cs, cp, ws, p)
+    rows = []
+    for c in range(z.shape[1]):
+        g, = torch.autograd.grad(z[:, c].sum(), p, create_graph=True)
+        rows.append(g)
+    J = torch.stack(rows, 1)                  # [B, r, pi]
+    loss = l1 * (J ** 2).mean()
+    grads = torch.autograd.grad(loss, ws, allow_unused=True)
+    return loss.item(), [g.numpy() if g is not None else None for g in grads]
