@@ -190,43 +190,70 @@ void launch_given_w(const float* x, const float* w, float* u, long B, int si, in
 // model_lr_to_w: w[a][s] = sum_k lr[a][k] Wh[k][s] + bh[s]   (siren.py:514-522 / Dense model.py:220-230)
 // write-bound (4*po bytes per point); each block keeps a slab of Wh rows in registers across points
 // ============================================================================================
+// A thread owns the 16-byte ALIGNED window of 4 output floats number blockIdx.x*256 + threadIdx.x of every row it visits.
+// Rows of w start at a * po floats and po is odd, so the window's first slot is s0 = 4 t - m with m = (a * po) mod 4 the
+// (wave-uniform) misalignment of row a: the thread keeps the 7 slots 4t-3 .. 4t+3 of the bias and of the first hyper row in
+// registers and picks its 4 by m.  Every store is one aligned dwordx4 (a wave writes 1 KiB of whole cache lines); with
+// row-relative windows (the r1 kernel) each lane's 16 bytes straddled a 16-byte boundary: 3.7 TB/s.
+template <int M>
+__device__ __forceinline__ void l2w_row(const float* __restrict__ theta, long off_Wh, int r, long po, const float* __restrict__ lrow,
+                                        const float (&bias)[7], const float (&w0)[7], long t4, float* __restrict__ wrow) {
+  const long s0 = t4 - M;                       // first slot of the window (may be negative / run past po at the row ends)
+  float acc[4];
+  const float z0 = lrow[0];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = fmaf(z0, w0[c + 3 - M], bias[c + 3 - M]);
+  for (int k = 1; k < r; ++k) {
+    const float zk = lrow[k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long sc = s0 + c;
+      if (sc >= 0 && sc < po) acc[c] = fmaf(zk, theta[off_Wh + (long)k * po + sc], acc[c]);
+    }
+  }
+  float* dst = wrow + s0;                       // (a * po + s0) * 4 bytes is a multiple of 16 by construction
+  if (s0 >= 0 && s0 + 4 <= po) {
+    f32x4 v; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
+#ifdef NIF_L2W_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
+    *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (s0 + c >= 0 && s0 + c < po) dst[c] = acc[c];
+  }
+}
 __global__ __launch_bounds__(256) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
                                                      long po, const float* __restrict__ lr, long B,
                                                      float* __restrict__ w) {
-  // a thread owns 4 consecutive slots (16-byte stores; rows of w are only 4-byte aligned since po is odd) and
-  // keeps its bias / first hyper rows in registers while it walks the points of its grid.y stripe
-  const long s0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (s0 >= po) return;
-  const int nv = (int)(po - s0 < 4 ? po - s0 : 4);
-  float bias[4], w0[4];
+  const long t4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t4 - 3 >= po) return;
+  float bias[7], w0[7];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    bias[c] = c < nv ? theta[off_bh + s0 + c] : 0.f;
-    w0[c] = c < nv ? theta[off_Wh + s0 + c] : 0.f;
+  for (int c = 0; c < 7; ++c) {
+    const long sc = t4 - 3 + c;
+    const bool in = sc >= 0 && sc < po;
+    bias[c] = in ? theta[off_bh + sc] : 0.f;
+    w0[c] = in ? theta[off_Wh + sc] : 0.f;
   }
+  const int wmis = (int)((reinterpret_cast<size_t>(w) >> 2) & 3);       // misalignment of the buffer itself (floats)
   for (long a = blockIdx.y; a < B; a += gridDim.y) {
-    float acc[4];
-    const float z0 = lr[a * r];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = fmaf(z0, w0[c], bias[c]);
-    for (int k = 1; k < r; ++k) {
-      const float zk = lr[a * r + k];
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < nv) acc[c] = fmaf(zk, theta[off_Wh + (long)k * po + s0 + c], acc[c]);
-    }
-    float* dst = w + a * po + s0;
-    if (nv == 4) {
-      f32x4u v; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
-      *reinterpret_cast<f32x4u*>(dst) = v;
-    } else {
-      for (int c = 0; c < nv; ++c) dst[c] = acc[c];
+    const int m = (int)((a * po + wmis) & 3);
+    const float* lrow = lr + a * r;
+    float* wrow = w + a * po;
+    switch (m) {
+      case 0: l2w_row<0>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
+      case 1: l2w_row<1>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
+      case 2: l2w_row<2>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
+      default: l2w_row<3>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
     }
   }
 }
 void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B, float* w,
                         hipStream_t st) {
-  dim3 grid((unsigned)((po + 1023) / 1024), (unsigned)(B < 2048 ? B : 2048)), block(256);
+  dim3 grid((unsigned)((po + 3 + 1023) / 1024), (unsigned)(B < 2048 ? B : 2048)), block(256);
   hipLaunchKernelGGL(k_latent_to_w, grid, block, 0, st, theta, off_Wh, off_bh, r, po, lr, B, w);
 }
 
