@@ -461,11 +461,16 @@ static GwArgs gw_fix(const GwArgs& in) {
 #ifndef NIF_GW_WAVES
 #define NIF_GW_WAVES 4   // 8 = two waves per SIMD, single-buffered: spills at 256 registers, slower
 #endif
+bool gw8_supported(const GwArgs& a, int NBI, int NBO);
+void launch_gw8(const GwArgs& a, int rows, hipStream_t st);
 void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
   constexpr int WV = NIF_GW_WAVES;
   dim3 block(64 * WV);
   static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
+  // 128-wide layers: the 8-wave shared-tile kernel reads every stash tile once (k_gw8.hip); NIF_GW8=0: the r1 kernels (A/B)
+  static const bool use_gw8 = [] { const char* e = getenv("NIF_GW8"); return !(e && e[0] == '0'); }();
+  if (use_gw8 && gw8_supported(a, NBI, NBO)) { launch_gw8(a, rows, st); return; }
   if (use_lds && NBI == NBO && (NBI <= 2 || NBI == 4)) {
 #define NIF_GWL(NBI_, OBC_, NBUF_)                                                                                         \
   do {                                                                                                                     \
