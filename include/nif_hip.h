@@ -183,7 +183,7 @@ int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, co
  * differentiates THROUGH the Jacobian).  loss = mse(u, y) + w_jac * mse(du/dx, dydx) with
  * dydx [B, so, nx]; x_idx are input-vector columns and must be coordinate columns (1..3 of them).  Built as
  * forward tangents + their hand-derived adjoint in one kernel (k_sob.hip) for NIFMultiScale (with or without
- * resblocks).  Same conventions as nif_loss_grad_dev (result in nif_grad_dev(), scaled by 1/B_global). */
+ * resblocks) and class NIF (any activation, skip connections).  Same conventions as nif_loss_grad_dev (result in nif_grad_dev(), scaled by 1/B_global). */
 int nif_sobolev_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
                               const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,
                               int32_t nx, float w_jac);

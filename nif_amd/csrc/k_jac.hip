@@ -29,22 +29,6 @@ struct JacArgs {
   int hj, hk; float* d2ydx2;
 };
 
-// second derivative of the activation (HessianLayer): f''(a)
-template <int ACT>
-__device__ __forceinline__ float act_d2(int act, float a) {
-  const int id = ACT >= 0 ? ACT : act;
-  switch (id) {
-    case ACT_SINE: { float s, c; nif_sincosf(a, &s, &c); return -s; }
-    case ACT_SWISH: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (2.0f + a * (1.0f - 2.0f * s)); }
-    case ACT_TANH: { const float t = tanhf(a); return -2.0f * t * (1.0f - t * t); }
-    case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (1.0f - 2.0f * s); }
-    case ACT_ELU: return a > 0.f ? 0.f : expf(a);
-    case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s); }
-    case ACT_GELU: return 0.3989422804014327f * expf(-0.5f * a * a) * (2.0f - a * a);
-    default: return 0.f;   // linear, relu
-  }
-}
-
 // HESS (HessianLayer, gradient.py:130-180, :234-261): streams 0 and 1 are the first-order tangents of two coordinate seeds
 // (j, k), stream 2 is the SECOND-order tangent of the pair:  a'' = w0 W(a) h'' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k  (the
 // first layer is linear in x: a'' = 0); it leaves through the linear last layer like a first-order tangent

@@ -147,6 +147,23 @@ __device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)
   }
 }
 
+// second derivative of the activation (HessianLayer): f''(a)
+template <int ACT>
+__device__ __forceinline__ float act_d2(int act, float a) {
+  const int id = ACT >= 0 ? ACT : act;
+  switch (id) {
+    case ACT_SINE: { float s, c; nif_sincosf(a, &s, &c); return -s; }
+    case ACT_SWISH: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (2.0f + a * (1.0f - 2.0f * s)); }
+    case ACT_TANH: { const float t = tanhf(a); return -2.0f * t * (1.0f - t * t); }
+    case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s) * (1.0f - 2.0f * s); }
+    case ACT_ELU: return a > 0.f ? 0.f : expf(a);
+    case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s); }
+    case ACT_GELU: return 0.3989422804014327f * expf(-0.5f * a * a) * (2.0f - a * a);
+    default: return 0.f;   // linear, relu
+  }
+}
+
+
 // ---- fp32 products as exact bf16 splits (k_snet4.hip has the derivation and the measured accuracy) ---------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

@@ -9,7 +9,8 @@
 //     dL/dM^(k) = w0 sum_p zt_k (h_in da^T + sum_d h'_in^d nu^dT)   -> the weight-gradient GEMMs simply see
 //                 (1+ns) x more "points": the tangent pairs are stashed as pseudo-tiles
 //     dL/dz_k  += w0 <h_in, M^(k) da> + <da, b^(k)> + w0 sum_d <h'_in^d, M^(k) nu^d>
-// Coordinate seeds only (spatial derivatives); NIFMultiScale with or without resblocks.
+// Coordinate seeds only (spatial derivatives); NIFMultiScale with or without resblocks and class NIF
+// (MODE 2: any Keras activation f with skip connections; the ring then holds c = f'(a) and -f''(a) in place of cos / sin).
 #include "k_snet3_dev.h"
 
 #define NIF_SOB_MAXSEED 3
@@ -32,6 +33,23 @@ struct SobArgs {
 // SGN (plain SIREN, training): the ring keeps only the tangent pre-activations a'^d of the ACTIVE seeds; cos(a) is
 // rebuilt from the stashed sin(a) (the next layer's primal input) and its sign bit (k_snet4's shift register) --
 // the ring was 5 blocks written + 5 read per layer, now ns written + ns read and one stash read
+// (h, c, sn) of a pre-activation tile: SIREN: (sin, cos, sin); class NIF (MODE 2): (f, f', -f'') of the runtime activation, so that
+// the adjoint formulas  nu = mu c ,  da = lambda c - sum mu sn a'  hold for both
+template <int NBL, int MODE>
+__device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&c)[NBL], f32x4 (&sn)[NBL], int n, int g) {
+  if (MODE != 2) {
+    sine16<NBL>(a, h, c);
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) sn[b] = h[b];
+  } else {
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sn[b][v] = -act_d2<-1>(act, a[b][v]);
+    act16<NBL, -1>(act, a, h, c, n, g);
+  }
+}
+
 // BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
 template <int NBL, int MODE, bool TRAIN, int BF, bool SGN>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
@@ -163,11 +181,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
       }
     }
     {
-      f32x4 c[NBL];
-      sine16<NBL>(aq[0], hq[0], c);
+      f32x4 c[NBL], sn0[NBL];
+      sob_act<NBL, MODE>(A.act, aq[0], hq[0], c, sn0, n, g);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
-        if (TRAIN && !SGN) { ring[0 * NBL * 64 + b * 64 + lane] = c[b]; ring[1 * NBL * 64 + b * 64 + lane] = hq[0][b]; }
+        if (TRAIN && !SGN) { ring[0 * NBL * 64 + b * 64 + lane] = c[b]; ring[1 * NBL * 64 + b * 64 + lane] = sn0[b]; }
 #pragma unroll
         for (int d = 0; d < NS; ++d) {
           if (TRAIN && d < ns) ring[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
@@ -217,12 +235,12 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
 #pragma unroll
         for (int b = 0; b < NBL; ++b) aq[0][b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
       }
-      f32x4 sn[NBL], c[NBL];
-      sine16<NBL>(aq[0], sn, c);
+      f32x4 sn[NBL], c[NBL], snr[NBL];      // sn = f(a); snr = what the adjoint needs in the ring (SIREN: sin again; NIF: -f'')
+      sob_act<NBL, MODE>(A.act, aq[0], sn, c, snr, n, g);
       f32x4* rl = ring + (long)(j + 1) * (2 + NS) * NBL * 64;
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
-        if (TRAIN && !SGN) { rl[0 * NBL * 64 + b * 64 + lane] = c[b]; rl[1 * NBL * 64 + b * 64 + lane] = sn[b]; }
+        if (TRAIN && !SGN) { rl[0 * NBL * 64 + b * 64 + lane] = c[b]; rl[1 * NBL * 64 + b * 64 + lane] = snr[b]; }
 #pragma unroll
         for (int d = 0; d < NS; ++d)
           if (TRAIN && d < ns) rl[(2 + d) * NBL * 64 + b * 64 + lane] = aq[1 + d][b];
@@ -232,8 +250,9 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
-          const f32x4 t = q == 0 ? sn[b] : c[b] * aq[q][b];   // sin(a) | cos(a) a'
+          const f32x4 t = q == 0 ? sn[b] : c[b] * aq[q][b];   // f(a) | f'(a) a'
           if (MODE == 0) hq[q][b] = t;
+          else if (MODE == 2) hq[q][b] += t;                   // class NIF: h = f(a) + h_in
           else if (!(j & 1)) { ub[q][b] = hq[q][b]; hq[q][b] = t; }
           else hq[q][b] = 0.5f * (ub[q][b] + t);
         }
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
       if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)so + J.wj * sej / (float)(so * ns));
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
-      f32x4 skip[MODE == 1 ? NQ : 1][MODE == 1 ? NBL : 1];
+      f32x4 skip[MODE != 0 ? NQ : 1][MODE != 0 ? NBL : 1];
       for (int j = nh - 1; j >= 0; --j) {
         const f32x4* rl = ring + (long)(j + 1) * (2 + NS) * NBL * 64;
         f32x4 vq[NQ][NBL];   // vq[0] = da, vq[1+d] = nu^d
@@ -331,6 +350,12 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
           for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int b = 0; b < NBL; ++b) { lam[q][b] *= 0.5f; skip[q][b] = lam[q][b]; }
+        }
+        if (MODE == 2) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) skip[q][b] = lam[q][b];
         }
         f32x4 cv[NBL], snv[NBL];
         if (SGN) {
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobAr
 #pragma unroll
           for (int b = 0; b < NBL; ++b) {
             lam[q][b] *= A.omega;
-            if (MODE == 1 && !(j & 1)) lam[q][b] += skip[q][b];
+            if (MODE == 2 || (MODE == 1 && !(j & 1))) lam[q][b] += skip[q][b];
           }
       }
       // ---- first layer ---------------------------------------------------------------------------
@@ -493,7 +518,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.seed[d] = d < ns ? seeds[d] : 0;
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
-  const bool sgn = !a.res && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register
+  const bool sgn = !a.res && !a.nif_skip && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register (SIREN only)
   const size_t plane = bf ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
@@ -505,7 +530,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_>), grid, block, shm, st, J);                                \
   }
 #define SBK(NBL_, BF_)                                                               \
-  if (a.res) { if (train) SBL(NBL_, 1, true, BF_, false) else SBL(NBL_, 1, false, BF_, false) }   \
+  if (a.nif_skip) { if (train) SBL(NBL_, 2, true, BF_, false) else SBL(NBL_, 2, false, BF_, false) }   \
+  else if (a.res) { if (train) SBL(NBL_, 1, true, BF_, false) else SBL(NBL_, 1, false, BF_, false) }   \
   else if (train) { if (sgn) SBL(NBL_, 0, true, BF_, true) else SBL(NBL_, 0, true, BF_, false) } \
   else SBL(NBL_, 0, false, BF_, false)
   switch (NBL) {

@@ -1147,8 +1147,8 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   const long ntiles = (B + 31) / 32;
   if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
   if (ns > 0) {
-    if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
-      return fail(NIF_ERR_INVALID, "Sobolev training is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
+    if (c->kind == NIF_KIND_LASTLAYER || !c->use_snet3)
+      return fail(NIF_ERR_INVALID, "Sobolev training is built for NIF / NIFMultiScale on the 16-point-tile path (units <= 128)");
     if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
   }
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
@@ -1270,8 +1270,8 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
-  if (c->kind != NIF_KIND_MULTISCALE || !c->use_snet3)
-    return fail(NIF_ERR_INVALID, "Sobolev path is built for NIFMultiScale on the 16-point-tile path (units <= 128)");
+  if (c->kind == NIF_KIND_LASTLAYER || !c->use_snet3)
+    return fail(NIF_ERR_INVALID, "Sobolev path is built for NIF / NIFMultiScale on the 16-point-tile path (units <= 128)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   launch_pnet(pa, c->NSTB, false, c->st);

@@ -807,12 +807,17 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     mean over the last axis, then the sample-weighted mean over the batch; for dys_dxs [B,so,nx] that is the
     mean over B*so*nx).  GradientTape differentiates through the inner tape; here: forward tangents
     (jacobian_analytic) and their adjoint, w.r.t. the materialised per-sample weights pnet_out [B,po], then
-    pnet_backward -- the reference formulation.  NIFMultiScale only; x_index = coordinate columns.
+    pnet_backward -- the reference formulation.  NIFMultiScale (SIREN, plain / resblock) and class NIF (any Keras
+    activation f with skip connections h_l = f(a_l) + h_{l-1}, model.py:309-320); x_index = coordinate columns.
+    With c = f'(a), -sn = f''(a):  nu = mu c ,  da = lambda c - sum mu sn a'.
     Returns (loss, grads in Keras order, u, dudx)."""
-    assert spec.kind == KIND_MS
+    assert spec.kind in (KIND_MS, KIND_NIF)
+    nif = spec.kind == KIND_NIF
     B = inputs.shape[0]
     Bg = B if batch_global is None else batch_global
-    si, so, n, om = spec.si, spec.so, spec.n, spec.omega_s
+    si, so, n, om = spec.si, spec.so, spec.n, (1.0 if nif else spec.omega_s)
+    f_, df_ = act_fn(spec.s_act if nif else "sine")
+    d2f_ = act_d2(spec.s_act if nif else "sine")
     seeds = [j - spec.pi for j in x_index]
     assert all(0 <= d < si for d in seeds)
     nx = len(seeds)
@@ -833,10 +838,12 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     for l in range(nl):
         a = om * _ein(h, W[l]) + bv[l]
         ad = [om * _ein(v, W[l]) for v in hd]
-        sn, cs = np.sin(a), np.cos(a)
+        fa, cs, sn = f_(a), df_(a), -d2f_(a)          # SIREN: sin, cos, sin
         tape.append((h, hd, sn, cs, ad))
-        t, td = sn, [cs * v for v in ad]
-        if spec.s_res and l >= 1:
+        t, td = fa, [cs * v for v in ad]
+        if nif and l >= 1:                            # class NIF: h = f(a) + h_in
+            h, hd = t + h, [v + u0 for v, u0 in zip(td, hd)]
+        elif spec.s_res and l >= 1:
             if (l - 1) % 2 == 0:
                 blk_in = (h, hd)
                 h, hd = t, td
@@ -883,8 +890,12 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
         gw[:, wslices[l][0]:wslices[l][1]] = (om * gW).reshape(B, -1)
         gw[:, bslices[l][0]:bslices[l][1]] = da
         if l > 0:
-            lam = om * _ein_t(W[l], da)
-            mu = [om * _ein_t(W[l], g) for g in nu]
+            lam_new = om * _ein_t(W[l], da)
+            mu_new = [om * _ein_t(W[l], g) for g in nu]
+            if nif:                                              # skip connection of every hidden layer
+                lam_new = lam_new + lam
+                mu_new = [a_ + b_ for a_, b_ in zip(mu_new, mu)]
+            lam, mu = lam_new, mu_new
             if spec.s_res and (l - 1) % 2 == 0:                  # first layer of a block: add the skip path
                 lam = lam + skip[0]
                 mu = [m + s_ for m, s_ in zip(mu, skip[1])]

@@ -404,7 +404,7 @@ def test_lbfgs_fine_tuning_reduces_loss():
 
 # ---- Sobolev training (BASELINE config 5): JacobianLayer as a trained output -----------------------------
 SOB = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1",
-       "ms_cfg5_64x4_si2", "ms_cfg3_128x6", "ms_64x8"]
+       "ms_cfg5_64x4_si2", "ms_cfg3_128x6", "ms_64x8", "nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2"]
 
 
 @pytest.mark.parametrize("name", SOB)
@@ -456,13 +456,13 @@ def test_sobolev_single_seed_and_zero_weight_degenerates():
     # plain step afterwards still right (stash geometry is shared)
     l2, g2 = m._engine.loss_and_grad(x, y, sw)
     assert l2 == l1 and np.array_equal(g1, g2)
-    # parameter columns / other classes are refused loudly
+    # parameter columns / the last-layer class are refused loudly
     import nif_amd
     with pytest.raises(nif_amd._lib.NifError):
         m._engine.sobolev_loss_and_grad(x, y, g, [0], 0.2, sw)
-    m2, model2, spec2, ws2, x2, y2, sw2 = _make("nif_cfg1_32x2")
+    m2, model2, spec2, ws2, x2, y2, sw2 = _make("ll_plain_32x2_r3")
     with pytest.raises(nif_amd._lib.NifError):
-        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], 1, 1), np.float32), [1], 0.2, None)
+        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], spec2.so, 1), np.float32), [1], 0.2, None)
 
 
 def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
