@@ -51,11 +51,13 @@ __device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&
 }
 
 // BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
-template <int NBL, int MODE, bool TRAIN, int BF, bool SGN>
-__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
+// NSD: seed streams the instantiation carries (register arrays and loops are sized by it): 1 or 2 seeds at n <= 64 leave room
+// for TWO workgroups per CU (256 registers), the 3-seed form needs all 512
+template <int NBL, int MODE, bool TRAIN, int BF, bool SGN, int NSD = NIF_SOB_MAXSEED>
+__global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD == 1)) ? 2 : (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
-  constexpr int NT = 256, WAVES = 4, NS = NIF_SOB_MAXSEED, NQ = 1 + NS;
+  constexpr int NT = 256, WAVES = 4, NS = NSD, NQ = 1 + NS;
   constexpr int NCH = NBL / 2, CF = NBL * 3 * 64, CB = NBL * 2 * 64;       // bf16 planes: K-step chunks, 16-B units
   constexpr int PLANE = BF ? NCH * CF * 4 : NBL * NBL * 256;              // floats per LDS plane buffer
   constexpr int UF = BF ? NCH * CF : PLANE / 4, UB = BF ? NCH * CB : PLANE / 4;   // 16-B units of a forward / adjoint plane
@@ -510,7 +512,11 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
-  const long cap = NBL <= 4 ? 256 * NIF_SOB_OCC : 256;
+  const bool bf_ = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
+  const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip;     // the 1- / 2-seed instantiations: two workgroups per CU
+  // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
+  const bool two = slim && (NBL <= 2 || ns == 1);
+  const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   if (query_only) return nblk;
   SobArgs J;
@@ -529,11 +535,34 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
                                 (int)shm);                                                                      \
     hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_>), grid, block, shm, st, J);                                \
   }
+#define SBN(NBL_, MODE_, TR_, BF_, SGN_, NSD_)                                                                      \
+  {                                                                                                             \
+    if (shm > 48 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_, BF_, SGN_, NSD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shm);                                                                      \
+    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_, NSD_>), grid, block, shm, st, J);                          \
+  }
+  // SIREN nets on the bf16 planes with 1 or 2 seeds (BASELINE configs[4]: d/dx, d/dy)
+#define SBS(NBL_, BF_, NSD_)                                                         \
+  if (a.res) { if (train) SBN(NBL_, 1, true, BF_, false, NSD_) else SBN(NBL_, 1, false, BF_, false, NSD_) }   \
+  else if (train) { if (sgn) SBN(NBL_, 0, true, BF_, true, NSD_) else SBN(NBL_, 0, true, BF_, false, NSD_) } \
+  else SBN(NBL_, 0, false, BF_, false, NSD_)
 #define SBK(NBL_, BF_)                                                               \
   if (a.nif_skip) { if (train) SBL(NBL_, 2, true, BF_, false) else SBL(NBL_, 2, false, BF_, false) }   \
   else if (a.res) { if (train) SBL(NBL_, 1, true, BF_, false) else SBL(NBL_, 1, false, BF_, false) }   \
   else if (train) { if (sgn) SBL(NBL_, 0, true, BF_, true) else SBL(NBL_, 0, true, BF_, false) } \
   else SBL(NBL_, 0, false, BF_, false)
+  if (slim) {
+    const int bfv = a.prec == 1 ? 2 : 1;
+    if (NBL == 4) {
+      if (bfv == 1) { if (ns == 1) { SBS(4, 1, 1) } else { SBS(4, 1, 2) } }
+      else { if (ns == 1) { SBS(4, 2, 1) } else { SBS(4, 2, 2) } }
+    } else {
+      if (bfv == 1) { if (ns == 1) { SBS(2, 1, 1) } else { SBS(2, 1, 2) } }
+      else { if (ns == 1) { SBS(2, 2, 1) } else { SBS(2, 2, 2) } }
+    }
+    return nblk;
+  }
   switch (NBL) {
     case 1: SBK(1, 0) break;
     case 2: if (bf && a.prec == 1) { SBK(2, 2) } else if (bf) { SBK(2, 1) } else { SBK(2, 0) } break;
@@ -543,6 +572,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     default: SBK(8, 0) break;
   }
 #undef SBK
+#undef SBS
+#undef SBN
 #undef SBL
   return nblk;
 }

@@ -541,7 +541,7 @@ def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
     assert np.array_equal(model2.predict(x), model.predict(x))
 
 
-@pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev"])
+@pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev", "cfg5_sobolev_bf16"])
 def test_full_size_shard_sum_other_configs(which):
     """The same size-independent properties at the TRUE per-GPU shard sizes and shapes of BASELINE configs[2..4]: the sum over 8
     contiguous shards of [grad | loss] equals the full-batch result, a repeated launch is bit-identical, and the
@@ -565,7 +565,7 @@ def test_full_size_shard_sum_other_configs(which):
     ws = O.init_weights(spec, rng, dtype=np.float32)
     names = [nm for nm, _ in spec.param_shapes()]
     ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * (30.0 if kind.endswith("Parameterized") else 2.0)).astype(np.float32)
-    m = getattr(nif_amd, kind)(cs, cp)
+    m = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_bfloat16" if which.endswith("bf16") else "float32")
     model = m.build(); model.set_weights(ws)
     e = m._engine
     ncol, so = spec.pi + spec.si, spec.so
@@ -606,7 +606,7 @@ def test_full_size_shard_sum_other_configs(which):
     else:
         lref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))[0]
         got = grad_of(0, n_s, n_s)[-1]
-    assert abs(got - lref) < 2e-5 * abs(lref), (got, lref)
+    assert abs(got - lref) < (2e-2 if which.endswith("bf16") else 2e-5) * abs(lref), (got, lref)   # bf16 policy: its own distance
     d_x.free(); d_y.free()
     if d_g is not None:
         d_g.free()
