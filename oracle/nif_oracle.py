@@ -808,8 +808,12 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     mean over B*so*nx).  GradientTape differentiates through the inner tape; here: forward tangents
     (jacobian_analytic) and their adjoint, w.r.t. the materialised per-sample weights pnet_out [B,po], then
     pnet_backward -- the reference formulation.  NIFMultiScale (SIREN, plain / resblock) and class NIF (any Keras
-    activation f with skip connections h_l = f(a_l) + h_{l-1}, model.py:309-320); x_index = coordinate columns.
+    activation f with skip connections h_l = f(a_l) + h_{l-1}, model.py:309-320).
     With c = f'(a), -sn = f''(a):  nu = mu c ,  da = lambda c - sum mu sn a'.
+    x_index may address ANY input column (gradient.py:207-231).  A parameter column j < pi seeds the ParameterNet: the
+    per-sample weights then carry a tangent of their own, pnet_out' = z' Wh (pnet_tangents), every layer gets the product-rule
+    term  a' = w0 (h' W + h W') + b' , and the adjoint yields dL/dpnet_out' next to dL/dpnet_out; both go back through the
+    hyper layer and the (primal, tangent) ParameterNet (pnet_tangents_backward).
     Returns (loss, grads in Keras order, u, dudx)."""
     assert spec.kind in (KIND_MS, KIND_NIF)
     nif = spec.kind == KIND_NIF
@@ -818,26 +822,39 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     si, so, n, om = spec.si, spec.so, spec.n, (1.0 if nif else spec.omega_s)
     f_, df_ = act_fn(spec.s_act if nif else "sine")
     d2f_ = act_d2(spec.s_act if nif else "sine")
-    seeds = [j - spec.pi for j in x_index]
-    assert all(0 <= d < si for d in seeds)
-    nx = len(seeds)
+    x_index = list(x_index)
+    assert all(0 <= j < spec.pi + si for j in x_index)
+    nx = len(x_index)
+    pcols = [j for j in x_index if j < spec.pi]          # parameter seeds (stream q is a parameter stream iff x_index[q] < pi)
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + si]
     pout, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    last = _pnet_split(spec, ws)[3]
     sl = spec.slices()
-    W = [pout[:, sl["w1"][0]:sl["w1"][1]].reshape(B, si, n)] + [pout[:, a:b].reshape(B, n, n) for (a, b) in sl["wh"]]
-    bv = [pout[:, sl["b1"][0]:sl["b1"][1]]] + [pout[:, a:b] for (a, b) in sl["bh"]]
-    Wl = pout[:, sl["wl"][0]:sl["wl"][1]].reshape(B, n, so)
-    bl = pout[:, sl["bl"][0]:sl["bl"][1]]
+
+    def carve(po_):
+        W_ = [po_[:, sl["w1"][0]:sl["w1"][1]].reshape(B, si, n)] + [po_[:, a:b].reshape(B, n, n) for (a, b) in sl["wh"]]
+        b_ = [po_[:, sl["b1"][0]:sl["b1"][1]]] + [po_[:, a:b] for (a, b) in sl["bh"]]
+        return W_, b_, po_[:, sl["wl"][0]:sl["wl"][1]].reshape(B, n, so), po_[:, sl["bl"][0]:sl["bl"][1]]
+    W, bv, Wl, bl = carve(pout)
+    tw = [None] * nx                                      # per stream: the weights' own tangent (parameter seeds) or None
+    if pcols:
+        _, zd, pctx = pnet_tangents(spec, ws, p, pcols)
+        for q, j in enumerate(x_index):
+            if j < spec.pi:
+                tw[q] = carve(zd[pcols.index(j)] @ last[0])
     nl = len(W)                     # sine layers: first + hidden matrices
-    # ---- forward: primal h and tangents hd[d] -----------------------------------------------------
+    # ---- forward: primal h and tangents hd[q] -----------------------------------------------------
     h = x
-    hd = [np.tile(np.eye(si, dtype=x.dtype)[d], (B, 1)) for d in seeds]
+    hd = [np.zeros((B, si), dtype=x.dtype) if j < spec.pi else np.tile(np.eye(si, dtype=x.dtype)[j - spec.pi], (B, 1)) for j in x_index]
     tape = []
     blk_in = None
     for l in range(nl):
         a = om * _ein(h, W[l]) + bv[l]
         ad = [om * _ein(v, W[l]) for v in hd]
+        for q in range(nx):
+            if tw[q] is not None:
+                ad[q] = ad[q] + om * _ein(h, tw[q][0][l]) + tw[q][1][l]
         fa, cs, sn = f_(a), df_(a), -d2f_(a)          # SIREN: sin, cos, sin
         tape.append((h, hd, sn, cs, ad))
         t, td = fa, [cs * v for v in ad]
@@ -854,6 +871,9 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
             h, hd = t, td
     u = _ein(h, Wl) + bl
     ud = [_ein(v, Wl) for v in hd]
+    for q in range(nx):
+        if tw[q] is not None:
+            ud[q] = ud[q] + _ein(h, tw[q][2]) + tw[q][3]
     J = np.stack(ud, axis=2)                                     # [B, so, nx]
     # ---- loss ------------------------------------------------------------------------------------
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
@@ -864,6 +884,7 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
     # ---- adjoint ---------------------------------------------------------------------------------
     gw = np.zeros((B, spec.po), dtype=u.dtype)
+    gwd = [np.zeros((B, spec.po), dtype=u.dtype) if tw[q] is not None else None for q in range(nx)]   # dL/dpnet_out'
     gWl = h[:, :, None] * g_u[:, None, :]
     for v, g in zip(hd, g_ud):
         gWl = gWl + v[:, :, None] * g[:, None, :]
@@ -871,6 +892,11 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     gw[:, sl["bl"][0]:sl["bl"][1]] = g_u
     lam = _ein_t(Wl, g_u)
     mu = [_ein_t(Wl, g) for g in g_ud]
+    for q in range(nx):
+        if tw[q] is not None:
+            gwd[q][:, sl["wl"][0]:sl["wl"][1]] = (h[:, :, None] * g_ud[q][:, None, :]).reshape(B, -1)
+            gwd[q][:, sl["bl"][0]:sl["bl"][1]] = g_ud[q]
+            lam = lam + _ein_t(tw[q][2], g_ud[q])
     wslices = [sl["w1"]] + list(sl["wh"])
     bslices = [sl["b1"]] + list(sl["bh"])
     skip = None
@@ -889,9 +915,16 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
             gW = gW + v[:, :, None] * g[:, None, :]
         gw[:, wslices[l][0]:wslices[l][1]] = (om * gW).reshape(B, -1)
         gw[:, bslices[l][0]:bslices[l][1]] = da
+        for q in range(nx):
+            if tw[q] is not None:
+                gwd[q][:, wslices[l][0]:wslices[l][1]] = (om * hin[:, :, None] * nu[q][:, None, :]).reshape(B, -1)
+                gwd[q][:, bslices[l][0]:bslices[l][1]] = nu[q]
         if l > 0:
             lam_new = om * _ein_t(W[l], da)
             mu_new = [om * _ein_t(W[l], g) for g in nu]
+            for q in range(nx):
+                if tw[q] is not None:
+                    lam_new = lam_new + om * _ein_t(tw[q][0][l], nu[q])
             if nif:                                              # skip connection of every hidden layer
                 lam_new = lam_new + lam
                 mu_new = [a_ + b_ for a_, b_ in zip(mu_new, mu)]
@@ -899,7 +932,18 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
             if spec.s_res and (l - 1) % 2 == 0:                  # first layer of a block: add the skip path
                 lam = lam + skip[0]
                 mu = [m + s_ for m, s_ in zip(mu, skip[1])]
-    return loss, pnet_backward(spec, ws, ptape, gw), u, J
+    if not pcols:
+        return loss, pnet_backward(spec, ws, ptape, gw), u, J
+    # hyper layer: pnet_out = z Wh + bh, pnet_out'_c = z'_c Wh ; then the (primal, tangent) ParameterNet
+    g_zd = [np.zeros_like(zd[0]) for _ in pcols]
+    g_last_w = z.T @ gw
+    for q in range(nx):
+        if tw[q] is not None:
+            ci = pcols.index(x_index[q])
+            g_last_w = g_last_w + zd[ci].T @ gwd[q]
+            g_zd[ci] = g_zd[ci] + gwd[q] @ last[0].T
+    core = pnet_tangents_backward(spec, ws, pctx, gw @ last[0].T, g_zd)
+    return loss, core + [g_last_w, gw.sum(0)], u, J
 
 
 def flatten(arrs):
@@ -985,24 +1029,18 @@ def jacobian_analytic(spec, ws, inputs, y_index, x_index):
     return u, J
 
 
-def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
-    """cfg_parameter_net["jac_reg"] (model.py:353-375 -> JacRegLatentLayer, gradient.py:52-127, :182-205):
-    loss = l1 * mean_{a,c,d} (d z_c / d p_d)^2 with z the latent, and its gradient w.r.t. every variable (Keras order; zero
-    for the layers downstream of z).  Forward-mode tangents of the ParameterNet + the hand-derived adjoint of the (primal,
-    tangent) program: nu_d = mu_d f'(a), da = lambda f'(a) + sum_d mu_d f''(a) a'_d, dW = s (h^T da + sum_d h'_d^T nu_d).
-    Pinned by torch double-backward in tests/test_oracle.py."""
+def pnet_tangents(spec, ws, p, cols):
+    """ParameterNet up to the latent with forward-mode tangents w.r.t. the parameter columns `cols`:
+    -> (z [B,r], zd = [dz/dp_c for c in cols], ctx for pnet_tangents_backward).  Same layer rules as pnet_forward
+    (mlp.py:62-79, :148-160; siren.py:256-281, :381-410)."""
     first, hidden, bott, last, rest = _pnet_split(spec, ws)
-    B, pi = p.shape
-    Bg = B if batch_global is None else batch_global
     siren = spec.p_siren
     s = spec.omega_p if siren else 1.0
     name = "sine" if siren else spec.p_act
     f, df = act_fn(name)
-    d2f = act_d2(name)
-    D = range(pi)
-    # forward
+    D = range(len(cols))
     a0 = s * (p @ first[0]) + first[1]
-    a0d = [np.broadcast_to(s * first[0][d], a0.shape) for d in D]
+    a0d = [np.broadcast_to(s * first[0][c], a0.shape) for c in cols]
     h = f(a0); hd = [df(a0) * a0d[d] for d in D]
     tape = []
     for lay in hidden:
@@ -1024,13 +1062,27 @@ def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
                 h, hd = 0.5 * (h + f(a2)), [0.5 * (hd[d] + df(a2) * a2d[d]) for d in D]
             else:
                 h, hd = f(a2), [df(a2) * a2d[d] for d in D]
+    z = h @ bott[0] + bott[1]
     zd = [hd[d] @ bott[0] for d in D]                       # [B, r] each
-    coef = l1 / (Bg * spec.r * pi)
-    loss = coef * sum((zd[d] ** 2).sum() for d in D)
-    # adjoint
-    muz = [2.0 * coef * zd[d] for d in D]
-    g_bott = [sum(hd[d].T @ muz[d] for d in D), np.zeros_like(bott[1])]
-    lam = np.zeros_like(h); mu = [muz[d] @ bott[0].T for d in D]
+    return z, zd, (p, list(cols), a0, a0d, tape, h, hd)
+
+
+def pnet_tangents_backward(spec, ws, ctx, g_z, g_zd):
+    """Adjoint of pnet_tangents: g_z = dL/dz [B,r] (or None), g_zd[d] = dL/d(dz/dp_cols[d]) -> gradients of the first / hidden
+    / bottleneck variables (Keras order).  With lambda = dL/dh, mu_d = dL/dh'_d:
+    nu_d = mu_d f'(a), da = lambda f'(a) + sum_d mu_d f''(a) a'_d, dW = s (h^T da + sum_d h'_d^T nu_d)."""
+    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    p, cols, a0, a0d, tape, h, hd = ctx
+    siren = spec.p_siren
+    s = spec.omega_p if siren else 1.0
+    name = "sine" if siren else spec.p_act
+    f, df = act_fn(name)
+    d2f = act_d2(name)
+    D = range(len(cols))
+    gz = np.zeros((p.shape[0], spec.r), dtype=h.dtype) if g_z is None else g_z
+    g_bott = [h.T @ gz + sum(hd[d].T @ g_zd[d] for d in D), gz.sum(0)]
+    lam = gz @ bott[0].T
+    mu = [g_zd[d] @ bott[0].T for d in D]
 
     def adj(a, ad, lam_, mu_, scale=1.0):
         da = scale * lam_ * df(a)
@@ -1065,11 +1117,26 @@ def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
     da0, nu0 = adj(a0, a0d, lam, mu)
     gw0 = s * (p.T @ da0)
     for d in D:
-        gw0[d] = gw0[d] + s * nu0[d].sum(0)
+        gw0[cols[d]] = gw0[cols[d]] + s * nu0[d].sum(0)
     grads = [gw0, da0.sum(0)]
     for g in reversed(g_hidden):
         grads += g
-    grads += g_bott + [np.zeros_like(last[0]), np.zeros_like(last[1])] + [np.zeros_like(w) for w in rest]
+    return grads + g_bott
+
+
+def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
+    """cfg_parameter_net["jac_reg"] (model.py:353-375 -> JacRegLatentLayer, gradient.py:52-127, :182-205):
+    loss = l1 * mean_{a,c,d} (d z_c / d p_d)^2 with z the latent, and its gradient w.r.t. every variable (Keras order; zero
+    for the layers downstream of z).  Forward-mode tangents of the ParameterNet + the hand-derived adjoint of the (primal,
+    tangent) program (pnet_tangents / pnet_tangents_backward).  Pinned by torch double-backward in tests/test_oracle.py."""
+    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    B, pi = p.shape
+    Bg = B if batch_global is None else batch_global
+    _, zd, ctx = pnet_tangents(spec, ws, p, list(range(pi)))
+    coef = l1 / (Bg * spec.r * pi)
+    loss = coef * sum((v ** 2).sum() for v in zd)
+    grads = pnet_tangents_backward(spec, ws, ctx, None, [2.0 * coef * v for v in zd])
+    grads += [np.zeros_like(last[0]), np.zeros_like(last[1])] + [np.zeros_like(w) for w in rest]
     return loss, grads
 
 

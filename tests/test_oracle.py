@@ -119,6 +119,30 @@ def test_sobolev_loss_and_grad_match_torch_double_backward(name):
     assert abs(l0 - l1) < 1e-14 and all(np.allclose(a, b, rtol=1e-12, atol=1e-14) for a, b in zip(g0, g1))
 
 
+@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "nif_swish", "nif_tanh_r2_so2"])
+@pytest.mark.parametrize("cols", ["param_only", "mixed"])
+def test_sobolev_parameter_columns_match_torch_double_backward(name, cols):
+    """JacobianLayer works for ANY input column (gradient.py:207-231): x_index addressing ParameterNet inputs -- the tangent
+    then runs through the ParameterNet, the hyper layer and every product h W(p) -- alone and mixed with coordinates"""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=7)
+    if cols == "param_only":
+        xi = list(range(spec.pi))
+    else:
+        xi = [spec.pi + spec.si - 1, 0] + ([spec.pi] if spec.si > 1 else [])       # coordinate, parameter, coordinate
+    rng = np.random.default_rng(6)
+    dydx = rng.uniform(-1, 1, size=(7, spec.so, len(xi)))
+    for sample_weight in (None, sw):
+        loss, grads, u, J = O.sobolev_loss_and_grad(spec, ws, inputs, y, dydx, xi, 0.3, sample_weight)
+        tl, tg, tu, tJ = T.sobolev_loss_and_grad(kind, cs, cp, ws, inputs, y, dydx, xi, 0.3, sample_weight)
+        assert np.allclose(u, tu, rtol=1e-12, atol=1e-12) and np.allclose(J, tJ, rtol=1e-9, atol=1e-11)
+        assert abs(loss - tl) <= 1e-12 * max(1.0, abs(tl))
+        for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
+            assert t is not None, nm
+            assert np.abs(g - t).max() / max(np.abs(t).max(), 1e-30) < 1e-9, nm
+
+
 def test_jacobian_shape_contract_notebook4():
     # tutorial/4 cells 12-18: JacobianLayer output shapes (B, ny), (B, len(y_index), len(x_index))
     kind, cs, cp, spec, ws, inputs, y, sw = _setup("nif_tanh_r2_so2", B=10)
