@@ -24,6 +24,11 @@ struct PJacArgs {
   float coef;           // l1 / (B_global * r * pi)
   float* MU;            // [(1 + pi) * tiles][r][32]: dL/dz'_d of the pseudo-tiles (zeros for the real tiles) -> k_gw_out
   float* loss_partial;  // [gridDim.x]
+  // Sobolev training with parameter columns in x_index (k_sob.hip, PAR) reuses this kernel on either side of the ShapeNet:
+  int mode;             // 0: the regulariser; 1: forward only, z'_d -> ZT; 2: the adjoint for GIVEN dL/dz'_d (MU_in), no loss
+  float* ZT;            // mode 1: [pi][tiles][r][32]
+  const float* MU_in;   // mode 2: blocks of [tiles][r][32]; column d reads block mu_blk[d] (< 0: zero)
+  int mu_blk[NIF_PJ_MAXPI];
 };
 
 __device__ __forceinline__ void pj_act(int act, float a, float* f0, float* f1, float* f2) {
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
   auto at = [&](int slot, int blk, int f) -> float* {
     return A.stash + (long)slot * A.slot_stride + (((long)blk * ntiles + tile) * FP + f) * 32 + pp;
   };
-  auto ST = [&](float* q, float v) { if (wr) *q = v; };
+  const bool fwd_only = J.mode == 1;
+  auto ST = [&](float* q, float v) { if (wr && !fwd_only) *q = v; };
   auto LD = [&](const float* q) -> float { return wr ? *q : 0.f; };
   const int S_IN = 0, S_DA0 = nm + 1, S_DA = nm + 2;
   float h[NST], hd[NIF_PJ_MAXPI][NST];
@@ -150,12 +156,15 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
     for (int d = 0; d < pi; ++d) {
       float zd = 0.f;
       for (int i = 0; i < nst; ++i) zd = fmaf(hd[d][i], th[A.bott_w + (long)i * r + c], zd);
-      lsum = fmaf(zd, zd, lsum);
-      const float m_ = ok ? 2.0f * J.coef * zd : 0.f;
+      if (fwd_only) { if (wr) J.ZT[(((long)d * ntiles + tile) * r + c) * 32 + pp] = ok ? zd : 0.f; continue; }
+      float m_;
+      if (J.mode == 2) m_ = (ok && J.mu_blk[d] >= 0) ? J.MU_in[(((long)J.mu_blk[d] * ntiles + tile) * r + c) * 32 + pp] : 0.f;
+      else { lsum = fmaf(zd, zd, lsum); m_ = ok ? 2.0f * J.coef * zd : 0.f; }
       ST(J.MU + (((long)(1 + d) * ntiles + tile) * r + c) * 32 + pp, m_);
       for (int i = 0; i < nst; ++i) mu[d][i] = fmaf(m_, th[A.bott_w + (long)i * r + c], mu[d][i]);
     }
   }
+  if (fwd_only) return;
   // ---------------- adjoint through the hidden layers: DA_m <- (da | nu_d) ----------------
   auto back = [&](long w_off, const float* da, const float (*nu)[NST], float* lo, float (*mo)[NST], float keep) {
     // lo = keep * lo + s W da ;  mo_d = keep * mo_d + s W nu_d
@@ -222,8 +231,30 @@ bool pjac_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
   return a.nst <= 64 && nm <= 4 && a.pi <= NIF_PJ_MAXPI && !a.ll_kind;
 }
+static int launch_pjac_any(const PJacArgs& J, hipStream_t st);
 int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st) {
   PJacArgs J; J.p = a; J.coef = coef; J.MU = MU; J.loss_partial = loss_partial;
+  J.mode = 0; J.ZT = nullptr; J.MU_in = nullptr;
+  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = -1;
+  return launch_pjac_any(J, st);
+}
+// z'_d = dz/dp_d of every parameter column -> ZT [pi][tiles][r][32] (no stash traffic)
+int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st) {
+  PJacArgs J; J.p = a; J.coef = 0.f; J.MU = ZT; J.loss_partial = nullptr;
+  J.mode = 1; J.ZT = ZT; J.MU_in = nullptr;
+  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = -1;
+  return launch_pjac_any(J, st);
+}
+// adjoint of the (primal, tangent) ParameterNet for given dL/dz'_d (block mu_blk[d] of MU_in; the primal dL/dz part is the
+// ordinary ParameterNet adjoint's business): operand pairs into the stash, MU for k_gw_out, like the regulariser
+int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st) {
+  PJacArgs J; J.p = a; J.coef = 0.f; J.MU = MU; J.loss_partial = loss_partial;
+  J.mode = 2; J.ZT = nullptr; J.MU_in = MU_in;
+  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = d < a.pi ? mu_blk[d] : -1;
+  return launch_pjac_any(J, st);
+}
+static int launch_pjac_any(const PJacArgs& J, hipStream_t st) {
+  const PNetArgs& a = J.p;
   const int nblk = (int)((a.B + 127) / 128);
   if (a.nst <= 32) hipLaunchKernelGGL((k_pjac<32>), dim3(nblk), dim3(128), 0, st, J);
   else hipLaunchKernelGGL((k_pjac<64>), dim3(nblk), dim3(128), 0, st, J);

@@ -15,7 +15,11 @@
 
 #define NIF_ACT_SLABS 32   // point slabs of the activity regulariser's plane pass
 static inline bool act_on(const nif_ctx* c) { return c->act_l1 != 0.f || c->act_l2 != 0.f; }
-static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg);
+static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg, const int* mu_blk = nullptr);
+// Sobolev streams of one x_index: coordinate seeds first, then the parameter seeds (their pseudo-tiles trail the stashes, so
+// that the first-layer reduction simply stops in front of them); gcol = the x_index position (column of dydx) of each stream
+struct SobPlan { int ns, nsc; int seeds[3]; int par[3]; int gcol[3]; bool any_par; };
+static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const SobPlan& sp, const SNetArgs& sa);
 
 #ifndef NIF_PIPE_CHUNK_DEFAULT
 #define NIF_PIPE_CHUNK_DEFAULT 131072L
@@ -184,7 +188,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -1025,7 +1029,8 @@ static int ensure_pipe(nif_ctx* c, int nchunk) {
 // the ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
 static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const float* sw0, long off, long B, long Bg, int ns,
                       const int* seeds, const float* gt, float wj, hipStream_t sa_st, hipStream_t sb_st, hipStream_t pb_st,
-                      float* partial, float* loss_partial, int* nloss_out, int chunk_idx, bool whole, SNetArgs* sa_edge = nullptr) {
+                      float* partial, float* loss_partial, int* nloss_out, int chunk_idx, bool whole, SNetArgs* sa_edge = nullptr,
+                      const SobPlan* sp = nullptr) {
   int rc;
   const int ncol = c->pi + c->si;
   const long ntiles = (B + 31) / 32, t0 = off / 32;       // off is a multiple of 32 points
@@ -1054,7 +1059,17 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   *nloss_out = nloss;
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
-    if (ns > 0) launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st);
+    if (ns > 0) {
+      SobPar spar; const SobPar* sparp = nullptr;
+      if (sp && sp->any_par) {
+        for (int d = 0; d < 3; ++d) { spar.par[d] = sp->par[d]; spar.gcol[d] = sp->gcol[d]; }
+        spar.ZT = c->zt_par; spar.DZT = c->dzt_par; sparp = &spar;
+      } else if (sp) {
+        for (int d = 0; d < 3; ++d) { spar.par[d] = -1; spar.gcol[d] = sp->gcol[d]; }
+        spar.ZT = nullptr; spar.DZT = nullptr; sparp = &spar;
+      }
+      launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st, sparp);
+    }
     else if (sa.fused_gw) launch_snet5(sa, partial, c->pstride, false, sa_st);
     else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
@@ -1098,6 +1113,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
   g.W = hyper_ref(c, 0, c->n, c->si, c->n);
   g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
+  if (sp) g.ntiles = ntiles * (1 + sp->nsc);      // a parameter stream has no tangent input here (x' = 0): its pairs go to sob_par_pass
   if (!fused_edge) launch_gw_first(g, c->NB, rows, sb_st);
   // ShapeNet hidden matrices
   for (int j = 0; j < c->nh && !sa.fused_gw; ++j) {
@@ -1141,7 +1157,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
 }
 
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
-                          const int* seeds, const float* gt, float wj) {
+                          const int* seeds, const float* gt, float wj, const SobPlan* sp = nullptr) {
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B + 31) / 32;
@@ -1152,6 +1168,16 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
   }
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
+  if (sp && sp->any_par) {   // z' = dz/dp of the parameter columns, in front of the ShapeNet
+    PNetArgs pa; fill_pnet(c, pa, xin, B);
+    if (!pjac_supported(pa))
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+    const long need_zt = (long)c->pi * ntiles * 32 * c->r, need_dzt = 3 * ntiles * 32 * c->r;
+    if (need_zt > c->zt_par_cap || need_dzt > c->dzt_par_cap) HIPCHK(hipStreamSynchronize(c->st));
+    if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
+    if (need_dzt > c->dzt_par_cap) { rc = grow(&c->dzt_par, &c->dzt_par_cap, need_dzt); if (rc) return rc; }
+    launch_pjac_fwd(pa, c->zt_par, c->st);
+  }
   c->reg_applied = false;
   if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
   // Two-stream pipeline over chunks of the batch (plain step on the 16-point-tile kernels): the fused ShapeNet kernel of
@@ -1165,7 +1191,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     const bool side = c->opt_side_pnet && B >= 65536;
     if (side) { rc = ensure_pipe(c, 1); if (rc) return rc; }
     rc = step_chunk(c, xin, y, sw, 0, B, Bg, ns, seeds, gt, wj, c->st, c->st, side ? c->st2 : c->st, c->partial, c->loss_partial,
-                    &nloss, 0, true, &sae);
+                    &nloss, 0, true, &sae, sp);
     if (rc) return rc;
     if (side) {
       HIPCHK(hipEventRecord(c->ev_done, c->st2));
@@ -1184,6 +1210,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
                           c->act_loss, (int)((B + 255) / 256), c->grad, c->P, c->st);
     }
     if (c->jac_l1 != 0.f) { rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
+    if (sp && sp->any_par) { rc = sob_par_pass(c, xin, B, Bg, *sp, sae); if (rc) return rc; }
     HIPCHK(hipGetLastError());
     return NIF_OK;
   }
@@ -1246,27 +1273,36 @@ extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
   return NIF_OK;
 }
 
-static int sobolev_seeds(nif_ctx* c, const int32_t* x_idx, int32_t nx, int* seeds) {
-  if (!x_idx || nx < 1 || nx > 3) return fail(NIF_ERR_INVALID, "Sobolev training takes 1..3 coordinate columns");
+static int sobolev_plan(nif_ctx* c, const int32_t* x_idx, int32_t nx, SobPlan* sp) {
+  if (!x_idx || nx < 1 || nx > 3) return fail(NIF_ERR_INVALID, "Sobolev training takes 1..3 input columns in x_index");
+  memset(sp, 0, sizeof(*sp));
+  sp->ns = nx;
   for (int d = 0; d < nx; ++d) {
-    if (x_idx[d] < c->pi || x_idx[d] >= c->pi + c->si)
-      return fail(NIF_ERR_INVALID, "Sobolev x_index must address coordinate columns (pi_dim <= i < pi_dim + si_dim)");
-    seeds[d] = x_idx[d] - c->pi;
+    if (x_idx[d] < 0 || x_idx[d] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "Sobolev x_index out of range (0 <= i < pi_dim + si_dim)");
+    for (int e = 0; e < d; ++e)
+      if (x_idx[e] == x_idx[d]) return fail(NIF_ERR_INVALID, "Sobolev x_index lists a column twice");
   }
+  int q = 0;
+  for (int d = 0; d < nx; ++d)
+    if (x_idx[d] >= c->pi) { sp->seeds[q] = x_idx[d] - c->pi; sp->par[q] = -1; sp->gcol[q] = d; ++q; }
+  sp->nsc = q;
+  for (int d = 0; d < nx; ++d)
+    if (x_idx[d] < c->pi) { sp->seeds[q] = 0; sp->par[q] = x_idx[d]; sp->gcol[q] = d; ++q; sp->any_par = true; }
+  for (; q < 3; ++q) { sp->seeds[q] = 0; sp->par[q] = -1; sp->gcol[q] = q; }
   return NIF_OK;
 }
 extern "C" int nif_sobolev_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* dydx, const float* sw,
                                          int64_t B, int64_t Bg, const int32_t* x_idx, int32_t nx, float w_jac) {
   if (!c || !xin || !y || !dydx || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
-  int seeds[3] = {0, 0, 0};
-  int rc = sobolev_seeds(c, x_idx, nx, seeds); if (rc) return rc;
-  return loss_grad_core(c, xin, y, sw, B, Bg, nx, seeds, dydx, w_jac);
+  SobPlan sp;
+  int rc = sobolev_plan(c, x_idx, nx, &sp); if (rc) return rc;
+  return loss_grad_core(c, xin, y, sw, B, Bg, nx, sp.seeds, dydx, w_jac, &sp);
 }
 extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, const int32_t* x_idx, int32_t nx, float* u,
                                        float* dudx) {
   if (!c || !xin || !u || !dudx || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
-  int seeds[3] = {0, 0, 0};
-  int rc = sobolev_seeds(c, x_idx, nx, seeds); if (rc) return rc;
+  SobPlan sp;
+  int rc = sobolev_plan(c, x_idx, nx, &sp); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
@@ -1275,9 +1311,20 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   launch_pnet(pa, c->NSTB, false, c->st);
+  SobPar spar;
+  for (int d = 0; d < 3; ++d) { spar.par[d] = sp.par[d]; spar.gcol[d] = sp.gcol[d]; }
+  spar.ZT = nullptr; spar.DZT = nullptr;
+  if (sp.any_par) {
+    if (!pjac_supported(pa))
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+    const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
+    if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
+    launch_pjac_fwd(pa, c->zt_par, c->st);
+    spar.ZT = c->zt_par;
+  }
   SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
   sa.u_out = u;
-  launch_sob(sa, false, nx, seeds, nullptr, 0.f, nullptr, dudx, false, c->st);
+  launch_sob(sa, false, nx, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
@@ -1306,7 +1353,9 @@ extern "C" int nif_set_jac_regularizer(nif_ctx* c, float l1) {
 }
 // The regulariser's own pass, on top of the reduced main gradient: loss += l1 mean (dz/dp)^2 and its gradient w.r.t. the
 // ParameterNet's first / hidden / bottleneck variables (the hyper layer is downstream of z and does not see it).
-static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg) {
+// mu_blk != null: the same pass as the adjoint of the Sobolev step's parameter streams -- dL/dz'_d is GIVEN (block mu_blk[d]
+// of c->dzt_par, written by k_sob), no loss term
+static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg, const int* mu_blk) {
   const int pi = c->pi;
   const long ntiles = (B + 31) / 32;
   int rc = ensure_capacity(c, ntiles * 32 * (1 + pi), true); if (rc) return rc;
@@ -1317,7 +1366,8 @@ static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg) {
   if (nlp > c->act_loss_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->act_loss, &c->act_loss_cap, nlp); if (rc) return rc; }
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   const float coef = c->jac_l1 / ((float)Bg * (float)c->r * (float)pi);
-  const int nloss = launch_pjac(pa, coef, c->jac_mu, c->act_loss, c->st);
+  const int nloss = mu_blk ? launch_pjac_adj(pa, c->dzt_par, mu_blk, c->jac_mu, c->act_loss, c->st)
+                           : launch_pjac(pa, coef, c->jac_mu, c->act_loss, c->st);
   const long nt_all = ntiles * (1 + pi);
   const int rows = rows_for(c, nt_all);
   GwArgs g;
@@ -1348,6 +1398,58 @@ static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg) {
   launch_axpy_cols(c->grad, c->jac_tmp, c->last_w, c->P, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
+}
+
+// Sobolev step with parameter seeds, the part the main reductions do not see (k_sob_dev.h, PAR).  For a parameter stream d:
+//   dL/dM^(k) += w0 sum_p zt'_k h_in nu_d^T , dL/db^(k) += sum_p zt'_k nu_d  (k < r): the SAME reductions as the main step with
+//   (h_in, nu_d) as the operand pair and zt' = dz/dp in the latent's place.  They run after the main row reduction, into the
+//   same partial rows; only the hyper KERNEL columns are kept (the kernels also fill the constant plane = hyper bias columns
+//   with sum h_in nu^T, which zt'_r = 0 excludes).  Then the ParameterNet side: the adjoint of (z, z') for the dL/dz' that
+//   k_sob left in c->dzt_par (jac_reg_pass with given mu).
+static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const SobPlan& sp, const SNetArgs& sa) {
+  const long ntiles = (B + 31) / 32;
+  const int ncol = c->pi + c->si;
+  const int rows = rows_for(c, ntiles);
+  if (!c->jac_tmp) HIPCHK(hipMalloc(&c->jac_tmp, sizeof(float) * (size_t)(c->P + 2)));
+  const long blk_s = ntiles * 1024 * c->NB;                 // floats of one block of tiles in a ShapeNet stash slot
+  float* sIN = sa.stash; float* sDA = sa.stash + (long)(c->nh + 1) * c->slot_s;
+  const long kcols = (long)c->r * c->po;                     // the hyper kernel [r][po] = columns last_w .. last_w + r*po
+  int mu_blk[3] = {-1, -1, -1};
+  for (int d = sp.nsc; d < sp.ns; ++d) {
+    const int col = sp.par[d];
+    mu_blk[col] = d;
+    const float* ZTd = c->zt_par + (long)col * ntiles * 32 * c->r;
+    GwArgs g;
+    auto base = [&](GwArgs& q) {
+      memset(&q, 0, sizeof(q));
+      q.ntiles = ntiles; q.zt_mod = ntiles; q.bias_ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride;
+      q.has_bias = 1; q.scale = 1.0f; q.Z = ZTd; q.r = c->r;
+    };
+    base(g); g.DA = sDA + (1 + d) * blk_s; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.scale = sa.omega;
+    g.W = hyper_ref(c, 0, c->n, c->si, c->n);
+    g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
+    launch_gw_first(g, c->NB, rows, c->st);
+    for (int j = 0; j < c->nh; ++j) {
+      base(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s + (1 + d) * blk_s; g.scale = sa.omega;
+      const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
+      const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
+      g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
+      g.Bv = hyper_ref(c, bslot, 0, 1, c->n);
+      launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
+    }
+    {
+      base(g); g.IN = sIN + (long)c->nh * c->slot_s; g.SM = sa.DU + (long)(1 + d) * ntiles * c->so * 32; g.nc = c->so;
+      const long wslot = (long)c->si * c->n + (long)c->nh * c->n * c->n;
+      const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
+      g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
+      g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
+      launch_gw_out(g, c->NB, rows, c->st);
+    }
+    launch_reduce(c->partial + c->last_w, c->pstride, rows, nullptr, 0, c->jac_tmp, kcols, c->st);
+    launch_axpy_cols(c->grad + c->last_w, c->jac_tmp, kcols, c->P - c->last_w, c->st);
+  }
+  HIPCHK(hipGetLastError());
+  return jac_reg_pass(c, xin, B, Bg, mu_blk);
 }
 
 // Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)

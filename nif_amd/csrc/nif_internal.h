@@ -169,8 +169,11 @@ int snet4_edge_ne(const SNetArgs& a);    // floats of one workgroup's edge parti
 void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
+// parameter seeds (x_index < pi_dim): stream d is a parameter stream iff par[d] >= 0 (then seeds[d] is unused); gcol[d] = the
+// column of gt / ju the stream fills; ZT = dz/dp [pi][tiles][r][32] (launch_pjac_fwd), DZT = dL/d(that) per stream
+struct SobPar { int par[3]; int gcol[3]; const float* ZT; float* DZT; };
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
-               bool query_only, hipStream_t st);
+               bool query_only, hipStream_t st, const SobPar* par = nullptr);
 bool snet3_supported(const SNetArgs& a);
 int snet3_nbl(int n);
 int snet3_nsm(int si, int so, int nh, int n);
@@ -214,6 +217,8 @@ void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
 // latent Jacobian regulariser (k_pjac.hip): tangents of the ParameterNet + their adjoint; operand pairs into the stash
 bool pjac_supported(const PNetArgs& a);
 int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st);
+int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st);      // dz/dp_d of every parameter column -> ZT [pi][tiles][r][32]
+int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st);
 void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st);
 // activity regulariser of the (virtual) pnet_output (k_misc.hip)
 int actreg_max_r();

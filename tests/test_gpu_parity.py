@@ -456,13 +456,58 @@ def test_sobolev_single_seed_and_zero_weight_degenerates():
     # plain step afterwards still right (stash geometry is shared)
     l2, g2 = m._engine.loss_and_grad(x, y, sw)
     assert l2 == l1 and np.array_equal(g1, g2)
-    # parameter columns / the last-layer class are refused loudly
+    # out-of-range / repeated columns and the last-layer class are refused loudly
     import nif_amd
     with pytest.raises(nif_amd._lib.NifError):
-        m._engine.sobolev_loss_and_grad(x, y, g, [0], 0.2, sw)
+        m._engine.sobolev_loss_and_grad(x, y, g, [spec.pi + spec.si], 0.2, sw)
+    with pytest.raises(nif_amd._lib.NifError):
+        m._engine.sobolev_loss_and_grad(x, y, np.concatenate([g, g], axis=2), [1, 1], 0.2, sw)
     m2, model2, spec2, ws2, x2, y2, sw2 = _make("ll_plain_32x2_r3")
     with pytest.raises(nif_amd._lib.NifError):
         m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], spec2.so, 1), np.float32), [1], 0.2, None)
+
+
+SOB_PAR = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1",
+           "ms_cfg5_64x4_si2", "nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2"]
+
+
+@pytest.mark.parametrize("name", SOB_PAR)
+@pytest.mark.parametrize("cols", ["param_only", "mixed"])
+def test_sobolev_parameter_columns_match_oracle(name, cols):
+    """x_index of JacobianLayer addressing ParameterNet inputs (gradient.py:207-231 takes any column): the tangent runs
+    through the ParameterNet (k_pjac), the hyper layer and the product rule of every h W(p) (k_sob, PAR), alone and mixed
+    with coordinate columns in an order that differs from the kernel's stream order"""
+    m, model, spec, ws, x, y, sw = _make(name)
+    B = x.shape[0]
+    if cols == "param_only":
+        xi = list(range(min(spec.pi, 3)))
+    else:
+        xi = [spec.pi + spec.si - 1, 0] + ([spec.pi] if spec.si > 1 else [])       # coordinate, parameter, coordinate
+    rng = np.random.default_rng(12)
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    wj = 0.05
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, wj, sw)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, wj,
+                                             sw.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    off = 0
+    for (nm, shp), r_ in zip(spec.param_shapes(), rg):
+        k = int(np.prod(shp))
+        got = grad[off:off + k].reshape(shp)
+        off += k
+        err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+        assert err < 3e-4, (nm, err)
+    from nif_amd import JacobianLayer, SobolevModel
+    sm = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi))
+    u, J = sm.predict(x)
+    assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
+    # the same columns through the forward-only JacobianLayer kernels (k_jac)
+    _, J2 = JacobianLayer(model, list(range(spec.so)), xi)(x)
+    assert _rel(J, J2.astype(np.float64)) < 2e-5
+    # a plain step afterwards is untouched by the side passes
+    l1, g1 = m._engine.loss_and_grad(x, y, sw)
+    rl1, rg1 = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
+    assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4
 
 
 def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
