@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
-  const int FP = ((n + 31) / 32) * 32;                    // feature rows per stash tile
+  const int FP = stash_fp(n);                             // feature rows per stash tile (nif_internal.h)
   const long nt16 = 2 * ((A.B + 31) / 32);                // 16-point tiles: always both halves of a stash tile
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
-  const int FP = ((n + 31) / 32) * 32;
+  const int FP = stash_fp(n);                             // feature rows per stash tile (nif_internal.h)
   const long nt16 = 2 * ((A.B + 31) / 32);
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 

@@ -12,7 +12,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
   const bool bf_ = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
-  const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par;     // the 1- / 2-seed instantiations: two workgroups per CU
+  const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par && !a.ll;     // the 1- / 2-seed instantiations: two workgroups per CU
   // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
   const bool two = slim && (NBL <= 2 || ns == 1);
   const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
@@ -33,6 +33,14 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t npw = any_par ? 1 + NIF_SOB_MAXSEED : 1;
   const size_t shm = (2 * plane + sm_tot + 4 * npw * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
+  J.ll_plane = 0;
+  if (a.ll) {
+    const size_t llw = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u)) * 16;
+    size_t shm_ll = shm + 4 * llw * sizeof(float);
+    if (shm_ll > 160u * 1024u && 4 * llw <= plane) { J.ll_plane = 1; shm_ll = shm; }   // scratch in the idle plane buffer
+    launch_sob_ll(J, train, bf, nblk, shm_ll, st);
+    return nblk;
+  }
   if (any_par) { launch_sob_par(J, train, bf, nblk, shm, st); return nblk; }
 #define SBL(NBL_, MODE_, TR_, BF_, SGN_)                                                                            \
   {                                                                                                             \

@@ -38,10 +38,13 @@ struct SobArgs {
   int par[NIF_SOB_MAXSEED];
   const float* ZT;              // z' = dz/dp_c of every parameter column [pi][tiles][r][32] (k_pjac, forward mode)
   float* DZT;                   // dL/dz' of stream d [ns][tiles][r][32] (rows of the parameter streams are written)
+  int ll_plane;                 // LL: the epilogue's per-wave scratch lives in the idle plane buffer (wide nets: no LDS left for it)
 };
 
 // parameter-seed instantiations (k_sob_par.hip)
 void launch_sob_par(const SobArgs& J, bool train, bool bf, int nblk, size_t shm, hipStream_t st);
+// last-layer class (k_sob_ll.hip)
+void launch_sob_ll(const SobArgs& J, bool train, bool bf, int nblk, size_t shm, hipStream_t st);
 
 // BF: n x n products as exact bf16 splits on v_mfma_f32_16x16x32_bf16 (forward 6-product, adjoint 3-product form, see
 // k_snet4.hip), whole bf16 planes per LDS step; otherwise the f32-input MFMA planes (odd block counts, n = 128)
@@ -68,7 +71,11 @@ __device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&
 // BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
 // NSD: seed streams the instantiation carries (register arrays and loops are sized by it): 1 or 2 seeds at n <= 64 leave room
 // for TWO workgroups per CU (256 registers), the 3-seed form needs all 512
-template <int NBL, int MODE, bool TRAIN, int BF, bool SGN, int NSD = NIF_SOB_MAXSEED, bool PAR = false>
+// LL: the last-layer-parameterised class (model.py:1044-1068, :1219-1269): SNetArgs as k_snet4 takes them for that class
+// (fill_snet_ll: r = 0, one shared plane per layer, so = so_u * rl outputs phi, Z = the ParameterNet output a [tiles][rl][32]).
+// u_i = sum_c phi[i*rl+c] a_c + bias_i and du_i/dx_d = sum_c phi'_d[i*rl+c] a_c; the adjoint starts from dphi = du (x) a,
+// dphi'_d = du'_d (x) a and also yields dL/da (and dL/dlatent through the rl x rl map of the ParameterNet's last layer).
+template <int NBL, int MODE, bool TRAIN, int BF, bool SGN, int NSD = NIF_SOB_MAXSEED, bool PAR = false, bool LL = false>
 __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD == 1)) ? 2 : (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm, ns = J.ns;
-  const int FP = ((n + 31) / 32) * 32;
+  const int FP = stash_fp(n);                             // feature rows per stash tile (nif_internal.h)
   const long nt32 = (A.B + 31) / 32;
   const long nt16 = 2 * nt32;
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
@@ -90,11 +97,16 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   float* sm = smem + 2 * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   constexpr int NPW = PAR ? 1 + NS : 1;                       // PAR: the same again per stream for (dL/dzt', zt')
-  float* dzs = sm + sm_tot + (long)wid * NPW * (r * 64 + r * 16);   // per wave dz partials [r][64], latent [r][16]
+  const int nrl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
+  const int llw = LL ? (2 * nrl + NQ * so + NQ * sou) * 16 : 0;   // LL per wave: a, dL/da [rl][16], phi / phi' [NQ][so][16], du / du' [NQ][so_u][16]
+  const int pwf = NPW * (r * 64 + r * 16) + ((LL && J.ll_plane) ? 0 : llw);   // per-wave floats
+  float* dzs = sm + sm_tot + (long)wid * pwf;                 // per wave dz partials [r][64], latent [r][16]
   float* zs = dzs + r * 64;
   float* dzts = zs + r * 16;                                  // [NS][r][64]
   float* zts = dzts + NS * r * 64;                            // [NS][r][16]
-  float* lsum = sm + sm_tot + (long)WAVES * NPW * (r * 64 + r * 16);
+  float* lsum = sm + sm_tot + (long)WAVES * pwf;
+  const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((nrl * nrl + 3) & ~3))) : 0;   // LL extras sit at the end of sm (snet4_nsm_ll)
+  const int o_lw = o_llb + ((sou + 3) & ~3);
   bool ispar[NS];
 #pragma unroll
   for (int d = 0; d < NS; ++d) ispar[d] = PAR && d < ns && J.par[d] >= 0;
@@ -125,6 +137,8 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
       else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      else if (LL && e >= o_llb && e < o_llb + sou) v = hyp3(A, k, s_bl + so + (e - o_llb));
+      else if (LL && e >= o_lw && e < o_lw + nrl * nrl) v = hyp3(A, k, s_bl + so + sou + (e - o_lw));
       sm[idx] = v;
     }
     if (nplanes > 0) {
@@ -315,6 +329,114 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       for (int b = 0; b < NBL; ++b) ZERO4(lam[q][b]);
     const float wsamp = (valid ? (A.sw ? A.sw[ptc] : 1.0f) : 0.0f);
     float se = 0.f, sej = 0.f;
+    if constexpr (LL) {
+      // per-wave scratch: its own LDS region, or (wide nets) a quarter of the plane buffer that is idle between the sweeps --
+      // the forward sweep's last plane has been consumed behind a barrier, the next DMA into it is issued after this block
+      float* lla = J.ll_plane ? reinterpret_cast<float*>(planes + ((gpar + 1) & 1) * (PLANE / 4)) + wid * llw
+                              : dzs + NPW * (r * 64 + r * 16);
+      float* llph = lla + nrl * 16;
+      float* lldq = llph + NQ * so * 16;
+      float* llda = lldq + NQ * sou * 16;
+      if (g == 0)
+        for (int cc = 0; cc < nrl; ++cc) lla[cc * 16 + p] = A.Z[(tile32 * nrl + cc) * 32 + poff];
+      // phi[q][o] of the tile into LDS (one value per point: lanes g = 0 write, every lane of the point reads)
+      for (int o = 0; o < so; ++o) {
+        float part[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) part[q] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            part[q] += (hq[q][b][0] * w[0] + hq[q][b][1] * w[1]) + (hq[q][b][2] * w[2] + hq[q][b][3] * w[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { part[q] += __shfl_xor(part[q], 16); part[q] += __shfl_xor(part[q], 32); }
+        part[0] += sm[o_bl + o];
+        if (g == 0) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) llph[(q * so + o) * 16 + p] = part[q];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // u_i = <phi[i,:], a> + bias_i , u'_i = <phi'[i,:], a> ; loss ; du, du' (every lane of the point computes the same)
+      for (int i = 0; i < sou; ++i) {
+        float uq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          float t = 0.f;
+          for (int cc = 0; cc < nrl; ++cc) t = fmaf(llph[(q * so + i * nrl + cc) * 16 + p], lla[cc * 16 + p], t);
+          uq[q] = t;
+        }
+        const float uo = uq[0] + sm[o_llb + i];
+        if (valid && g == 0) {
+          if (A.u_out) A.u_out[pt * sou + i] = uo;
+          if (J.JU)
+#pragma unroll
+            for (int d = 0; d < NS; ++d)
+              if (d < ns) J.JU[(pt * sou + i) * ns + J.gcol[d]] = uq[1 + d];
+        }
+        if (TRAIN) {
+          float dq[NQ];
+          const float e = uo - A.y[ptc * sou + i];
+          se = fmaf(e, e, se);
+          dq[0] = 2.0f * wsamp * e * A.inv_bg / (float)sou;
+#pragma unroll
+          for (int d = 0; d < NS; ++d) {
+            dq[1 + d] = 0.f;
+            if (d < ns) {
+              const float ej = uq[1 + d] - J.gt[(ptc * sou + i) * ns + J.gcol[d]];
+              sej = fmaf(ej, ej, sej);
+              dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * ns);
+            }
+          }
+          if (g == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) lldq[(q * sou + i) * 16 + p] = dq[q];
+            if (active) A.DU[(tile32 * sou + i) * 32 + poff] = dq[0];        // -> last_layer_bias gradient
+          }
+        }
+      }
+      if (TRAIN) {
+        __builtin_amdgcn_wave_barrier();
+        // dL/da_c = sum_i sum_q du^q_i phi^q[i*rl+c] ; dL/dlatent_c' = sum_c dL/da_c last_w[c'][c] (a = latent last_w + last_b)
+        if (g == 0) {
+          for (int cc = 0; cc < nrl; ++cc) {
+            float t = 0.f;
+            for (int i = 0; i < sou; ++i)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+                if (q <= ns) t = fmaf(lldq[(q * sou + i) * 16 + p], llph[(q * so + i * nrl + cc) * 16 + p], t);
+            if (active) A.DA_ll[(tile32 * nrl + cc) * 32 + poff] = t;
+            llda[cc * 16 + p] = t;
+          }
+          for (int c2 = 0; c2 < nrl; ++c2) {
+            float t = 0.f;
+            for (int cc = 0; cc < nrl; ++cc) t = fmaf(llda[cc * 16 + p], sm[o_lw + c2 * nrl + cc], t);
+            if (active) A.DZL[(tile32 * nrl + c2) * 32 + poff] = t;
+          }
+        }
+        // dphi^q[o] = du^q_{o / rl} a_{o % rl} -> the phi layer's weight gradient (k_gw_out over real + pseudo tiles) and lambda
+        for (int o = 0; o < so; ++o) {
+          const int i = o / nrl, cc = o - i * nrl;
+          const float av = lla[cc * 16 + p];
+          float dph[NQ];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            dph[q] = lldq[(q * sou + i) * 16 + p] * av;
+            if (q <= ns && active && g == 0) A.DPHI[(((long)q * nt32 + tile32) * so + o) * 32 + poff] = dph[q];
+          }
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sm + o_wl + o * NP + 16 * b + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) lam[q][b] += dph[q] * w;
+          }
+        }
+      }
+      if (J.ll_plane) __syncthreads();       // every wave is done with its scratch before the next plane's DMA lands there
+    } else
     for (int o = 0; o < so; ++o) {
       f32x4 wg[NBL];
 #pragma unroll
@@ -432,7 +554,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       }
     }
     if (TRAIN) {
-      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)so + J.wj * sej / (float)(so * ns));
+      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)sou + J.wj * sej / (float)(sou * ns));
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       f32x4 skip[MODE != 0 ? NQ : 1][MODE != 0 ? NBL : 1];

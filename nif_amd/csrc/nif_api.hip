@@ -381,6 +381,8 @@ static int ensure_capacity(nif_ctx* c, long B, bool train) {
       c->slot_p = (long)c->NSTB * 32 * newcap;
       HIPCHK(hipMalloc(&c->stash_s, sizeof(float) * (size_t)(c->slot_s * 2 * (c->nh + 1))));
       HIPCHK(hipMalloc(&c->stash_p, sizeof(float) * (size_t)(c->slot_p * (2 * c->nm + 2))));
+      if (c->NB * 32 > ((c->n + 15) / 16) * 16)    // 65..96 (and 33..48) units: the rows the fused kernels never write must read as zero
+        HIPCHK(hipMemsetAsync(c->stash_s, 0, sizeof(float) * (size_t)(c->slot_s * 2 * (c->nh + 1)), c->st));
     } else if (newcap > c->cap && c->stash_s) {
       HIPCHK(hipFree(c->stash_s)); HIPCHK(hipFree(c->stash_p));
       c->stash_s = c->stash_p = nullptr;
@@ -519,6 +521,7 @@ static int ensure_packed(nif_ctx* c) {
   if (c->NSTB > 1) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   ProfScope ps_(c, NIF_PROF_PACK);
   if (c->kind == NIF_KIND_LASTLAYER) {
+    c->ll_packed32 = false;
     const long plane_l = (long)c->NB * c->NB * 256;
     for (int i = 0; i < c->L; ++i) {
       if (!c->cfg.s_resblock) {
@@ -842,9 +845,35 @@ extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, 
 }
 
 // ---- last-layer-parameterised class: loss and gradient ---------------------------------------------
-static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const float* sw, long B, long Bg) {
+// SNetArgs of the last-layer class for k_sob (Sobolev step / its predict): k_snet4's arguments for that class plus, beyond the
+// widths whose bf16 planes fit the LDS (n > 96), the f32-input MFMA planes of the shared hidden matrices, packed on demand
+static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B) {
+  if (!c->use_ll4) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: ShapeNet widths of the 16-point-tile path (even 16-blocks, units <= 128, so * latent_dim <= 32)");
+  fill_snet_ll(c, sa, xin, c->pi + c->si, c->pi, B);
+  if (!sob_ll_supported(sa)) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: unsupported ShapeNet shape");
+  const int NBL = snet3_nbl(c->n);
+  if (NBL > 6) {
+    const long plane_s = snet3_plane_floats(c->n) / 4;
+    if (!c->ll_packed32) {
+      for (int j = 0; j < c->nh; ++j) {
+        long w_off;
+        if (!c->cfg.s_resblock) w_off = c->s_hid_w[j];
+        else { const int i = j / 2; w_off = (j & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; }
+        launch_pack16(c->theta, dense_ref(w_off, c->n, c->n), NBL, c->sWF + (long)j * plane_s, c->sWB + (long)j * plane_s, c->st);
+      }
+      c->ll_packed32 = true;
+    }
+    sa.WF = c->sWF; sa.WB = c->sWB; sa.WF4 = nullptr; sa.WB4 = nullptr;
+  }
+  return NIF_OK;
+}
+
+static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const float* sw, long B, long Bg, int ns = 0,
+                        const SobPlan* sp = nullptr, const float* gt = nullptr, float wj = 0.f) {
   const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
+  if (ns > 0 && sp->any_par)
+    return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
   LLArgs la; fill_ll(c, la, B);
@@ -854,7 +883,18 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   int nloss = (int)((ntiles * 32 + 255) / 256);
-  if (c->use_ll4) {
+  if (ns > 0) {   // Sobolev: primal + tangents + their adjoint on k_sob<.., LL>; stashes and DPHI hold (1 + ns) blocks of tiles
+    SNetArgs sa; int rc = fill_snet_ll_sob(c, sa, xin, B); if (rc) return rc;
+    sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+    nloss = launch_sob(sa, true, ns, sp->seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
+    const long need = (long)nloss * 4 * sob_ring_floats_per_wave(c->n, c->nh);
+    if (need > c->dring_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc; }
+    SobPar spar;
+    for (int d = 0; d < 3; ++d) { spar.par[d] = -1; spar.gcol[d] = sp->gcol[d]; }
+    spar.ZT = nullptr; spar.DZT = nullptr;
+    ProfScope p_(c, NIF_PROF_SNET);
+    launch_sob(sa, true, ns, sp->seeds, gt, wj, c->dring, nullptr, false, c->st, &spar);
+  } else if (c->use_ll4) {
     SNetArgs sa; fill_snet_ll(c, sa, xin, ncol, c->pi, B);
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
     nloss = launch_snet4(sa, true, true, c->st);
@@ -887,19 +927,26 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     };
     const int nms = c->nh;  // hidden matrices of the ShapeNet (2L with resblocks)
     float* sST = c->stash_s;
+    auto sbase = [&](GwArgs& q) {   // Sobolev: the ShapeNet reductions also run over the tangent pseudo-tiles
+      base(q);
+      if (ns > 0) {
+        q.ntiles = ntiles * (1 + ns); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
+        for (int d = 0; d < 3; ++d) q.seed[d] = d < ns ? sp->seeds[d] : 0;
+      }
+    };
     // ShapeNet (dense SIREN): first, hidden matrices, bottleneck (n -> r*so), last_layer_bias
-    base(g); g.DA = sST + (long)(nms + 1) * c->slot_s; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.scale = ma.omega;
+    sbase(g); g.DA = sST + (long)(nms + 1) * c->slot_s; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.scale = ma.omega;
     g.W = dense_ref(c->s_first_w, c->si, c->n); g.Bv = vec_ref(c->s_first_b, c->n);
     launch_gw_first(g, c->NB, rows, c->st);
     for (int mi = 0; mi < nms; ++mi) {
-      base(g); g.IN = sST + (long)mi * c->slot_s; g.DA = sST + (long)(nms + 2 + mi) * c->slot_s; g.scale = ma.omega;
+      sbase(g); g.IN = sST + (long)mi * c->slot_s; g.DA = sST + (long)(nms + 2 + mi) * c->slot_s; g.scale = ma.omega;
       long w_off, b_off;
       if (!c->cfg.s_resblock) { w_off = c->s_hid_w[mi]; b_off = c->s_hid_b[mi]; }
       else { const int i = mi / 2; w_off = (mi & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (mi & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
       g.W = dense_ref(w_off, c->n, c->n); g.Bv = vec_ref(b_off, c->n);
       launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
     }
-    base(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
+    sbase(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
     g.W = dense_ref(c->s_bott_w, c->n, c->r * c->so); g.Bv = vec_ref(c->s_bott_b, c->r * c->so);
     launch_gw_out(g, c->NB, rows, c->st);
     base(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DU; g.nc = c->so;   // only the bias part: W.nin = 0
@@ -1163,9 +1210,11 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   const long ntiles = (B + 31) / 32;
   if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
   if (ns > 0) {
-    if (c->kind == NIF_KIND_LASTLAYER || !c->use_snet3)
-      return fail(NIF_ERR_INVALID, "Sobolev training is built for NIF / NIFMultiScale on the 16-point-tile path (units <= 128)");
+    if (c->kind != NIF_KIND_LASTLAYER && !c->use_snet3)
+      return fail(NIF_ERR_INVALID, "Sobolev training is built for the 16-point-tile path (units <= 128)");
     if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
+    if (c->kind == NIF_KIND_LASTLAYER && sp && sp->any_par)
+      return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
   }
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
   if (sp && sp->any_par) {   // z' = dz/dp of the parameter columns, in front of the ShapeNet
@@ -1179,7 +1228,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     launch_pjac_fwd(pa, c->zt_par, c->st);
   }
   c->reg_applied = false;
-  if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg);
+  if (c->kind == NIF_KIND_LASTLAYER) return loss_grad_ll(c, xin, y, sw, B, Bg, ns, sp, gt, wj);
   // Two-stream pipeline over chunks of the batch (plain step on the 16-point-tile kernels): the fused ShapeNet kernel of
   // chunk i+1 (VALU / latency bound, 2 workgroups per CU) overlaps the HBM-bound weight-gradient reductions of chunk i
   const long chunk = (ns == 0 && c->use_snet3 && !act_on(c) && c->jac_l1 == 0.f) ? pipe_chunk_points(c, B) : 0;
@@ -1306,14 +1355,22 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
-  if (c->kind == NIF_KIND_LASTLAYER || !c->use_snet3)
-    return fail(NIF_ERR_INVALID, "Sobolev path is built for NIF / NIFMultiScale on the 16-point-tile path (units <= 128)");
+  if (c->kind != NIF_KIND_LASTLAYER && !c->use_snet3)
+    return fail(NIF_ERR_INVALID, "Sobolev path is built for the 16-point-tile path (units <= 128)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   launch_pnet(pa, c->NSTB, false, c->st);
   SobPar spar;
   for (int d = 0; d < 3; ++d) { spar.par[d] = sp.par[d]; spar.gcol[d] = sp.gcol[d]; }
   spar.ZT = nullptr; spar.DZT = nullptr;
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    if (sp.any_par) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
+    SNetArgs sl; rc = fill_snet_ll_sob(c, sl, xin, B); if (rc) return rc;
+    sl.u_out = u;
+    launch_sob(sl, false, nx, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
+    HIPCHK(hipGetLastError());
+    return NIF_OK;
+  }
   if (sp.any_par) {
     if (!pjac_supported(pa))
       return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");

@@ -115,6 +115,11 @@ __host__ __device__ inline long slot_b1(const SNetArgs& a) { return slot_wl(a) +
 __host__ __device__ inline long slot_bh(const SNetArgs& a, int j) { return slot_b1(a) + a.n + (long)j * a.n; }
 __host__ __device__ inline long slot_bl(const SNetArgs& a) { return slot_b1(a) + a.n + (long)a.nh * a.n; }
 
+// feature rows of a ShapeNet stash tile: the gradient kernels come in 32-, 64- and 128-row forms (nif_ctx::NB = 1, 2, 4), so a
+// 65..96-unit layer is stored with 128 rows like a 128-unit one (rows >= 16 * ceil(n / 16) are never written: zero from the
+// allocation's memset).  Producers (k_snet3 / k_snet4 / k_sob) and consumers (k_gw*) must agree on this.
+__host__ __device__ inline int stash_fp(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : 128); }
+
 // ------------------------------------------------------------------------------------------
 // weight-gradient kernels: C[k][in][out] = scale * sum_p zt_k[p] * IN[p][in] * DA[p][out]
 // ------------------------------------------------------------------------------------------
@@ -169,6 +174,7 @@ int snet4_edge_ne(const SNetArgs& a);    // floats of one workgroup's edge parti
 void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
+bool sob_ll_supported(const SNetArgs& a);   // last-layer class under k_sob (k_sob_ll.hip)
 // parameter seeds (x_index < pi_dim): stream d is a parameter stream iff par[d] >= 0 (then seeds[d] is unused); gcol[d] = the
 // column of gt / ju the stream fills; ZT = dz/dp [pi][tiles][r][32] (launch_pjac_fwd), DZT = dL/d(that) per stream
 struct SobPar { int par[3]; int gcol[3]; const float* ZT; float* DZT; };

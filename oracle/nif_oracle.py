@@ -815,6 +815,8 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     term  a' = w0 (h' W + h W') + b' , and the adjoint yields dL/dpnet_out' next to dL/dpnet_out; both go back through the
     hyper layer and the (primal, tangent) ParameterNet (pnet_tangents_backward).
     Returns (loss, grads in Keras order, u, dudx)."""
+    if spec.kind == KIND_LL:
+        return _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight, batch_global)
     assert spec.kind in (KIND_MS, KIND_NIF)
     nif = spec.kind == KIND_NIF
     B = inputs.shape[0]
@@ -946,6 +948,42 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     return loss, core + [g_last_w, gw.sum(0)], u, J
 
 
+def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
+    """Sobolev step of the last-layer-parameterised class (model.py:1044-1068, :1219-1269 under JacobianLayer): the shared
+    SIREN ShapeNet x -> phi [B,so,r] carries the coordinate tangents phi'_d (_mlp_tangents), u = Dot(phi, a) + bias and
+    du/dx_d = Dot(phi'_d, a) with a = the ParameterNet output; coordinate columns only."""
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    si, so, r = spec.si, spec.so, spec.r
+    seeds = [j - spec.pi for j in x_index]
+    assert all(0 <= d < si for d in seeds)
+    nx = len(seeds)
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + si]
+    a, z, ptape = pnet_forward(spec, ws, p, keep=True)                 # po = r for this class (model.py:583-585)
+    *_, rest = _pnet_split(spec, ws)
+    first, hidden, bott, bias = _snet_split(spec, rest)
+    layers = (first, hidden, bott)
+    phi_f, phid_f, sctx = _mlp_tangents(layers, True, spec.omega_s, "sine", spec.s_res, x, seeds)
+    phi = phi_f.reshape(B, so, r)
+    phid = [v.reshape(B, so, r) for v in phid_f]
+    u = np.einsum("bsj,bj->bs", phi, a) + bias
+    J = np.stack([np.einsum("bsj,bj->bs", v, a) for v in phid], axis=2)      # [B, so, nx]
+    w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
+    e = u - y
+    ej = J - np.asarray(dydx).reshape(B, so, nx)
+    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
+    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    g_a = np.einsum("bsj,bs->bj", phi, g_u)
+    for v, g in zip(phid, g_ud):
+        g_a = g_a + np.einsum("bsj,bs->bj", v, g)
+    g_phi = (g_u[:, :, None] * a[:, None, :]).reshape(B, -1)
+    g_phid = [(g[:, :, None] * a[:, None, :]).reshape(B, -1) for g in g_ud]
+    g_snet = _mlp_tangents_backward(layers, True, spec.omega_s, "sine", spec.s_res, sctx, g_phi, g_phid)
+    return loss, pnet_backward(spec, ws, ptape, g_a) + g_snet + [g_u.sum(0)], u, J
+
+
 def flatten(arrs):
     return np.concatenate([np.asarray(a).ravel() for a in arrs])
 
@@ -1035,8 +1073,23 @@ def pnet_tangents(spec, ws, p, cols):
     (mlp.py:62-79, :148-160; siren.py:256-281, :381-410)."""
     first, hidden, bott, last, rest = _pnet_split(spec, ws)
     siren = spec.p_siren
-    s = spec.omega_p if siren else 1.0
-    name = "sine" if siren else spec.p_act
+    return _mlp_tangents((first, hidden, bott), siren, spec.omega_p if siren else 1.0, "sine" if siren else spec.p_act, spec.p_res,
+                         p, cols)
+
+
+def pnet_tangents_backward(spec, ws, ctx, g_z, g_zd):
+    """Adjoint of pnet_tangents: g_z = dL/dz [B,r] (or None), g_zd[d] = dL/d(dz/dp_cols[d]) -> gradients of the first / hidden
+    / bottleneck variables (Keras order)."""
+    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    siren = spec.p_siren
+    return _mlp_tangents_backward((first, hidden, bott), siren, spec.omega_p if siren else 1.0, "sine" if siren else spec.p_act,
+                                  spec.p_res, ctx, g_z, g_zd)
+
+
+def _mlp_tangents(layers, siren, s, name, res, p, cols):
+    """A shared-weight MLP of the reference's layer kinds (first / hidden / linear bottleneck) with forward-mode tangents
+    w.r.t. its input columns `cols`: the ParameterNet (pnet_tangents) and the last-layer class's ShapeNet x -> phi."""
+    first, hidden, bott = layers
     f, df = act_fn(name)
     D = range(len(cols))
     a0 = s * (p @ first[0]) + first[1]
@@ -1044,7 +1097,7 @@ def pnet_tangents(spec, ws, p, cols):
     h = f(a0); hd = [df(a0) * a0d[d] for d in D]
     tape = []
     for lay in hidden:
-        if not spec.p_res:
+        if not res:
             a = s * (h @ lay[0]) + lay[1]; ad = [s * (hd[d] @ lay[0]) for d in D]
             tape.append(("plain", h, hd, a, ad))
             if siren:
@@ -1067,19 +1120,15 @@ def pnet_tangents(spec, ws, p, cols):
     return z, zd, (p, list(cols), a0, a0d, tape, h, hd)
 
 
-def pnet_tangents_backward(spec, ws, ctx, g_z, g_zd):
-    """Adjoint of pnet_tangents: g_z = dL/dz [B,r] (or None), g_zd[d] = dL/d(dz/dp_cols[d]) -> gradients of the first / hidden
-    / bottleneck variables (Keras order).  With lambda = dL/dh, mu_d = dL/dh'_d:
+def _mlp_tangents_backward(layers, siren, s, name, res, ctx, g_z, g_zd):
+    """Adjoint of _mlp_tangents.  With lambda = dL/dh, mu_d = dL/dh'_d:
     nu_d = mu_d f'(a), da = lambda f'(a) + sum_d mu_d f''(a) a'_d, dW = s (h^T da + sum_d h'_d^T nu_d)."""
-    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    first, hidden, bott = layers
     p, cols, a0, a0d, tape, h, hd = ctx
-    siren = spec.p_siren
-    s = spec.omega_p if siren else 1.0
-    name = "sine" if siren else spec.p_act
     f, df = act_fn(name)
     d2f = act_d2(name)
     D = range(len(cols))
-    gz = np.zeros((p.shape[0], spec.r), dtype=h.dtype) if g_z is None else g_z
+    gz = np.zeros((p.shape[0], bott[0].shape[1]), dtype=h.dtype) if g_z is None else g_z
     g_bott = [h.T @ gz + sum(hd[d].T @ g_zd[d] for d in D), gz.sum(0)]
     lam = gz @ bott[0].T
     mu = [g_zd[d] @ bott[0].T for d in D]

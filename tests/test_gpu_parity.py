@@ -57,6 +57,13 @@ CONFIGS = {
     "ms_cfg5_64x4_si2": (_cfg("NIFMultiScale", 64, 4, 32, 2, 1, 2, 1, 1, p_act="swish"), 300),
     "ll_cfg4_128x6_r10_so3": (_cfg("LL", 128, 6, 32, 2, 10, 3, 3, 1, p_act="swish"), 160),
     "ll_128x4_r4": (_cfg("LL", 128, 4, 32, 2, 4, 2, 1, 1), 70),
+    "ll_res_64x1_r4_so2": (_cfg("LL", 64, 1, 40, 2, 4, 3, 2, 2, s_res=True, p_res=True, p_act="swish"), 130),
+    "ll_96x2_r5": (_cfg("LL", 96, 2, 32, 1, 5, 2, 3, 1), 77),
+    # 65..96 units = six 16-blocks in the fused kernels but 128-row stash tiles for the gradient kernels (stash_fp): r1 / early r2
+    # builds disagreed on the tile stride there and produced wrong ShapeNet weight gradients without any error
+    "ms_96x2_r2": (_cfg("NIFMultiScale", 96, 2, 32, 1, 2, 2, 1, 1), 77),
+    "ms_res_80x1_so2": (_cfg("NIFMultiScale", 80, 1, 32, 1, 1, 2, 2, 1, s_res=True), 140),
+    "nif_80x2_swish_r2": (_cfg("NIF", 80, 2, 32, 2, 2, 1, 1, 1, act="swish"), 100),
 }
 
 
@@ -404,7 +411,8 @@ def test_lbfgs_fine_tuning_reduces_loss():
 
 # ---- Sobolev training (BASELINE config 5): JacobianLayer as a trained output -----------------------------
 SOB = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1",
-       "ms_cfg5_64x4_si2", "ms_cfg3_128x6", "ms_64x8", "nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2"]
+       "ms_cfg5_64x4_si2", "ms_cfg3_128x6", "ms_64x8", "nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_96x2_r2", "ms_res_80x1_so2",
+       "nif_80x2_swish_r2"]
 
 
 @pytest.mark.parametrize("name", SOB)
@@ -462,9 +470,49 @@ def test_sobolev_single_seed_and_zero_weight_degenerates():
         m._engine.sobolev_loss_and_grad(x, y, g, [spec.pi + spec.si], 0.2, sw)
     with pytest.raises(nif_amd._lib.NifError):
         m._engine.sobolev_loss_and_grad(x, y, np.concatenate([g, g], axis=2), [1, 1], 0.2, sw)
+    # last-layer class: parameter columns, and ShapeNet widths outside its 16-point-tile path (48 = three 16-blocks)
     m2, model2, spec2, ws2, x2, y2, sw2 = _make("ll_plain_32x2_r3")
     with pytest.raises(nif_amd._lib.NifError):
-        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], spec2.so, 1), np.float32), [1], 0.2, None)
+        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], spec2.so, 1), np.float32), [0], 0.2, None)
+    m3, model3, spec3, ws3, x3, y3, sw3 = _make("ll_res_48x2_r4")
+    with pytest.raises(nif_amd._lib.NifError):
+        m3._engine.sobolev_loss_and_grad(x3, y3, np.zeros((x3.shape[0], spec3.so, 1), np.float32), [spec3.pi], 0.2, None)
+
+
+SOB_LL = ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_cfg4_128x6_r10_so3", "ll_128x4_r4", "ll_res_64x1_r4_so2", "ll_96x2_r5"]
+
+
+@pytest.mark.parametrize("name", SOB_LL)
+@pytest.mark.parametrize("weighted", [False, True])
+def test_sobolev_last_layer_class_matches_oracle(name, weighted):
+    """JacobianLayer as a trained output of NIFMultiScaleLastLayerParameterized (model.py:1044-1068, :1219-1269): the shared
+    SIREN ShapeNet carries the coordinate tangents, u = Dot(phi, a) + bias, du/dx = Dot(phi', a) (k_sob<.., LL>)"""
+    m, model, spec, ws, x, y, sw = _make(name)
+    B = x.shape[0]
+    xi = list(range(spec.pi, spec.pi + spec.si))[::-1][:3]          # reversed order: stream <-> dydx column mapping
+    rng = np.random.default_rng(13)
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    sample_weight = sw if weighted else None
+    wj = 0.05
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, wj, sample_weight)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, wj,
+                                             None if sample_weight is None else sample_weight.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    off = 0
+    for (nm, shp), r_ in zip(spec.param_shapes(), rg):
+        k = int(np.prod(shp))
+        got = grad[off:off + k].reshape(shp)
+        off += k
+        err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+        assert err < 3e-4, (nm, err)
+    from nif_amd import JacobianLayer, SobolevModel
+    sm = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi))
+    u, J = sm.predict(x)
+    assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
+    # the plain step of the class afterwards (k_snet4<.., LL>) is untouched
+    l1, g1 = m._engine.loss_and_grad(x, y, sw)
+    rl1, rg1 = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
+    assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4
 
 
 SOB_PAR = ["ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres", "ms_mlp_pres_so2", "ms_cfg3_128x3", "ms_tiny_b1",

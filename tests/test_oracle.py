@@ -95,7 +95,7 @@ def test_jacobian_fd_vs_analytic_vs_autograd(name):
     assert np.allclose(Jp, tJ[:, :, :spec.pi], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "nif_swish", "nif_tanh_r2_so2"])
+@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "nif_swish", "nif_tanh_r2_so2", "ll_plain", "ll_res"])
 def test_sobolev_loss_and_grad_match_torch_double_backward(name):
     """Sobolev step (JacobianLayer as a trained output): the oracle's hand-derived adjoint of the tangent
     program against torch autograd through the input gradient, with and without sample weights."""
