@@ -188,73 +188,163 @@ void launch_given_w(const float* x, const float* w, float* u, long B, int si, in
 
 // ============================================================================================
 // model_lr_to_w: w[a][s] = sum_k lr[a][k] Wh[k][s] + bh[s]   (siren.py:514-522 / Dense model.py:220-230)
-// write-bound (4*po bytes per point); each block keeps a slab of Wh rows in registers across points
+// A pure write stream (4*po bytes per point).  What decides its speed is the LENGTH of the contiguous bursts: 4 KB per
+// workgroup per row (the r1 / early-r2 kernels, whatever the alignment) stops at 3.5 TB/s even with no arithmetic at all, one
+// linear stream reaches 5.6 of the 6.4 TB/s hipMemset gets (tools/exp/l2w_probe.hip).  Two forms, both with Wh / bh staged in
+// LDS by a 1024-thread workgroup: k_latent_to_w_flat (below) when the whole layer fits, else this one -- a column window as wide
+// as the LDS takes, over a block of CONSECUTIVE rows.  Rows start at a * po floats with po odd: every store is still one 16-byte ALIGNED
+// unit (unit U of row a = slots 4U - m .. 4U - m + 3, m = (a * po + buffer offset) mod 4, wave-uniform); the LDS reads are
+// dword reads at the unaligned slot, the few units that hang over a row end are written slot by slot.
 // ============================================================================================
-// A thread owns the 16-byte ALIGNED window of 4 output floats number blockIdx.x*256 + threadIdx.x of every row it visits.
-// Rows of w start at a * po floats and po is odd, so the window's first slot is s0 = 4 t - m with m = (a * po) mod 4 the
-// (wave-uniform) misalignment of row a: the thread keeps the 7 slots 4t-3 .. 4t+3 of the bias and of the first hyper row in
-// registers and picks its 4 by m.  Every store is one aligned dwordx4 (a wave writes 1 KiB of whole cache lines); with
-// row-relative windows (the r1 kernel) each lane's 16 bytes straddled a 16-byte boundary: 3.7 TB/s.
-template <int M>
-__device__ __forceinline__ void l2w_row(const float* __restrict__ theta, long off_Wh, int r, long po, const float* __restrict__ lrow,
-                                        const float (&bias)[7], const float (&w0)[7], long t4, float* __restrict__ wrow) {
-  const long s0 = t4 - M;                       // first slot of the window (may be negative / run past po at the row ends)
-  float acc[4];
-  const float z0 = lrow[0];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = fmaf(z0, w0[c + 3 - M], bias[c + 3 - M]);
-  for (int k = 1; k < r; ++k) {
-    const float zk = lrow[k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const long sc = s0 + c;
-      if (sc >= 0 && sc < po) acc[c] = fmaf(zk, theta[off_Wh + (long)k * po + sc], acc[c]);
-    }
+#define NIF_L2W_T 1024
+__global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
+                                                          long po, const float* __restrict__ lr, long B,
+                                                          float* __restrict__ w, int CU, int LW, long rows_per_block) {
+  extern __shared__ float l2w_sm[];            // [(r+1)][LW]: planes k < r = Wh rows, plane r = bh; slot s at [s - c0 + 3]
+  const long c0 = 4L * blockIdx.x * CU;        // first slot of this column window's units (row-relative, before the -m shift)
+  for (int idx = threadIdx.x; idx < (r + 1) * LW; idx += NIF_L2W_T) {
+    const int k = idx / LW, e = idx - k * LW;
+    const long sc = c0 - 3 + e;
+    float v = 0.f;
+    if (sc >= 0 && sc < po) v = k < r ? theta[off_Wh + (long)k * po + sc] : theta[off_bh + sc];
+    l2w_sm[idx] = v;
   }
-  float* dst = wrow + s0;                       // (a * po + s0) * 4 bytes is a multiple of 16 by construction
-  if (s0 >= 0 && s0 + 4 <= po) {
-    f32x4 v; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
-#ifdef NIF_L2W_NT
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
-#else
-    *reinterpret_cast<f32x4*>(dst) = v;
-#endif
-  } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (s0 + c >= 0 && s0 + c < po) dst[c] = acc[c];
-  }
-}
-__global__ __launch_bounds__(256) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
-                                                     long po, const float* __restrict__ lr, long B,
-                                                     float* __restrict__ w) {
-  const long t4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (t4 - 3 >= po) return;
-  float bias[7], w0[7];
-#pragma unroll
-  for (int c = 0; c < 7; ++c) {
-    const long sc = t4 - 3 + c;
-    const bool in = sc >= 0 && sc < po;
-    bias[c] = in ? theta[off_bh + sc] : 0.f;
-    w0[c] = in ? theta[off_Wh + sc] : 0.f;
-  }
+  __syncthreads();
   const int wmis = (int)((reinterpret_cast<size_t>(w) >> 2) & 3);       // misalignment of the buffer itself (floats)
-  for (long a = blockIdx.y; a < B; a += gridDim.y) {
+  const long a0 = (long)blockIdx.y * rows_per_block;
+  const long a1 = a0 + rows_per_block < B ? a0 + rows_per_block : B;
+  const float* sB = l2w_sm + (long)r * LW;
+  for (long a = a0; a < a1; ++a) {
     const int m = (int)((a * po + wmis) & 3);
     const float* lrow = lr + a * r;
     float* wrow = w + a * po;
-    switch (m) {
-      case 0: l2w_row<0>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
-      case 1: l2w_row<1>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
-      case 2: l2w_row<2>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
-      default: l2w_row<3>(theta, off_Wh, r, po, lrow, bias, w0, t4, wrow); break;
+    const long nun = (po + m + 3) / 4;                     // units of this row
+    for (int ul = threadIdx.x; ul < CU; ul += NIF_L2W_T) {
+      const long U = (long)blockIdx.x * CU + ul;
+      if (U >= nun) break;
+      const int e0 = 4 * ul - m + 3;                       // LDS index of the unit's first slot
+      float acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = sB[e0 + c];
+      for (int k = 0; k < r; ++k) {
+        const float zk = lrow[k];
+        const float* sW = l2w_sm + (long)k * LW + e0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(zk, sW[c], acc[c]);
+      }
+      const long s0 = 4 * U - m;
+      float* dst = wrow + s0;                              // (a * po + s0) * 4 bytes is a multiple of 16 by construction
+      if (s0 >= 0 && s0 + 4 <= po) {
+        f32x4 v; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (s0 + c >= 0 && s0 + c < po) dst[c] = acc[c];
+      }
+    }
+  }
+}
+// The whole hyper layer fits the LDS (cfg-2: 134 KB): the output is ONE array of B * po floats, cut into 16-byte aligned units;
+// a workgroup streams a contiguous span of units, (row, column) of a unit by one division, the few units that straddle a row
+// boundary pick up the next row's latent on the way.  5.6 TB/s where the row-walking form above stays at 3.5-4.1 (its bursts end
+// at every row: 67 KB) -- tools/exp/l2w_probe.hip.
+// R > 0: latent_dim known at compile time, the row's latent lives in registers (one load per unit, reloaded at a row
+// boundary); R = 0: any latent_dim, loaded per element
+template <int R>
+__global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w_flat(const float* __restrict__ theta, long off_Wh, long off_bh, int r_,
+                                                               int po, const float* __restrict__ lr, long B,
+                                                               float* __restrict__ w, long nunits, long span) {
+  extern __shared__ float l2w_sm[];            // [(r+1)][po]: planes k < r = Wh rows, plane r = bh
+  const int r = R > 0 ? R : r_;
+  for (long idx = threadIdx.x; idx < (long)(r + 1) * po; idx += NIF_L2W_T) {
+    const int k = (int)(idx / po); const int e = (int)(idx - (long)k * po);
+    l2w_sm[idx] = k < r ? theta[off_Wh + (long)k * po + e] : theta[off_bh + e];
+  }
+  __syncthreads();
+  const int wmis = (int)((reinterpret_cast<size_t>(w) >> 2) & 3);       // misalignment of the buffer itself (floats)
+  const long n = B * (long)po;
+  const float* sB = l2w_sm + r * po;
+  const long u0 = (long)blockIdx.x * span;
+  const long u1 = u0 + span < nunits ? u0 + span : nunits;
+  for (long u = u0 + threadIdx.x; u < u1; u += NIF_L2W_T) {
+    const long e = 4 * u - wmis;               // flat index of the unit's first float (may be < 0 for u = 0)
+    long a = (e < 0 ? 0 : e) / po;
+    int sc = (int)(e - a * po);                // column of the first float (negative only for e < 0)
+    float zr[R > 0 ? R : 1];
+    if (R > 0) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) zr[k] = a < B ? lr[a * R + k] : 0.f;
+    }
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float acc = 0.f;
+      if (sc >= 0) {
+        acc = sB[sc];
+        if (R > 0) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) acc = fmaf(zr[k], l2w_sm[k * po + sc], acc);
+        } else if (a < B) {
+          for (int k = 0; k < r; ++k) acc = fmaf(lr[a * r + k], l2w_sm[k * po + sc], acc);
+        }
+      }
+      v[c] = acc;
+      if (++sc == po) {
+        sc = 0; ++a;
+        if (R > 0) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) zr[k] = a < B ? lr[a * R + k] : 0.f;
+        }
+      }
+    }
+    if (e >= 0 && e + 4 <= n) {
+      f32x4 q; q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+      *reinterpret_cast<f32x4*>(w + e) = q;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (e + c >= 0 && e + c < n) w[e + c] = v[c];
     }
   }
 }
 void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B, float* w,
                         hipStream_t st) {
-  dim3 grid((unsigned)((po + 3 + 1023) / 1024), (unsigned)(B < 2048 ? B : 2048)), block(256);
-  hipLaunchKernelGGL(k_latent_to_w, grid, block, 0, st, theta, off_Wh, off_bh, r, po, lr, B, w);
+  if ((size_t)(r + 1) * po * sizeof(float) <= 144u * 1024u) {
+    const long nunits = (B * po + 3 + 3) / 4;
+    const long nb = 4096;
+    const long span = ((nunits + nb - 1) / nb + NIF_L2W_T - 1) / NIF_L2W_T * NIF_L2W_T;
+    const long nblk = (nunits + span - 1) / span;
+    const size_t shm = sizeof(float) * (size_t)(r + 1) * po;
+#define NIF_L2WF(R_)                                                                                                       \
+    {                                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)k_latent_to_w_flat<R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      hipLaunchKernelGGL(k_latent_to_w_flat<R_>, dim3((unsigned)nblk), dim3(NIF_L2W_T), shm, st, theta, off_Wh, off_bh, r, (int)po, lr, \
+                         B, w, nunits, span);                                                                               \
+    }
+    switch (r) {
+      case 1: NIF_L2WF(1) break;
+      case 2: NIF_L2WF(2) break;
+      case 3: NIF_L2WF(3) break;
+      case 4: NIF_L2WF(4) break;
+      default: NIF_L2WF(0) break;
+    }
+#undef NIF_L2WF
+    return;
+  }
+  // units per column window: as many as fit 144 KB of LDS
+  const long units_row = (po + 3 + 3) / 4;
+  long CU = (144L * 1024 / 4 / (r + 1) - 8) / 4;
+  if (CU > units_row) CU = units_row;
+  const int LW = (int)(4 * CU + 8);
+  const long ncw = (units_row + CU - 1) / CU;
+  long nrb = 8192 / ncw; if (nrb < 1) nrb = 1; if (nrb > B) nrb = B;
+  const long rpb = (B + nrb - 1) / nrb;
+  nrb = (B + rpb - 1) / rpb;
+  const size_t shm = sizeof(float) * (size_t)(r + 1) * LW;
+  (void)hipFuncSetAttribute((const void*)k_latent_to_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL(k_latent_to_w, dim3((unsigned)ncw, (unsigned)nrb), dim3(NIF_L2W_T), shm, st, theta, off_Wh, off_bh, r, po, lr, B,
+                     w, (int)CU, LW, rpb);
 }
 
 // ============================================================================================
