@@ -20,6 +20,7 @@ static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg, const int
 // that the first-layer reduction simply stops in front of them); gcol = the x_index position (column of dydx) of each stream
 struct SobPlan { int ns, nsc; int seeds[3]; int par[3]; int gcol[3]; bool any_par; };
 static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const SobPlan& sp, const SNetArgs& sa);
+static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B, bool f32_planes = false);
 
 #ifndef NIF_PIPE_CHUNK_DEFAULT
 #define NIF_PIPE_CHUNK_DEFAULT 131072L
@@ -715,10 +716,59 @@ extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_
     if (x_idx[j] < c->pi || x_idx[j] >= c->pi + c->si)
       return fail(NIF_ERR_INVALID, "HessianLayer is built for coordinate columns (pi_dim <= x_index < pi_dim + si_dim): second-order "
                                    "tangents through the ParameterNet are not");
-  if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "HessianLayer is built for NIF / NIFMultiScale");
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
+  if (c->kind == NIF_KIND_LASTLAYER) {
+    // u_i = sum_c phi[i,c] a_c + bias_i with a independent of the coordinates: second-order tangents of the shared SIREN
+    // ShapeNet x -> phi (the r = 0 case of the same kernel, so * latent_dim outputs), contracted with a on the host (this
+    // entry point takes and returns host arrays)
+    rc = ensure_capacity(c, B, false); if (rc) return rc;
+    const int ncol = c->pi + c->si, rl = c->r, sop = c->so * c->r;
+    rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
+    rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * sop); if (rc) return rc;
+    rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * sop * nx); if (rc) return rc;
+    rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * sop * nx * nx); if (rc) return rc;
+    PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+    launch_pnet(pa, c->NSTB, false, c->st);
+    SNetArgs sa; rc = fill_snet_ll_sob(c, sa, c->d_a, B, true); if (rc) return rc;
+    for (int j = 0; j < nx; ++j)
+      for (int k = j; k < nx; ++k) {
+        sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
+        launch_hess(sa, x_idx[j] - c->pi, x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st);
+      }
+    HIPCHK(hipGetLastError());
+    const long ntl = (B + 31) / 32;
+    std::vector<float> f0((size_t)B * sop), fj((size_t)B * sop * nx), fh((size_t)B * sop * nx * nx), za((size_t)ntl * rl * 32), bias(c->so);
+    HIPCHK(hipMemcpyAsync(f0.data(), c->d_d, sizeof(float) * f0.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(fj.data(), c->d_b, sizeof(float) * fj.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(fh.data(), c->d_c, sizeof(float) * fh.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(za.data(), c->Z, sizeof(float) * za.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(bias.data(), c->theta + c->ll_bias, sizeof(float) * bias.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int64_t a_ = 0; a_ < B; ++a_) {
+      const float* av = za.data() + (size_t)(a_ >> 5) * rl * 32 + (a_ & 31);       // a_c at av[c * 32]
+      for (int i = 0; i < c->so; ++i) {
+        double u = bias[i];
+        for (int cc = 0; cc < rl; ++cc) u += (double)f0[(size_t)a_ * sop + i * rl + cc] * av[cc * 32];
+        y_out[a_ * c->so + i] = (float)u;
+      }
+      for (int i = 0; i < ny; ++i) {
+        const size_t src = (size_t)a_ * sop + (size_t)y_idx[i] * rl;
+        for (int j = 0; j < nx; ++j) {
+          double t = 0.0;
+          for (int cc = 0; cc < rl; ++cc) t += (double)fj[(src + cc) * nx + j] * av[cc * 32];
+          dydx_out[(a_ * ny + i) * nx + j] = (float)t;
+          for (int k = 0; k < nx; ++k) {
+            double h = 0.0;
+            for (int cc = 0; cc < rl; ++cc) h += (double)fh[((src + cc) * nx + j) * nx + k] * av[cc * 32];
+            d2_out[((a_ * ny + i) * nx + j) * nx + k] = (float)h;
+          }
+        }
+      }
+    }
+    return NIF_OK;
+  }
   rc = ensure_packed32(c); if (rc) return rc;
   if (!c->use_snet3) return fail(NIF_ERR_INVALID, "HessianLayer needs the 16-point-tile path (units <= 128, small latent)");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -847,12 +897,12 @@ extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, 
 // ---- last-layer-parameterised class: loss and gradient ---------------------------------------------
 // SNetArgs of the last-layer class for k_sob (Sobolev step / its predict): k_snet4's arguments for that class plus, beyond the
 // widths whose bf16 planes fit the LDS (n > 96), the f32-input MFMA planes of the shared hidden matrices, packed on demand
-static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B) {
+static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B, bool f32_planes) {
   if (!c->use_ll4) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: ShapeNet widths of the 16-point-tile path (even 16-blocks, units <= 128, so * latent_dim <= 32)");
   fill_snet_ll(c, sa, xin, c->pi + c->si, c->pi, B);
   if (!sob_ll_supported(sa)) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: unsupported ShapeNet shape");
   const int NBL = snet3_nbl(c->n);
-  if (NBL > 6) {
+  if (NBL > 6 || f32_planes) {     // (k_jac / the Hessian take the f32-input planes at every width)
     const long plane_s = snet3_plane_floats(c->n) / 4;
     if (!c->ll_packed32) {
       for (int j = 0; j < c->nh; ++j) {
@@ -863,7 +913,8 @@ static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B) 
       }
       c->ll_packed32 = true;
     }
-    sa.WF = c->sWF; sa.WB = c->sWB; sa.WF4 = nullptr; sa.WB4 = nullptr;
+    sa.WF = c->sWF; sa.WB = c->sWB;
+    if (NBL > 6) { sa.WF4 = nullptr; sa.WB4 = nullptr; }
   }
   return NIF_OK;
 }

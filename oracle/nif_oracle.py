@@ -1032,7 +1032,20 @@ def jacobian(spec, ws, inputs, y_index, x_index, h=1e-6):
 
 def jacobian_analytic(spec, ws, inputs, y_index, x_index):
     """Forward-mode tangent for coordinate columns (x_index >= pi) of the
-    hypernetwork classes; used to cross-check the central-difference oracle."""
+    hypernetwork classes (and, through the shared ShapeNet's tangents, of the last-layer class); used to cross-check the
+    central-difference oracle."""
+    if spec.kind == KIND_LL:
+        seeds = [j - spec.pi for j in x_index]
+        assert all(0 <= d < spec.si for d in seeds), "analytic tangent only for coordinate columns"
+        a_out, _ = pnet_forward(spec, ws, inputs[:, :spec.pi])
+        *_, rest = _pnet_split(spec, ws)
+        first, hidden, bott, bias = _snet_split(spec, rest)
+        B = inputs.shape[0]
+        phi, phid, _ = _mlp_tangents((first, hidden, bott), True, spec.omega_s, "sine", spec.s_res,
+                                     inputs[:, spec.pi:spec.pi + spec.si], seeds)
+        u = np.einsum("bsj,bj->bs", phi.reshape(B, spec.so, spec.r), a_out) + bias
+        J = np.stack([np.einsum("bsj,bj->bs", v.reshape(B, spec.so, spec.r), a_out) for v in phid], axis=2)
+        return u, J[:, list(y_index), :]
     assert spec.kind in (KIND_NIF, KIND_MS)
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + spec.si]
@@ -1215,6 +1228,8 @@ def hessian_analytic(spec, ws, inputs, y_index, x_index):
     forward-mode tangents: returns (y [B, so], dy/dx [B, ny, nx], d2y/dx2 [B, ny, nx, nx]).  Per layer, with a' / a'' the
     first / second-order tangents of the pre-activation:  h' = f'(a) a' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k ;  the
     first layer is linear in x (a'' = 0).  Pinned by central differences of jacobian_analytic and by torch autograd."""
+    if spec.kind == KIND_LL:
+        return _hessian_ll(spec, ws, inputs, y_index, x_index)
     assert spec.kind in (KIND_NIF, KIND_MS)
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + spec.si]
@@ -1262,6 +1277,56 @@ def hessian_analytic(spec, ws, inputs, y_index, x_index):
             ujk = _ein(hjk, Wl)[:, yi]
             H[:, :, jj, kk] = ujk
             H[:, :, kk, jj] = ujk
+    return u, J, H
+
+
+def _hessian_ll(spec, ws, inputs, y_index, x_index):
+    """HessianLayer on the last-layer-parameterised class (model.py:1219-1269): u_i = sum_c phi[i,c](x) a_c(p) + bias_i, so the
+    coordinate derivatives are those of the shared SIREN ShapeNet x -> phi (second-order forward mode through its plain /
+    resblock layers, siren.py:256-281, :381-410) contracted with the ParameterNet output a."""
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    a_out, _ = pnet_forward(spec, ws, p)
+    *_, rest = _pnet_split(spec, ws)
+    first, hidden, bott, bias = _snet_split(spec, rest)
+    om = spec.omega_s
+    B = x.shape[0]
+    nx = len(x_index)
+    yi = list(y_index)
+    u = np.einsum("bsj,bj->bs", snet_phi(spec, ws, x), a_out) + bias
+    J = np.zeros((B, len(yi), nx), dtype=u.dtype)
+    H = np.zeros((B, len(yi), nx, nx), dtype=u.dtype)
+
+    def layer(a, W, sj, sk, sjk):
+        aj_, ak_, ajk_ = om * (sj @ W), om * (sk @ W), om * (sjk @ W)
+        return np.cos(a) * aj_, np.cos(a) * ak_, np.cos(a) * ajk_ - np.sin(a) * aj_ * ak_
+
+    def out(v):
+        return np.einsum("bsj,bj->bs", (v @ bott[0]).reshape(B, spec.so, spec.r), a_out)[:, yi]
+    for jj in range(nx):
+        for kk in range(jj, nx):
+            dj, dk = x_index[jj] - spec.pi, x_index[kk] - spec.pi
+            assert 0 <= dj < spec.si and 0 <= dk < spec.si, "analytic Hessian only for coordinate columns"
+            a0 = om * (x @ first[0]) + first[1]
+            aj, ak = om * first[0][dj][None, :], om * first[0][dk][None, :]
+            h = np.sin(a0)
+            hj, hk, hjk = np.cos(a0) * aj, np.cos(a0) * ak, -np.sin(a0) * aj * ak
+            for lay in hidden:
+                if spec.s_res:
+                    a1 = om * (h @ lay[0]) + lay[1]
+                    t = np.sin(a1)
+                    tj, tk, tjk = layer(a1, lay[0], hj, hk, hjk)
+                    a2 = om * (t @ lay[2]) + lay[3]
+                    vj, vk, vjk = layer(a2, lay[2], tj, tk, tjk)
+                    h = 0.5 * (h + np.sin(a2))
+                    hj, hk, hjk = 0.5 * (hj + vj), 0.5 * (hk + vk), 0.5 * (hjk + vjk)
+                else:
+                    a1 = om * (h @ lay[0]) + lay[1]
+                    hj, hk, hjk = layer(a1, lay[0], hj, hk, hjk)
+                    h = np.sin(a1)
+            J[:, :, jj] = out(hj)
+            J[:, :, kk] = out(hk)
+            H[:, :, jj, kk] = H[:, :, kk, jj] = out(hjk)
     return u, J, H
 
 

@@ -909,7 +909,8 @@ def test_mixed_bfloat16_training_and_sobolev_step():
 
 # ---- HessianLayer (N3; reference gradient.py:130-180) ------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres",
-                                  "ms_cfg5_64x4_si2", "ms_cfg3_128x3", "ms_32x2_r7_si3"])
+                                  "ms_cfg5_64x4_si2", "ms_cfg3_128x3", "ms_32x2_r7_si3", "ms_96x2_r2", "ll_plain_32x2_r3",
+                                  "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5"])
 def test_hessian_layer_matches_oracle(name):
     """(y, dy/dx, d2y/dx2) for the coordinate columns: second-order forward-mode tangents in one kernel per coordinate pair
     against the fp64 oracle (pinned by torch double-backward in tests/test_oracle.py).  With w0 = 30 the second derivatives
@@ -929,7 +930,7 @@ def test_hessian_layer_matches_oracle(name):
     y1, J1, H1 = nif_amd.HessianLayer(model, spec.so - 1, [xi[-1]])(x)
     assert H1.shape == (x.shape[0], 1, 1, 1)
     assert np.allclose(H1[:, 0, 0, 0], H[:, spec.so - 1, -1, -1], rtol=1e-5, atol=1e-6 * np.abs(H).max())
-    # parameter columns / the last-layer class are refused loudly
+    # parameter columns are refused loudly
     with pytest.raises(nif_amd._lib.NifError):
         nif_amd.HessianLayer(model, yi, [0])(x)
 

@@ -214,7 +214,7 @@ def test_plane_formulation_equals_the_materialised_reference_formulation(name):
     assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.015625, -3.140625, 0.0]))      # ties to even, 8-bit significand
 
 
-@pytest.mark.parametrize("name", ["nif_tanh_r2_so2", "nif_swish", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres"])
+@pytest.mark.parametrize("name", ["nif_tanh_r2_so2", "nif_swish", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "ll_plain", "ll_res"])
 def test_hessian_analytic_vs_fd_of_the_jacobian_and_torch(name):
     """HessianLayer oracle: second-order forward mode against central differences of the analytic Jacobian and against
     torch autograd (double backward) of the independent torch restatement"""
