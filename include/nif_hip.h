@@ -186,7 +186,8 @@ int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, co
  * takes any column; a parameter column runs its tangent through the ParameterNet, the hyper layer and the product rule of every
  * h W(p): k_pjac + k_sob<PAR> + a second weight-gradient reduction).  Built as forward tangents + their hand-derived adjoint in
  * one kernel (k_sob_dev.h) for NIFMultiScale (with or without resblocks), class NIF (any activation, skip connections) and
- * the last-layer class (coordinate columns; ShapeNet widths of its 16-point-tile path).
+ * the last-layer class (ShapeNet widths of its 16-point-tile path; a parameter column there is one more contraction of phi with
+ * a' = (dz/dp) last_w in the kernel's epilogue).
  * Same conventions as nif_loss_grad_dev (result in nif_grad_dev(), scaled by 1/B_global). */
 int nif_sobolev_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
                               const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,

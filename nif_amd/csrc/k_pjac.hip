@@ -229,7 +229,7 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
 
 bool pjac_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
-  return a.nst <= 64 && nm <= 4 && a.pi <= NIF_PJ_MAXPI && !a.ll_kind;
+  return a.nst <= 64 && nm <= 4 && a.pi <= NIF_PJ_MAXPI;     // (first / hidden / bottleneck only: the same for every class)
 }
 static int launch_pjac_any(const PJacArgs& J, hipStream_t st);
 int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st) {

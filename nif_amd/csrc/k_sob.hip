@@ -26,6 +26,14 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     J.par[d] = (par && d < ns) ? par->par[d] : -1;
   }
   J.ZT = par ? par->ZT : nullptr; J.DZT = par ? par->DZT : nullptr;
+  J.npar = 0; J.nx_tot = ns; J.DAT = nullptr; J.ZTL = nullptr; J.zl_rows = 0;
+  for (int d = 0; d < NIF_SOB_MAXSEED; ++d) { J.parc[d] = 0; J.pcol[d] = 0; }
+  if (a.ll && par) {       // last-layer class: parameter columns are heads of the epilogue, not streams
+    J.npar = par->npar; J.nx_tot = ns + par->npar; J.DAT = par->DAT; J.ZTL = par->ZTL; J.zl_rows = par->zl_rows;
+    for (int e = 0; e < par->npar; ++e) { J.parc[e] = par->parc[e]; J.pcol[e] = par->pcol[e]; }
+    for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.par[d] = -1;
+    any_par = false;
+  }
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
   const bool sgn = !a.res && !a.nif_skip && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register (SIREN only)
@@ -35,7 +43,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const size_t shm = (2 * plane + sm_tot + 4 * npw * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
   J.ll_plane = 0;
   if (a.ll) {
-    const size_t llw = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u)) * 16;
+    const size_t llw = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16;
     size_t shm_ll = shm + 4 * llw * sizeof(float);
     if (shm_ll > 160u * 1024u && 4 * llw <= plane) { J.ll_plane = 1; shm_ll = shm; }   // scratch in the idle plane buffer
     launch_sob_ll(J, train, bf, nblk, shm_ll, st);

@@ -39,6 +39,15 @@ struct SobArgs {
   const float* ZT;              // z' = dz/dp_c of every parameter column [pi][tiles][r][32] (k_pjac, forward mode)
   float* DZT;                   // dL/dz' of stream d [ns][tiles][r][32] (rows of the parameter streams are written)
   int ll_plane;                 // LL: the epilogue's per-wave scratch lives in the idle plane buffer (wide nets: no LDS left for it)
+  // LL with parameter columns: the ShapeNet does not see p, so such a column is no stream but one more contraction of the SAME
+  // phi: du_i/dp_c = sum_k phi[i,k] a'_k with a' = (dz/dp_c) last_w ("head" e).  dL/da' -> DAT, dL/dz' -> DZT (block e), and a
+  // zero-padded copy of z' in the latent-row layout of the r x r layer's gradient kernel -> ZTL
+  int npar;                     // heads (0..3); the kernel then carries ns = coordinate streams only
+  int nx_tot;                   // ns + npar = columns of gt / JU (LL epilogue)
+  int parc[NIF_SOB_MAXSEED];    // parameter column of head e
+  int pcol[NIF_SOB_MAXSEED];    // column of gt / JU that head e fills
+  float* DAT;                   // [npar][tiles][rl][32]
+  float* ZTL; int zl_rows;      // [npar][tiles][zl_rows][32]
 };
 
 // parameter-seed instantiations (k_sob_par.hip)
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   constexpr int NPW = PAR ? 1 + NS : 1;                       // PAR: the same again per stream for (dL/dzt', zt')
   const int nrl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
-  const int llw = LL ? (2 * nrl + NQ * so + NQ * sou) * 16 : 0;   // LL per wave: a, dL/da [rl][16], phi / phi' [NQ][so][16], du / du' [NQ][so_u][16]
+  // LL per wave: a, dL/da [rl][16], phi / phi' [NQ][so][16], du / du' [NQ][so_u][16]; heads: a', dL/da' [3][rl][16], du_e [3][so_u][16]
+  const int llw = LL ? (2 * nrl + NQ * so + NQ * sou + NIF_SOB_MAXSEED * (2 * nrl + sou)) * 16 : 0;
   const int pwf = NPW * (r * 64 + r * 16) + ((LL && J.ll_plane) ? 0 : llw);   // per-wave floats
   float* dzs = sm + sm_tot + (long)wid * pwf;                 // per wave dz partials [r][64], latent [r][16]
   float* zs = dzs + r * 64;
@@ -337,8 +347,20 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       float* llph = lla + nrl * 16;
       float* lldq = llph + NQ * so * 16;
       float* llda = lldq + NQ * sou * 16;
-      if (g == 0)
+      float* llap = llda + nrl * 16;                         // a'_e [3][rl][16]
+      float* lldap = llap + NIF_SOB_MAXSEED * nrl * 16;      // dL/da'_e
+      float* lldqp = lldap + NIF_SOB_MAXSEED * nrl * 16;     // du_e [3][so_u][16]
+      const int npar = J.npar, nxt = J.nx_tot;
+      if (g == 0) {
         for (int cc = 0; cc < nrl; ++cc) lla[cc * 16 + p] = A.Z[(tile32 * nrl + cc) * 32 + poff];
+        for (int e = 0; e < npar; ++e)
+          for (int cc = 0; cc < nrl; ++cc) {
+            float t = 0.f;
+            for (int c2 = 0; c2 < nrl; ++c2)
+              t = fmaf(J.ZT[(((long)J.parc[e] * nt32 + tile32) * nrl + c2) * 32 + poff], sm[o_lw + c2 * nrl + cc], t);
+            llap[(e * nrl + cc) * 16 + p] = t;
+          }
+      }
       // phi[q][o] of the tile into LDS (one value per point: lanes g = 0 write, every lane of the point reads)
       for (int o = 0; o < so; ++o) {
         float part[NQ];
@@ -375,7 +397,14 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
           if (J.JU)
 #pragma unroll
             for (int d = 0; d < NS; ++d)
-              if (d < ns) J.JU[(pt * sou + i) * ns + J.gcol[d]] = uq[1 + d];
+              if (d < ns) J.JU[(pt * sou + i) * nxt + J.gcol[d]] = uq[1 + d];
+        }
+        float up[NIF_SOB_MAXSEED];
+        for (int e = 0; e < npar; ++e) {
+          float t = 0.f;
+          for (int cc = 0; cc < nrl; ++cc) t = fmaf(llph[(i * nrl + cc) * 16 + p], llap[(e * nrl + cc) * 16 + p], t);
+          up[e] = t;
+          if (valid && g == 0 && J.JU) J.JU[(pt * sou + i) * nxt + J.pcol[e]] = t;
         }
         if (TRAIN) {
           float dq[NQ];
@@ -386,10 +415,15 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
           for (int d = 0; d < NS; ++d) {
             dq[1 + d] = 0.f;
             if (d < ns) {
-              const float ej = uq[1 + d] - J.gt[(ptc * sou + i) * ns + J.gcol[d]];
+              const float ej = uq[1 + d] - J.gt[(ptc * sou + i) * nxt + J.gcol[d]];
               sej = fmaf(ej, ej, sej);
-              dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * ns);
+              dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * nxt);
             }
+          }
+          for (int e2 = 0; e2 < npar; ++e2) {
+            const float ej = up[e2] - J.gt[(ptc * sou + i) * nxt + J.pcol[e2]];
+            sej = fmaf(ej, ej, sej);
+            if (g == 0) lldqp[(e2 * sou + i) * 16 + p] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * nxt);
           }
           if (g == 0) {
 #pragma unroll
@@ -416,6 +450,24 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
             for (int cc = 0; cc < nrl; ++cc) t = fmaf(llda[cc * 16 + p], sm[o_lw + c2 * nrl + cc], t);
             if (active) A.DZL[(tile32 * nrl + c2) * 32 + poff] = t;
           }
+          // heads: dL/da'_e = sum_i du_e,i phi[i,:] ; dL/dz'_e through the rl x rl map ; z'_e in latent-row layout
+          for (int e = 0; e < npar; ++e) {
+            for (int cc = 0; cc < nrl; ++cc) {
+              float t = 0.f;
+              for (int i = 0; i < sou; ++i) t = fmaf(lldqp[(e * sou + i) * 16 + p], llph[(i * nrl + cc) * 16 + p], t);
+              if (active) J.DAT[(((long)e * nt32 + tile32) * nrl + cc) * 32 + poff] = t;
+              lldap[(e * nrl + cc) * 16 + p] = t;
+            }
+            for (int c2 = 0; c2 < nrl; ++c2) {
+              float t = 0.f;
+              for (int cc = 0; cc < nrl; ++cc) t = fmaf(lldap[(e * nrl + cc) * 16 + p], sm[o_lw + c2 * nrl + cc], t);
+              if (active) {
+                J.DZT[(((long)e * nt32 + tile32) * nrl + c2) * 32 + poff] = t;
+                J.ZTL[(((long)e * nt32 + tile32) * J.zl_rows + c2) * 32 + poff] =
+                    valid ? J.ZT[(((long)J.parc[e] * nt32 + tile32) * nrl + c2) * 32 + poff] : 0.f;
+              }
+            }
+          }
         }
         // dphi^q[o] = du^q_{o / rl} a_{o % rl} -> the phi layer's weight gradient (k_gw_out over real + pseudo tiles) and lambda
         for (int o = 0; o < so; ++o) {
@@ -425,6 +477,8 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
             dph[q] = lldq[(q * sou + i) * 16 + p] * av;
+            if (q == 0)
+              for (int e = 0; e < npar; ++e) dph[0] = fmaf(lldqp[(e * sou + i) * 16 + p], llap[(e * nrl + cc) * 16 + p], dph[0]);
             if (q <= ns && active && g == 0) A.DPHI[(((long)q * nt32 + tile32) * so + o) * 32 + poff] = dph[q];
           }
 #pragma unroll
@@ -554,7 +608,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       }
     }
     if (TRAIN) {
-      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)sou + J.wj * sej / (float)(sou * ns));
+      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)sou + J.wj * sej / (float)(sou * (LL ? J.nx_tot : ns)));
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       f32x4 skip[MODE != 0 ? NQ : 1][MODE != 0 ? NBL : 1];

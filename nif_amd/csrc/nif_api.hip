@@ -189,7 +189,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -923,8 +923,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
                         const SobPlan* sp = nullptr, const float* gt = nullptr, float wj = 0.f) {
   const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
-  if (ns > 0 && sp->any_par)
-    return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
+  const int nsc = ns > 0 ? sp->nsc : 0, nhead = ns > 0 ? sp->ns - sp->nsc : 0;   // coordinate streams / parameter-column heads
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
   LLArgs la; fill_ll(c, la, B);
@@ -937,14 +936,25 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   if (ns > 0) {   // Sobolev: primal + tangents + their adjoint on k_sob<.., LL>; stashes and DPHI hold (1 + ns) blocks of tiles
     SNetArgs sa; int rc = fill_snet_ll_sob(c, sa, xin, B); if (rc) return rc;
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
-    nloss = launch_sob(sa, true, ns, sp->seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
+    nloss = launch_sob(sa, true, nsc, sp->seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
     const long need = (long)nloss * 4 * sob_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc; }
-    SobPar spar;
+    SobPar spar{};
     for (int d = 0; d < 3; ++d) { spar.par[d] = -1; spar.gcol[d] = sp->gcol[d]; }
-    spar.ZT = nullptr; spar.DZT = nullptr;
+    if (nhead > 0) {     // parameter columns: heads of the epilogue (z' = dz/dp sits in c->zt_par, loss_grad_core)
+      const long need_a = 3 * ntiles * 32 * c->r, need_l = 3 * ntiles * 32 * 32 * c->RB;
+      if (need_a > c->dat_par_cap || need_l > c->ztl_par_cap) HIPCHK(hipStreamSynchronize(c->st));
+      if (need_a > c->dat_par_cap) { rc = grow(&c->dat_par, &c->dat_par_cap, need_a); if (rc) return rc; }
+      if (need_l > c->ztl_par_cap) {
+        rc = grow(&c->ztl_par, &c->ztl_par_cap, need_l); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->ztl_par, 0, sizeof(float) * (size_t)need_l, c->st));     // the padding rows stay zero
+      }
+      spar.npar = nhead; spar.ZT = c->zt_par; spar.DZT = c->dzt_par; spar.DAT = c->dat_par; spar.ZTL = c->ztl_par;
+      spar.zl_rows = 32 * c->RB;
+      for (int e = 0; e < nhead; ++e) { spar.parc[e] = sp->par[nsc + e]; spar.pcol[e] = sp->gcol[nsc + e]; }
+    }
     ProfScope p_(c, NIF_PROF_SNET);
-    launch_sob(sa, true, ns, sp->seeds, gt, wj, c->dring, nullptr, false, c->st, &spar);
+    launch_sob(sa, true, nsc, sp->seeds, gt, wj, c->dring, nullptr, false, c->st, &spar);
   } else if (c->use_ll4) {
     SNetArgs sa; fill_snet_ll(c, sa, xin, ncol, c->pi, B);
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
@@ -980,9 +990,9 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     float* sST = c->stash_s;
     auto sbase = [&](GwArgs& q) {   // Sobolev: the ShapeNet reductions also run over the tangent pseudo-tiles
       base(q);
-      if (ns > 0) {
-        q.ntiles = ntiles * (1 + ns); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
-        for (int d = 0; d < 3; ++d) q.seed[d] = d < ns ? sp->seeds[d] : 0;
+      if (nsc > 0) {
+        q.ntiles = ntiles * (1 + nsc); q.zt_mod = ntiles; q.bias_ntiles = ntiles;
+        for (int d = 0; d < 3; ++d) q.seed[d] = d < nsc ? sp->seeds[d] : 0;
       }
     };
     // ShapeNet (dense SIREN): first, hidden matrices, bottleneck (n -> r*so), last_layer_bias
@@ -1028,6 +1038,25 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   {
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
+  }
+  if (nhead > 0) {
+    // the heads' share of the r x r layer: dL/dlast_w += z'^T dL/da' (a' = z' last_w has no bias), the same reduction as the
+    // main one with (z', dL/da') as the operand pair; then the (primal, tangent) ParameterNet for dL/dz' (jac_reg_pass, given mu)
+    if (!c->jac_tmp) HIPCHK(hipMalloc(&c->jac_tmp, sizeof(float) * (size_t)(c->P + 2)));
+    int mu_blk[3] = {-1, -1, -1};
+    const long rr = (long)c->r * c->r;
+    for (int e = 0; e < nhead; ++e) {
+      mu_blk[sp->par[nsc + e]] = e;
+      GwArgs g; memset(&g, 0, sizeof(g));
+      g.ntiles = ntiles; g.B = B; g.partial = c->partial; g.pstride = c->pstride; g.has_bias = 1; g.scale = 1.0f; g.r = 0;
+      g.IN = c->ztl_par + (long)e * ntiles * 32 * 32 * c->RB; g.SM = c->dat_par + (long)e * ntiles * 32 * c->r; g.nc = c->r;
+      g.W = dense_ref(c->last_w, c->r, c->r); g.Bv = vec_ref(c->last_b, c->r);     // (the bias columns are not taken over)
+      launch_gw_out(g, c->RB, rows, c->st);
+      launch_reduce(c->partial + c->last_w, c->pstride, rows, nullptr, 0, c->jac_tmp, rr, c->st);
+      launch_axpy_cols(c->grad + c->last_w, c->jac_tmp, rr, c->P - c->last_w, c->st);
+    }
+    HIPCHK(hipGetLastError());
+    return jac_reg_pass(c, xin, B, Bg, mu_blk);
   }
   HIPCHK(hipGetLastError());
   return NIF_OK;
@@ -1158,7 +1187,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) {
-      SobPar spar; const SobPar* sparp = nullptr;
+      SobPar spar{}; const SobPar* sparp = nullptr;
       if (sp && sp->any_par) {
         for (int d = 0; d < 3; ++d) { spar.par[d] = sp->par[d]; spar.gcol[d] = sp->gcol[d]; }
         spar.ZT = c->zt_par; spar.DZT = c->dzt_par; sparp = &spar;
@@ -1264,8 +1293,6 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     if (c->kind != NIF_KIND_LASTLAYER && !c->use_snet3)
       return fail(NIF_ERR_INVALID, "Sobolev training is built for the 16-point-tile path (units <= 128)");
     if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
-    if (c->kind == NIF_KIND_LASTLAYER && sp && sp->any_par)
-      return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
   }
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
   if (sp && sp->any_par) {   // z' = dz/dp of the parameter columns, in front of the ShapeNet
@@ -1411,14 +1438,22 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   launch_pnet(pa, c->NSTB, false, c->st);
-  SobPar spar;
+  SobPar spar{};
   for (int d = 0; d < 3; ++d) { spar.par[d] = sp.par[d]; spar.gcol[d] = sp.gcol[d]; }
-  spar.ZT = nullptr; spar.DZT = nullptr;
   if (c->kind == NIF_KIND_LASTLAYER) {
-    if (sp.any_par) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class takes coordinate columns (pi_dim <= i < pi_dim + si_dim)");
+    if (sp.any_par) {       // parameter columns: heads of the epilogue on z' = dz/dp
+      if (!pjac_supported(pa))
+        return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+      const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
+      if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
+      launch_pjac_fwd(pa, c->zt_par, c->st);
+      spar.npar = sp.ns - sp.nsc; spar.ZT = c->zt_par;
+      for (int e = 0; e < spar.npar; ++e) { spar.parc[e] = sp.par[sp.nsc + e]; spar.pcol[e] = sp.gcol[sp.nsc + e]; }
+      for (int d = 0; d < 3; ++d) spar.par[d] = -1;
+    }
     SNetArgs sl; rc = fill_snet_ll_sob(c, sl, xin, B); if (rc) return rc;
     sl.u_out = u;
-    launch_sob(sl, false, nx, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
+    launch_sob(sl, false, sp.nsc, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
     HIPCHK(hipGetLastError());
     return NIF_OK;
   }

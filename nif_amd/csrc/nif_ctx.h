@@ -52,7 +52,8 @@ struct nif_ctx {
   double* metric = nullptr;  // device {sum, count}
   // activity regulariser of the ParameterNet output (nif_set_activity_regularizer): L2 wins over L1 like in the reference
   bool ll_packed32 = false;     // last-layer class under k_sob at n > 96: f32-input MFMA planes of the shared hidden matrices in sWF / sWB
-  float* zt_par = nullptr; long zt_par_cap = 0; float* dzt_par = nullptr; long dzt_par_cap = 0;   // Sobolev with parameter seeds: dz/dp, dL/d(dz/dp)
+  float* zt_par = nullptr; long zt_par_cap = 0; float* dzt_par = nullptr; long dzt_par_cap = 0;
+  float* dat_par = nullptr; long dat_par_cap = 0; float* ztl_par = nullptr; long ztl_par_cap = 0;   // last-layer class: dL/da', z' in latent-row layout   // Sobolev with parameter seeds: dz/dp, dL/d(dz/dp)
   float jac_l1 = 0.f; float* jac_mu = nullptr; long jac_mu_cap = 0; float* jac_tmp = nullptr;   // latent Jacobian regulariser (k_pjac)
   float act_l1 = 0.f, act_l2 = 0.f; float* act_part = nullptr; long act_part_cap = 0; float* act_loss = nullptr; long act_loss_cap = 0;
   float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;

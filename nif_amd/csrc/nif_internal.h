@@ -177,7 +177,11 @@ long sob_ring_floats_per_wave(int n, int nh);
 bool sob_ll_supported(const SNetArgs& a);   // last-layer class under k_sob (k_sob_ll.hip)
 // parameter seeds (x_index < pi_dim): stream d is a parameter stream iff par[d] >= 0 (then seeds[d] is unused); gcol[d] = the
 // column of gt / ju the stream fills; ZT = dz/dp [pi][tiles][r][32] (launch_pjac_fwd), DZT = dL/d(that) per stream
-struct SobPar { int par[3]; int gcol[3]; const float* ZT; float* DZT; };
+struct SobPar {
+  int par[3]; int gcol[3]; const float* ZT; float* DZT;
+  // last-layer class: parameter columns as heads of the epilogue (k_sob_dev.h): column, dydx position, dL/da', padded z'
+  int npar; int parc[3]; int pcol[3]; float* DAT; float* ZTL; int zl_rows;
+};
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
                bool query_only, hipStream_t st, const SobPar* par = nullptr);
 bool snet3_supported(const SNetArgs& a);

@@ -347,7 +347,7 @@ class SobolevModel(Model):
     loss='mse' and loss_weights=[1, w]: a two-output model (u, du/dx) whose training differentiates through
     the Jacobian (reference nif/layers/gradient.py:36-49, SURVEY 3.4 / BASELINE config 5 "Sobolev training").
     Built for all three classes, all outputs (y_index = range(so)), 1..3 distinct input columns in x_index
-    (coordinates and / or ParameterNet inputs, as gradient.py:207-231 allows; the last-layer class: coordinates).
+    (coordinates and / or ParameterNet inputs, as gradient.py:207-231 allows).
         m = SobolevModel(JacobianLayer(model, y_index, x_index)); m.compile("adam", "mse", loss_weights=[1, .1])
         m.fit(x, [y, dydx], ...);  u, dudx = m.predict(x)"""
 

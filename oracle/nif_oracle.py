@@ -951,37 +951,63 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
 def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
     """Sobolev step of the last-layer-parameterised class (model.py:1044-1068, :1219-1269 under JacobianLayer): the shared
     SIREN ShapeNet x -> phi [B,so,r] carries the coordinate tangents phi'_d (_mlp_tangents), u = Dot(phi, a) + bias and
-    du/dx_d = Dot(phi'_d, a) with a = the ParameterNet output; coordinate columns only."""
+    du/dx_d = Dot(phi'_d, a) with a = the ParameterNet output.  A parameter column c leaves phi alone and moves a:
+    du/dp_c = Dot(phi, a'_c), a'_c = (dz/dp_c) last_w (pnet_tangents)."""
     B = inputs.shape[0]
     Bg = B if batch_global is None else batch_global
     si, so, r = spec.si, spec.so, spec.r
-    seeds = [j - spec.pi for j in x_index]
-    assert all(0 <= d < si for d in seeds)
-    nx = len(seeds)
+    x_index = list(x_index)
+    nx = len(x_index)
+    assert all(0 <= j < spec.pi + si for j in x_index)
+    seeds = [j - spec.pi for j in x_index if j >= spec.pi]
+    pcols = [j for j in x_index if j < spec.pi]
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + si]
     a, z, ptape = pnet_forward(spec, ws, p, keep=True)                 # po = r for this class (model.py:583-585)
-    *_, rest = _pnet_split(spec, ws)
+    _, _, _, last, rest = _pnet_split(spec, ws)
     first, hidden, bott, bias = _snet_split(spec, rest)
     layers = (first, hidden, bott)
     phi_f, phid_f, sctx = _mlp_tangents(layers, True, spec.omega_s, "sine", spec.s_res, x, seeds)
     phi = phi_f.reshape(B, so, r)
     phid = [v.reshape(B, so, r) for v in phid_f]
+    if pcols:
+        _, zd, pctx = pnet_tangents(spec, ws, p, pcols)
+        ad = [v @ last[0] for v in zd]                                  # a'_c [B, r]
     u = np.einsum("bsj,bj->bs", phi, a) + bias
-    J = np.stack([np.einsum("bsj,bj->bs", v, a) for v in phid], axis=2)      # [B, so, nx]
+    cols = []
+    for j in x_index:
+        if j >= spec.pi:
+            cols.append(np.einsum("bsj,bj->bs", phid[seeds.index(j - spec.pi)], a))
+        else:
+            cols.append(np.einsum("bsj,bj->bs", phi, ad[pcols.index(j)]))
+    J = np.stack(cols, axis=2)                                          # [B, so, nx]
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
     e = u - y
     ej = J - np.asarray(dydx).reshape(B, so, nx)
     loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
     g_u = 2.0 * e * w_a[:, None] / (Bg * so)
-    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    g_J = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
     g_a = np.einsum("bsj,bs->bj", phi, g_u)
-    for v, g in zip(phid, g_ud):
-        g_a = g_a + np.einsum("bsj,bs->bj", v, g)
-    g_phi = (g_u[:, :, None] * a[:, None, :]).reshape(B, -1)
-    g_phid = [(g[:, :, None] * a[:, None, :]).reshape(B, -1) for g in g_ud]
-    g_snet = _mlp_tangents_backward(layers, True, spec.omega_s, "sine", spec.s_res, sctx, g_phi, g_phid)
-    return loss, pnet_backward(spec, ws, ptape, g_a) + g_snet + [g_u.sum(0)], u, J
+    g_phi = g_u[:, :, None] * a[:, None, :]
+    g_phid = [np.zeros((B, so * r), dtype=u.dtype) for _ in seeds]
+    g_ad = [np.zeros((B, r), dtype=u.dtype) for _ in pcols]
+    for k, j in enumerate(x_index):
+        if j >= spec.pi:
+            d = seeds.index(j - spec.pi)
+            g_a = g_a + np.einsum("bsj,bs->bj", phid[d], g_J[k])
+            g_phid[d] = g_phid[d] + (g_J[k][:, :, None] * a[:, None, :]).reshape(B, -1)
+        else:
+            ci = pcols.index(j)
+            g_phi = g_phi + g_J[k][:, :, None] * ad[ci][:, None, :]
+            g_ad[ci] = g_ad[ci] + np.einsum("bsj,bs->bj", phi, g_J[k])
+    g_snet = _mlp_tangents_backward(layers, True, spec.omega_s, "sine", spec.s_res, sctx, g_phi.reshape(B, -1), g_phid)
+    if not pcols:
+        g_pnet = pnet_backward(spec, ws, ptape, g_a)
+    else:
+        g_last_w = z.T @ g_a + sum(zd[ci].T @ g_ad[ci] for ci in range(len(pcols)))
+        core = pnet_tangents_backward(spec, ws, pctx, g_a @ last[0].T, [g @ last[0].T for g in g_ad])
+        g_pnet = core + [g_last_w, g_a.sum(0)]
+    return loss, g_pnet + g_snet + [g_u.sum(0)], u, J
 
 
 def flatten(arrs):

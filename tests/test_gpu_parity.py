@@ -470,10 +470,7 @@ def test_sobolev_single_seed_and_zero_weight_degenerates():
         m._engine.sobolev_loss_and_grad(x, y, g, [spec.pi + spec.si], 0.2, sw)
     with pytest.raises(nif_amd._lib.NifError):
         m._engine.sobolev_loss_and_grad(x, y, np.concatenate([g, g], axis=2), [1, 1], 0.2, sw)
-    # last-layer class: parameter columns, and ShapeNet widths outside its 16-point-tile path (48 = three 16-blocks)
-    m2, model2, spec2, ws2, x2, y2, sw2 = _make("ll_plain_32x2_r3")
-    with pytest.raises(nif_amd._lib.NifError):
-        m2._engine.sobolev_loss_and_grad(x2, y2, np.zeros((x2.shape[0], spec2.so, 1), np.float32), [0], 0.2, None)
+    # last-layer class: ShapeNet widths outside its 16-point-tile path (48 = three 16-blocks)
     m3, model3, spec3, ws3, x3, y3, sw3 = _make("ll_res_48x2_r4")
     with pytest.raises(nif_amd._lib.NifError):
         m3._engine.sobolev_loss_and_grad(x3, y3, np.zeros((x3.shape[0], spec3.so, 1), np.float32), [spec3.pi], 0.2, None)
@@ -510,6 +507,42 @@ def test_sobolev_last_layer_class_matches_oracle(name, weighted):
     u, J = sm.predict(x)
     assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
     # the plain step of the class afterwards (k_snet4<.., LL>) is untouched
+    l1, g1 = m._engine.loss_and_grad(x, y, sw)
+    rl1, rg1 = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
+    assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4
+
+
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5"])
+@pytest.mark.parametrize("cols", ["param_only", "mixed"])
+def test_sobolev_last_layer_class_parameter_columns(name, cols):
+    """x_index addressing ParameterNet inputs on the last-layer class: the ShapeNet does not see p, du/dp_c = Dot(phi, a'_c) with
+    a'_c = (dz/dp_c) last_w -- one more contraction of the same phi in the kernel's epilogue, its adjoint through the r x r layer
+    and the (primal, tangent) ParameterNet"""
+    m, model, spec, ws, x, y, sw = _make(name)
+    B = x.shape[0]
+    if cols == "param_only":
+        xi = list(range(min(spec.pi, 3)))
+    else:
+        xi = [spec.pi + spec.si - 1, spec.pi - 1, spec.pi]               # coordinate, parameter, coordinate
+    rng = np.random.default_rng(14)
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    wj = 0.05
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, wj, sw)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, wj,
+                                             sw.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    off = 0
+    for (nm, shp), r_ in zip(spec.param_shapes(), rg):
+        k = int(np.prod(shp))
+        got = grad[off:off + k].reshape(shp)
+        off += k
+        err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+        assert err < 3e-4, (nm, err)
+    from nif_amd import JacobianLayer, SobolevModel
+    u, J = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi)).predict(x)
+    assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
+    _, J2 = JacobianLayer(model, list(range(spec.so)), xi)(x)             # the forward-only kernels of the class
+    assert _rel(J, J2.astype(np.float64)) < 2e-5
     l1, g1 = m._engine.loss_and_grad(x, y, sw)
     rl1, rg1 = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
     assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4

@@ -119,7 +119,7 @@ def test_sobolev_loss_and_grad_match_torch_double_backward(name):
     assert abs(l0 - l1) < 1e-14 and all(np.allclose(a, b, rtol=1e-12, atol=1e-14) for a, b in zip(g0, g1))
 
 
-@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "nif_swish", "nif_tanh_r2_so2"])
+@pytest.mark.parametrize("name", ["ms_plain", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "nif_swish", "nif_tanh_r2_so2", "ll_plain", "ll_res"])
 @pytest.mark.parametrize("cols", ["param_only", "mixed"])
 def test_sobolev_parameter_columns_match_torch_double_backward(name, cols):
     """JacobianLayer works for ANY input column (gradient.py:207-231): x_index addressing ParameterNet inputs -- the tangent
