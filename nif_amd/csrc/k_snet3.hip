@@ -471,7 +471,9 @@ static size_t snet3_shmem(const SNetArgs& a, int NBL, int waves) {
 bool snet3_supported(const SNetArgs& a) {
   const int NBL = nbl_of(a.n);
   if (a.n > 128) return false;
-  return snet3_shmem(a, NBL, waves_of(NBL)) <= (NBL <= 4 ? 52u : 160u) * 1024u;
+  // (narrow nets: up to 52 KB keeps three workgroups per CU; beyond that the kernel still runs, at lower occupancy -- far better
+  // than the 32-point fallback kernel, and JacobianLayer / HessianLayer / Sobolev exist only on this path)
+  return snet3_shmem(a, NBL, waves_of(NBL)) <= 160u * 1024u;
 }
 long snet3_plane_floats(int n) { const int NBL = nbl_of(n); return (long)NBL * NBL * 256; }
 long snet3_ring_floats_per_wave(int n, int nh) { return (long)(nh + 1) * nbl_of(n) * 256; }

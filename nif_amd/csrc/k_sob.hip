@@ -17,6 +17,18 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const bool two = slim && (NBL <= 2 || ns == 1);
   const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
+  {   // LDS the launch below will ask for (same arithmetic): -1 = does not fit one CU, the caller refuses the shape
+    const bool bfq = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
+    const size_t planeq = bfq ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
+    const size_t smq = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+    const size_t npwq = (any_par && !a.ll) ? 1 + NIF_SOB_MAXSEED : 1;
+    size_t need = (2 * planeq + smq + 4 * npwq * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
+    if (a.ll) {
+      const size_t llwq = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16;
+      if (need + 4 * llwq * sizeof(float) > 160u * 1024u && 4 * llwq > planeq) need += 4 * llwq * sizeof(float);
+    }
+    if (need > 160u * 1024u) return -1;
+  }
   if (query_only) return nblk;
   SobArgs J;
   J.s = a; J.ns = ns; J.gt = gt; J.wj = wj; J.ring = ring; J.JU = ju;

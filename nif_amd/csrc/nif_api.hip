@@ -937,6 +937,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     SNetArgs sa; int rc = fill_snet_ll_sob(c, sa, xin, B); if (rc) return rc;
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
     nloss = launch_sob(sa, true, nsc, sp->seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
+    if (nloss < 0) return fail(NIF_ERR_INVALID, "Sobolev step: the kernel's working set of this shape does not fit the 160 KB LDS of a CU");
     const long need = (long)nloss * 4 * sob_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc; }
     SobPar spar{};
@@ -1065,11 +1066,15 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
 // Workspace sizing of the fused ShapeNet kernel the step will launch (no launch): number of workgroups (= loss partials),
 // the act'(a) ring, the optional edge-gradient partials.  Grows buffers when needed (stream sync + hipMalloc): call
 // nif_reserve() once up front to keep that out of the timed steps.
-static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nloss, bool* fused_edge) {
+static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nloss, bool* fused_edge, const int* par_of = nullptr) {
   int rc;
   *fused_edge = false;
   if (ns > 0) {
-    const int nblk = launch_sob(sa, true, ns, seeds, nullptr, 0.f, nullptr, nullptr, true, c->st);
+    SobPar spq{};     // (the parameter streams' extra per-wave LDS counts)
+    for (int d = 0; d < 3; ++d) spq.par[d] = par_of ? par_of[d] : -1;
+    const int nblk = launch_sob(sa, true, ns, seeds, nullptr, 0.f, nullptr, nullptr, true, c->st, &spq);
+    if (nblk < 0)
+      return fail(NIF_ERR_INVALID, "Sobolev step: the kernel's working set of this shape (units, latent_dim, parameter columns) does not fit the 160 KB LDS of a CU");
     const long need = (long)nblk * 4 * sob_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
@@ -1181,7 +1186,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   if (!whole) sa.wg_cap = c->opt_pipe_wgs;        // leave room on every CU for the reductions of the previous chunk
   int nloss = (int)((ntiles + 3) / 4);
   bool fused_edge = false;
-  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge); if (rc) return rc;
+  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge, sp ? sp->par : nullptr); if (rc) return rc;
   if (!whole && fused_edge) { fused_edge = false; sa.EDGE = nullptr; sa.edge_ne = 0; }
   *nloss_out = nloss;
   {
@@ -1453,7 +1458,8 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
     }
     SNetArgs sl; rc = fill_snet_ll_sob(c, sl, xin, B); if (rc) return rc;
     sl.u_out = u;
-    launch_sob(sl, false, sp.nsc, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
+    if (launch_sob(sl, false, sp.nsc, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar) < 0)
+      return fail(NIF_ERR_INVALID, "Sobolev path: the kernel's working set of this shape does not fit the 160 KB LDS of a CU");
     HIPCHK(hipGetLastError());
     return NIF_OK;
   }
@@ -1467,7 +1473,8 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   }
   SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
   sa.u_out = u;
-  launch_sob(sa, false, nx, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar);
+  if (launch_sob(sa, false, nx, sp.seeds, nullptr, 0.f, nullptr, dudx, false, c->st, &spar) < 0)
+    return fail(NIF_ERR_INVALID, "Sobolev path: the kernel's working set of this shape (units, latent_dim, parameter columns) does not fit the 160 KB LDS of a CU");
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }

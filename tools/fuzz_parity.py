@@ -1,0 +1,117 @@
+"""Random-shape parity sweep on the GPU (not part of pytest: a bug hunter).  Draws configurations over all three classes, widths
+that are NOT multiples of the kernels' block sizes, every ParameterNet layer kind, odd batch sizes, and checks forward, loss,
+per-tensor gradient, Jacobian and the Sobolev step against the oracle.  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+import traceback
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nif_amd                                     # noqa: E402
+from oracle import nif_oracle as O                 # noqa: E402
+from tests.test_gpu_parity import _cfg, _rel      # noqa: E402
+
+
+def draw(rng):
+    kind = rng.choice(["NIF", "NIFMultiScale", "LL"], p=[0.25, 0.45, 0.3])
+    n = int(rng.choice([8, 16, 24, 30, 32, 40, 48, 56, 64, 72, 80, 96, 100, 112, 128]))
+    L = int(rng.integers(1, 5))
+    nst = int(rng.choice([6, 16, 20, 32, 40, 64]))
+    lst = int(rng.integers(1, 3))
+    r = int(rng.integers(1, 5)) if kind != "LL" else int(rng.integers(1, 9))
+    si = int(rng.integers(1, 4)); so = int(rng.integers(1, 4)); pi = int(rng.integers(1, 3))
+    s_res = bool(rng.integers(0, 2)) and kind != "NIF"
+    p_res = bool(rng.integers(0, 2)) and kind != "NIF"
+    p_act = str(rng.choice(["sine", "swish", "tanh"]))
+    act = str(rng.choice(["swish", "tanh", "gelu"]))
+    if kind == "LL" and so * r > 32:
+        r = max(1, 32 // so)
+    B = int(rng.choice([1, 31, 33, 64, 97, 130, 257, 515]))
+    if kind == "NIF":
+        cfg = _cfg("NIF", n, L, nst, lst, r, si, so, pi, act=act)
+    else:
+        cfg = _cfg(kind, n, L, nst, lst, r, si, so, pi, s_res=s_res, p_act=p_act, p_res=p_res)
+    return cfg, B, dict(kind=kind, n=n, L=L, nst=nst, lst=lst, r=r, si=si, so=so, pi=pi, s_res=s_res, p_res=p_res, p_act=p_act, act=act, B=B)
+
+
+def run_case(cfg, B, seed):
+    kind, cs, cp = cfg
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(seed)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    names = [nm for nm, _ in spec.param_shapes()]
+    if kind == "NIFMultiScale":
+        ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 2.0).astype(np.float32)
+    if kind == "NIFMultiScaleLastLayerParameterized":
+        ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 30.0).astype(np.float32)
+    m = getattr(nif_amd, kind)(cs, cp)
+    model = m.build()
+    model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    x64, y64, sw64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+    bad = []
+    u = model.predict(x)
+    e = _rel(u, O.forward(spec, ws64, x64))
+    if e > 1e-5:
+        bad.append(("forward", e))
+    loss, grad = m._engine.loss_and_grad(x, y, sw)
+    rl, rg = O.loss_and_grad(spec, ws64, x64, y64, sw64)
+    if abs(loss - rl) > 2e-5 * abs(rl):
+        bad.append(("loss", loss, rl))
+    off = 0
+    for (nm, shp), r_ in zip(spec.param_shapes(), rg):
+        k = int(np.prod(shp)); got = grad[off:off + k].reshape(shp); off += k
+        err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+        if err > 3e-4:
+            bad.append(("grad " + nm, err))
+    yi = list(range(spec.so)); xi_all = list(range(spec.pi + spec.si))
+    try:
+        _, J = nif_amd.JacobianLayer(model, yi, xi_all)(x)
+        _, Jr = O.jacobian(spec, ws64, x64, yi, xi_all)
+        ej = _rel(J, Jr)
+        if ej > 2e-4:                      # the oracle side is central differences here
+            bad.append(("jacobian", ej))
+    except nif_amd._lib.NifError as ex:
+        bad.append(("jacobian refused", str(ex)[:80]))
+    xi = [spec.pi + spec.si - 1, 0] + ([spec.pi] if spec.si > 1 else [])
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    try:
+        sl, sg = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.05, sw)
+        rsl, rsg, _, _ = O.sobolev_loss_and_grad(spec, ws64, x64, y64, g.astype(np.float64), xi, 0.05, sw64)
+        if abs(sl - rsl) > 2e-5 * abs(rsl):
+            bad.append(("sobolev loss", sl, rsl))
+        off = 0
+        for (nm, shp), r_ in zip(spec.param_shapes(), rsg):
+            k = int(np.prod(shp)); got = sg[off:off + k].reshape(shp); off += k
+            err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
+            if err > 4e-4:
+                bad.append(("sobolev grad " + nm, err))
+    except nif_amd._lib.NifError as ex:
+        bad.append(("sobolev refused", str(ex)[:80]))
+    return bad
+
+
+def main():
+    ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    nbad = 0
+    for i in range(ncase):
+        cfg, B, desc = draw(rng)
+        try:
+            bad = run_case(cfg, B, seed * 1000 + i)
+        except Exception as ex:      # noqa: BLE001
+            bad = [("EXCEPTION", repr(ex)[:200])]
+            traceback.print_exc()
+        real = [b for b in bad if "refused" not in b[0]]
+        tag = "FAIL" if real else ("refu" if bad else "ok  ")
+        nbad += bool(real)
+        print(tag, i, desc, bad if bad else "", flush=True)
+    print("cases %d, failing %d" % (ncase, nbad))
+
+
+if __name__ == "__main__":
+    main()
