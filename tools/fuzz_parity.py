@@ -91,6 +91,58 @@ def run_case(cfg, B, seed):
                 bad.append(("sobolev grad " + nm, err))
     except nif_amd._lib.NifError as ex:
         bad.append(("sobolev refused", str(ex)[:80]))
+    # three-stage factorisation (README.md:99-117) / the last-layer class's sub-models
+    try:
+        pp, xs = x[:, :spec.pi], x[:, spec.pi:]
+        lr = m.model_p_to_lr().predict(pp)
+        if kind == "NIFMultiScaleLastLayerParameterized":
+            u3 = m.model_x_to_u_given_w().predict([xs, lr])
+        else:
+            w = m.model_lr_to_w().predict(lr)
+            if _rel(w, O.model_lr_to_w(spec, ws64, lr.astype(np.float64))) > 1e-6:
+                bad.append(("lr_to_w", _rel(w, O.model_lr_to_w(spec, ws64, lr.astype(np.float64)))))
+            u3 = m.model_x_to_u_given_w().predict([xs, w])
+        if _rel(u3, O.forward(spec, ws64, x64)) > 2e-5:
+            bad.append(("three-stage", _rel(u3, O.forward(spec, ws64, x64))))
+    except nif_amd._lib.NifError as ex:
+        bad.append(("three-stage refused", str(ex)[:80]))
+    # HessianLayer on the coordinate columns
+    try:
+        xc = list(range(spec.pi, spec.pi + spec.si))
+        _, Jh, H = nif_amd.HessianLayer(model, yi, xc)(x[:64])
+        _, Jr2, Hr = O.hessian_analytic(spec, ws64, x64[:64], yi, xc)
+        if _rel(Jh, Jr2) > 2e-5 or _rel(H, Hr) > 2e-4:
+            bad.append(("hessian", _rel(Jh, Jr2), _rel(H, Hr)))
+    except nif_amd._lib.NifError as ex:
+        bad.append(("hessian refused", str(ex)[:80]))
+    # three Adam steps through fit() against the oracle's trajectory
+    try:
+        model.compile(nif_amd.Adam(1e-3), "mse")
+        h = model.fit(x, y, epochs=3, batch_size=B, shuffle=False, verbose=0, sample_weight=sw)
+        th = O.flatten(ws64); mm = np.zeros_like(th); vv = np.zeros_like(th)
+        f32 = lambda a: float(np.float32(a))
+        ls = []
+        for t in range(1, 4):
+            l_, g_ = O.loss_and_grad(spec, O.unflatten(spec, th), x64, y64, sw64)
+            ls.append(l_)
+            th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+        if not np.allclose(h.history["loss"], ls, rtol=2e-3):      # (Adam's first steps are +-lr per weight: sign flips of ~0 gradients)
+            bad.append(("fit trajectory", h.history["loss"], ls))
+    except nif_amd._lib.NifError as ex:
+        bad.append(("fit refused", str(ex)[:80]))
+    # the mixed_bfloat16 policy against the oracle with the same casts (hypernetwork classes)
+    # (widths with an odd number of 16-blocks -- 1..16, 33..48 units -- have no bf16-split kernel: the policy then runs on the
+    # f32-input MFMAs, i.e. MORE precisely than it asks for, and the emulating oracle is not the right yardstick)
+    if kind != "NIFMultiScaleLastLayerParameterized" and ((spec.n + 15) // 16) % 2 == 0:
+        try:
+            mb = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_bfloat16")
+            modelb = mb.build(); modelb.set_weights(ws)
+            rlb, rgb, rub = O.planes_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round)
+            lb, gb = mb._engine.loss_and_grad(x, y, sw)
+            if abs(lb - rlb) > 1e-3 * abs(rlb) or _rel(gb, O.flatten(rgb)) > 5e-3:
+                bad.append(("bf16 policy", lb, rlb, _rel(gb, O.flatten(rgb))))
+        except (nif_amd._lib.NifError, NotImplementedError) as ex:
+            bad.append(("bf16 refused", str(ex)[:80]))
     return bad
 
 
