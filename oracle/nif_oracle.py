@@ -1249,71 +1249,139 @@ def act_d2(name):
     raise ValueError("unknown activation %r" % (name,))
 
 
+def _mlp_tangents2(layers, siren, s, name, res, p, cj, ck):
+    """Second-order forward mode through a shared-weight MLP (the ParameterNet's first / hidden / bottleneck layers) for the
+    pair of input columns (cj, ck): -> (z, dz/dp_cj, dz/dp_ck, d2z/dp_cj dp_ck).  h'' = f'(a) a'' + f''(a) a'_j a'_k."""
+    first, hidden, bott = layers
+    f, df = act_fn(name)
+    d2f = act_d2(name)
+
+    def act3(a, aj, ak, ajk):
+        return f(a), df(a) * aj, df(a) * ak, df(a) * ajk + d2f(a) * aj * ak
+    a0 = s * (p @ first[0]) + first[1]
+    aj = np.broadcast_to(s * first[0][cj], a0.shape); ak = np.broadcast_to(s * first[0][ck], a0.shape)
+    h, hj, hk, hjk = act3(a0, aj, ak, np.zeros_like(a0))
+
+    def lin(W, b, v, vj, vk, vjk):
+        return s * (v @ W) + b, s * (vj @ W), s * (vk @ W), s * (vjk @ W)
+    for lay in hidden:
+        if not res:
+            t = act3(*lin(lay[0], lay[1], h, hj, hk, hjk))
+            if siren:
+                h, hj, hk, hjk = t
+            else:
+                h, hj, hk, hjk = h + t[0], hj + t[1], hk + t[2], hjk + t[3]
+        else:
+            t = act3(*lin(lay[0], lay[1], h, hj, hk, hjk))
+            a2 = lin(lay[2], lay[3], *t)
+            if not siren:
+                a2 = (a2[0] + h, a2[1] + hj, a2[2] + hk, a2[3] + hjk)
+            v = act3(*a2)
+            if siren:
+                h, hj, hk, hjk = 0.5 * (h + v[0]), 0.5 * (hj + v[1]), 0.5 * (hk + v[2]), 0.5 * (hjk + v[3])
+            else:
+                h, hj, hk, hjk = v
+    return h @ bott[0] + bott[1], hj @ bott[0], hk @ bott[0], hjk @ bott[0]
+
+
+def pnet_tangents2(spec, ws, p, cj, ck):
+    first, hidden, bott, last, rest = _pnet_split(spec, ws)
+    siren = spec.p_siren
+    return _mlp_tangents2((first, hidden, bott), siren, spec.omega_p if siren else 1.0, "sine" if siren else spec.p_act, spec.p_res,
+                          p, cj, ck)
+
+
 def hessian_analytic(spec, ws, inputs, y_index, x_index):
-    """HessianLayer (gradient.py:130-180, :234-261) for coordinate columns of the hypernetwork classes, by second-order
-    forward-mode tangents: returns (y [B, so], dy/dx [B, ny, nx], d2y/dx2 [B, ny, nx, nx]).  Per layer, with a' / a'' the
-    first / second-order tangents of the pre-activation:  h' = f'(a) a' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k ;  the
-    first layer is linear in x (a'' = 0).  Pinned by central differences of jacobian_analytic and by torch autograd."""
+    """HessianLayer (gradient.py:130-180, :234-261) for ANY columns of the model input, by second-order forward-mode tangents:
+    returns (y [B, so], dy/dx [B, ny, nx], d2y/dx2 [B, ny, nx, nx]).  Per layer a = w0 h W + b with per-sample W, b = slices of
+    pnet_output(p); for the pair (j, k), with ' the first- and '' the second-order tangents,
+        a'_j  = w0 (h'_j W + h W'_j) + b'_j
+        a''   = w0 (h'' W + h'_j W'_k + h'_k W'_j + h W'') + b''          W' = z' Wh , W'' = z'' Wh  (zero for coordinate columns)
+        h'    = f'(a) a' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k
+    (the reference formulation with the weights' tangents materialised).  Pinned by central differences of jacobian_analytic
+    and by torch autograd over all input columns."""
     if spec.kind == KIND_LL:
         return _hessian_ll(spec, ws, inputs, y_index, x_index)
     assert spec.kind in (KIND_NIF, KIND_MS)
+    nif = spec.kind == KIND_NIF
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + spec.si]
-    pout, _ = pnet_forward(spec, ws, p)
-    u, tape = shapenet_given_w(spec, x, pout, keep=True)
     B = x.shape[0]
-    nx = len(x_index)
-    J = np.zeros((B, len(y_index), nx), dtype=u.dtype)
-    H = np.zeros((B, len(y_index), nx, nx), dtype=u.dtype)
-    acts, Wh, W1, Wl = tape["acts"], tape["Wh"], tape["W1"], tape["Wl"]
-    nif = spec.kind == KIND_NIF
+    si, so, n = spec.si, spec.so, spec.n
+    pout, z = pnet_forward(spec, ws, p)
+    last = _pnet_split(spec, ws)[3]
+    sl = spec.slices()
     om = 1.0 if nif else spec.omega_s
     name = spec.s_act if nif else "sine"
-    _, df = act_fn(name)
+    f, df = act_fn(name)
     d2f = act_d2(name)
+
+    def carve(po_):
+        W_ = [po_[:, sl["w1"][0]:sl["w1"][1]].reshape(B, si, n)] + [po_[:, a_:b_].reshape(B, n, n) for (a_, b_) in sl["wh"]]
+        b_ = [po_[:, sl["b1"][0]:sl["b1"][1]]] + [po_[:, a_:b_] for (a_, b_) in sl["bh"]]
+        return W_, b_, po_[:, sl["wl"][0]:sl["wl"][1]].reshape(B, n, so), po_[:, sl["bl"][0]:sl["bl"][1]]
+    P0 = carve(pout)
+    zero = carve(np.zeros_like(pout))
+    u = shapenet_given_w(spec, x, pout)
+    nx = len(x_index)
     yi = list(y_index)
+    J = np.zeros((B, len(yi), nx), dtype=u.dtype)
+    H = np.zeros((B, len(yi), nx, nx), dtype=u.dtype)
+
+    def seed(col):
+        if col >= spec.pi:
+            return np.tile(np.eye(si, dtype=x.dtype)[col - spec.pi], (B, 1))
+        return np.zeros((B, si), dtype=x.dtype)
     for jj in range(nx):
         for kk in range(jj, nx):
-            dj, dk = x_index[jj] - spec.pi, x_index[kk] - spec.pi
-            assert dj >= 0 and dk >= 0, "analytic Hessian only for coordinate columns"
-            a0 = acts[0][1]
-            aj, ak = om * W1[:, dj, :], om * W1[:, dk, :]
-            hj, hk, hjk = df(a0) * aj, df(a0) * ak, d2f(a0) * aj * ak
-
-            def layer(a, W, sj, sk, sjk):
-                aj_, ak_, ajk_ = om * _ein(sj, W), om * _ein(sk, W), om * _ein(sjk, W)
-                return df(a) * aj_, df(a) * ak_, df(a) * ajk_ + d2f(a) * aj_ * ak_
-            if nif:
-                for i in range(spec.L):
-                    _, a = acts[i + 1]
-                    tj, tk, tjk = layer(a, Wh[i], hj, hk, hjk)
-                    hj, hk, hjk = tj + hj, tk + hk, tjk + hjk
-            elif spec.s_res:
-                for i in range(spec.L):
-                    _, a1, t, a2 = acts[i + 1]
-                    tj, tk, tjk = layer(a1, Wh[2 * i], hj, hk, hjk)
-                    vj, vk, vjk = layer(a2, Wh[2 * i + 1], tj, tk, tjk)
-                    hj, hk, hjk = 0.5 * (hj + vj), 0.5 * (hk + vk), 0.5 * (hjk + vjk)
-            else:
-                for i in range(spec.L):
-                    _, a = acts[i + 1]
-                    hj, hk, hjk = layer(a, Wh[i], hj, hk, hjk)
-            J[:, :, jj] = _ein(hj, Wl)[:, yi]
-            J[:, :, kk] = _ein(hk, Wl)[:, yi]
-            ujk = _ein(hjk, Wl)[:, yi]
-            H[:, :, jj, kk] = ujk
-            H[:, :, kk, jj] = ujk
+            cj, ck = x_index[jj], x_index[kk]
+            assert 0 <= cj < spec.pi + si and 0 <= ck < spec.pi + si
+            Pj = Pk = Pjk = zero
+            if cj < spec.pi or ck < spec.pi:
+                _, zj, zk, zjk = pnet_tangents2(spec, ws, p, min(cj, spec.pi - 1), min(ck, spec.pi - 1))
+                if cj < spec.pi:
+                    Pj = carve(zj @ last[0])
+                if ck < spec.pi:
+                    Pk = carve(zk @ last[0])
+                if cj < spec.pi and ck < spec.pi:
+                    Pjk = carve(zjk @ last[0])
+            h, hj, hk, hjk = x, seed(cj), seed(ck), np.zeros((B, si), dtype=x.dtype)
+            blk = None
+            for l in range(len(P0[0])):
+                W, Wj, Wk, Wjk = P0[0][l], Pj[0][l], Pk[0][l], Pjk[0][l]
+                a = om * _ein(h, W) + P0[1][l]
+                aj = om * (_ein(hj, W) + _ein(h, Wj)) + Pj[1][l]
+                ak = om * (_ein(hk, W) + _ein(h, Wk)) + Pk[1][l]
+                ajk = om * (_ein(hjk, W) + _ein(hj, Wk) + _ein(hk, Wj) + _ein(h, Wjk)) + Pjk[1][l]
+                t, tj, tk, tjk = f(a), df(a) * aj, df(a) * ak, df(a) * ajk + d2f(a) * aj * ak
+                if nif and l >= 1:
+                    h, hj, hk, hjk = h + t, hj + tj, hk + tk, hjk + tjk
+                elif spec.s_res and l >= 1:
+                    if (l - 1) % 2 == 0:
+                        blk = (h, hj, hk, hjk)
+                        h, hj, hk, hjk = t, tj, tk, tjk
+                    else:
+                        h, hj, hk, hjk = 0.5 * (blk[0] + t), 0.5 * (blk[1] + tj), 0.5 * (blk[2] + tk), 0.5 * (blk[3] + tjk)
+                else:
+                    h, hj, hk, hjk = t, tj, tk, tjk
+            uj = _ein(hj, P0[2]) + _ein(h, Pj[2]) + Pj[3]
+            uk = _ein(hk, P0[2]) + _ein(h, Pk[2]) + Pk[3]
+            ujk = _ein(hjk, P0[2]) + _ein(hj, Pk[2]) + _ein(hk, Pj[2]) + _ein(h, Pjk[2]) + Pjk[3]
+            J[:, :, jj] = uj[:, yi]
+            J[:, :, kk] = uk[:, yi]
+            H[:, :, jj, kk] = H[:, :, kk, jj] = ujk[:, yi]
     return u, J, H
 
 
 def _hessian_ll(spec, ws, inputs, y_index, x_index):
-    """HessianLayer on the last-layer-parameterised class (model.py:1219-1269): u_i = sum_c phi[i,c](x) a_c(p) + bias_i, so the
-    coordinate derivatives are those of the shared SIREN ShapeNet x -> phi (second-order forward mode through its plain /
-    resblock layers, siren.py:256-281, :381-410) contracted with the ParameterNet output a."""
+    """HessianLayer on the last-layer-parameterised class (model.py:1219-1269): u_i = sum_c phi[i,c](x) a_c(p) + bias_i: coordinate
+    derivatives are those of the shared SIREN ShapeNet x -> phi (second-order forward mode through its plain / resblock layers,
+    siren.py:256-281, :381-410), parameter derivatives those of a = z last_w + last_b (pnet_tangents2):
+    d2u/dx dx' = phi''.a ,  d2u/dx dp = phi'_x.a'_p ,  d2u/dp dp' = phi.a''."""
     p = inputs[:, :spec.pi]
     x = inputs[:, spec.pi:spec.pi + spec.si]
     a_out, _ = pnet_forward(spec, ws, p)
-    *_, rest = _pnet_split(spec, ws)
+    _, _, _, last, rest = _pnet_split(spec, ws)
     first, hidden, bott, bias = _snet_split(spec, rest)
     om = spec.omega_s
     B = x.shape[0]
@@ -1322,38 +1390,51 @@ def _hessian_ll(spec, ws, inputs, y_index, x_index):
     u = np.einsum("bsj,bj->bs", snet_phi(spec, ws, x), a_out) + bias
     J = np.zeros((B, len(yi), nx), dtype=u.dtype)
     H = np.zeros((B, len(yi), nx, nx), dtype=u.dtype)
-
-    def layer(a, W, sj, sk, sjk):
-        aj_, ak_, ajk_ = om * (sj @ W), om * (sk @ W), om * (sjk @ W)
-        return np.cos(a) * aj_, np.cos(a) * ak_, np.cos(a) * ajk_ - np.sin(a) * aj_ * ak_
-
-    def out(v):
-        return np.einsum("bsj,bj->bs", (v @ bott[0]).reshape(B, spec.so, spec.r), a_out)[:, yi]
+    zeros_x = np.zeros((1, spec.n))
     for jj in range(nx):
         for kk in range(jj, nx):
-            dj, dk = x_index[jj] - spec.pi, x_index[kk] - spec.pi
-            assert 0 <= dj < spec.si and 0 <= dk < spec.si, "analytic Hessian only for coordinate columns"
-            a0 = om * (x @ first[0]) + first[1]
-            aj, ak = om * first[0][dj][None, :], om * first[0][dk][None, :]
-            h = np.sin(a0)
-            hj, hk, hjk = np.cos(a0) * aj, np.cos(a0) * ak, -np.sin(a0) * aj * ak
-            for lay in hidden:
-                if spec.s_res:
-                    a1 = om * (h @ lay[0]) + lay[1]
-                    t = np.sin(a1)
-                    tj, tk, tjk = layer(a1, lay[0], hj, hk, hjk)
-                    a2 = om * (t @ lay[2]) + lay[3]
-                    vj, vk, vjk = layer(a2, lay[2], tj, tk, tjk)
-                    h = 0.5 * (h + np.sin(a2))
-                    hj, hk, hjk = 0.5 * (hj + vj), 0.5 * (hk + vk), 0.5 * (hjk + vjk)
-                else:
-                    a1 = om * (h @ lay[0]) + lay[1]
-                    hj, hk, hjk = layer(a1, lay[0], hj, hk, hjk)
-                    h = np.sin(a1)
-            J[:, :, jj] = out(hj)
-            J[:, :, kk] = out(hk)
-            H[:, :, jj, kk] = H[:, :, kk, jj] = out(hjk)
+            cj, ck = x_index[jj], x_index[kk]
+            assert 0 <= cj < spec.pi + spec.si and 0 <= ck < spec.pi + spec.si
+            # ShapeNet side: phi, phi'_j, phi'_k, phi''_jk (zero tangents for parameter columns)
+            xs = lambda c: (first[0][c - spec.pi][None, :] if c >= spec.pi else zeros_x)
+            phi, phj, phk, phjk = _mlp_tangents2_seeded((first, hidden, bott), om, spec.s_res, x, xs(cj), xs(ck))
+            # ParameterNet side: a, a'_j, a'_k, a''_jk (zero for coordinate columns)
+            aj = ak = ajk = np.zeros_like(a_out)
+            if cj < spec.pi or ck < spec.pi:
+                _, zj, zk, zjk = pnet_tangents2(spec, ws, p, min(cj, spec.pi - 1), min(ck, spec.pi - 1))
+                if cj < spec.pi:
+                    aj = zj @ last[0]
+                if ck < spec.pi:
+                    ak = zk @ last[0]
+                if cj < spec.pi and ck < spec.pi:
+                    ajk = zjk @ last[0]
+            c = lambda ph, av: np.einsum("bsj,bj->bs", ph.reshape(B, spec.so, spec.r), av)[:, yi]
+            J[:, :, jj] = c(phj, a_out) + c(phi, aj)
+            J[:, :, kk] = c(phk, a_out) + c(phi, ak)
+            H[:, :, jj, kk] = H[:, :, kk, jj] = c(phjk, a_out) + c(phj, ak) + c(phk, aj) + c(phi, ajk)
     return u, J, H
+
+
+def _mlp_tangents2_seeded(layers, om, res, x, wj, wk):
+    """second-order forward mode through the SIREN ShapeNet of the last-layer class for first-layer tangent rows wj, wk
+    (= first_w[column] for a coordinate seed, zeros for none): -> (phi, phi'_j, phi'_k, phi''_jk), flat [B, so*r]"""
+    first, hidden, bott = layers
+
+    def act3(a, aj, ak, ajk):
+        return np.sin(a), np.cos(a) * aj, np.cos(a) * ak, np.cos(a) * ajk - np.sin(a) * aj * ak
+
+    def lin(W, b, v, vj, vk, vjk):
+        return om * (v @ W) + b, om * (vj @ W), om * (vk @ W), om * (vjk @ W)
+    a0 = om * (x @ first[0]) + first[1]
+    h, hj, hk, hjk = act3(a0, np.broadcast_to(om * wj, a0.shape), np.broadcast_to(om * wk, a0.shape), np.zeros_like(a0))
+    for lay in hidden:
+        if res:
+            t = act3(*lin(lay[0], lay[1], h, hj, hk, hjk))
+            v = act3(*lin(lay[2], lay[3], *t))
+            h, hj, hk, hjk = 0.5 * (h + v[0]), 0.5 * (hj + v[1]), 0.5 * (hk + v[2]), 0.5 * (hjk + v[3])
+        else:
+            h, hj, hk, hjk = act3(*lin(lay[0], lay[1], h, hj, hk, hjk))
+    return h @ bott[0] + bott[1], hj @ bott[0], hk @ bott[0], hjk @ bott[0]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -236,6 +236,12 @@ def test_hessian_analytic_vs_fd_of_the_jacobian_and_torch(name):
         assert np.allclose(H[:, :, :, kk], fd, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(H).max())), (name, kk)   # FD truncation (w0 = 30)
     tH = T.hessian(kind, cs, cp, ws, inputs)            # [B, so, ncol, ncol] over all input columns
     assert np.allclose(H, tH[:, :, xi][:, :, :, xi], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(H).max()))
+    # every input column, parameters included (tutorial 4 differentiates w.r.t. all of them), in a shuffled order
+    xa = list(range(spec.pi + spec.si))[::-1]
+    ua, Ja, Ha = O.hessian_analytic(spec, ws, inputs, yi, xa)
+    tu, tJ = T.jacobian(kind, cs, cp, ws, inputs)
+    assert np.allclose(ua, tu) and np.allclose(Ja, tJ[:, :, xa], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Ja).max()))
+    assert np.allclose(Ha, tH[:, :, xa][:, :, :, xa], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Ha).max()))
 
 
 @pytest.mark.parametrize("name", ["nif_swish", "nif_tanh_r2_so2", "ms_plain", "ms_plain_r3_si2", "ms_res_pres", "ms_mlp_pnet", "ms_mlp_pres"])
