@@ -166,9 +166,10 @@ int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* 
 
 /* HessianLayer(model, y_index, x_index)(x): nif/layers/gradient.py:130-180, :234-261.  y_out [B, so], dydx_out [B, ny, nx],
  * d2ydx2_out [B, ny, nx, nx] with d2[a,i,j,k] = d^2 y[a, y_idx[i]] / d input[a, x_idx[j]] d input[a, x_idx[k]]: second-order
- * forward-mode tangents (k_jac<.., HESS>), one launch per coordinate pair.  Built for the COORDINATE columns of all three
- * classes (the last-layer class: second-order tangents of the shared ShapeNet x -> phi, contracted with the ParameterNet
- * output; ShapeNet widths of its 16-point-tile path); parameter columns return NIF_ERR_INVALID. */
+ * forward-mode tangents (k_jac<.., HESS>), one launch per column pair.  Any input columns of all three classes: a parameter
+ * column brings dz/dp (k_pjac) and, for a pair of them, d2z/dp dp' (k_pjac2) and the second-order product rule of every layer;
+ * the last-layer class: second-order tangents of the shared ShapeNet x -> phi contracted with the ParameterNet output and its
+ * parameter derivatives (ShapeNet widths of its 16-point-tile path). */
 int nif_hessian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
                 int32_t nx, float* y_out, float* dydx_out, float* d2ydx2_out);
 

@@ -31,7 +31,11 @@ struct JacArgs {
 
 // HESS (HessianLayer, gradient.py:130-180, :234-261): streams 0 and 1 are the first-order tangents of two coordinate seeds
 // (j, k), stream 2 is the SECOND-order tangent of the pair:  a'' = w0 W(a) h'' ,  h'' = f'(a) a'' + f''(a) a'_j a'_k  (the
-// first layer is linear in x: a'' = 0); it leaves through the linear last layer like a first-order tangent
+// first layer is linear in x: a'' = 0); it leaves through the linear last layer like a first-order tangent.
+// Parameter columns in the pair (seed < 0, ZD = dz/dp, and for two of them ZD[2] = d2z/dp_j dp_k from k_pjac2): the weights carry
+// tangents of their own and every layer gets the second-order product rule,
+//   a'' = w0 sum_k (zt_k h'' + z'_j,k h'_k + z'_k,k h'_j + z''_k h) M^(k) + sum_k z''_k b^(k)
+// formed from the UNSCALED partial products T = h . M^(k), T_j = h'_j . M^(k), T_k = h'_k . M^(k) of the plane in LDS.
 template <int NBL, int ACT, int MODE, bool HESS = false>
 __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
         zs[k * 16 + p] = A.Z[(tile32 * r + k) * 32 + poff];
 #pragma unroll
         for (int d = 0; d < NS; ++d)
-          zds[(d * r + k) * 16 + p] = (d < ns && J.seed[d] < 0) ? J.ZD[d][(tile32 * r + k) * 32 + poff] : 0.f;
+          zds[(d * r + k) * 16 + p] = (d < ns && J.seed[d] < 0 && J.ZD[d]) ? J.ZD[d][(tile32 * r + k) * 32 + poff] : 0.f;
       }
     const float* zt_base = zs + p;
     const float* zd_base = zds + p;   // zd(d,k) = zd_base[(d*r+k)*16]
@@ -124,6 +128,12 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
             if (J.seed[d] >= 0) accd[d][b] += (zt * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[d] * NP + 16 * b);
             else if (k < r) accd[d][b] += zd_base[(d * r + k) * 16] * tk;
           }
+        if (HESS && anyp && k < r) {   // a''_0 = sum_k (z'_j,k dt_k/dx_k-seed + z'_k,k dt_k/dx_j-seed + z''_k t_k), t_k linear in x
+          f32x4 t2 = zd_base[(2 * r + k) * 16] * tk;
+          if (J.seed[1] >= 0) t2 += (zd_base[(0 * r + k) * 16] * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[1] * NP + 16 * b);
+          if (J.seed[0] >= 0) t2 += (zd_base[(1 * r + k) * 16] * A.omega) * *reinterpret_cast<const f32x4*>(s0 + o_w1 + J.seed[0] * NP + 16 * b);
+          accd[2][b] += t2;
+        }
       }
     }
     {
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
         for (int b = 0; b < NBL; ++b) hd[d][b] = dv[b] * accd[d][b];
       if (HESS) {
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) hd[2][b] = d2[b] * accd[0][b] * accd[1][b];
+        for (int b = 0; b < NBL; ++b) hd[2][b] = dv[b] * accd[2][b] + d2[b] * accd[0][b] * accd[1][b];
       }
     }
     // ---- hidden hyper-matrices -------------------------------------------------------------------
@@ -187,10 +197,19 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
 #pragma unroll
         for (int d = 0; d < NS; ++d)
           if (d < ns) {
-            f32x4 hz[NBL];
+            if (HESS && anyp && k < r && d < 2) {
+              // unscaled T_d = h'_d . M^(k): a'_d += zt T_d, and the pair's second-order stream takes z'_(other) T_d
+              f32x4 Td[NBL];
+              mfma16<NBL, false>(cur, hd[d], Td, lane);
+              const float zo = zd_base[((1 - d) * r + k) * 16];
 #pragma unroll
-            for (int b = 0; b < NBL; ++b) hz[b] = zt * hd[d][b];
-            mfma16<NBL, true>(cur, hz, accd[d], lane);
+              for (int b = 0; b < NBL; ++b) { accd[d][b] += zt * Td[b]; accd[2][b] += zo * Td[b]; }
+            } else {
+              f32x4 hz[NBL];
+#pragma unroll
+              for (int b = 0; b < NBL; ++b) hz[b] = zt * hd[d][b];
+              mfma16<NBL, true>(cur, hz, accd[d], lane);
+            }
           }
         if (has_next) {
           f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);
@@ -289,6 +308,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
             if (g == 0) pd[d] = fmaf(zd, s0[o_bl + o], pd[d]);   // the bias term once per point (pd is summed over g)
           }
         }
+        if (HESS && anyp && k < r)      // u'' += sum_k (z'_j,k <h'_k, Wl^(k)> + z'_k,k <h'_j, Wl^(k)>)
+          pd[2] = fmaf(zd_base[(0 * r + k) * 16], skd[1], fmaf(zd_base[(1 * r + k) * 16], skd[0], pd[2]));
       }
       part += __shfl_xor(part, 16);
       part += __shfl_xor(part, 32);
@@ -321,11 +342,13 @@ void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const*
 }
 // one coordinate pair (seed_j at x position hj, seed_k at hk) of the Hessian: fills columns hj, hk of dydx and the entries
 // (hj, hk), (hk, hj) of d2ydx2 [B][so][nx][nx]
-void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st) {
+void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st,
+                 const float* zd_j, const float* zd_k, const float* zdd) {
   JacArgs J;
   J.s = a; J.ns = 3; J.nx_total = nx_total; J.x0 = 0; J.dydx = dydx; J.hj = hj; J.hk = hk; J.d2ydx2 = d2ydx2;
-  J.seed[0] = seed_j; J.seed[1] = seed_k; J.seed[2] = 0;
-  for (int d = 0; d < NIF_JAC_MAXSEED; ++d) J.ZD[d] = nullptr;
+  J.seed[0] = seed_j; J.seed[1] = seed_k;
+  J.seed[2] = zdd ? -1 : 0;          // stream 2 carries z'' like a parameter seed carries z' (bias / partial-product terms)
+  J.ZD[0] = seed_j < 0 ? zd_j : nullptr; J.ZD[1] = seed_k < 0 ? zd_k : nullptr; J.ZD[2] = zdd;
   launch_jac_impl(J, true, st);
 }
 static void launch_jac_impl(JacArgs& J, bool hess, hipStream_t st) {

@@ -227,6 +227,85 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
   if (threadIdx.x == 0) J.loss_partial[blockIdx.x] = red[0];
 }
 
+// Second-order forward mode for ONE pair of parameter columns (cj, ck): d2z/dp_cj dp_ck -> ZDD [tiles][r][32] (HessianLayer with
+// parameter columns, nif/layers/gradient.py:130-180).  h'' = f'(a) a'' + f''(a) a'_j a'_k through the same layer kinds; one
+// thread per point, no stash traffic.
+template <int NST>
+__global__ __launch_bounds__(128) void k_pjac2(PNetArgs A, int cj, int ck, float* __restrict__ ZDD) {
+  const long pt = (long)blockIdx.x * 128 + threadIdx.x;
+  const long ntiles = (A.B + 31) / 32;
+  if (pt >= ntiles * 32) return;
+  const bool ok = pt < A.B;
+  const long ptc = ok ? pt : A.B - 1;
+  const long tile = pt >> 5; const int pp = (int)(pt & 31);
+  const int pi = A.pi, nst = A.nst, lst = A.lst, r = A.r, res = A.res;
+  const float s = A.siren ? A.omega : 1.0f;
+  const int act = A.siren ? ACT_SINE : A.act;
+  const float* th = A.theta;
+  float h[NST], hj[NST], hk[NST], hjk[NST];
+  for (int j = 0; j < nst; ++j) {
+    float a = 0.f;
+    for (int d = 0; d < pi; ++d) a = fmaf(A.xin[ptc * A.ncol + A.col0 + d], th[A.first_w + (long)d * nst + j], a);
+    a = s * a + th[A.first_b + j];
+    const float aj = s * th[A.first_w + (long)cj * nst + j], ak = s * th[A.first_w + (long)ck * nst + j];
+    float f0, f1, f2; pj_act(act, a, &f0, &f1, &f2);
+    h[j] = f0; hj[j] = f1 * aj; hk[j] = f1 * ak; hjk[j] = f2 * aj * ak;
+  }
+  float o0[NST], oj[NST], ok_[NST], ojk[NST];
+  // (o0 | oj | ok_ | ojk) = s (v W) (+ b), v in (v0 | vj | vk | vjk)
+  auto matvec = [&](long w_off, long b_off, const float* v0, const float* vj, const float* vk, const float* vjk) {
+    for (int j = 0; j < nst; ++j) {
+      float a = 0.f, aj = 0.f, ak = 0.f, ajk = 0.f;
+      for (int i = 0; i < nst; ++i) {
+        const float w = th[w_off + (long)i * nst + j];
+        a = fmaf(v0[i], w, a); aj = fmaf(vj[i], w, aj); ak = fmaf(vk[i], w, ak); ajk = fmaf(vjk[i], w, ajk);
+      }
+      o0[j] = s * a + th[b_off + j]; oj[j] = s * aj; ok_[j] = s * ak; ojk[j] = s * ajk;
+    }
+  };
+  // in place: (o0 | ..) <- (f(a), f' a'_j, f' a'_k, f' a'' + f'' a'_j a'_k)
+  auto act4 = [&]() {
+    for (int j = 0; j < nst; ++j) {
+      float f0, f1, f2; pj_act(act, o0[j], &f0, &f1, &f2);
+      const float aj = oj[j], ak = ok_[j];
+      o0[j] = f0; oj[j] = f1 * aj; ok_[j] = f1 * ak; ojk[j] = fmaf(f1, ojk[j], f2 * aj * ak);
+    }
+  };
+  for (int i = 0; i < lst; ++i) {
+    if (!res) {
+      matvec(A.hid_w[i], A.hid_b[i], h, hj, hk, hjk);
+      act4();
+      for (int j = 0; j < nst; ++j) {
+        if (A.siren) { h[j] = o0[j]; hj[j] = oj[j]; hk[j] = ok_[j]; hjk[j] = ojk[j]; }
+        else { h[j] += o0[j]; hj[j] += oj[j]; hk[j] += ok_[j]; hjk[j] += ojk[j]; }          // MLP_SimpleShortCut
+      }
+    } else {
+      matvec(A.hid_w[i], A.hid_b[i], h, hj, hk, hjk);
+      act4();
+      float t0[NST], tj[NST], tk[NST], tjk[NST];
+      for (int j = 0; j < nst; ++j) { t0[j] = o0[j]; tj[j] = oj[j]; tk[j] = ok_[j]; tjk[j] = ojk[j]; }
+      matvec(A.hid_w2[i], A.hid_b2[i], t0, tj, tk, tjk);
+      if (!A.siren) for (int j = 0; j < nst; ++j) { o0[j] += h[j]; oj[j] += hj[j]; ok_[j] += hk[j]; ojk[j] += hjk[j]; }   // MLP_ResNet
+      act4();
+      for (int j = 0; j < nst; ++j) {
+        if (A.siren) { h[j] = 0.5f * (h[j] + o0[j]); hj[j] = 0.5f * (hj[j] + oj[j]); hk[j] = 0.5f * (hk[j] + ok_[j]); hjk[j] = 0.5f * (hjk[j] + ojk[j]); }
+        else { h[j] = o0[j]; hj[j] = oj[j]; hk[j] = ok_[j]; hjk[j] = ojk[j]; }
+      }
+    }
+  }
+  for (int c = 0; c < r; ++c) {
+    float zdd = 0.f;
+    for (int i = 0; i < nst; ++i) zdd = fmaf(hjk[i], th[A.bott_w + (long)i * r + c], zdd);
+    ZDD[(tile * r + c) * 32 + pp] = ok ? zdd : 0.f;
+  }
+}
+void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st) {
+  const long ntiles = (a.B + 31) / 32;
+  const int nblk = (int)((ntiles * 32 + 127) / 128);
+  if (a.nst <= 32) hipLaunchKernelGGL((k_pjac2<32>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
+  else hipLaunchKernelGGL((k_pjac2<64>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
+}
+
 bool pjac_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
   return a.nst <= 64 && nm <= 4 && a.pi <= NIF_PJ_MAXPI;     // (first / hidden / bottleneck only: the same for every class)

@@ -712,78 +712,127 @@ extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_
     return fail(NIF_ERR_INVALID, "bad argument");
   for (int i = 0; i < ny; ++i)
     if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
-  for (int j = 0; j < nx; ++j)
-    if (x_idx[j] < c->pi || x_idx[j] >= c->pi + c->si)
-      return fail(NIF_ERR_INVALID, "HessianLayer is built for coordinate columns (pi_dim <= x_index < pi_dim + si_dim): second-order "
-                                   "tangents through the ParameterNet are not");
+  bool anyp = false;
+  for (int j = 0; j < nx; ++j) {
+    if (x_idx[j] < 0 || x_idx[j] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "x_index out of range (0 <= i < pi_dim + si_dim)");
+    anyp = anyp || x_idx[j] < c->pi;
+  }
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
+  rc = ensure_capacity(c, B, false); if (rc) return rc;
+  const int ncol = c->pi + c->si;
+  const long ntl = (B + 31) / 32;
+  rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
+  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+  launch_pnet(pa, c->NSTB, false, c->st);
+  // parameter columns: z' = dz/dp of every parameter column once (k_pjac, forward mode), z'' per pair of them (k_pjac2)
+  float* zdd = nullptr;
+  if (anyp) {
+    if (!pjac_supported(pa))
+      return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+    const long need_zt = (long)c->pi * ntl * 32 * c->r, need_dd = ntl * 32 * c->r;
+    if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
+    if (need_dd > c->dzt_par_cap) { rc = grow(&c->dzt_par, &c->dzt_par_cap, need_dd); if (rc) return rc; }
+    launch_pjac_fwd(pa, c->zt_par, c->st);
+    zdd = c->dzt_par;
+  }
+  auto zt_of = [&](int col) -> const float* { return c->zt_par + (long)col * ntl * 32 * c->r; };
   if (c->kind == NIF_KIND_LASTLAYER) {
-    // u_i = sum_c phi[i,c] a_c + bias_i with a independent of the coordinates: second-order tangents of the shared SIREN
-    // ShapeNet x -> phi (the r = 0 case of the same kernel, so * latent_dim outputs), contracted with a on the host (this
-    // entry point takes and returns host arrays)
-    rc = ensure_capacity(c, B, false); if (rc) return rc;
-    const int ncol = c->pi + c->si, rl = c->r, sop = c->so * c->r;
-    rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
+    // u_i = sum_c phi[i,c](x) a_c(p) + bias_i: the coordinates only move phi (second-order tangents of the shared SIREN ShapeNet,
+    // the r = 0 case of the same kernel with so * latent_dim outputs), the parameters only move a = latent last_w + last_b:
+    //   d2u/dx dx' = phi''.a ,  d2u/dx dp = phi'_x.a'_p ,  d2u/dp dp' = phi.a''   -- contracted on the host (this entry point
+    // takes and returns host arrays)
+    const int rl = c->r, sop = c->so * c->r;
+    std::vector<int> xc, xp;                         // positions (in x_idx) of the coordinate / parameter columns
+    for (int j = 0; j < nx; ++j) (x_idx[j] >= c->pi ? xc : xp).push_back(j);
+    const int nxc = xc.empty() ? 1 : (int)xc.size();
     rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * sop); if (rc) return rc;
-    rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * sop * nx); if (rc) return rc;
-    rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * sop * nx * nx); if (rc) return rc;
-    PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
-    launch_pnet(pa, c->NSTB, false, c->st);
+    rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * sop * nxc); if (rc) return rc;
+    rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * sop * nxc * nxc); if (rc) return rc;
     SNetArgs sa; rc = fill_snet_ll_sob(c, sa, c->d_a, B, true); if (rc) return rc;
-    for (int j = 0; j < nx; ++j)
-      for (int k = j; k < nx; ++k) {
+    if (xc.empty()) { sa.u_out = c->d_d; launch_hess(sa, 0, 0, 0, 0, 1, c->d_b, c->d_c, c->st); }     // phi alone
+    for (size_t j = 0; j < xc.size(); ++j)
+      for (size_t k = j; k < xc.size(); ++k) {
         sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
-        launch_hess(sa, x_idx[j] - c->pi, x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st);
+        launch_hess(sa, x_idx[xc[j]] - c->pi, x_idx[xc[k]] - c->pi, (int)j, (int)k, nxc, c->d_b, c->d_c, c->st);
       }
     HIPCHK(hipGetLastError());
-    const long ntl = (B + 31) / 32;
-    std::vector<float> f0((size_t)B * sop), fj((size_t)B * sop * nx), fh((size_t)B * sop * nx * nx), za((size_t)ntl * rl * 32), bias(c->so);
+    std::vector<float> f0((size_t)B * sop), fj((size_t)B * sop * nxc), fh((size_t)B * sop * nxc * nxc), za((size_t)ntl * rl * 32),
+        bias(c->so), lw((size_t)rl * rl), zt1(anyp ? (size_t)c->pi * ntl * 32 * rl : 0);
     HIPCHK(hipMemcpyAsync(f0.data(), c->d_d, sizeof(float) * f0.size(), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipMemcpyAsync(fj.data(), c->d_b, sizeof(float) * fj.size(), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipMemcpyAsync(fh.data(), c->d_c, sizeof(float) * fh.size(), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipMemcpyAsync(za.data(), c->Z, sizeof(float) * za.size(), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipMemcpyAsync(bias.data(), c->theta + c->ll_bias, sizeof(float) * bias.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(lw.data(), c->theta + c->last_w, sizeof(float) * lw.size(), hipMemcpyDeviceToHost, c->st));
+    if (anyp) HIPCHK(hipMemcpyAsync(zt1.data(), c->zt_par, sizeof(float) * zt1.size(), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    for (int64_t a_ = 0; a_ < B; ++a_) {
-      const float* av = za.data() + (size_t)(a_ >> 5) * rl * 32 + (a_ & 31);       // a_c at av[c * 32]
-      for (int i = 0; i < c->so; ++i) {
-        double u = bias[i];
-        for (int cc = 0; cc < rl; ++cc) u += (double)f0[(size_t)a_ * sop + i * rl + cc] * av[cc * 32];
-        y_out[a_ * c->so + i] = (float)u;
+    // a''_{jk} for the parameter pairs: one k_pjac2 launch + copy each
+    const size_t np_ = xp.size();
+    std::vector<std::vector<float>> zt2(np_ * np_);
+    for (size_t j = 0; j < np_; ++j)
+      for (size_t k = j; k < np_; ++k) {
+        launch_pjac2(pa, x_idx[xp[j]], x_idx[xp[k]], zdd, c->st);
+        zt2[j * np_ + k].resize((size_t)ntl * rl * 32);
+        HIPCHK(hipMemcpyAsync(zt2[j * np_ + k].data(), zdd, sizeof(float) * zt2[j * np_ + k].size(), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(hipStreamSynchronize(c->st));
+        zt2[k * np_ + j] = zt2[j * np_ + k];
       }
-      for (int i = 0; i < ny; ++i) {
-        const size_t src = (size_t)a_ * sop + (size_t)y_idx[i] * rl;
-        for (int j = 0; j < nx; ++j) {
+    std::vector<double> av(rl), ad((size_t)(np_ ? np_ : 1) * rl), add((size_t)(np_ ? np_ * np_ : 1) * rl);
+    for (int64_t a_ = 0; a_ < B; ++a_) {
+      const size_t zoff = (size_t)(a_ >> 5) * rl * 32 + (a_ & 31);       // latent-layout arrays: element c at [zoff + c * 32]
+      for (int cc = 0; cc < rl; ++cc) av[cc] = za[zoff + (size_t)cc * 32];
+      auto through_lw = [&](const float* zsrc, double* dst) {            // a' = z' last_w (no bias)
+        for (int cc = 0; cc < rl; ++cc) {
           double t = 0.0;
-          for (int cc = 0; cc < rl; ++cc) t += (double)fj[(src + cc) * nx + j] * av[cc * 32];
-          dydx_out[(a_ * ny + i) * nx + j] = (float)t;
-          for (int k = 0; k < nx; ++k) {
-            double h = 0.0;
-            for (int cc = 0; cc < rl; ++cc) h += (double)fh[((src + cc) * nx + j) * nx + k] * av[cc * 32];
-            d2_out[((a_ * ny + i) * nx + j) * nx + k] = (float)h;
+          for (int c2 = 0; c2 < rl; ++c2) t += (double)zsrc[zoff + (size_t)c2 * 32] * lw[(size_t)c2 * rl + cc];
+          dst[cc] = t;
+        }
+      };
+      for (size_t j = 0; j < np_; ++j) {
+        through_lw(zt1.data() + (size_t)x_idx[xp[j]] * ntl * 32 * rl, &ad[j * rl]);
+        for (size_t k = 0; k < np_; ++k) through_lw(zt2[j * np_ + k].data(), &add[(j * np_ + k) * rl]);
+      }
+      auto dot = [&](const float* ph, size_t stride, const double* v) {  // sum_c ph[c * stride] v[c]
+        double t = 0.0;
+        for (int cc = 0; cc < rl; ++cc) t += (double)ph[(size_t)cc * stride] * v[cc];
+        return t;
+      };
+      for (int i = 0; i < c->so; ++i) y_out[a_ * c->so + i] = (float)(dot(&f0[(size_t)a_ * sop + (size_t)i * rl], 1, av.data()) + bias[i]);
+      for (int i = 0; i < ny; ++i) {
+        const size_t src = (size_t)a_ * sop + (size_t)y_idx[i] * rl;      // phi[a, y_i, 0]
+        auto phi1 = [&](int jc) { return &fj[src * nxc + jc]; };          // phi'_{jc}[c] at stride nxc
+        auto phi2 = [&](int jc, int kc) { return &fh[(src * nxc + jc) * nxc + kc]; };
+        for (size_t j = 0; j < xc.size(); ++j) dydx_out[(a_ * ny + i) * nx + xc[j]] = (float)dot(phi1((int)j), nxc, av.data());
+        for (size_t j = 0; j < np_; ++j) dydx_out[(a_ * ny + i) * nx + xp[j]] = (float)dot(&f0[src], 1, &ad[j * rl]);
+        float* h = d2_out + (size_t)(a_ * ny + i) * nx * nx;
+        for (size_t j = 0; j < xc.size(); ++j) {
+          for (size_t k = 0; k < xc.size(); ++k) h[xc[j] * nx + xc[k]] = (float)dot(phi2((int)j, (int)k), (size_t)nxc * nxc, av.data());
+          for (size_t k = 0; k < np_; ++k) {
+            const float v = (float)dot(phi1((int)j), nxc, &ad[k * rl]);
+            h[xc[j] * nx + xp[k]] = v; h[xp[k] * nx + xc[j]] = v;
           }
         }
+        for (size_t j = 0; j < np_; ++j)
+          for (size_t k = 0; k < np_; ++k) h[xp[j] * nx + xp[k]] = (float)dot(&f0[src], 1, &add[(j * np_ + k) * rl]);
       }
     }
     return NIF_OK;
   }
   rc = ensure_packed32(c); if (rc) return rc;
   if (!c->use_snet3) return fail(NIF_ERR_INVALID, "HessianLayer needs the 16-point-tile path (units <= 128, small latent)");
-  rc = ensure_capacity(c, B, false); if (rc) return rc;
-  const int ncol = c->pi + c->si;
-  rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
   rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * c->so * nx * nx); if (rc) return rc;
-  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
-  launch_pnet(pa, c->NSTB, false, c->st);
   SNetArgs sa; fill_snet(c, sa, c->d_a, ncol, c->pi, B);
   for (int j = 0; j < nx; ++j)
     for (int k = j; k < nx; ++k) {
       sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
-      launch_hess(sa, x_idx[j] - c->pi, x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st);
+      const bool pj = x_idx[j] < c->pi, pk = x_idx[k] < c->pi;
+      if (pj && pk) launch_pjac2(pa, x_idx[j], x_idx[k], zdd, c->st);
+      launch_hess(sa, pj ? -1 : x_idx[j] - c->pi, pk ? -1 : x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st,
+                  pj ? zt_of(x_idx[j]) : nullptr, pk ? zt_of(x_idx[k]) : nullptr, (pj && pk) ? zdd : nullptr);
     }
   HIPCHK(hipGetLastError());
   std::vector<float> fj((size_t)B * c->so * nx), fh((size_t)B * c->so * nx * nx);

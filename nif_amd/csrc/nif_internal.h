@@ -191,7 +191,10 @@ long snet3_plane_floats(int n);
 long snet3_ring_floats_per_wave(int n, int nh);
 void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
                 hipStream_t st);
-void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st);
+// seed_j / seed_k: coordinate index, or -1 for a parameter column (then zd_j / zd_k = dz/dp of that column [tiles][r][32], and
+// zdd = d2z/dp_j dp_k when both are parameter columns)
+void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int nx_total, float* dydx, float* d2ydx2, hipStream_t st,
+                 const float* zd_j = nullptr, const float* zd_k = nullptr, const float* zdd = nullptr);
 void launch_mlp_jac(const PNetArgs& a, int NB, int seed, float* ZD, hipStream_t st);
 void launch_ll_jac_out(const float* PHI, const float* Z, const float* PHID, const float* ZD, long B, int r, int so,
                        int nx_total, int xcol, float* dydx, hipStream_t st);
@@ -227,6 +230,7 @@ void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
 // latent Jacobian regulariser (k_pjac.hip): tangents of the ParameterNet + their adjoint; operand pairs into the stash
 bool pjac_supported(const PNetArgs& a);
 int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st);
+void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st);   // d2z/dp_cj dp_ck -> ZDD [tiles][r][32]
 int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st);      // dz/dp_d of every parameter column -> ZT [pi][tiles][r][32]
 int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st);
 void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st);

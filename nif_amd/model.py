@@ -327,7 +327,7 @@ class HessianLayer(object):
     """reference nif/layers/gradient.py:130-180: `y, dys_dxs, dys2_dxs2 = HessianLayer(model, y_index, x_index)(x)` with
     dys2_dxs2[a, i, j, k] = d^2 y[a, y_index[i]] / d x[a, x_index[j]] d x[a, x_index[k]].  Second-order forward-mode
     tangents in one HIP kernel per coordinate pair (the reference nests two GradientTapes and batch_jacobian, :251-261);
-    built for the coordinate columns of all three classes."""
+    built for any input columns of all three classes."""
 
     def __init__(self, model, y_index, x_index, **kwargs):
         if not isinstance(model, Model) or model._role != "full":

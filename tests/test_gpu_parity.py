@@ -963,9 +963,37 @@ def test_hessian_layer_matches_oracle(name):
     y1, J1, H1 = nif_amd.HessianLayer(model, spec.so - 1, [xi[-1]])(x)
     assert H1.shape == (x.shape[0], 1, 1, 1)
     assert np.allclose(H1[:, 0, 0, 0], H[:, spec.so - 1, -1, -1], rtol=1e-5, atol=1e-6 * np.abs(H).max())
-    # parameter columns are refused loudly
+    # every input column, parameters included (the reference's tutorial 4 differentiates w.r.t. all of them), shuffled order:
+    # second-order tangents through the ParameterNet (k_pjac2) and the second-order product rule of every layer
+    xa = list(range(spec.pi + spec.si))[::-1]
+    ya, Ja, Ha = nif_amd.HessianLayer(model, yi, xa)(x)
+    ura, Jra, Hra = O.hessian_analytic(spec, ws, x.astype(np.float64), yi, xa)
+    assert Ha.shape == (x.shape[0], spec.so, len(xa), len(xa))
+    assert _rel(ya, ura) < 1e-5 and _rel(Ja, Jra) < 2e-5, (_rel(ya, ura), _rel(Ja, Jra))
+    assert _rel(Ha, Hra) < 2e-4, _rel(Ha, Hra)
+    for a_, b_ in ((0, 0), (0, len(xa) - 1), (len(xa) - 1, len(xa) - 1)):       # blocks: (x,x), (x,p), (p,p)
+        blk, ref = Ha[:, :, a_, b_], Hra[:, :, a_, b_]
+        assert np.linalg.norm(blk - ref) <= 3e-4 * max(np.linalg.norm(ref), 1e-3 * np.linalg.norm(Hra)), (a_, b_)
+    assert np.array_equal(Ha, np.swapaxes(Ha, 2, 3))
     with pytest.raises(nif_amd._lib.NifError):
-        nif_amd.HessianLayer(model, yi, [0])(x)
+        nif_amd.HessianLayer(model, yi, [spec.pi + spec.si])(x)
+
+
+def test_tutorial4_shape_contract_of_the_reference():
+    """tests/golden/tutorial_logs.json: the reference's tutorial 4 wraps a model with 4 inputs and 5 outputs, x_index = all inputs,
+    y_index = all outputs, 10 points, and prints (10, 5), (10, 5, 4), (10, 5, 4, 4)"""
+    import json
+    import os
+    import nif_amd
+    log = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tutorial_logs.json")))
+    kind, cs, cp = _cfg("NIFMultiScale", 32, 2, 32, 1, 1, 3, 5, 1)           # (t; x, y, z) -> 5 outputs
+    nif_amd.set_seed(0)
+    model = nif_amd.NIFMultiScale(cs, cp).build()
+    x = np.random.default_rng(0).uniform(0, 1, size=(log["y_shape"][0], len(log["x_index"]))).astype(np.float32)
+    y, dydx = nif_amd.JacobianLayer(model, log["y_index"], log["x_index"])(x)
+    assert list(y.shape) == log["y_shape"] and list(dydx.shape) == log["dydx_shape"]
+    y2, dydx2, d2 = nif_amd.HessianLayer(model, log["y_index"], log["x_index"])(x)
+    assert list(d2.shape) == log["d2ydx2_shape"] and np.allclose(dydx, dydx2, rtol=1e-4, atol=1e-6)
 
 
 # ---- activity regularisers of the ParameterNet output (N3; reference model.py:118-125, :226, :659, :731) -----------------------

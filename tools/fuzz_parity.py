@@ -106,9 +106,9 @@ def run_case(cfg, B, seed):
             bad.append(("three-stage", _rel(u3, O.forward(spec, ws64, x64))))
     except nif_amd._lib.NifError as ex:
         bad.append(("three-stage refused", str(ex)[:80]))
-    # HessianLayer on the coordinate columns
+    # HessianLayer on every input column (parameters included), shuffled
     try:
-        xc = list(range(spec.pi, spec.pi + spec.si))
+        xc = list(range(spec.pi + spec.si))[::-1]
         _, Jh, H = nif_amd.HessianLayer(model, yi, xc)(x[:64])
         _, Jr2, Hr = O.hessian_analytic(spec, ws64, x64[:64], yi, xc)
         if _rel(Jh, Jr2) > 2e-5 or _rel(H, Hr) > 2e-4:
