@@ -169,7 +169,7 @@ int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* 
  * forward-mode tangents (k_jac<.., HESS>), one launch per column pair.  Any input columns of all three classes: a parameter
  * column brings dz/dp (k_pjac) and, for a pair of them, d2z/dp dp' (k_pjac2) and the second-order product rule of every layer;
  * the last-layer class: second-order tangents of the shared ShapeNet x -> phi contracted with the ParameterNet output and its
- * parameter derivatives (ShapeNet widths of its 16-point-tile path). */
+ * parameter derivatives. */
 int nif_hessian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
                 int32_t nx, float* y_out, float* dydx_out, float* d2ydx2_out);
 
@@ -187,8 +187,8 @@ int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, co
  * takes any column; a parameter column runs its tangent through the ParameterNet, the hyper layer and the product rule of every
  * h W(p): k_pjac + k_sob<PAR> + a second weight-gradient reduction).  Built as forward tangents + their hand-derived adjoint in
  * one kernel (k_sob_dev.h) for NIFMultiScale (with or without resblocks), class NIF (any activation, skip connections) and
- * the last-layer class (ShapeNet widths of its 16-point-tile path; a parameter column there is one more contraction of phi with
- * a' = (dz/dp) last_w in the kernel's epilogue).
+ * the last-layer class (a parameter column there is one more contraction of phi with a' = (dz/dp) last_w in the kernel's
+ * epilogue).  Shapes whose working set exceeds one CU's LDS return NIF_ERR_INVALID.
  * Same conventions as nif_loss_grad_dev (result in nif_grad_dev(), scaled by 1/B_global). */
 int nif_sobolev_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
                               const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,

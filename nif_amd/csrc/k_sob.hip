@@ -21,7 +21,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     const bool bfq = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
     const size_t planeq = bfq ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
     const size_t smq = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-    const size_t npwq = (any_par && !a.ll) ? 1 + NIF_SOB_MAXSEED : 1;
+    size_t npwq = 1;
+    if (par && !a.ll) for (int d = 0; d < ns; ++d) npwq += par->par[d] >= 0;
     size_t need = (2 * planeq + smq + 4 * npwq * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
     if (a.ll) {
       const size_t llwq = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16;
@@ -51,7 +52,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const bool sgn = !a.res && !a.nif_skip && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register (SIREN only)
   const size_t plane = bf ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  const size_t npw = any_par ? 1 + NIF_SOB_MAXSEED : 1;
+  size_t npw = 1;
+  if (any_par) for (int d = 0; d < ns; ++d) npw += J.par[d] >= 0;
   const size_t shm = (2 * plane + sm_tot + 4 * npw * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
   J.ll_plane = 0;
   if (a.ll) {

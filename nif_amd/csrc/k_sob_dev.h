@@ -105,15 +105,21 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   f32x4* planes = reinterpret_cast<f32x4*>(smem);
   float* sm = smem + 2 * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  constexpr int NPW = PAR ? 1 + NS : 1;                       // PAR: the same again per stream for (dL/dzt', zt')
+  // PAR: the per-wave (dL/dzt, zt) block once more per PARAMETER stream (they are the last npar of the ns streams)
+  int nsc = ns;
+#pragma unroll
+  for (int d = NS - 1; d >= 0; --d)
+    if (PAR && d < ns && J.par[d] >= 0) nsc = d;
+  const int npar_s = PAR ? ns - nsc : 0;
+  const int NPW = 1 + npar_s;
   const int nrl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
   // LL per wave: a, dL/da [rl][16], phi / phi' [NQ][so][16], du / du' [NQ][so_u][16]; heads: a', dL/da' [3][rl][16], du_e [3][so_u][16]
   const int llw = LL ? (2 * nrl + NQ * so + NQ * sou + NIF_SOB_MAXSEED * (2 * nrl + sou)) * 16 : 0;
   const int pwf = NPW * (r * 64 + r * 16) + ((LL && J.ll_plane) ? 0 : llw);   // per-wave floats
   float* dzs = sm + sm_tot + (long)wid * pwf;                 // per wave dz partials [r][64], latent [r][16]
   float* zs = dzs + r * 64;
-  float* dzts = zs + r * 16;                                  // [NS][r][64]
-  float* zts = dzts + NS * r * 64;                            // [NS][r][16]
+  float* dzts = zs + r * 16 - nsc * r * 64;                   // [npar][r][64], indexed by the STREAM number d >= nsc
+  float* zts = zs + r * 16 + npar_s * r * 64 - nsc * r * 16;  // [npar][r][16], likewise
   float* lsum = sm + sm_tot + (long)WAVES * pwf;
   const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((nrl * nrl + 3) & ~3))) : 0;   // LL extras sit at the end of sm (snet4_nsm_ll)
   const int o_lw = o_llb + ((sou + 3) & ~3);
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
     if (PAR && g == 0)
       for (int d = 0; d < NS; ++d)
         for (int k = 0; k < r; ++k)
-          zts[(d * r + k) * 16 + p] = ispar[d] ? J.ZT[(((long)J.par[d] * nt32 + tile32) * r + k) * 32 + poff] : 0.f;
+          if (ispar[d]) zts[(d * r + k) * 16 + p] = J.ZT[(((long)J.par[d] * nt32 + tile32) * r + k) * 32 + poff];
     const float* zt_base = zs + p;
     const float* ztd_base = zts + p;                          // zt'_k of stream d at ztd_base[(d * r + k) * 16]
     // stash rows of stream q (0 = primal, 1+d = tangent d): pseudo-tile q*nt32 + tile32
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
     if (TRAIN && PAR)
-      for (int e = 0; e < NS * r; ++e) dzts[e * 64 + lane] = 0.f;
+      for (int e = nsc * r; e < ns * r; ++e) dzts[e * 64 + lane] = 0.f;
 
     // hq[0] = h, hq[1+d] = h'^d ; aq likewise for the pre-activation accumulators
     f32x4 hq[NQ][NBL], aq[NQ][NBL];

@@ -162,10 +162,11 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpf, (size_t)snet4_phi_fwd_elems(c->n) * 2);
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpb, (size_t)snet4_phi_bwd_elems(c->n) * 2);
-    if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess)
-      e = hipMalloc(&c->ll_slots, sizeof(float) * (size_t)((long)c->si * c->n + (long)nh * c->n * c->n + (long)c->n * c->so * c->r +
-                                                             c->n + (long)nh * c->n + c->so * c->r + c->so + c->r * c->r + 64));
   }
+  // slot-ordered copy of the dense ShapeNet parameters of the last-layer class (k_snet4<LL>, k_sob<LL>, k_jac on the r = 0 arguments)
+  if (c->kind == NIF_KIND_LASTLAYER && nh > 0 && c->n <= 128 && e == hipSuccess)
+    e = hipMalloc(&c->ll_slots, sizeof(float) * (size_t)((long)c->si * c->n + (long)nh * c->n * c->n + (long)c->n * c->so * c->r +
+                                                           c->n + (long)nh * c->n + c->so * c->r + c->so + c->r * c->r + 64));
   const size_t pk_l = (size_t)(nh > 0 ? nh : 1) * c->NB * c->NB * 256 * sizeof(f32x4);
   if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWF, pk_l);
   if (e == hipSuccess && c->kind == NIF_KIND_LASTLAYER) e = hipMalloc(&c->lWB, pk_l);
@@ -537,7 +538,7 @@ static int ensure_packed(nif_ctx* c) {
       static const bool ll_old = [] { const char* e = getenv("NIF_LL_MLP"); return e && e[0] == '1'; }();
       c->use_ll4 = c->sWF4 && c->ll_slots && c->ll_wpf && c->ll_wpb && !ll_old && snet4_supported(probe);
     }
-    if (c->use_ll4) {
+    if (c->ll_slots) {
       const int n = c->n, nh = c->nh, sop = c->so * c->r;
       LLSlotMap m; m.nseg = 0;
       auto seg = [&](long src, long dst, long len) { m.seg[m.nseg].src = src; m.seg[m.nseg].dst = dst; m.seg[m.nseg].len = len; ++m.nseg; };
@@ -550,14 +551,15 @@ static int ensure_packed(nif_ctx* c) {
         if (!c->cfg.s_resblock) { w_off = c->s_hid_w[j]; b_off = c->s_hid_b[j]; }
         else { const int i = j / 2; w_off = (j & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (j & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
         seg(b_off, s_bh + (long)j * n, n);
-        launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
-                       (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2, c->st);
+        if (c->use_ll4)
+          launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
+                         (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2, c->st);
       }
       seg(c->s_bott_b, s_bl, sop);
       seg(c->ll_bias, s_bl + sop, c->so);
       seg(c->last_w, s_bl + sop + c->so, (long)c->r * c->r);
       launch_ll_slots(c->theta, m, c->ll_slots, c->st);
-      launch_pack_phi(c->theta, c->s_bott_w, n, sop, c->ll_wpf, c->ll_wpb, c->st);
+      if (c->use_ll4) launch_pack_phi(c->theta, c->s_bott_w, n, sop, c->ll_wpf, c->ll_wpb, c->st);
     }
     HIPCHK(hipGetLastError());
     c->packed = true;
@@ -947,10 +949,11 @@ extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, 
 // SNetArgs of the last-layer class for k_sob (Sobolev step / its predict): k_snet4's arguments for that class plus, beyond the
 // widths whose bf16 planes fit the LDS (n > 96), the f32-input MFMA planes of the shared hidden matrices, packed on demand
 static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B, bool f32_planes) {
-  if (!c->use_ll4) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: ShapeNet widths of the 16-point-tile path (even 16-blocks, units <= 128, so * latent_dim <= 32)");
+  if (!c->ll_slots) return fail(NIF_ERR_INVALID, "JacobianLayer-as-output / HessianLayer on the last-layer class: ShapeNet with at least one hidden layer and units <= 128");
   fill_snet_ll(c, sa, xin, c->pi + c->si, c->pi, B);
-  if (!sob_ll_supported(sa)) return fail(NIF_ERR_INVALID, "Sobolev on the last-layer class: unsupported ShapeNet shape");
+  if (!sob_ll_supported(sa)) return fail(NIF_ERR_INVALID, "JacobianLayer-as-output / HessianLayer on the last-layer class: so * latent_dim <= 64");
   const int NBL = snet3_nbl(c->n);
+  if (!c->use_ll4) { sa.WF4 = nullptr; sa.WB4 = nullptr; f32_planes = true; }   // (bf16-split planes are packed for k_snet4<LL> only)
   if (NBL > 6 || f32_planes) {     // (k_jac / the Hessian take the f32-input planes at every width)
     const long plane_s = snet3_plane_floats(c->n) / 4;
     if (!c->ll_packed32) {
