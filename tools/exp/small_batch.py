@@ -17,6 +17,3 @@ for bs in (512, 2048, 10000):
     dt = time.perf_counter() - t0
     nsteps = ep * ((10000 + bs - 1) // bs)
     print("batch %5d: %7.1f us/step (%d steps, fit wall %.3f s)" % (bs, dt / nsteps * 1e6, nsteps, dt))
-e = m._engine
-dx = e.alloc(x.size); dy = e.alloc(y.size)
-e.upload(dx, x) if hasattr(e, "upload") else None
