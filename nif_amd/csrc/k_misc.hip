@@ -679,6 +679,57 @@ void launch_actreg_apply(const float* part, int nslab, int r, long po, float coe
                      loss_partial, nloss, g, P);
 }
 
+// Activity regulariser on the last-layer class: the ParameterNet output IS the small tensor a [B, r] (model.py:583-585), so the
+// term c/B sum phi(a) is one pass over the points: dL/da += c/B phi'(a) in front of the r x r layer's gradient, dL/dlatent +=
+// (that) last_w^T in front of the ParameterNet adjoint, per-block loss partials.  phi = |.| (l1) or (.)^2.
+__global__ __launch_bounds__(256) void k_ll_actreg(const float* __restrict__ Za, const float* __restrict__ lw, int r, long B, float coef,
+                                                   int l1, float* __restrict__ DA, float* __restrict__ DZL,
+                                                   float* __restrict__ loss_partial) {
+  __shared__ float red[256];
+  const long pt = (long)blockIdx.x * 256 + threadIdx.x;
+  float ls = 0.f;
+  if (pt < B) {
+    const long base = (pt >> 5) * r * 32 + (pt & 31);
+    for (int c2 = 0; c2 < r; ++c2) {
+      float t = 0.f;
+      for (int cc = 0; cc < r; ++cc) {
+        const float a = Za[base + (long)cc * 32];
+        const float g = coef * (l1 ? (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) : 2.0f * a);
+        t = fmaf(g, lw[c2 * r + cc], t);
+        if (c2 == 0) { DA[base + (long)cc * 32] += g; ls += coef * (l1 ? fabsf(a) : a * a); }
+      }
+      DZL[base + (long)c2 * 32] += t;
+    }
+  }
+  red[threadIdx.x] = ls;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_partial[blockIdx.x] = red[0];
+}
+int launch_ll_actreg(const float* Za, const float* lw, int r, long B, float coef, bool l1, float* DA, float* DZL, float* loss_partial,
+                     hipStream_t st) {
+  const int nblk = (int)((B + 255) / 256);
+  hipLaunchKernelGGL(k_ll_actreg, dim3(nblk), dim3(256), 0, st, Za, lw, r, B, coef, l1 ? 1 : 0, DA, DZL, loss_partial);
+  return nblk;
+}
+// dst[0] += sum(parts[0..n)) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void k_add_sum(const float* __restrict__ parts, int n, float* __restrict__ dst) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += parts[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[0] += red[0];
+}
+void launch_add_sum(const float* parts, int n, float* dst, hipStream_t st) { hipLaunchKernelGGL(k_add_sum, dim3(1), dim3(256), 0, st, parts, n, dst); }
+
 // g[0..ncols) += tmp[0..ncols) ,  g[P] += tmp[ncols]   (a side pass's reduced columns and loss on top of the main gradient)
 __global__ void k_axpy_cols(float* __restrict__ g, const float* __restrict__ tmp, long ncols, long P) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1026,6 +1026,13 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     launch_ll_out(la, true, c->st);
     launch_pnet_bwd(ma, c->NB, c->st);
   }
+  int n_act = 0;
+  if (act_on(c)) {    // + c/Bg phi'(a) into dL/da and dL/dlatent, before their consumers; the loss term joins after the row reduction
+    const long nlp = (B + 255) / 256;
+    if (nlp > c->act_loss_cap) { HIPCHK(hipStreamSynchronize(c->st)); int rc = grow(&c->act_loss, &c->act_loss_cap, nlp); if (rc) return rc; }
+    const bool l1 = c->act_l2 == 0.f;
+    n_act = launch_ll_actreg(c->Z, c->theta + c->last_w, c->r, B, (l1 ? c->act_l1 : c->act_l2) / (float)Bg, l1, c->DA, c->DZL, c->act_loss, c->st);
+  }
   int rows = (int)((ntiles + 3) / 4);
   if (rows > c->rows_cap) rows = c->rows_cap;
   if (rows < 1) rows = 1;
@@ -1092,6 +1099,8 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
   }
+  if (n_act > 0) launch_add_sum(c->act_loss, n_act, c->grad + c->P, c->st);
+  if (c->jac_l1 != 0.f) { int rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
   if (nhead > 0) {
     // the heads' share of the r x r layer: dL/dlast_w += z'^T dL/da' (a' = z' last_w has no bias), the same reduction as the
     // main one with (z', dL/da') as the operand pair; then the (primal, tangent) ParameterNet for dL/dz' (jac_reg_pass, given mu)
@@ -1546,7 +1555,6 @@ extern "C" int nif_set_regularizer(nif_ctx* c, float l1, float l2, int64_t lo, i
 extern "C" int nif_set_jac_regularizer(nif_ctx* c, float l1) {
   if (!c || l1 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
   if (l1 != 0.f) {
-    if (c->kind == NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "jac_reg is built for NIF / NIFMultiScale");
     PNetArgs pa; fill_pnet(c, pa, nullptr, 32);
     if (!pjac_supported(pa)) return fail(NIF_ERR_INVALID, "jac_reg: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
   }
@@ -1657,9 +1665,7 @@ static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const Sob
 // Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)
 extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
   if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
-  if ((l1 != 0.f || l2 != 0.f) && c->kind == NIF_KIND_LASTLAYER)
-    return fail(NIF_ERR_INVALID, "activity regularisers are built for NIF / NIFMultiScale");
-  if ((l1 != 0.f || l2 != 0.f) && c->r > actreg_max_r()) return fail(NIF_ERR_INVALID, "activity regularisers: latent_dim <= 8");
+  if ((l1 != 0.f || l2 != 0.f) && c->kind != NIF_KIND_LASTLAYER && c->r > actreg_max_r()) return fail(NIF_ERR_INVALID, "activity regularisers: latent_dim <= 8");
   c->act_l1 = l2 != 0.f ? 0.f : l1; c->act_l2 = l2;
   return NIF_OK;
 }

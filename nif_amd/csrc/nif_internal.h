@@ -234,6 +234,10 @@ void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st)
 int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st);      // dz/dp_d of every parameter column -> ZT [pi][tiles][r][32]
 int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st);
 void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st);
+// activity regulariser of the last-layer class (the ParameterNet output is the materialised [B, r] tensor there)
+int launch_ll_actreg(const float* Za, const float* lw, int r, long B, float coef, bool l1, float* DA, float* DZL, float* loss_partial,
+                     hipStream_t st);
+void launch_add_sum(const float* parts, int n, float* dst, hipStream_t st);
 // activity regulariser of the (virtual) pnet_output (k_misc.hip)
 int actreg_max_r();
 void launch_actreg_points(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, float coef,

@@ -425,9 +425,6 @@ class NIF(object):
         self.p_l2_reg = cfg_parameter_net.get("l2_reg", None)
         self.p_act_l1_reg = cfg_parameter_net.get("act_l1_reg", None)
         self.p_act_l2_reg = cfg_parameter_net.get("act_l2_reg", None)
-        if self._KIND == "NIFMultiScaleLastLayerParameterized" and any(
-                isinstance(v, (float, int)) and v for v in (self.p_jac_reg, self.p_act_l1_reg, self.p_act_l2_reg)):
-            raise NotImplementedError("jac_reg / act_l1_reg / act_l2_reg are built for NIF / NIFMultiScale")
         # activity regulariser of the ParameterNet output: L2 wins over L1 (model.py:118-125)
         self._act_reg = (0.0, 0.0)
         if isinstance(self.p_act_l2_reg, (float, int)):

@@ -783,6 +783,14 @@ def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, ac
     g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
     if spec.kind == KIND_LL:
         g_pout = np.einsum("bsj,bs->bj", phi, g_u)
+        if act_reg is not None and (act_reg[0] or act_reg[1]):     # the ParameterNet output of this class is a [B, r]
+            l1, l2 = act_reg
+            if l2:
+                loss = loss + l2 * (pout ** 2).sum() / Bg
+                g_pout = g_pout + 2.0 * l2 * pout / Bg
+            else:
+                loss = loss + l1 * np.abs(pout).sum() / Bg
+                g_pout = g_pout + l1 * np.sign(pout) / Bg
         g_phi = g_u[:, :, None] * pout[:, None, :]
         g_snet = _snet_backward(spec, ws, stape, g_phi)
         g_bias = g_u.sum(0)

@@ -994,7 +994,8 @@ def test_tutorial4_shape_contract_of_the_reference():
 
 
 # ---- activity regularisers of the ParameterNet output (N3; reference model.py:118-125, :226, :659, :731) -----------------------
-@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_32x2_r7_si3"])
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_32x2_r7_si3", "ll_plain_32x2_r3",
+                                  "ll_cfg4_128x2_r10_so3", "ll_res_48x2_r4"])
 @pytest.mark.parametrize("which", ["act_l2_reg", "act_l1_reg"])
 def test_activity_regularisers_match_oracle(name, which):
     """loss += c/B sum phi(pnet_output) on the never materialised [B, po] tensor (two recompute passes, k_actreg_*) against
@@ -1042,6 +1043,8 @@ JAC = {
     "ms_siren_res_pnet_r3": _cfg("NIFMultiScale", 32, 1, 40, 2, 3, 2, 1, 2, p_res=True),
     "ms_mlp_res_pnet": _cfg("NIFMultiScale", 32, 1, 24, 1, 2, 1, 2, 3, p_act="tanh", p_res=True),
     "ms_mlp_short_pnet_64": _cfg("NIFMultiScale", 32, 2, 64, 3, 2, 2, 1, 1, p_act="swish"),
+    "ll_siren_pnet_r3": _cfg("LL", 32, 2, 32, 2, 3, 2, 2, 2),
+    "ll_mlp_res_pnet_48": _cfg("LL", 48, 1, 24, 1, 4, 1, 1, 1, s_res=True, p_act="tanh", p_res=True),
 }
 
 

@@ -262,3 +262,28 @@ def test_jac_reg_matches_torch_double_backward(name):
             assert np.abs(g - t).max() <= 1e-9 * max(np.abs(t).max(), 1e-30), nm
     l2, g2 = O.jac_reg_loss_and_grad(spec, ws, p, 0.7, batch_global=18)
     assert abs(l2 - loss / 3) < 1e-15 * max(1.0, loss)
+
+
+@pytest.mark.parametrize("name", ["nif_swish", "ms_plain_r3_si2", "ms_res", "ll_plain", "ll_res"])
+@pytest.mark.parametrize("which", ["l1", "l2"])
+def test_activity_regulariser_matches_torch_autograd(name, which):
+    """Keras activity_regularizer on the last ParameterNet layer (model.py:118-125, :226): loss += c * sum(phi(pnet_output)) /
+    batch, phi = |.| or (.)^2 -- the oracle's term and its gradient against torch autograd of the independent restatement"""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=6)
+    act = (0.03, 0.0) if which == "l1" else (0.0, 0.02)
+    loss, grads = O.loss_and_grad(spec, ws, inputs, y, sw, act_reg=act)
+    wt = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
+    xin = torch.tensor(inputs, dtype=torch.float64)
+    u = T.forward(kind, cs, cp, wt, xin)
+    per = ((u - torch.tensor(y)) ** 2).mean(dim=1) * torch.tensor(sw)
+    z = T.latent(kind, cs, cp, wt, xin[:, :spec.pi])
+    npn = len([nm for nm, _ in spec.param_shapes() if nm.startswith("pnet_")])
+    pout = z @ wt[npn - 2] + wt[npn - 1]                       # the last ParameterNet layer (Dense / HyperLinearForSIREN)
+    reg = (act[0] * pout.abs().sum() + act[1] * (pout ** 2).sum()) / u.shape[0]
+    tl = per.sum() / u.shape[0] + reg
+    tg = torch.autograd.grad(tl, wt, allow_unused=True)
+    assert abs(loss - tl.item()) <= 1e-12 * max(1.0, abs(tl.item()))
+    for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
+        assert np.abs(g - t.numpy()).max() / max(np.abs(t.numpy()).max(), 1e-30) < 1e-9, nm
