@@ -26,7 +26,7 @@ def draw(rng):
     act = str(rng.choice(["swish", "tanh", "gelu"]))
     if kind == "LL" and so * r > 32:
         r = max(1, 32 // so)
-    B = int(rng.choice([1, 31, 33, 64, 97, 130, 257, 515]))
+    B = int(rng.choice([1, 31, 33, 64, 97, 130, 257, 515, 1031, 4099]))
     if kind == "NIF":
         cfg = _cfg("NIF", n, L, nst, lst, r, si, so, pi, act=act)
     else:
@@ -130,6 +130,26 @@ def run_case(cfg, B, seed):
             bad.append(("fit trajectory", h.history["loss"], ls))
     except nif_amd._lib.NifError as ex:
         bad.append(("fit refused", str(ex)[:80]))
+    # cfg_parameter_net regularisers: weight L2, activity L2 / L1, latent Jacobian -- one model with all of them
+    try:
+        l2w, lact, ljac = 3e-3, 2e-3, 0.04
+        which = "act_l2_reg" if (seed & 1) else "act_l1_reg"
+        cpr = dict(cp, l2_reg=l2w, jac_reg=ljac); cpr[which] = lact
+        mr = getattr(nif_amd, kind)(cs, cpr)
+        modelr = mr.build(); modelr.set_weights(ws)
+        lr_, gr_ = mr._engine.loss_and_grad(x, y, sw)
+        act = (0.0, lact) if which == "act_l2_reg" else (lact, 0.0)
+        l0, g0 = O.loss_and_grad(spec, ws64, x64, y64, sw64, act_reg=act)
+        lj, gj = O.jac_reg_loss_and_grad(spec, ws64, x64[:, :spec.pi], ljac)
+        ref_g = O.flatten(g0) + O.flatten(gj)
+        npn = sum(int(np.prod(s_)) for nm, s_ in spec.param_shapes() if nm.startswith("pnet_"))
+        th = O.flatten(ws64)
+        ref_l = l0 + lj + l2w * float((th[:npn] ** 2).sum())
+        ref_g[:npn] += 2.0 * l2w * th[:npn]
+        if abs(lr_ - ref_l) > 3e-5 * abs(ref_l) or _rel(gr_, ref_g) > 3e-4:
+            bad.append(("regularisers", lr_, ref_l, _rel(gr_, ref_g)))
+    except (nif_amd._lib.NifError, NotImplementedError) as ex:
+        bad.append(("regularisers refused", str(ex)[:80]))
     # the mixed_bfloat16 policy against the oracle with the same casts (hypernetwork classes)
     # (widths with an odd number of 16-blocks -- 1..16, 33..48 units -- have no bf16-split kernel: the policy then runs on the
     # f32-input MFMAs, i.e. MORE precisely than it asks for, and the emulating oracle is not the right yardstick)
