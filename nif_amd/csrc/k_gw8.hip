@@ -22,7 +22,11 @@ typedef __bf16 g8_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float g8_f32x16 __attribute__((ext_vector_type(16)));
 
 // byte offset of points [p0, p0+4) of feature f inside a [128][32] bf16 plane (64-byte rows, 16-byte columns swizzled)
-__device__ __forceinline__ int g8_off(int f, int p0) { return f * 64 + ((((p0 >> 3) ^ (f >> 1)) & 3) << 4) + ((p0 & 7) << 1); }
+// swizzle key (f >> 2) & 3: rows f and f + 4 start at the same bank (64-byte rows, 256 bytes of banks), a 16-lane phase of a
+// ds_read_b128 covers 16 consecutive rows = 4 rows per bank base, which the key sends to 4 different 16-byte columns (with the
+// (f >> 1) key of the first version rows f and f + 8 collided: 1.0e7 conflict cycles next to 7.0e6 LDS issue cycles per launch;
+// now 8e3 -- the kernel's time did not move, 1.12 -> 1.09 ms on cfg-3: it is not LDS-bound either)
+__device__ __forceinline__ int g8_off(int f, int p0) { return f * 64 + ((((p0 >> 3) ^ (f >> 2)) & 3) << 4) + ((p0 & 7) << 1); }
 
 template <int R>   // R = 1: planes k = 0 (x zt), 1; R = 0: one plane
 __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
@@ -103,12 +107,12 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
     const char* Bhi = S + 2 * NPL * PLANE, *Blo = Bhi + PLANE;                                                         \
     const int fa = 32 * ubi + i32;                                                                                     \
     _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                                 \
-      const int ca = ((((2 * hh + kg) ^ (fa >> 1)) & 3) << 4);                                                         \
+      const int ca = ((((2 * hh + kg) ^ (fa >> 2)) & 3) << 4);                                                         \
       const g8_bf16x8 ah = *reinterpret_cast<const g8_bf16x8*>(Ahi + fa * 64 + ca);                                    \
       const g8_bf16x8 al = *reinterpret_cast<const g8_bf16x8*>(Alo + fa * 64 + ca);                                    \
       _Pragma("unroll") for (int o = 0; o < NOB; ++o) {                                                                \
         const int fb = 32 * (ob0 + o) + i32;                                                                           \
-        const int cb = ((((2 * hh + kg) ^ (fb >> 1)) & 3) << 4);                                                       \
+        const int cb = ((((2 * hh + kg) ^ (fb >> 2)) & 3) << 4);                                                       \
         const g8_bf16x8 bh = *reinterpret_cast<const g8_bf16x8*>(Bhi + fb * 64 + cb);                                  \
         const g8_bf16x8 bl = *reinterpret_cast<const g8_bf16x8*>(Blo + fb * 64 + cb);                                  \
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[o], 0, 0, 0);                                     \
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
     }
   }
 }
+
 
 bool gw8_supported(const GwArgs& a, int NBI, int NBO) {
   return NBI == 4 && NBO == 4 && (a.r == 0 || a.r == 1);
