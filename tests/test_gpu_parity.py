@@ -623,6 +623,33 @@ def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
     assert mse_j < mse_j_plain, (mse_j, mse_j_plain)
 
 
+@pytest.mark.parametrize("name", ["ms_64x2_mlp_pnet_r3", "ll_plain_32x2_r3"])
+def test_sobolev_fit_with_a_time_derivative_follows_the_oracle(name):
+    """SobolevModel.fit with x_index = [t, x]: d/dt is a PARAMETER column (PDE-constrained training differentiates w.r.t. time),
+    d/dx a coordinate.  Three Adam steps through fit() against the oracle's Sobolev loss / gradient + Keras-Adam trajectory,
+    hypernetwork and last-layer class."""
+    import nif_amd
+    from nif_amd import JacobianLayer, SobolevModel
+    m, model, spec, ws, x, y, sw = _make(name)
+    xi = [0, spec.pi]
+    rng = np.random.default_rng(21)
+    g = rng.uniform(-1, 1, size=(x.shape[0], spec.so, 2)).astype(np.float32)
+    sm = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi))
+    sm.compile(nif_amd.Adam(1e-3), "mse", loss_weights=[1.0, 0.05])
+    h = sm.fit(x, [y, g], batch_size=x.shape[0], epochs=3, shuffle=False, verbose=0)
+    th = O.flatten(ws); mm = np.zeros_like(th); vv = np.zeros_like(th)
+    f32 = lambda a: float(np.float32(a))
+    ls = []
+    for t in range(1, 4):
+        l_, g_, _, _ = O.sobolev_loss_and_grad(spec, O.unflatten(spec, th), x.astype(np.float64), y.astype(np.float64),
+                                               g.astype(np.float64), xi, 0.05)
+        ls.append(l_)
+        th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+    assert np.allclose(h.history["loss"], ls, rtol=2e-3), (h.history["loss"], ls)
+    u, J = sm.predict(x)
+    assert J.shape == (x.shape[0], spec.so, 2)
+
+
 @pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ms_res_48x2_pres"])
 def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
     """Two epochs of fit() (partial last batch) against the oracle's loss/grad + Keras-Adam trajectory for the
