@@ -785,6 +785,13 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
     hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, false, false, true>), grid, block, shm, st, a);            \
   }
+#define S4LP(NBL_, TR_, MODE_, SGN_)   /* last-layer class under the policy: the shared n x n products as ONE bf16 product */ \
+  {                                                                                                                 \
+    if (shm > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_SINE, MODE_, SGN_, true, false, true>,               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_SINE, MODE_, SGN_, true, false, true>), grid, block, shm, st, a);         \
+  }
 #define S4LE(NBL_)                                                                                                  \
   {                                                                                                                 \
     if (shm > 48 * 1024)                                                                                            \
@@ -793,7 +800,11 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
     hipLaunchKernelGGL((k_snet4<NBL_, true, ACT_SINE, 0, true, false, true>), grid, block, shm, st, a);             \
   }
 #define S4(NBL_)                                                            \
-  if (a.ll) {                                                               \
+  if (a.ll && a.prec == 1) {                                                \
+    if (a.res) { if (train) S4LP(NBL_, true, 1, false) else S4LP(NBL_, false, 1, false) } \
+    else if (train) { if (snet4_sign_ring(a)) S4LP(NBL_, true, 0, true) else S4LP(NBL_, true, 0, false) } \
+    else S4LP(NBL_, false, 0, false)                                        \
+  } else if (a.ll) {                                                        \
     if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, true) else S4L(NBL_, false, ACT_SINE, 1, false, true) } \
     else if (train) { if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, true) else S4L(NBL_, true, ACT_SINE, 0, false, true) } \
     else S4L(NBL_, false, ACT_SINE, 0, false, true)                         \
@@ -820,6 +831,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   }
 #undef S4
 #undef S4LE
+#undef S4LP
 #undef S4P
 #undef S4L
   return nblk;

@@ -99,8 +99,6 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     return fail(NIF_ERR_INVALID, "unknown model kind");
   if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->mixed_policy != NIF_POLICY_MIXED_BF16)
     return fail(NIF_ERR_INVALID, "unknown mixed_policy");
-  if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->kind == NIF_KIND_LASTLAYER)
-    return fail(NIF_ERR_INVALID, "mixed_bfloat16 is built for NIF / NIFMultiScale");
   for (int i = 0; i < 7; ++i) if (cfg->reserved[i] != 0) return fail(NIF_ERR_INVALID, "reserved fields must be zero");
   if (cfg->kind == NIF_KIND_LASTLAYER && cfg->latent_dim * cfg->so_dim > 64)
     return fail(NIF_ERR_INVALID, "last-layer class: latent_dim * output_dim must be <= 64");
@@ -460,6 +458,7 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
   a.DU = c->DU; a.DZ = nullptr; a.dring = c->dring;
   a.ll = 1; a.rl = c->r; a.so_u = c->so; a.DPHI = c->DPHI; a.DA_ll = c->DA; a.DZL = c->DZL;
   a.WPF = c->ll_wpf; a.WPB = c->ll_wpb;
+  a.prec = (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 && !c->opt_fp32_mfma) ? 1 : 0;     // (k_snet4<LL> only; k_sob / k_jac stay exact)
   a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
   a.tl = c->tl;
 }

@@ -21,8 +21,6 @@ class Spec(object):
         if mixed_policy not in _lib.POLICY_IDS:
             raise NotImplementedError("mixed_policy %r: 'float32' and 'mixed_bfloat16' are built (float16 needs loss scaling, "
                                       "which the reference does not set up either)" % (mixed_policy,))
-        if mixed_policy != "float32" and kind == "NIFMultiScaleLastLayerParameterized":
-            raise NotImplementedError("mixed_bfloat16 is built for NIF / NIFMultiScale")
         self.kind = kind
         self.cfg_shape_net = cfg_shape_net
         self.cfg_parameter_net = cfg_parameter_net

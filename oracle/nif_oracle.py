@@ -657,23 +657,25 @@ def _snet_split(spec, rest):
     return first, hidden, bott, bias
 
 
-def snet_phi(spec, ws, x, keep=False):
-    """x [B,si] -> phi [B,so,r] (model.py:1219-1238; layers siren.py:256-281,:381-410)."""
+def snet_phi(spec, ws, x, keep=False, rnd=None):
+    """x [B,si] -> phi [B,so,r] (model.py:1219-1238; layers siren.py:256-281,:381-410).
+    rnd = bf16_round: the build's mixed_bfloat16 policy (both operands of the hidden n x n products rounded to bf16)."""
     *_, rest = _pnet_split(spec, ws)
     first, hidden, bott, _ = _snet_split(spec, rest)
+    R = (lambda a_: a_) if rnd is None else rnd
     om = spec.omega_s
     a = om * (x @ first[0]) + first[1]
     h = np.sin(a)
     tape = [("first", x, a)]
     for lay in hidden:
         if spec.s_res:
-            a1 = om * (h @ lay[0]) + lay[1]
+            a1 = om * (R(h) @ R(lay[0])) + lay[1]
             t = np.sin(a1)
-            a2 = om * (t @ lay[2]) + lay[3]
+            a2 = om * (R(t) @ R(lay[2])) + lay[3]
             tape.append(("sres", h, a1, t, a2))
             h = 0.5 * (h + np.sin(a2))
         else:
-            a1 = om * (h @ lay[0]) + lay[1]
+            a1 = om * (R(h) @ R(lay[0])) + lay[1]
             tape.append(("siren", h, a1))
             h = np.sin(a1)
     phi = (h @ bott[0] + bott[1]).reshape(x.shape[0], spec.so, spec.r)
@@ -682,9 +684,10 @@ def snet_phi(spec, ws, x, keep=False):
     return phi
 
 
-def _snet_backward(spec, ws, tape_h, g_phi):
+def _snet_backward(spec, ws, tape_h, g_phi, rnd=None):
     *_, rest = _pnet_split(spec, ws)
     first, hidden, bott, _ = _snet_split(spec, rest)
+    R = (lambda a_: a_) if rnd is None else rnd      # policy: dL/da and the weights rounded in the data adjoint; weight gradients fp32
     tape, hL = tape_h
     om = spec.omega_s
     g = g_phi.reshape(g_phi.shape[0], -1)
@@ -696,16 +699,16 @@ def _snet_backward(spec, ws, tape_h, g_phi):
             _, hin, a1, t, a2 = rec
             ga2 = 0.5 * gh * np.cos(a2)
             gw2 = om * (t.T @ ga2); gb2 = ga2.sum(0)
-            gt = om * (ga2 @ lay[2].T)
+            gt = om * (R(ga2) @ R(lay[2]).T)
             ga1 = gt * np.cos(a1)
             gw1 = om * (hin.T @ ga1); gb1 = ga1.sum(0)
-            gh = 0.5 * gh + om * (ga1 @ lay[0].T)
+            gh = 0.5 * gh + om * (R(ga1) @ R(lay[0]).T)
             g_hidden.append([gw1, gb1, gw2, gb2])
         else:
             _, hin, a1 = rec
             ga1 = gh * np.cos(a1)
             g_hidden.append([om * (hin.T @ ga1), ga1.sum(0)])
-            gh = om * (ga1 @ lay[0].T)
+            gh = om * (R(ga1) @ R(lay[0]).T)
     _, x, a = tape[0]
     ga = gh * np.cos(a)
     grads = [om * (x.T @ ga), ga.sum(0)]
@@ -758,6 +761,26 @@ def mse_loss(u, y, sample_weight=None):
     if sample_weight is not None:
         per = per * sample_weight
     return per.sum() / u.shape[0]
+
+
+def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None):
+    """last-layer class under the build's mixed_bfloat16 policy (rnd=bf16_round): -> (loss, grads, u), the counterpart of
+    planes_loss_and_grad for the shared dense ShapeNet (hidden n x n products on rounded operands, everything else fp32)"""
+    assert spec.kind == KIND_LL
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + spec.si]
+    pout, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    phi, stape = snet_phi(spec, ws, x, keep=True, rnd=rnd)
+    u = np.einsum("bsj,bj->bs", phi, pout) + ws[-1]
+    e = u - y
+    w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
+    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
+    g_pout = np.einsum("bsj,bs->bj", phi, g_u)
+    g_snet = _snet_backward(spec, ws, stape, g_u[:, :, None] * pout[:, None, :], rnd=rnd)
+    return loss, pnet_backward(spec, ws, ptape, g_pout) + g_snet + [g_u.sum(0)], u
 
 
 def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, act_reg=None):

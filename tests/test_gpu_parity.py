@@ -931,6 +931,32 @@ def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
     assert _rel(model32.predict(x), O.forward(spec, ws, x64)) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5"])
+def test_mixed_bfloat16_policy_on_the_last_layer_class(name):
+    """the policy on NIFMultiScaleLastLayerParameterized: operands of the SHARED hidden n x n products rounded to bf16 (one product,
+    fp32 accumulation), the phi layer / Dot / loss / weight-gradient sums fp32 -- against the oracle with the same casts
+    (ll_policy_loss_and_grad(rnd=bf16_round)); the float32 model of the same class is untouched"""
+    m, model, spec, ws, x, y, sw = _make_policy(name, "mixed_bfloat16")
+    names = [nm for nm, _ in spec.param_shapes()]
+    ws[names.index("pnet_last_w")] = ws[names.index("pnet_last_w")] * 30.0       # weight_init_factor 0.01 makes the r x r map ~0
+    model.set_weights([w.astype(np.float32) for w in ws])
+    ws = [w.astype(np.float32).astype(np.float64) for w in ws]
+    assert m.compute_Dtype == "bfloat16"
+    x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+    rl, rg, ru = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round)
+    u = model.predict(x)
+    assert _rel(u, ru) < 5e-4, _rel(u, ru)
+    loss, g = m._engine.loss_and_grad(x, y, sw)
+    assert abs(loss - rl) <= 5e-4 * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, g, O.flatten(rg))
+    assert max(rel.values()) < 3e-3, rel
+    d_u = _rel(u, O.forward(spec, ws, x64))
+    assert 1e-6 < d_u < 5e-2, d_u                     # the policy IS a different computation
+    m32, model32, *_ = _make_policy(name, "float32")
+    model32.set_weights([w.astype(np.float32) for w in ws])
+    assert _rel(model32.predict(x), O.forward(spec, ws, x64)) < 1e-5
+
+
 def test_mixed_bfloat16_training_and_sobolev_step():
     """fit() under the policy follows the emulating oracle's Adam trajectory; the Sobolev step (configs[4]) runs on the
     single-product planes and stays within the policy's distance of the exact oracle"""
@@ -960,8 +986,6 @@ def test_mixed_bfloat16_training_and_sobolev_step():
     assert abs(l32 - rl) < 2e-5 * abs(rl) and loss != l32          # the policy really changes the arithmetic
     with pytest.raises(NotImplementedError):
         nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
-    with pytest.raises(NotImplementedError):
-        nif_amd.NIFMultiScaleLastLayerParameterized(*CONFIGS["ll_plain_32x2_r3"][0][1:], mixed_policy="mixed_bfloat16")
 
 
 # ---- HessianLayer (N3; reference gradient.py:130-180) ------------------------------------------------------------------------

@@ -35,6 +35,8 @@ WORK = {
     "cfg5_sobolev_2d_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1, 2], "mixed_bfloat16"),
     "cfg2_wave_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 1, 1, 1), 1 << 20, None, "mixed_bfloat16"),
     "cfg4_linear_nif_3d_128x6": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
+    "cfg4_linear_nif_3d_128x6_bf16": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None,
+                                      "mixed_bfloat16"),
     "cfg1_nif_swish_2x32": ("NIF", ({"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"},
                                     {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}), 1 << 20, None),
 }
