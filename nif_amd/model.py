@@ -175,13 +175,17 @@ class Model(object):
         return 0
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
-            sample_weight=None, initial_epoch=0, **kwargs):
+            sample_weight=None, initial_epoch=0, validation_data=None, **kwargs):
         """Keras Model.fit semantics for in-memory arrays (or one file of a shard dataset, nif_amd.data): per epoch
         optionally shuffle, walk batches of `batch_size` (default 32, last one partial), one Adam step per batch; the
         epoch 'loss' is the sample-weighted mean of the batch losses.  The table is made resident in HBM once; a
         shuffled epoch uploads only its permutation and gathers on the device; batches are device-pointer slices.  Under `nif_amd.distributed` every rank walks its own
         shard and the flat gradient is SUM-all-reduced (RCCL) before the identical Adam update
-        (tf.distribute.MirroredStrategy, README.md:39-49)."""
+        (tf.distribute.MirroredStrategy, README.md:39-49).
+        validation_data = (x_val, y_val[, sample_weight_val]): Keras' per-epoch evaluation, logged as 'val_loss' (seen by the
+        callbacks and History; evaluated through predict on this rank's device)."""
+        if validation_data is not None and not (isinstance(validation_data, (tuple, list)) and len(validation_data) in (2, 3)):
+            raise ValueError("validation_data = (x_val, y_val) or (x_val, y_val, sample_weight_val)")
         if self.optimizer is None:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
         if kwargs:
@@ -283,6 +287,9 @@ class Model(object):
                     e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
                 tot, cnt = e.metric_read(reset=True)   # accumulated on the device: one host sync per epoch
                 logs = {"loss": tot / max(cnt, 1.0)}
+                if validation_data is not None:
+                    logs["val_loss"] = self.evaluate(validation_data[0], validation_data[1],
+                                                     sample_weight=validation_data[2] if len(validation_data) == 3 else None)
                 for cb in callbacks:
                     if hasattr(cb, "on_epoch_end"):
                         cb.on_epoch_end(epoch, logs)

@@ -41,6 +41,10 @@ class OracleEngine(object):
         self.calls = []
         self._slot_free = [True, True]
 
+    def forward(self, inputs):
+        x = np.asarray(inputs, dtype=np.float64)
+        return O.forward(self.o, O.unflatten(self.o, self.theta), x[:, :self.o.pi + self.o.si]).astype(np.float32)
+
     # ---- what Model.fit uses ------------------------------------------------------------------------
     def alloc(self, n):
         return _HostArray(n)
