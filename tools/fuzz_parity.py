@@ -55,7 +55,7 @@ def run_case(cfg, B, seed):
     bad = []
     u = model.predict(x)
     e = _rel(u, O.forward(spec, ws64, x64))
-    if e > 1e-5:
+    if e > (1e-5 if B >= 8 else 4e-5):        # (a handful of points: the rel-L2 is one point's fp32 error through w0 = 30 layers)
         bad.append(("forward", e))
     loss, grad = m._engine.loss_and_grad(x, y, sw)
     rl, rg = O.loss_and_grad(spec, ws64, x64, y64, sw64)
@@ -102,7 +102,7 @@ def run_case(cfg, B, seed):
             if _rel(w, O.model_lr_to_w(spec, ws64, lr.astype(np.float64))) > 1e-6:
                 bad.append(("lr_to_w", _rel(w, O.model_lr_to_w(spec, ws64, lr.astype(np.float64)))))
             u3 = m.model_x_to_u_given_w().predict([xs, w])
-        if _rel(u3, O.forward(spec, ws64, x64)) > 2e-5:
+        if _rel(u3, O.forward(spec, ws64, x64)) > (2e-5 if B >= 8 else 8e-5):
             bad.append(("three-stage", _rel(u3, O.forward(spec, ws64, x64))))
     except nif_amd._lib.NifError as ex:
         bad.append(("three-stage refused", str(ex)[:80]))
@@ -154,7 +154,8 @@ def run_case(cfg, B, seed):
     # (widths with an odd number of 16-blocks -- 1..16, 33..48 units -- have no bf16-split kernel: the policy then runs on the
     # f32-input MFMAs, i.e. MORE precisely than it asks for, and the emulating oracle is not the right yardstick)
     ll = kind == "NIFMultiScaleLastLayerParameterized"
-    if ((spec.n + 15) // 16) % 2 == 0 and not (ll and spec.so * spec.r > 32):     # (LL: the k_snet4 path of the class)
+    no_tile_path = any("16-point-tile path" in str(b[1]) for b in bad if "refused" in b[0])   # the 32-point fallback kernel: fp32 only
+    if ((spec.n + 15) // 16) % 2 == 0 and not (ll and spec.so * spec.r > 32) and not no_tile_path:     # (LL: the k_snet4 path of the class)
         try:
             mb = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_bfloat16")
             modelb = mb.build(); modelb.set_weights(ws)
