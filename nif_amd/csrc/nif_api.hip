@@ -568,7 +568,9 @@ static int ensure_packed(nif_ctx* c) {
   c->use_snet3 = snet3_supported(probe);
   // NIF_FP32_MFMA=1 in the environment keeps every product on the f32-input MFMAs (k_snet3) for A/B runs
   const bool fp32_only = c->opt_fp32_mfma;
-  c->use_snet4 = c->use_snet3 && c->sWF4 && !fp32_only && snet4_supported(probe);
+  // (the bf16-split kernel streams its planes in chunks: it also takes the shapes whose whole fp32 planes do not fit the LDS --
+  // 128 units with latent_dim >= 3 and many matrices -- which k_snet3 / k_jac / k_sob at that width cannot)
+  c->use_snet4 = c->sWF4 && !fp32_only && snet4_supported(probe);
   c->packed32 = false;
   if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
@@ -1150,7 +1152,7 @@ static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nl
     }
     *nloss = nblk;
     sa.fused_gw = 1;
-  } else if (c->use_snet3) {
+  } else if (c->use_snet3 || c->use_snet4) {
     int waves = 4;
     static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
     if (c->use_snet4 && want_edge) {  // opt-in: first/last-layer weight gradients inside k_snet4 (no DA_0 / IN_nh / DU stashes)

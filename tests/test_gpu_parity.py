@@ -64,6 +64,8 @@ CONFIGS = {
     "ms_96x2_r2": (_cfg("NIFMultiScale", 96, 2, 32, 1, 2, 2, 1, 1), 77),
     "ms_res_80x1_so2": (_cfg("NIFMultiScale", 80, 1, 32, 1, 1, 2, 2, 1, s_res=True), 140),
     "nif_80x2_swish_r2": (_cfg("NIF", 80, 2, 32, 2, 2, 1, 1, 1, act="swish"), 100),
+    # whole fp32 planes + the (r+1) copies of the small vectors exceed the LDS: the bf16-split kernel (chunked planes) still takes it
+    "ms_res_128x4_r4_so2": (_cfg("NIFMultiScale", 128, 4, 32, 2, 4, 1, 2, 2, s_res=True), 97),
 }
 
 
