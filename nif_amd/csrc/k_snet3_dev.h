@@ -48,11 +48,17 @@ __device__ __forceinline__ void st_store16(float* __restrict__ slot, long row0, 
 #ifdef NIF_ABL_NOSTORE
   if (h[0][0] != 12345.678f) return;
 #endif
-  // row0 = (tile32 * FP) * 32 + 16*half + p   (floats); feature f lives at row0 + f*32
+  // row0 = (tile32 * FP) * 32 + 16*half + p   (floats); feature f lives at row0 + f*32.  One base address per PAIR of
+  // blocks: the 8 accesses of a pair then sit within the 12-bit immediate offset (r2: hipcc kept 8 extra 64-bit per-feature
+  // offsets in 16 VGPRs and spent a v_lshl_add_u64 per access on the second half of the tile)
 #pragma unroll
-  for (int b = 0; b < NBL; ++b)
+  for (int b = 0; b < NBL; b += 2) {
+    float* q = slot + (row0 + (long)(16 * b + 4 * g) * 32);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) slot[row0 + (long)(16 * b + 4 * g + v) * 32] = h[b][v];
+    for (int bb = 0; bb < 2 && b + bb < NBL; ++bb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) q[(16 * bb + v) * 32] = h[b + bb][v];
+  }
 }
 template <int NBL>
 __device__ __forceinline__ void st_load16(const float* __restrict__ slot, long row0, f32x4 (&h)[NBL], int g) {
@@ -64,9 +70,13 @@ __device__ __forceinline__ void st_load16(const float* __restrict__ slot, long r
   }
 #endif
 #pragma unroll
-  for (int b = 0; b < NBL; ++b)
+  for (int b = 0; b < NBL; b += 2) {
+    const float* q = slot + (row0 + (long)(16 * b + 4 * g) * 32);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) h[b][v] = slot[row0 + (long)(16 * b + 4 * g + v) * 32];
+    for (int bb = 0; bb < 2 && b + bb < NBL; ++bb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) h[b + bb][v] = q[(16 * bb + v) * 32];
+  }
 }
 
 // activation of a tile.  Padded features (>= n) need no masking: their weight rows/columns in the packed
@@ -82,24 +92,42 @@ __device__ __forceinline__ void act16_t(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], 
       h[b][v] = hv; d[b][v] = dv;
     }
 }
+// |a| >= 2^20 somewhere in the tile (never on a working SIREN; the wave-uniform test costs 8 v_max3 per tile): a ROLLED loop
+// over the elements of two blocks at a time (dynamic register indexing with a uniform index), so that the hot kernels carry
+// NBL / 2 copies of the fp64 argument reduction instead of 16 x NBL inlined copies per call site (r2: 900 fp64 instructions
+// and 32 spilled registers in k_snet4's benchmark instantiation)
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NBL>
-__device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
+__device__ __forceinline__ void sine16_slow(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
+#pragma unroll
+  for (int q = 0; q < NBL; q += 2) {
+    f32x8 va, vs, vc;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { va[t] = q + (t >> 2) < NBL ? a[(q + (t >> 2)) % NBL][t & 3] : 0.f; vs[t] = 0.f; vc[t] = 0.f; }
+#pragma nounroll
+    for (int i = 0; i < 8; ++i) {
+      float sv, cv;
+      nif_sincosf(va[i], &sv, &cv);
+      vs[i] = sv; vc[i] = cv;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (q + (t >> 2) < NBL) { h[(q + (t >> 2)) % NBL][t & 3] = vs[t]; d[(q + (t >> 2)) % NBL][t & 3] = vc[t]; }
+  }
+}
+template <int NBL>
+__device__ __forceinline__ bool sine16_big(const f32x4 (&a)[NBL]) {
   float mx = 0.f;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
     for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
-  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) {   // wave-uniform, once per tile
-#pragma unroll
-    for (int b = 0; b < NBL; ++b)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float hv, dv;
-        nif_sincosf_big(a[b][v], &hv, &dv);
-        h[b][v] = hv; d[b][v] = dv;
-      }
-    return;
-  }
+  return __builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0);   // wave-uniform, once per tile
+}
+template <int NBL>
+__device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
+  if (sine16_big<NBL>(a)) { sine16_slow<NBL>(a, h, d); return; }
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
@@ -112,12 +140,7 @@ __device__ __forceinline__ void sine16(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f
 // SIREN tile, training with the sign-bit cosine: h = sin(a) and d = a float carrying only the SIGN of cos(a)
 template <int NBL>
 __device__ __forceinline__ void sine16_sign(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], f32x4 (&d)[NBL]) {
-  float mx = 0.f;
-#pragma unroll
-  for (int b = 0; b < NBL; ++b)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(a[b][v]));
-  if (__builtin_expect(__any(!(mx < NIF_SINCOS_FAST_LIMIT)), 0)) { sine16<NBL>(a, h, d); return; }
+  if (sine16_big<NBL>(a)) { sine16_slow<NBL>(a, h, d); return; }
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
@@ -125,6 +148,58 @@ __device__ __forceinline__ void sine16_sign(const f32x4 (&a)[NBL], f32x4 (&h)[NB
       float hv, dv;
       nif_sin_cossign_core(a[b][v], &hv, &dv);
       h[b][v] = hv; d[b][v] = dv;
+    }
+}
+// SIREN tile, training, the cosine's sign TAGGED into the sine (k_snet4): h = sin(a) with the least significant mantissa bit
+// replaced by [cos(a) < 0].  cos(a) < 0  <=>  rint(a / pi) is odd, and the parity of rint(a / pi) is the mantissa LSB of
+// fma(a, 1/pi, 1.5 * 2^23) (|a| < 2^20 here): one packed fma per two elements and one v_bfi_b32 per element -- instead of
+// v_sub + 3 pack instructions + a 128-bit shift register (r2).  The activation moves by at most one ulp (6e-8): the tagged
+// value is what the next layer, the stash and the weight-gradient kernels see; near cos(a) = 0, where the parity can
+// disagree with the true sign, the cosine rebuilt from it is ~0 anyway.
+template <int NBL>
+__device__ __forceinline__ void sine16_tag(const f32x4 (&a)[NBL], f32x4 (&h)[NBL]) {
+  if (sine16_big<NBL>(a)) {
+    f32x4 s[NBL], c[NBL];
+    sine16_slow<NBL>(a, s, c);
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) h[b][v] = __uint_as_float((__float_as_uint(s[b][v]) & ~1u) | (__float_as_uint(c[b][v]) >> 31));
+    return;
+  }
+  // two elements per instruction (v_pk_fma_f32 / v_pk_add_f32); rint(x / 2pi) by the 1.5 * 2^23 trick (|x / 2pi| < 2^22 here)
+  const f32x2 C = {0.15915493667125702f, 0.15915493667125702f}, CL = {6.420638326565253e-09f, 6.420638326565253e-09f};
+  const f32x2 M = {12582912.0f, 12582912.0f}, IP = {0.318309886183790672f, 0.318309886183790672f};
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; v += 2) {
+      const f32x2 x = {a[b][v], a[b][v + 1]};
+      const f32x2 k = __builtin_elementwise_fma(x, C, M) - M;
+      f32x2 f = __builtin_elementwise_fma(x, C, -k);
+      f = __builtin_elementwise_fma(x, CL, f);
+      const f32x2 t = __builtin_elementwise_fma(x, IP, M);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sv = __builtin_amdgcn_sinf(f[e]);
+        unsigned o;
+        // (t & 1) | (sv & ~1).  The s_nop is the wait state a non-transcendental VALU read of a v_sin_f32 result needs on gfx950:
+        // hipcc inserts it for its own instructions but cannot see into the asm (without it: stale lanes, r3 first attempt)
+        asm("s_nop 0\n\tv_bfi_b32 %0, 1, %1, %2" : "=v"(o) : "v"(__float_as_uint(t[e])), "v"(__float_as_uint(sv)));
+        h[b][v + e] = __uint_as_float(o);
+      }
+    }
+}
+// cos(a) from the tagged sine: sqrt(1 - s^2) with the sign from the tag bit
+template <int NBL>
+__device__ __forceinline__ void tag_cos(const f32x4 (&sn)[NBL], f32x4 (&d)[NBL]) {
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float s = sn[b][v];
+      const float c = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(fmaf(-s, s, 1.0f), 0.0f, 1.0f));   // v_sqrt_f32 (1 ulp)
+      d[b][v] = __uint_as_float(__float_as_uint(c) | (__float_as_uint(s) << 31));
     }
 }
 template <int NBL, int ACT>
@@ -195,21 +270,23 @@ __device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL /
 // Two output blocks at a time: their 6-MFMA chains interleave (a dependent v_mfma_f32_16x16x32_bf16 cannot issue
 // back to back) and one LDS round trip feeds 12 MFMAs
 // PR (the mixed_bfloat16 policy of the build): operands rounded to bf16, ONE product a0*b0 instead of the exact split
-template <int NBL, bool PR = false>
+// ZI: the chains start from zero (the first MFMA of every chain takes the inline constant 0 as C: no v_mov zeroing)
+template <int NBL, bool PR = false, bool ZI = false>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ob = 0; ob < NBL; ob += 2) {
     if (PR) {
       const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
-      T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
-      T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ob + 1], 0, 0, 0);
+      T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ob], 0, 0, 0);
+      T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, ZI ? z4 : T[ob + 1], 0, 0, 0);
       continue;
     }
     const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], a1 = cur[(ob * 3 + 1) * 64 + lane], a2 = cur[(ob * 3 + 2) * 64 + lane];
     const bf16x8 c0 = cur[(ob * 3 + 3) * 64 + lane], c1 = cur[(ob * 3 + 4) * 64 + lane], c2 = cur[(ob * 3 + 5) * 64 + lane];
-    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, T[ob], 0, 0, 0);
-    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b1, T[ob + 1], 0, 0, 0);
+    T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ZI ? z4 : T[ob], 0, 0, 0);
+    T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b1, ZI ? z4 : T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, T[ob], 0, 0, 0);
     T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b2, T[ob + 1], 0, 0, 0);
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, T[ob], 0, 0, 0);
@@ -224,21 +301,22 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
-template <int NBL, bool PR = false>
+template <int NBL, bool PR = false, bool ZI = false>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
   __builtin_amdgcn_s_setprio(1);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ib = 0; ib < NBL; ib += 2) {
     if (PR) {
       const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
-      T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
-      T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
+      T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ib], 0, 0, 0);
+      T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, ZI ? z4 : T[ib + 1], 0, 0, 0);
       continue;
     }
     const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
     const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
-    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, T[ib], 0, 0, 0);
-    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, T[ib + 1], 0, 0, 0);
+    T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ZI ? z4 : T[ib], 0, 0, 0);
+    T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, ZI ? z4 : T[ib + 1], 0, 0, 0);
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ib], 0, 0, 0);
     T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, b0, T[ib + 1], 0, 0, 0);
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);

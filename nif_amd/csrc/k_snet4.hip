@@ -23,6 +23,9 @@
 #ifndef NIF_S4_OCC
 #define NIF_S4_OCC 3
 #endif
+#ifndef NIF_S4_NBUF
+#define NIF_S4_NBUF 2     // LDS chunk buffers of the <= 64-wide instantiations (the DMA runs NBUF - 1 chunk steps ahead)
+#endif
 #ifndef NIF_S4_OCC_WIDE
 #define NIF_S4_OCC_WIDE 2   // workgroups per CU of the 96- and 128-wide instantiations: 2 x 256 registers with ~200 spilled beat 1 x 512 (cfg-3: 3.45 -> 2.79 ms)
 #endif
@@ -33,8 +36,9 @@
 //   fwd chunk (plane, ks): unit ((ob*3 + s)*64 + lane), 8 bf16: split s of M[in = slot(ks,g,t)][out = 16ob + (lane&15)]
 //   bwd chunk (plane, ks): unit ((ib*2 + s)*64 + lane), 8 bf16: split s of M[in = 16ib + (lane&15)][out = slot(ks,g,t)]
 // blockIdx.y = matrix j of a batch of equally shaped matrices `mstride` slots apart (the hidden hyper-matrices)
+// scale: omega_0 of the SIREN layer, folded into the planes (r3) so that no consumer multiplies by it per element
 __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstride, int NBL, __bf16* __restrict__ WF,
-                          __bf16* __restrict__ WB, long fstride, long bstride) {
+                          __bf16* __restrict__ WB, long fstride, long bstride, float scale) {
   m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
   WF += (long)blockIdx.y * fstride; WB += (long)blockIdx.y * bstride;
   const int NCH = NBL / 2;
@@ -55,7 +59,7 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstrid
     const int slot = 16 * (2 * ks + (t >> 2)) + 4 * (lane >> 4) + (t & 3);
     const int row = 16 * blk + (lane & 15);
     const int in = fwd ? slot : row, out = fwd ? row : slot;
-    const float x = (in < m.nin && out < m.nout) ? theta[matref_index(m, k, in, out)] : 0.f;
+    const float x = (in < m.nin && out < m.nout) ? scale * theta[matref_index(m, k, in, out)] : 0.f;
     const __bf16 x0 = (__bf16)x;
     const float r1 = x - (float)x0;
     const __bf16 x1 = (__bf16)r1;
@@ -63,16 +67,16 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstrid
     (fwd ? WF : WB)[e] = s == 0 ? x0 : (s == 1 ? x1 : x2);
   }
 }
-void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st) {
-  launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, st);
+void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st) {
+  launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, scale, st);
 }
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
-                          long fstride_elems, long bstride_elems, hipStream_t st) {
+                          long fstride_elems, long bstride_elems, float scale, hipStream_t st) {
   const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m0.r + 1);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pack16b, dim3(grid, nmat), dim3(256), 0, st, theta, m0, mstride, NBL, (__bf16*)WF, (__bf16*)WB,
-                     fstride_elems, bstride_elems);
+                     fstride_elems, bstride_elems, scale);
 }
 
 // phi layer of the last-layer class: dense W[n][sop], sop <= 32 (two 16-output blocks)
@@ -111,74 +115,44 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
   hipLaunchKernelGGL(k_pack_phi, dim3(64), dim3(256), 0, st, theta, w_off, n, sop, snet3_nbl(n), (__bf16*)WPF, (__bf16*)WPB);
 }
 
-// sum over the 16 lanes of a DPP row (= the 16 points of a tile for one feature group); result in lane 15 of the row
-__device__ __forceinline__ float row_sum16(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-  return v;
-}
-// Edge-gradient accumulation  E[m][f] += sum_{p<16} W[m][p] * T[p][f]  for one 16-point tile:
-//   T   the wave's register tile (lane (p,g): features 16b+4g+v) -- transposed through 2 KB of private LDS, 32 features at
-//       a time, so that a lane (f&15, kk) reads 4 consecutive points of one feature: the B operand of v_mfma_f32_16x16x4_f32
-//       with the K order  step t <-> point 4*kk + t;
-//   W   at most 16 per-point weight rows m (built by the caller in the SAME K order): the A operand;
-//   E   rows m < nrows of the D tile (lanes with 4*(lane>>4)+v == m) added into the wave's LDS accumulators [m][NP].
-// ~45 instructions per 32 features instead of 8 DPP row reductions per value.
-template <int NBL>
-__device__ __forceinline__ void edge_accum(const f32x4 (&T)[NBL], const f32x4 wA /*A operand: rows m, k-steps t=0..3*/, int nrows,
-                                           float* __restrict__ eacc_rows, float* __restrict__ tT, int lane) {
-  const int p = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int half = 0; half < NBL; half += 2) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) tT[(16 * b + 4 * g + v) * 16 + p] = T[half + b][v];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(tT + (16 * b + p) * 16 + 4 * g);   // feature 16b + (lane&15), points 4g..4g+3
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[t], bq[t], d, 0, 0, 0);
-      // d[v] = E[m = 4g + v][f = 16(half+b) + p]
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (4 * g + v < nrows) eacc_rows[(4 * g + v) * (16 * NBL) + 16 * (half + b) + p] += d[v];
-    }
-  }
-}
 #define ZERO4_(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
 // MODE: 0 = plain (NIFMultiScale without resblock), 1 = SIREN resblock, 2 = NIF skip connection
-// SGN (plain SIREN only): no act'(a) ring.  The next layer's stashed input IS sin(a), so cos(a) = +-sqrt(1 - sin^2):
-// only the SIGN of cos(a) is kept -- 4*NBL bits per layer in a 128-bit shift register (4 VGPRs), pushed forward,
-// popped in the adjoint.  Removes 2 x 4n bytes/point/layer of write + re-read traffic.  |error| of the rebuilt
-// cosine <= 2.4e-4 in the measure-zero neighbourhood of cos = 0, ~1e-7 typically: gradient-path only.
+// SGN (plain SIREN only): no act'(a) ring.  The next layer's stashed input IS sin(a), so cos(a) = +-sqrt(1 - sin^2): only the
+// SIGN of cos(a) is kept -- as the least significant mantissa bit of the stashed sine itself (sine16_tag / tag_cos in
+// k_snet3_dev.h; r3 -- r2 kept a 128-bit shift register per lane, which cost 3 pack instructions per element and limited the
+// form to (nh + 1) * 4 * NBL <= 128 bits).  |error| of the rebuilt cosine <= 2.4e-4 in the measure-zero neighbourhood of
+// cos = 0, ~1e-7 typically: gradient-path only; the forward activations move by at most one ulp.
 // LL: last-layer-parameterised class (model.py:1044-1068, :1219-1269): the ShapeNet is a shared-weight dense SIREN
 // (r = 0, one plane per layer) whose last layer emits phi [so_u x rl]; u = Dot(phi, a) + bias with the ParameterNet
 // output a; the adjoint starts from dphi = du (x) a and also yields dL/da (and dL/dlatent through the rl x rl map).
-// EDGE: the first-/last-layer weight gradients are accumulated in the kernel (edge_accum) instead of being stashed for
-// k_gw_first / k_gw_out.  Measured on cfg-2: -0.15 ms in the gradient kernels, +0.07 ms here (72 spilled registers at
-// the 168-register budget): no net gain yet, so it is opt-in (NIF_FUSE_EDGE=1) and a separate instantiation.
-template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool EDGE = false, bool PR = false>
+//
+// r3 (VALU diet): omega_0 is folded into the packed planes and into the LDS image of the first layer, the
+// per-plane biases start the MFMA accumulators (no bias FMAs, no zeroing: acc = b^(r) + sum_k zt_k (b^(k) + h (w0 M^(k)))),
+// zero-started chains take the inline constant as C, the chunk stream is a running pointer with a phase counter.
+template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool PR = false>
 __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
   constexpr int NCH = NBL / 2;                      // K-step chunks per plane
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr int QF = (CF + NT - 1) / NT;
+  // LDS ring of the chunk stream: NBUF buffers, the DMA runs DIST = NBUF - 1 chunk steps ahead of the MFMAs.  r2 had two buffers
+  // and drained vmcnt(0) in front of every barrier: the L2 -> LDS latency of a chunk (~1.5-2 k cycles) had to hide behind ONE
+  // chunk's 24 MFMAs (384 cycles) -- the s_memtime timeline showed ~1.3 k ticks per chunk step, i.e. the kernel was bound by
+  // that latency, not by VALU issue (r3: the VALU diet alone moved it 1.10 -> 1.03 ms).  Three buffers for the <= 64-wide nets
+  // (36 KB), two for the 96/128-wide ones (their chunks carry 4x the MFMAs and 2 x 24 KB is what fits twice per CU)
+  constexpr int NBUF = NBL <= 4 ? NIF_S4_NBUF : 2, DIST = NBUF - 1;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
+  const int n = A.n, r = LL ? 0 : A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
   const int FP = stash_fp(n);                             // feature rows per stash tile (nif_internal.h)
   const long nt16 = 2 * ((A.B + 31) / 32);
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 
-  bf16x8* chunks = reinterpret_cast<bf16x8*>(smem);            // 2 x CF units
-  float* sm = smem + 2 * CF * 4;
+  bf16x8* chunks = reinterpret_cast<bf16x8*>(smem);            // NBUF x CF units
+  float* sm = smem + NBUF * CF * 4;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   const int rl = LL ? A.rl : 0, sou = LL ? A.so_u : so;
   // per-wave input rows [column][16 points] of the tile: coordinates, latent (ParameterNet output), targets, sample
@@ -187,55 +161,81 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   const int nz = LL ? rl : r;
   const int CX = (si + 3) & ~3, CZ = (nz + 3) & ~3, CY = (sou + 3) & ~3;
   const int NI = (CX + CZ + CY + 4) * 16;
-  constexpr bool edge = EDGE && TRAIN && !LL;            // first/last-layer weight gradients accumulated here
-  const int NE = edge ? A.edge_ne : 0;
-  const int pw = 2 * r * 64 + (LL ? (rl + so + sou) * 16 : 0) + 2 * NI + NE + (edge ? 512 + so * 16 : 0);   // per-wave LDS floats
+  const int pw = 2 * r * 64 + (LL ? (rl + so + sou) * 16 : 0) + 2 * NI;   // per-wave LDS floats
   float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
   float* phis = sks + r * 64;       // LL: phi / dphi [so][16], dL/da [rl][16], du [sou][16]
   float* das = phis + (LL ? so * 16 : 0);
   float* dul = das + rl * 16;
   float* inp = dul + (LL ? sou * 16 : 0);
-  float* eacc = inp + 2 * NI;        // edge-gradient accumulators of this wave (whole kernel)
-  float* tT = eacc + NE;             // 32 x 16 transposition scratch
-  float* dus = tT + 512;             // dL/du of the tile [so][16]
-  if (edge)
-    for (int e = lane; e < NE; e += 64) eacc[e] = 0.f;
-  const int e_l = (r + 1) * (si + 1) * (16 * NBL);          // start of the last-layer part
-  const int e_b = e_l + (r + 1) * so * (16 * NBL);          // start of the last-layer bias part
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((rl * rl + 3) & ~3))) : 0;   // LL extras sit at the end of sm
   const int o_lw = o_llb + ((sou + 3) & ~3);
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
-  const int NPL = nh * (r + 1);
-  const int nfwd = NPL * NCH;
+  // ---- the chunk stream: a running source pointer and a phase counter --------------------------------------------------
+  //   phase 0: the forward planes (nh (r+1) NCH chunks of CF units, contiguous in WF);  1: the phi layer's forward chunks (LL);
+  //   2: its adjoint chunk (LL, TRAIN);  3 + q: the adjoint planes of hidden matrix nh-1-q ((r+1) NCH chunks of CB units).
+  // cs_next() issues the DMA of the next chunk of the stream into LDS buffer `buf` and steps the state; behind the last
+  // phase the stream wraps to the next tile group's phase 0, or ends (cs_left < 0) when this workgroup has no further group.
   constexpr int PHF = 2 * 3 * 64;                       // units of a phi-layer forward chunk (LL)
-  const int nphi = LL ? NCH + (TRAIN ? 1 : 0) : 0;      // LL: phi forward chunks, then its adjoint chunk, sit between the sweeps
-  const int nchunks = (TRAIN ? 2 * nfwd : nfwd) + nphi;
-  const bf16x8* WF = reinterpret_cast<const bf16x8*>(A.WF4);
-  const bf16x8* WB = reinterpret_cast<const bf16x8*>(A.WB4);
-  auto chunk_units = [&](int i) -> int { return i < nfwd ? CF : ((LL && i < nfwd + NCH) ? PHF : CB); };
-  auto chunk_src = [&](int i) -> const bf16x8* {
-    if (i < nfwd) return WF + (long)i * CF;
-    if (LL && i < nfwd + NCH) return reinterpret_cast<const bf16x8*>(A.WPF) + (long)(i - nfwd) * PHF;
-    if (LL && i == nfwd + NCH) return reinterpret_cast<const bf16x8*>(A.WPB);
-    const int ii = i - nfwd - nphi;
-    const int pp = ii / NCH, ks = ii - pp * NCH;
-    const int j = nh - 1 - pp / (r + 1), k = pp % (r + 1);
-    return WB + (((long)j * (r + 1) + k) * NCH + ks) * CB;
+  const int NPC = (r + 1) * NCH;                        // chunks of one hidden matrix
+  const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
+  int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
+  long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;      // tile groups of this workgroup behind the current one
+  auto cs_phase_step = [&]() {          // the current phase has been issued completely: find the next one that has chunks
+    for (;;) {
+      ++cs_phase;
+      if (cs_phase == 1) { if (LL) { cs_src = reinterpret_cast<const bf16x8*>(A.WPF); cs_units = PHF; cs_left = NCH; return; } }
+      else if (cs_phase == 2) { if (LL && TRAIN) { cs_src = reinterpret_cast<const bf16x8*>(A.WPB); cs_units = CB; cs_left = 1; return; } }
+      else if (TRAIN && cs_phase < 3 + nh) {
+        cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 3)) * NPC * CB; cs_units = CB; cs_left = NPC; return;
+      } else {
+        if (cs_groups <= 0) { cs_left = -1; return; }
+        --cs_groups; cs_phase = 0;
+        cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CF; cs_left = nh * NPC; return;
+      }
+    }
   };
-  auto dma = [&](int i, int buf) {
-    const bf16x8* src = chunk_src(i);
+  // vector-memory bookkeeping for the chunk waits (vmcnt decrements in issue order): vm_y1 = instructions this wave has issued
+  // AFTER the DMA of the chunk the next wait is for, vm_y2 = after the newest DMA.  Stash stores / loads that are noted (vm_note)
+  // may then still be in flight when the wait returns -- in r2 every chunk barrier also waited for the 16 stash stores of the
+  // layer, i.e. for the HBM write path (the kernel without stash traffic: 0.71 ms, with: 1.04).  Un-noted instructions only make
+  // a wait stricter; a noted one must really be issued, and after the DMA it is counted against (the fence in cs_next)
+  int vm_y1 = 0, vm_y2 = 0;
+  auto vm_note = [&](int n) { vm_y1 += n; vm_y2 += n; };
+  auto cs_next = [&](int buf) -> int {        // returns the number of DMA instructions this WAVE issued
+    if (cs_left < 0) return 0;
     bf16x8* dst = chunks + buf * CF;
-    const int nun = chunk_units(i);
+    int nis = 0;
 #pragma unroll
     for (int q = 0; q < QF; ++q)
-      if (wid * 64 + NT * q < nun)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + NT * q),
+      if (wid * 64 + NT * q < cs_units) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + tid + NT * q),
                                          (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
+        ++nis;
+      }
+    asm volatile("" ::: "memory");      // nothing that is counted as younger than this DMA may be hoisted above it
+    cs_src += cs_units;
+    if (--cs_left == 0) cs_phase_step();
+    vm_y1 += nis; vm_y2 = 0;
+    return nis;
   };
+  // s_waitcnt vmcnt(n) alone (lgkmcnt / expcnt untouched; gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4] = 7,
+  // lgkmcnt [11:8] = 15).  The immediate must be a constant: the allowance is rounded DOWN (which only waits for more) to
+  // {0, 1, 2} stash tiles' worth of instructions plus 0..3 DMA instructions -- the values that occur in the steady state
+#define NIF_VMW(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+#define NIF_VMW4(B_, R_) { if ((R_) >= 3) NIF_VMW((B_) + 3); else if ((R_) == 2) NIF_VMW((B_) + 2); else if ((R_) == 1) NIF_VMW((B_) + 1); else NIF_VMW(B_); }
+  auto wait_vm = [&](int n) {
+    constexpr int S = 4 * NBL;
+    if (DIST == 1) { NIF_VMW(0); return; }
+    if (n >= 2 * S) NIF_VMW4(2 * S, n - 2 * S)
+    else if (n >= S) NIF_VMW4(S, n - S)
+    else NIF_VMW4(0, n)
+  };
+#undef NIF_VMW4
+#undef NIF_VMW
   auto prefetch_inputs = [&](long tgn, int set) {
     long t16n = tgn * WAVES + wid;
     if (t16n >= nt16) t16n = nt16 - 1;
@@ -269,10 +269,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     const long s_wl = (long)si * n + (long)nh * n * n;
     const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
     prefetch_inputs(blockIdx.x, 0);
+    // LDS image of the small hyper-vectors, per plane k: first-layer rows (times omega_0), last-layer columns, biases
     for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
       const int k = idx / nsm, e = idx - k * nsm;
       float v = 0.f;
-      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = hyp3(A, k, (long)dd * n + f); }
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
       else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
       else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
@@ -281,10 +282,13 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
       else if (LL && e >= o_lw && e < o_lw + rl * rl) v = hyp3(A, k, s_bl + so + sou + (e - o_lw));
       sm[idx] = v;
     }
-    if (nchunks > 0) dma(0, 0);
+    if (cs_left <= 0) cs_left = -1;
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) cs_next(d);       // the first DIST chunks
   }
   __syncthreads();
-  int gpar = 0;
+  vm_y1 = 0; vm_y2 = 0;                              // (the fence in front of the barrier drained vmcnt(0))
+  int cbuf = 0, nbuf = DIST;                         // ring positions of the chunk being multiplied / the chunk being fetched
   int tlc = 0; (void)tlc;
 #ifdef NIF_TIMELINE
 #define NIF_TL(id) do { if (A.tl && blockIdx.x == 0 && tid == 0 && tlc < 250) { A.tl[2 * tlc] = (id); A.tl[2 * tlc + 1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
@@ -293,27 +297,32 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 #endif
   float loss_lane = 0.f;
   float* dring = (TRAIN && !SGN) ? A.dring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (NBL * 256) : nullptr;
-  constexpr int SW = 4 * NBL;   // sign bits per layer
   float* IN0 = A.stash;
   float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
 
-// one chunk step: start the DMA of the next chunk into the other buffer, compute on the current one, barrier
-// (hipcc drains the DMA with s_waitcnt vmcnt(0) in front of the barrier).  Tried and not kept (cfg-2, 1.11 ms): whole
-// planes per step (half the barriers, 54 KB LDS, still 3 workgroups/CU): 1.40 ms; 12-wave workgroups (a third of
-// the L2->LDS plane traffic): 1.13 ms.  Ablations: no DMA -8 %, no barrier -3 %, no MFMA/LDS reads -13 %, no stash
-// stores -10 %, no activation -5 %: a latency chain with no dominant term (3 waves/SIMD at 168 VGPRs)
+// one chunk step: start the DMA of chunk c + DIST into the buffer that chunk c - 1 left, multiply chunk c, then wait until
+// chunk c + 1 has landed -- i.e. until at most the vm_y1 instructions issued after ITS DMA are outstanding -- and meet the
+// other three waves.  A raw s_barrier: __syncthreads() would make
+// hipcc drain vmcnt(0) in front of it; the LDS traffic that has to be ordered here are the DMA writes (vmcnt, waited above) and
+// the ds_reads of the chunk (their data is consumed by the MFMAs above); the empty asm statements keep the compiler from moving
+// LDS accesses across.  Tried and not kept in r1/r2 (cfg-2, 1.11 ms): whole planes per step (half the barriers): 1.40 ms;
+// 12-wave workgroups: 1.13 ms.
 #define NIF_CHUNK(...)                                                        \
   {                                                                           \
-    if ((cc + 1 < nchunks) || !last_group) dma(cc + 1 < nchunks ? cc + 1 : 0, (gpar + 1) & 1); \
-    const bf16x8* cur = chunks + (gpar & 1) * CF;                             \
+    cs_next(nbuf);                                                            \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
     __VA_ARGS__                                                               \
-    __syncthreads();                                                          \
-    ++gpar; ++cc;                                                             \
+    wait_vm(vm_y1);                                                           \
+    vm_y1 = vm_y2;                                                            \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    cbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1;                                   \
+    nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;                                   \
   }
 
   int iset = 0;
   for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
-    const bool last_group = tg + gridDim.x >= ngroups;
     const long t16_raw = tg * WAVES + wid;
     const bool active = t16_raw < nt16;
     const long t16 = active ? t16_raw : nt16 - 1;
@@ -327,75 +336,78 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     const float* ys = zs + CZ * 16 + p;                 // y_o = ys[o*16]
     const float* wsp = zs + (CZ + CY) * 16 + p;
     const float* zt_base = zs + p;
+#ifdef NIF_ABL_STASHMASK      // measurement builds: the stash traffic folded onto a cache-resident window (results are wrong)
+    const long row0 = (tile32 & NIF_ABL_STASHMASK) * (long)FP * 32 + poff;
+#else
     const long row0 = tile32 * (long)FP * 32 + poff;
+#endif
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
 
     NIF_TL(1);
     f32x4 h[NBL], acc[NBL];
-    unsigned long long sg_lo = 0ull, sg_hi = 0ull;
-    // ---- first layer ---------------------------------------------------------------------------
-    ZERO_T(acc)
-    for (int k = 0; k <= r; ++k) {
-      const float zt = k < r ? zt_base[k * 16] : 1.0f;
+    // ---- first layer: a = sum_k zt_k (x . (w0 W1^(k)) + b1^(k)) ---------------------------------------------------
+    {
+      const float* s0 = sm + r * nsm + 4 * g;           // the constant plane starts the sum
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] = s;
+      }
+    }
+    for (int k = 0; k < r; ++k) {
+      const float zt = zt_base[k * 16];
       const float* s0 = sm + k * nsm + 4 * g;
 #pragma unroll
       for (int b = 0; b < NBL; ++b) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
         for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-        acc[b] += zt * (A.omega * s + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b));
+        acc[b] += zt * s;
       }
     }
-    {
+    if (TRAIN && SGN) sine16_tag<NBL>(acc, h);          // h = sin(a), the cosine's sign in its last mantissa bit
+    else {
       f32x4 d[NBL];
-      if (TRAIN && SGN) sine16_sign<NBL>(acc, h, d);    // only the sign of cos(a) is kept: no v_cos_f32
-      else act16<NBL, ACT>(A.act, acc, h, d, n, g);
-      if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(d), SW);
-      if (TRAIN && !SGN) {
+      act16<NBL, ACT>(A.act, acc, h, d, n, g);
+      if (TRAIN) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) reinterpret_cast<f32x4*>(dring)[b * 64 + lane] = d[b];
       }
     }
     NIF_TL(2);
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);   // lands behind the hidden-layer barriers of THIS tile
-    // ---- hidden hyper-matrices -------------------------------------------------------------------
-    int cc = 0;
+    // ---- hidden hyper-matrices: a = b^(r) + h (w0 M^(r)) + sum_{k<r} zt_k (b^(k) + h (w0 M^(k))) -------------------
     f32x4 ublk[MODE == 1 ? NBL : 1];
     for (int j = 0; j < nh; ++j) {
-      if (TRAIN && active) st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g);
+      if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g); vm_note(4 * NBL); }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
       NIF_TL(10 + j);
-      ZERO_T(acc)
-      for (int k = 0; k <= r; ++k) {
-        if (k < r) {
-          f32x4 T[NBL];
-          ZERO_T(T)
+      {
+        const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
 #pragma unroll
-          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
-          const float zt = zt_base[k * 16];
-#pragma unroll
-          for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
-        }
+        for (int b = 0; b < NBL; ++b) acc[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
       }
-      NIF_TL(30 + j);
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) acc[b] *= A.omega;
-      for (int k = 0; k <= r; ++k) {
-        const float zt = k < r ? zt_base[k * 16] : 1.0f;
+      for (int k = 0; k < r; ++k) {
+        f32x4 T[NBL];
         const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) acc[b] += zt * *reinterpret_cast<const f32x4*>(sb + 16 * b);
+        for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+#pragma unroll
+        for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
+        const float zt = zt_base[k * 16];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      {
+#pragma unroll
+      for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+      NIF_TL(30 + j);
+      if (TRAIN && SGN) sine16_tag<NBL>(acc, acc);
+      else {
         f32x4 d[NBL];
-        if (TRAIN && SGN) sine16_sign<NBL>(acc, acc, d);
-        else act16<NBL, ACT>(A.act, acc, acc, d, n, g);
-        if (TRAIN && SGN) sgn_push(sg_lo, sg_hi, sgn_pack<NBL>(d), SW);
-        if (TRAIN && !SGN) {
+        act16<NBL, ACT>(A.act, acc, acc, d, n, g);
+        if (TRAIN) {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) reinterpret_cast<f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane] = d[b];
         }
@@ -418,14 +430,14 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     }
     NIF_TL(3);
     // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
-    if (TRAIN && active && !edge) st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g);
+    if (TRAIN && active) { st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g); vm_note(4 * NBL); }
     f32x4 gh[NBL];
     ZERO_T(gh)
     const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
     float se = 0.f;
     if (LL) {
-      // phi[o] = <h, Wl[:, o]> + bl[o] into the wave's LDS row, then per point u = Dot(phi, a) + bias
-      // phi = Wl^T h on the matrix cores (two 16-output blocks, the 6-product form), into the wave's LDS rows
+      // phi = Wl^T h + bl on the matrix cores (two 16-output blocks, the 6-product form), into the wave's LDS rows,
+      // then per point u = Dot(phi, a) + bias
       {
         bf16x8 b0[NCH], b1[NCH], b2[NCH];
         split3<NBL>(h, b0, b1, b2);
@@ -520,8 +532,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         const float e = uo - ys[o * 16];
         se = fmaf(e, e, se);
         const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
-        if (!edge && active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
-        if (edge && g == 0) dus[o * 16 + p] = du;     // dL/du of this tile, for the edge accumulation below
+        if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
         for (int k = 0; k < r; ++k) {
@@ -531,36 +542,20 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         }
       }
     }
-    if (edge) {
-      // dL/dWl^(k)[f][o] += sum_p zt_k du_o h[f] ,  dL/dbl^(k)[o] += sum_p zt_k du_o :  rows m = k*so + o
-      const int nrow = (r + 1) * so;
-      const int m = p, kk_ = g;                      // A operand: lane (row m, k-group): points 4kk..4kk+3
-      f32x4 wA = {0.f, 0.f, 0.f, 0.f};
-      if (m < nrow) {
-        const int k = m / so, o = m - k * so;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wA[t] = (k < r ? zs[k * 16 + 4 * kk_ + t] : 1.0f) * dus[o * 16 + 4 * kk_ + t];
-      }
-      edge_accum<NBL>(h, wA, nrow, eacc + e_l, tT, lane);
-      float sb_ = (wA[0] + wA[1]) + (wA[2] + wA[3]);
-      sb_ += __shfl_xor(sb_, 16);
-      sb_ += __shfl_xor(sb_, 32);
-      if (g == 0 && m < nrow) eacc[e_b + m] += sb_;
-    }
     if (TRAIN) {
       if (g == 0) loss_lane += wsamp * se / (float)sou * A.inv_bg;
       NIF_TL(4);
-      // ---- adjoint through the hidden hyper-matrices --------------------------------------------
+      // ---- adjoint through the hidden hyper-matrices: dL/dh_in = sum_k zt_k (w0 M^(k)) dL/da -------------------------
       f32x4 skip[MODE == 0 ? 1 : NBL];
       f32x4 dnext[NBL], hin[NBL];
       if (SGN) {
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) hin[b] = h[b];     // sin(a) of the top hidden layer is the last layer's input
+        for (int b = 0; b < NBL; ++b) hin[b] = h[b];     // (tagged) sin(a) of the top hidden layer is the last layer's input
       }
       for (int j = nh - 1; j >= 0; --j) {
         f32x4 ga[NBL];
         if (SGN) {
-          sgn_cos<NBL>(hin, sgn_pop(sg_lo, sg_hi, SW), dnext);
+          tag_cos<NBL>(hin, dnext);
           st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
         } else {
 #pragma unroll
@@ -577,7 +572,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
           }
         }
-        if (active) st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g);
+        if (active) { st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g); vm_note(4 * NBL); }
         // <dL/da, b^(k)> now, so that dL/da is dead once it is split and stashed (16 registers less across the planes)
         for (int k = 0; k < r; ++k) {
           const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
@@ -592,36 +587,41 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         bf16x8 b0[NCH], b1[NCH];
         split2<NBL>(ga, b0, b1);
         NIF_TL(50 + j);
-        ZERO_T(gh)
-        for (int k = 0; k <= r; ++k) {
-          if (k < r) {
-            f32x4 U[NBL];
-            ZERO_T(U)
+        for (int k = 0; k < r; ++k) {
+          f32x4 U[NBL];
 #pragma unroll
-            for (int ks = 0; ks < NCH; ++ks)
+          for (int ks = 0; ks < NCH; ++ks) {
+            if (ks == 0) {
               NIF_CHUNK({
-                mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane);
-                if (!SGN && ks == 0) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
+                mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], U, lane);
+                if (!SGN) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
               })
-            const float zt = zt_base[k * 16];
-            float s = 0.f;
+            } else NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane); })
+          }
+          const float zt = zt_base[k * 16];
+          float s = 0.f;
 #pragma unroll
-            for (int b = 0; b < NBL; ++b) {
-              gh[b] += zt * U[b];
+          for (int b = 0; b < NBL; ++b)
 #pragma unroll
-              for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
-            }
-            dzs[k * 64 + lane] = fmaf(A.omega, s, dzs[k * 64 + lane]);
+            for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
+          if (k == 0) {
+#pragma unroll
+            for (int b = 0; b < NBL; ++b) gh[b] = zt * U[b];
           } else {
 #pragma unroll
-            for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
+            for (int b = 0; b < NBL; ++b) gh[b] += zt * U[b];
           }
+          dzs[k * 64 + lane] += s;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NCH; ++ks) {
+          if (LL && ks == 0) NIF_CHUNK({ mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], gh, lane); })   // r = 0: the chain starts here
+          else NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
         }
         NIF_TL(70 + j);
+        if (MODE == 2 || (MODE == 1 && !(j & 1))) {
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) {
-          gh[b] *= A.omega;
-          if (MODE == 2 || (MODE == 1 && !(j & 1))) gh[b] += skip[b];
+          for (int b = 0; b < NBL; ++b) gh[b] += skip[b];
         }
       }
       NIF_TL(5);
@@ -629,36 +629,21 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
       {
         f32x4 ga[NBL];
         if (SGN) {
-          sgn_cos<NBL>(hin, sgn_pop(sg_lo, sg_hi, SW), dnext);
+          tag_cos<NBL>(hin, dnext);
         } else {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[b * 64 + lane];
         }
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
-        if (active && !edge) st_store16<NBL>(DA0, row0, ga, g);
-        if (edge) {
-          // dL/dW1^(k)[d][f] += sum_p zt_k x_d da0[f] (w0 is applied in k_reduce_edge); row d = si is the bias: m = k*(si+1) + d
-          const int nrow = (r + 1) * (si + 1);
-          const int m = p, kk_ = g;
-          f32x4 wA = {0.f, 0.f, 0.f, 0.f};
-          if (m < nrow && active) {
-            const int k = m / (si + 1), dd = m - k * (si + 1);
-            const float* xr = inp + (iset & 1) * NI;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              wA[t] = (k < r ? zs[k * 16 + 4 * kk_ + t] : 1.0f) * (dd < si ? xr[dd * 16 + 4 * kk_ + t] : 1.0f);
-          }
-          edge_accum<NBL>(ga, wA, nrow, eacc, tT, lane);
-        }
+        if (active) { st_store16<NBL>(DA0, row0, ga, g); vm_note(4 * NBL); }
         for (int k = 0; k < r; ++k) {
           const float* s0 = sm + k * nsm + 4 * g;
           float s = 0.f;
 #pragma unroll
           for (int b = 0; b < NBL; ++b) {
-            f32x4 xw = {0.f, 0.f, 0.f, 0.f};
-            for (int dd = 0; dd < si; ++dd) xw += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-            const f32x4 t = A.omega * xw + *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+            f32x4 t = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+            for (int dd = 0; dd < si; ++dd) t += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
             s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
           }
           float tot = dzs[k * 64 + lane] + s;
@@ -674,11 +659,6 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
     if (lane == 0) lsum[wid] = loss_lane;
     __syncthreads();
-    if (edge) {   // the four waves' accumulators -> this workgroup's compact partial (fixed order)
-      const float* e0 = sm + sm_tot + (pw - NE - 512 - so * 16);
-      for (int e = tid; e < NE; e += NT)
-        A.EDGE[(long)blockIdx.x * NE + e] = (e0[e] + e0[pw + e]) + (e0[2 * pw + e] + e0[3 * pw + e]);
-    }
     if (tid == 0) A.loss_partial[blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
   }
 }
@@ -688,8 +668,8 @@ static size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const int nz = a.ll ? a.rl : a.r, sou = a.ll ? a.so_u : a.so;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((nz + 3) & ~3) + ((sou + 3) & ~3) + 4) * 16;
-  const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni + (a.EDGE ? a.edge_ne + 512 + a.so * 16 : 0);
-  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);
+  const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni;
+  return (size_t)(NBL <= 4 ? NIF_S4_NBUF : 2) * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);   // NBUF chunk buffers
 }
 // floats per k of the LDS small-vector image (last-layer class: + last_layer_bias and the rl x rl map)
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl) {
@@ -713,54 +693,8 @@ bool snet4_supported(const SNetArgs& a) {
 long snet4_fwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 3 * 64 * 8 * (r + 1); }
 long snet4_bwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 2 * 64 * 8 * (r + 1); }
 
-bool snet4_sign_ring(const SNetArgs& a);
-int snet4_edge_ne(const SNetArgs& a) {
-  if (a.ll || !snet4_sign_ring(a)) return 0;     // built for the plain-SIREN training instantiation
-  const int NP = 16 * snet3_nbl(a.n);
-  const long ne = (long)(a.r + 1) * (a.si + 1) * NP + (long)(a.r + 1) * a.so * NP + (long)(a.r + 1) * a.so;
-  const long ne4 = (ne + 3) & ~3L;
-  if ((a.r + 1) * (a.si + 1) > 16 || (a.r + 1) * a.so > 16) return 0;   // rows of one 16-row MFMA operand
-  return ne4 <= 1024 ? (int)ne4 : 0;       // 4 waves x 4 KB of LDS at most
-}
-// edge partials [nblk][ne] -> the first-/last-layer entries of the flat gradient (fixed summation order)
-__global__ __launch_bounds__(256) void k_reduce_edge(SNetArgs A, const float* __restrict__ edge, int nblk, int ne, int NP,
-                                                     float* __restrict__ g) {
-  __shared__ float red[4][64];
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (e < ne)
-    for (int b = rg; b < nblk; b += 4) s += edge[(long)b * ne + e];
-  red[rg][col] = s;
-  __syncthreads();
-  if (rg != 0 || e >= ne) return;
-  const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-  const int r = A.r, si = A.si, so = A.so, n = A.n;
-  const long s_wl = (long)si * n + (long)A.nh * n * n, s_b1 = s_wl + (long)n * so, s_bl = s_b1 + n + (long)A.nh * n;
-  const int e_l = (r + 1) * (si + 1) * NP, e_b = e_l + (r + 1) * so * NP;
-  auto base = [&](int k) -> long { return k < r ? A.off_Wh + (long)k * A.po : A.off_bh; };
-  if (e < e_l) {
-    const int f = e % NP, kd = e / NP, k = kd / (si + 1), dd = kd % (si + 1);
-    if (f < n) {
-      if (dd < si) g[base(k) + (long)dd * n + f] = A.omega * v;
-      else g[base(k) + s_b1 + f] = v;
-    }
-  } else if (e < e_b) {
-    const int e2 = e - e_l, f = e2 % NP, ko = e2 / NP, k = ko / so, o = ko % so;
-    if (f < n) g[base(k) + s_wl + (long)f * so + o] = v;
-  } else if (e < e_b + (r + 1) * so) {
-    const int ko = e - e_b, k = ko / so, o = ko % so;
-    g[base(k) + s_bl + o] = v;
-  }
-}
-void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st) {
-  const int ne = a.edge_ne;
-  hipLaunchKernelGGL(k_reduce_edge, dim3((ne + 63) / 64), dim3(256), 0, st, a, edge, nblk, ne, 16 * snet3_nbl(a.n), grad);
-}
-// plain SIREN whose sign bits fit the 128-bit shift register: the act'(a) ring is not needed
-bool snet4_sign_ring(const SNetArgs& a) {
-  return !a.nif_skip && !a.res && (long)(a.nh + 1) * 4 * snet3_nbl(a.n) <= 128;
-}
+// plain SIREN: the act'(a) ring is not needed (the cosine's sign rides in the stashed sine, any depth / width)
+bool snet4_sign_ring(const SNetArgs& a) { return !a.nif_skip && !a.res; }
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st) {
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
@@ -771,68 +705,41 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   if (query_only) return nblk;
   dim3 grid(nblk), block(256);
   const size_t shm = snet4_shmem(a, NBL);
-#define S4L(NBL_, TR_, ACT_, MODE_, SGN_, LL_)                                                                         \
+#define S4L(NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_)                                                                    \
   {                                                                                                                 \
     if (shm > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>,                                 \
+      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_>), grid, block, shm, st, a);                           \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_>), grid, block, shm, st, a);                      \
   }
-#define S4P(NBL_, TR_, ACT_, MODE_, SGN_)   /* mixed_bfloat16 policy: single bf16 product per n x n operand pair */        \
-  {                                                                                                                 \
-    if (shm > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, false, false, true>,                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, false, false, true>), grid, block, shm, st, a);            \
-  }
-#define S4LP(NBL_, TR_, MODE_, SGN_)   /* last-layer class under the policy: the shared n x n products as ONE bf16 product */ \
-  {                                                                                                                 \
-    if (shm > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_SINE, MODE_, SGN_, true, false, true>,               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_SINE, MODE_, SGN_, true, false, true>), grid, block, shm, st, a);         \
-  }
-#define S4LE(NBL_)                                                                                                  \
-  {                                                                                                                 \
-    if (shm > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, true, ACT_SINE, 0, true, false, true>,                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, true, ACT_SINE, 0, true, false, true>), grid, block, shm, st, a);             \
-  }
+// PR_: the mixed_bfloat16 policy (ONE bf16 product per n x n operand pair); plain SIREN training always takes the tagged-sine form
+#define S4M(NBL_, LL_, PR_)                                                                                         \
+  if (a.nif_skip) { if (train) S4L(NBL_, true, -1, 2, false, LL_, PR_) else S4L(NBL_, false, -1, 2, false, LL_, PR_) }    \
+  else if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
+  else if (train) S4L(NBL_, true, ACT_SINE, 0, true, LL_, PR_)                                                      \
+  else S4L(NBL_, false, ACT_SINE, 0, false, LL_, PR_)
+#define S4N(NBL_, LL_, PR_)   /* last-layer class: no NIF skip form */                                              \
+  if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
+  else if (train) S4L(NBL_, true, ACT_SINE, 0, true, LL_, PR_)                                                      \
+  else S4L(NBL_, false, ACT_SINE, 0, false, LL_, PR_)
 #define S4(NBL_)                                                            \
-  if (a.ll && a.prec == 1) {                                                \
-    if (a.res) { if (train) S4LP(NBL_, true, 1, false) else S4LP(NBL_, false, 1, false) } \
-    else if (train) { if (snet4_sign_ring(a)) S4LP(NBL_, true, 0, true) else S4LP(NBL_, true, 0, false) } \
-    else S4LP(NBL_, false, 0, false)                                        \
-  } else if (a.ll) {                                                        \
-    if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, true) else S4L(NBL_, false, ACT_SINE, 1, false, true) } \
-    else if (train) { if (snet4_sign_ring(a)) S4L(NBL_, true, ACT_SINE, 0, true, true) else S4L(NBL_, true, ACT_SINE, 0, false, true) } \
-    else S4L(NBL_, false, ACT_SINE, 0, false, true)                         \
-  } else if (a.prec == 1) {                                                 \
-    if (a.nif_skip) { if (train) S4P(NBL_, true, -1, 2, false) else S4P(NBL_, false, -1, 2, false) } \
-    else if (a.res) { if (train) S4P(NBL_, true, ACT_SINE, 1, false) else S4P(NBL_, false, ACT_SINE, 1, false) } \
-    else if (train) { if (snet4_sign_ring(a)) S4P(NBL_, true, ACT_SINE, 0, true) else S4P(NBL_, true, ACT_SINE, 0, false) } \
-    else S4P(NBL_, false, ACT_SINE, 0, false)                               \
-  } else if (a.nif_skip) {                                                  \
-    if (train) S4L(NBL_, true, -1, 2, false, false) else S4L(NBL_, false, -1, 2, false, false) \
-  } else if (a.res) {                                                       \
-    if (train) S4L(NBL_, true, ACT_SINE, 1, false, false) else S4L(NBL_, false, ACT_SINE, 1, false, false) \
-  } else if (train) {                                                       \
-    if (snet4_sign_ring(a)) { if (a.EDGE) S4LE(NBL_) else S4L(NBL_, true, ACT_SINE, 0, true, false) } \
-    else S4L(NBL_, true, ACT_SINE, 0, false, false) \
-  } else {                                                                  \
-    S4L(NBL_, false, ACT_SINE, 0, false, false)                             \
-  }
+  if (a.ll && a.prec == 1) { S4N(NBL_, true, true) }                        \
+  else if (a.ll) { S4N(NBL_, true, false) }                                 \
+  else if (a.prec == 1) { S4M(NBL_, false, true) }                          \
+  else { S4M(NBL_, false, false) }
+#ifdef NIF_S4_DEV      // ISA work (tools/isa_hist.py): only the benchmark shape's training / inference instantiations
+  if (train) S4L(4, true, ACT_SINE, 0, true, false, false) else S4L(4, false, ACT_SINE, 0, false, false, false)
+#else
   switch (NBL) {
     case 2: S4(2) break;
     case 4: S4(4) break;
     case 6: S4(6) break;
     default: S4(8) break;
   }
+#endif
 #undef S4
-#undef S4LE
-#undef S4LP
-#undef S4P
+#undef S4N
+#undef S4M
 #undef S4L
   return nblk;
 }

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm, ns = J.ns;
   const int FP = stash_fp(n);                             // feature rows per stash tile (nif_internal.h)
+  const float om_post = BF ? 1.0f : A.omega;              // the bf16-split planes hold omega_0 M (k_pack16b); the fp32 planes do not
   const long nt32 = (A.B + 31) / 32;
   const long nt16 = 2 * nt32;
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) aq[q][b] *= A.omega;
+        for (int b = 0; b < NBL; ++b) aq[q][b] *= om_post;
       for (int k = 0; k <= r; ++k) {
         const float zt = k < r ? zt_base[k * 16] : 1.0f;
         const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
                 sbv += (vq[0][b][0] * bb[0] + vq[0][b][1] * bb[1]) + (vq[0][b][2] * bb[2] + vq[0][b][3] * bb[3]);
               }
-              dzs[k * 64 + lane] += fmaf(A.omega, dzk, sbv);
+              dzs[k * 64 + lane] += fmaf(om_post, dzk, sbv);
               if (PAR) {
                 _Pragma("unroll") for (int d = 0; d < NS; ++d)
                   if (ispar[d]) {
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
                       const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
                       sv += (vq[1 + d][b][0] * bb[0] + vq[1 + d][b][1] * bb[1]) + (vq[1 + d][b][2] * bb[2] + vq[1 + d][b][3] * bb[3]);
                     }
-                    dzts[(d * r + k) * 64 + lane] += fmaf(A.omega, dztk[d], sv);
+                    dzts[(d * r + k) * 64 + lane] += fmaf(om_post, dztk[d], sv);
                   }
               }
             }
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
           for (int b = 0; b < NBL; ++b) {
-            lam[q][b] *= A.omega;
+            lam[q][b] *= om_post;
             if (MODE == 2 || (MODE == 1 && !(j & 1))) lam[q][b] += skip[q][b];
           }
       }

@@ -120,7 +120,6 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   nif_ctx* c = new nif_ctx();
   c->cfg = *cfg;
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
-  { const char* e = getenv("NIF_FUSED_GW"); if (e && e[0]) c->opt_fused_gw = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
   { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
@@ -189,7 +188,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
   void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->edge, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -552,7 +551,8 @@ static int ensure_packed(nif_ctx* c) {
         seg(b_off, s_bh + (long)j * n, n);
         if (c->use_ll4)
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
-                         (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2, c->st);
+                         (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2,
+                         c->cfg.s_omega0, c->st);
       }
       seg(c->s_bott_b, s_bl, sop);
       seg(c->ll_bias, s_bl + sop, c->so);
@@ -574,7 +574,7 @@ static int ensure_packed(nif_ctx* c) {
   c->packed32 = false;
   if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
-                         c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), c->st);
+                         c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st);
   HIPCHK(hipGetLastError());
   c->packed = true;
   if (!c->use_snet4) return ensure_packed32(c);
@@ -1128,9 +1128,8 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
 // Workspace sizing of the fused ShapeNet kernel the step will launch (no launch): number of workgroups (= loss partials),
 // the act'(a) ring, the optional edge-gradient partials.  Grows buffers when needed (stream sync + hipMalloc): call
 // nif_reserve() once up front to keep that out of the timed steps.
-static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nloss, bool* fused_edge, const int* par_of = nullptr) {
+static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nloss, const int* par_of = nullptr) {
   int rc;
-  *fused_edge = false;
   if (ns > 0) {
     SobPar spq{};     // (the parameter streams' extra per-wave LDS counts)
     for (int d = 0; d < 3; ++d) spq.par[d] = par_of ? par_of[d] : -1;
@@ -1143,31 +1142,9 @@ static int snet_plan(nif_ctx* c, SNetArgs& sa, int ns, const int* seeds, int* nl
       rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
     }
     *nloss = nblk;
-  } else if (c->use_snet4 && c->opt_fused_gw && sa.wg_cap == 0 && snet5_supported(sa)) {
-    const int nblk = launch_snet5(sa, nullptr, 0, true, c->st);
-    const long need = (long)nblk * 8 * snet5_ring_floats_per_wave(c->n, c->nh);
-    if (need > c->dring_cap) {
-      HIPCHK(hipStreamSynchronize(c->st));
-      rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc;
-    }
-    *nloss = nblk;
-    sa.fused_gw = 1;
   } else if (c->use_snet3 || c->use_snet4) {
     int waves = 4;
-    static const bool want_edge = [] { const char* e = getenv("NIF_FUSE_EDGE"); return e && e[0] == '1'; }();
-    if (c->use_snet4 && want_edge) {  // opt-in: first/last-layer weight gradients inside k_snet4 (no DA_0 / IN_nh / DU stashes)
-      sa.edge_ne = snet4_edge_ne(sa);
-      *fused_edge = sa.edge_ne > 0;
-    }
     const int nblk = c->use_snet4 ? launch_snet4(sa, true, true, c->st) : launch_snet3(sa, true, true, &waves, c->st);
-    if (*fused_edge) {
-      const long need_e = (long)nblk * sa.edge_ne;
-      if (need_e > c->edge_cap) {
-        HIPCHK(hipStreamSynchronize(c->st));
-        rc = grow(&c->edge, &c->edge_cap, need_e); if (rc) return rc;
-      }
-      sa.EDGE = c->edge;
-    }
     const long need = (long)nblk * waves * snet3_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
@@ -1223,7 +1200,7 @@ static int ensure_pipe(nif_ctx* c, int nchunk) {
 // the ShapeNet stashes then hold (1+ns) blocks of tiles (real, then one block of tangent pseudo-tiles per seed).
 static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const float* sw0, long off, long B, long Bg, int ns,
                       const int* seeds, const float* gt, float wj, hipStream_t sa_st, hipStream_t sb_st, hipStream_t pb_st,
-                      float* partial, float* loss_partial, int* nloss_out, int chunk_idx, bool whole, SNetArgs* sa_edge = nullptr,
+                      float* partial, float* loss_partial, int* nloss_out, int chunk_idx, bool whole, SNetArgs* sa_out = nullptr,
                       const SobPlan* sp = nullptr) {
   int rc;
   const int ncol = c->pi + c->si;
@@ -1247,9 +1224,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   sa.y = y; sa.sw = sw; sa.u_out = nullptr; sa.loss_partial = loss_partial; sa.inv_bg = 1.0f / (float)Bg;
   if (!whole) sa.wg_cap = c->opt_pipe_wgs;        // leave room on every CU for the reductions of the previous chunk
   int nloss = (int)((ntiles + 3) / 4);
-  bool fused_edge = false;
-  rc = snet_plan(c, sa, ns, seeds, &nloss, &fused_edge, sp ? sp->par : nullptr); if (rc) return rc;
-  if (!whole && fused_edge) { fused_edge = false; sa.EDGE = nullptr; sa.edge_ne = 0; }
+  rc = snet_plan(c, sa, ns, seeds, &nloss, sp ? sp->par : nullptr); if (rc) return rc;
   *nloss_out = nloss;
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
@@ -1264,7 +1239,6 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
       }
       launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st, sparp);
     }
-    else if (sa.fused_gw) launch_snet5(sa, partial, c->pstride, false, sa_st);
     else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
     else launch_snet(sa, c->NB, true, sa_st);
@@ -1281,13 +1255,13 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     if (sb_st != sa_st) HIPCHK(hipStreamWaitEvent(sb_st, c->ev_chunk[chunk_idx], 0));
     if (pb_st != sa_st && pb_st != sb_st) HIPCHK(hipStreamWaitEvent(pb_st, c->ev_chunk[chunk_idx], 0));
   }
-  // weight gradients -> partial rows (the fused kernel wrote the hidden matrices' columns of ITS rows: everybody uses as many)
-  const int rows = sa.fused_gw ? nloss : rows_for(c, ntiles);
+  // weight gradients -> partial rows
+  const int rows = rows_for(c, ntiles);
   { ProfScope p_(c, NIF_PROF_PNET_BWD, pb_st);
     // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
     // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
     static const bool touch_on = [] { const char* e = getenv("NIF_PBW_TOUCH"); return !(e && e[0] == '0'); }();
-    const float* touch = (touch_on && !fused_edge && whole && pb_st == sb_st) ? sa.stash + (long)(c->nh + 1) * c->slot_s : nullptr;
+    const float* touch = (touch_on && whole && pb_st == sb_st) ? sa.stash + (long)(c->nh + 1) * c->slot_s : nullptr;
     if (fused_p) launch_pnet_bwg(pa, partial, c->pstride, rows, pb_st, touch, (long)c->NB * 1024);
     else launch_pnet_bwd(pa, c->NSTB, pb_st); }
   ProfScope pgw(c, NIF_PROF_GW, sb_st);
@@ -1308,9 +1282,9 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   g.W = hyper_ref(c, 0, c->n, c->si, c->n);
   g.Bv = hyper_ref(c, (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so, 0, 1, c->n);
   if (sp) g.ntiles = ntiles * (1 + sp->nsc);      // a parameter stream has no tangent input here (x' = 0): its pairs go to sob_par_pass
-  if (!fused_edge) launch_gw_first(g, c->NB, rows, sb_st);
+  launch_gw_first(g, c->NB, rows, sb_st);
   // ShapeNet hidden matrices
-  for (int j = 0; j < c->nh && !sa.fused_gw; ++j) {
+  for (int j = 0; j < c->nh; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
@@ -1325,7 +1299,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     const long bslot = wslot + (long)c->n * c->so + c->n + (long)c->nh * c->n;
     g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
     g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
-    if (!fused_edge) launch_gw_out(g, c->NB, rows, sb_st);
+    launch_gw_out(g, c->NB, rows, sb_st);
   }
   // ParameterNet: first, hidden matrices, bottleneck
   float* pST = pa.stash;
@@ -1345,7 +1319,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
   launch_gw_out(g, c->NSTB, rows, pb_st);
   }
-  if (sa_edge) { *sa_edge = sa; if (!fused_edge) sa_edge->EDGE = nullptr; }   // whole batch: the kernel's own first/last-layer partials
+  if (sa_out) *sa_out = sa;
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
@@ -1391,10 +1365,9 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
       HIPCHK(hipEventRecord(c->ev_done, c->st2));
       HIPCHK(hipStreamWaitEvent(c->st, c->ev_done, 0));
     }
-    const int rows = sae.fused_gw ? nloss : rows_for(c, ntiles);
+    const int rows = rows_for(c, ntiles);
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
-    if (sae.EDGE) launch_reduce_edge(sae, c->edge, nloss, c->grad, c->st);   // overwrites the first/last-layer entries
     if (act_on(c)) {   // the plane side of the activity regulariser and its loss, on top of the reduced gradient
       const long need = (long)NIF_ACT_SLABS * (c->r + 1) * c->po;
       if (need > c->act_part_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->act_part, &c->act_part_cap, need); if (rc) return rc; }
@@ -1459,9 +1432,9 @@ extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
     return NIF_OK;
   }
   SNetArgs sa; fill_snet(c, sa, nullptr, c->pi + c->si, c->pi, B_max);
-  int nloss = 0; bool fe = false;
+  int nloss = 0;
   const int seeds[3] = {0, 0, 0};
-  rc = snet_plan(c, sa, n_tangents, seeds, &nloss, &fe); if (rc) return rc;
+  rc = snet_plan(c, sa, n_tangents, seeds, &nloss); if (rc) return rc;
   const long chunk = (n_tangents == 0 && c->use_snet3) ? pipe_chunk_points(c, B_max) : 0;
   if (chunk > 0 && chunk < B_max) { rc = ensure_pipe(c, (int)((B_max + chunk - 1) / chunk)); if (rc) return rc; }
   return NIF_OK;
@@ -1725,7 +1698,6 @@ extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
     c->packed = false; c->packed32 = false; c->packed_p32 = false;
     return NIF_OK;
   }
-  if (strcmp(key, "fused_gw") == 0) { c->opt_fused_gw = value != 0; return NIF_OK; }     // k_snet5 instead of k_snet4 + k_gw_lds
   if (strcmp(key, "side_pnet") == 0) { c->opt_side_pnet = value != 0; return NIF_OK; }   // ParameterNet adjoint on the second stream
   if (strcmp(key, "pipe_chunk") == 0) { c->opt_pipe_chunk = value; return NIF_OK; }   // points per chunk, 0 = off, -1 = default
   if (strcmp(key, "pipe_wgs") == 0) { c->opt_pipe_wgs = value; return NIF_OK; }       // workgroups of the fused kernel per chunk

@@ -38,7 +38,6 @@ struct nif_ctx {
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)
   void *ll_wpf = nullptr, *ll_wpb = nullptr;   // phi layer as bf16-split MFMA operands (launch_pack_phi)
-  float* edge = nullptr; long edge_cap = 0;    // per-workgroup first/last-layer gradient partials of k_snet4
   f32x4 *pWF = nullptr, *pWB = nullptr, *sWF = nullptr, *sWB = nullptr, *lWF = nullptr, *lWB = nullptr;
   // workspaces (capacity in points)
   long cap = 0;
@@ -78,7 +77,6 @@ struct nif_ctx {
   long opt_pipe_chunk = -1; int opt_pipe_wgs = 512;    // points per chunk (-1 default, 0 off); fused-kernel workgroups per chunk
   // shard streaming (nif_h2d_async): a copy stream and, per staging slot, 'copy landed' / 'slot consumed' events
   hipStream_t st_copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool opt_fused_gw = false;     // nif_set_option("fused_gw") / NIF_FUSED_GW: hidden-layer weight gradients inside the fused kernel (k_snet5)
   bool opt_fp32_mfma = false;      // nif_set_option("fp32_mfma"): A/B switch, default from NIF_FP32_MFMA
 };
 

@@ -86,15 +86,11 @@ struct SNetArgs {
   // last-layer-parameterised class on k_snet4 (r = 0: shared dense SIREN; theta = the slot-ordered copy built by
   // launch_ll_slots; so = so_u * rl outputs phi): u = Dot(phi, a) + bias, a = Z [tiles][rl][32]
   int ll, rl, so_u;
-  // fused first-/last-layer weight gradients (k_snet4, hypernetwork classes): per-workgroup compact partials
-  //   [(k, d')][NP] first layer (d' = si: bias) | [(k, o)][NP] last layer | [(k, o)] last bias ;  NP = 16*NBL
-  float* EDGE; int edge_ne;               // [gridDim.x][edge_ne] or null (then the stashes feed k_gw_first / k_gw_out)
   const void* WPF; const void* WPB;       // bf16-split planes of the phi layer [n][so <= 32] (launch_pack_phi)
   float* DPHI;                            // [tiles][so][32]   dL/dphi (weight gradient of the phi layer)
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
   int prec;                               // 0: fp32-exact products; 1: mixed_bfloat16 policy (operands of the n x n products rounded to bf16)
-  int fused_gw;                           // set by the orchestration when k_snet5 runs the step (hidden-layer gradients in-kernel)
   int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
@@ -160,18 +156,12 @@ void launch_pnet_bwg(const PNetArgs& a, float* partial, long pstride, int rows, 
 bool snet4_supported(const SNetArgs& a);
 long snet4_fwd_elems(int n, int r);
 long snet4_bwd_elems(int n, int r);
-void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, hipStream_t st);
+// (scale = omega_0 of the layer: the bf16-split planes hold omega_0 M, see k_snet4.hip)
+void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st);
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
-                          long fstride_elems, long bstride_elems, hipStream_t st);
+                          long fstride_elems, long bstride_elems, float scale, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
-// k_snet5.hip: the plain-SIREN training step with the hidden layers' weight gradients accumulated in the kernel; writes the
-// hidden hyper-matrices' columns of `nblk` partial-gradient rows (returns nblk; the other gradient kernels must use it as `rows`)
-bool snet5_supported(const SNetArgs& a);
-long snet5_ring_floats_per_wave(int n, int nh);
-int launch_snet5(const SNetArgs& a, float* partial, long pstride, bool query_only, hipStream_t st);
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
-int snet4_edge_ne(const SNetArgs& a);    // floats of one workgroup's edge partial; 0 = not fusable (falls back to k_gw_first/out)
-void launch_reduce_edge(const SNetArgs& a, const float* edge, int nblk, float* grad, hipStream_t st);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
 bool sob_ll_supported(const SNetArgs& a);   // last-layer class under k_sob (k_sob_ll.hip)

@@ -8,9 +8,12 @@ context's own HIP stream on the library's own buffer: no host synchronisation, n
 
 Process model: RANK / WORLD_SIZE / LOCAL_RANK from the environment (what the usual one-process-per-GPU launchers export; `bench.py
 --gpus N` launches its own ranks the same way).  The only thing that has to travel between the processes on
-the host is RCCL's 128-byte unique id: rank 0 publishes it in a file, the others read it (single node, like the
-reference's MirroredStrategy).  The file is named after NIF_RDZV_KEY, else MASTER_ADDR / MASTER_PORT and the launcher's
-pid, which all ranks of one launch share and no other launch does.
+the host is RCCL's 128-byte unique id (single node, like the reference's MirroredStrategy): a handshake through files in a
+PRIVATE directory (mode 0700, files 0600) named after NIF_RDZV_KEY, else MASTER_ADDR / MASTER_PORT -- what all ranks of one
+launch share, whatever wrapper shells sit between the launcher and the ranks.  Every other rank first publishes a random
+nonce, rank 0 answers with [id | the nonces it saw]: a reader only accepts an answer that carries ITS nonce, so a file a
+crashed earlier launch left behind under the same key can never be taken for this launch's id; rank 0 removes everything
+it wrote in a `finally`.  NIF_COMM_TIMEOUT (seconds, default 300) bounds every wait.
 
 The communicator object is pluggable (`install`): the CPU tests put a gloo-backed double with the same methods here to
 run `Model.fit`'s real sharding logic on two processes without a GPU."""
@@ -32,55 +35,108 @@ class RcclComm(object):
     time it takes part in a collective; all ranks create their engines in the same order (SPMD), so the n-th
     communicator of every rank is the same one."""
 
-    def __init__(self, rank, world, local_rank, key=None, directory=None, timeout=300.0):
+    def __init__(self, rank, world, local_rank, key=None, directory=None, timeout=None):
         self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
-        self._key = key or os.environ.get("NIF_RDZV_KEY") or "%s_%s_%d" % (
-            os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), os.getppid())
-        self._dir = directory or os.environ.get("NIF_RDZV_DIR") or tempfile.gettempdir()
-        self._timeout = float(timeout)
+        key = key or os.environ.get("NIF_RDZV_KEY")
+        if not key:
+            if self.world > 1 and "MASTER_PORT" not in os.environ:
+                raise _lib.NifError("multi-process run without NIF_RDZV_KEY or MASTER_ADDR / MASTER_PORT: the ranks have nothing "
+                                    "to find each other by (launch through torch.distributed.run, `bench.py --gpus N`, or export NIF_RDZV_KEY)")
+            key = "%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"))
+        self._key = key
+        base = directory or os.environ.get("NIF_RDZV_DIR") or os.path.join(tempfile.gettempdir(), "nif_rdzv_%d" % os.getuid())
+        os.makedirs(base, mode=0o700, exist_ok=True)
+        try:
+            os.chmod(base, 0o700)
+        except OSError:
+            pass
+        self._dir = base
+        self._timeout = float(timeout if timeout is not None else os.environ.get("NIF_COMM_TIMEOUT", "300"))
         self._seq = 0
 
     # ---- host-side rendezvous of the 128-byte id -------------------------------------------------
-    def _id_path(self, seq):
+    def _path(self, kind, seq, rank=None):
         safe = "".join(ch if ch.isalnum() or ch in "._-" else "_" for ch in self._key)
-        return os.path.join(self._dir, "nif_rccl_id_%s_%d" % (safe, seq))
+        return os.path.join(self._dir, "nif_rccl_%s_%s_%d%s" % (kind, safe, seq, "" if rank is None else "_%d" % rank))
+
+    def _id_path(self, seq):
+        return self._path("id", seq)
+
+    @staticmethod
+    def _publish(path, payload):
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)     # atomic: a reader sees either the old file, nothing, or all of the new one
+
+    @staticmethod
+    def _read(path, nbytes):
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+            return raw if len(raw) == nbytes else None
+        except OSError:
+            return None
+
+    def _expired(self, t0, what):
+        if time.time() - t0 > self._timeout:
+            raise _lib.NifError("rank %d: %s after %.0f s (NIF_COMM_TIMEOUT)" % (self.rank, what, self._timeout))
+        time.sleep(0.005)
+
+    NONCE = 16
 
     def _exchange_id(self, lib):
-        path = self._id_path(self._seq)
+        """-> (id, files_to_remove).  Collective over the ranks of the job."""
+        seq = self._seq
         self._seq += 1
+        idp = self._path("id", seq)
+        nb = _lib.COMM_ID_BYTES + (self.world - 1) * self.NONCE
         if self.rank == 0:
-            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-            check(lib.nif_comm_unique_id(buf))
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "wb") as f:
-                f.write(buf.raw)
-            os.replace(tmp, path)     # atomic: a reader sees either nothing or all 128 bytes
-            return buf.raw, path
-        t0 = time.time()
-        while True:
+            mine = [idp]
             try:
-                with open(path, "rb") as f:
-                    raw = f.read()
-                if len(raw) == _lib.COMM_ID_BYTES:
-                    return raw, None
+                os.remove(idp)    # whatever a crashed launch left under this key
             except OSError:
                 pass
-            if time.time() - t0 > self._timeout:
-                raise _lib.NifError("rank %d: no RCCL id from rank 0 at %s after %.0f s" % (self.rank, path, self._timeout))
-            time.sleep(0.005)
+            nonces = []
+            t0 = time.time()
+            for r in range(1, self.world):
+                hp = self._path("hello", seq, r)
+                mine.append(hp)
+                while True:
+                    n = self._read(hp, self.NONCE)
+                    if n is not None:
+                        nonces.append(n)
+                        break
+                    self._expired(t0, "no hello from rank %d at %s" % (r, hp))
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            check(lib.nif_comm_unique_id(buf))
+            self._publish(idp, buf.raw + b"".join(nonces))
+            return buf.raw, mine
+        nonce = os.urandom(self.NONCE)
+        self._publish(self._path("hello", seq, self.rank), nonce)
+        lo = _lib.COMM_ID_BYTES + (self.rank - 1) * self.NONCE
+        t0 = time.time()
+        while True:
+            raw = self._read(idp, nb)
+            if raw is not None and raw[lo:lo + self.NONCE] == nonce:
+                return raw[:_lib.COMM_ID_BYTES], []
+            self._expired(t0, "no RCCL id from rank 0 at %s" % idp)
 
     def attach(self, engine):
         """Join `engine`'s context to a fresh communicator of all ranks (collective)."""
         if getattr(engine, "_comm_joined", False):
             return
         if self.world > 1 or os.environ.get("NIF_FORCE_RCCL") == "1":
-            raw, path = self._exchange_id(engine.lib)
-            check(engine.lib.nif_comm_init_rank(engine.ctx, raw, self.rank, self.world))
-            if path is not None:      # ncclCommInitRank returned on rank 0: every rank has read the id
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
+            raw, mine = self._exchange_id(engine.lib)
+            try:
+                check(engine.lib.nif_comm_init_rank(engine.ctx, raw, self.rank, self.world))
+            finally:                  # ncclCommInitRank returned (every rank has read the id) or failed: nothing stays behind
+                for q in mine:
+                    try:
+                        os.remove(q)
+                    except OSError:
+                        pass
         engine._comm_joined = True
 
     # ---- collectives ---------------------------------------------------------------------------

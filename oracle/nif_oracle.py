@@ -559,6 +559,10 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
         T = [(R(u) if rounded else u) @ (R(mat(k, ab, shape)) if rounded else mat(k, ab, shape)) for k in range(K)]
         return sum(zt[:, k:k + 1] * T[k] for k in range(K)), T
 
+    def prodw(u, ab, shape):              # hidden n x n products: sum_k zt_k (u . (om M_k)); the kernels' packed planes hold
+        # om M_k (omega_0 folded in at pack time, round 3), so under the policy it is om M_k that is rounded to bf16
+        return sum(zt[:, k:k + 1] * (R(u) @ R(om * mat(k, ab, shape))) for k in range(K))
+
     def bias(ab):
         return sum(zt[:, k:k + 1] * vec(k, ab)[None, :] for k in range(K))
 
@@ -570,17 +574,17 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
     nh = spec.n_hidden_mats
     if nif:
         for i in range(nh):
-            a = prod(u, sl["wh"][i], (n, n), True)[0] + bias(sl["bh"][i])
+            a = prodw(u, sl["wh"][i], (n, n)) + bias(sl["bh"][i])
             acts.append((u, a)); u = f(a) + u
     elif spec.s_res:
         for i in range(spec.L):
-            a1 = om * prod(u, sl["wh"][2 * i], (n, n), True)[0] + bias(sl["bh"][2 * i])
+            a1 = prodw(u, sl["wh"][2 * i], (n, n)) + bias(sl["bh"][2 * i])
             t = np.sin(a1)
-            a2 = om * prod(t, sl["wh"][2 * i + 1], (n, n), True)[0] + bias(sl["bh"][2 * i + 1])
+            a2 = prodw(t, sl["wh"][2 * i + 1], (n, n)) + bias(sl["bh"][2 * i + 1])
             acts.append((u, a1, t, a2)); u = 0.5 * (u + np.sin(a2))
     else:
         for i in range(nh):
-            a = om * prod(u, sl["wh"][i], (n, n), True)[0] + bias(sl["bh"][i])
+            a = prodw(u, sl["wh"][i], (n, n)) + bias(sl["bh"][i])
             acts.append((u, a)); u = np.sin(a)
     sL, TL = prod(u, sl["wl"], (n, so), False)
     out = sL + bias(sl["bl"])
@@ -603,7 +607,11 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
             gzt[:, k] += ga @ vec(k, ab)
 
     def back(ab, shape, ga, hin, scale, rounded):     # dL/dh_in and the latent part through the matrix
-        U = [(R(ga) if rounded else ga) @ (R(mat(k, ab, shape)) if rounded else mat(k, ab, shape)).T for k in range(K)]
+        if rounded:                                   # hidden matrices: the adjoint planes hold scale * M_k as well
+            U = [R(ga) @ R(scale * mat(k, ab, shape)).T for k in range(K)]
+            scale = 1.0
+        else:
+            U = [ga @ mat(k, ab, shape).T for k in range(K)]
         for k in range(K):
             gzt[:, k] += scale * (hin * U[k]).sum(1)
         return scale * sum(zt[:, k:k + 1] * U[k] for k in range(K))
@@ -669,13 +677,13 @@ def snet_phi(spec, ws, x, keep=False, rnd=None):
     tape = [("first", x, a)]
     for lay in hidden:
         if spec.s_res:
-            a1 = om * (R(h) @ R(lay[0])) + lay[1]
+            a1 = R(h) @ R(om * lay[0]) + lay[1]       # (the packed planes hold om W: that product is what gets rounded)
             t = np.sin(a1)
-            a2 = om * (R(t) @ R(lay[2])) + lay[3]
+            a2 = R(t) @ R(om * lay[2]) + lay[3]
             tape.append(("sres", h, a1, t, a2))
             h = 0.5 * (h + np.sin(a2))
         else:
-            a1 = om * (R(h) @ R(lay[0])) + lay[1]
+            a1 = R(h) @ R(om * lay[0]) + lay[1]
             tape.append(("siren", h, a1))
             h = np.sin(a1)
     phi = (h @ bott[0] + bott[1]).reshape(x.shape[0], spec.so, spec.r)
@@ -699,16 +707,16 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None):
             _, hin, a1, t, a2 = rec
             ga2 = 0.5 * gh * np.cos(a2)
             gw2 = om * (t.T @ ga2); gb2 = ga2.sum(0)
-            gt = om * (R(ga2) @ R(lay[2]).T)
+            gt = R(ga2) @ R(om * lay[2]).T
             ga1 = gt * np.cos(a1)
             gw1 = om * (hin.T @ ga1); gb1 = ga1.sum(0)
-            gh = 0.5 * gh + om * (R(ga1) @ R(lay[0]).T)
+            gh = 0.5 * gh + R(ga1) @ R(om * lay[0]).T
             g_hidden.append([gw1, gb1, gw2, gb2])
         else:
             _, hin, a1 = rec
             ga1 = gh * np.cos(a1)
             g_hidden.append([om * (hin.T @ ga1), ga1.sum(0)])
-            gh = om * (R(ga1) @ R(lay[0]).T)
+            gh = R(ga1) @ R(om * lay[0]).T
     _, x, a = tape[0]
     ga = gh * np.cos(a)
     grads = [om * (x.T @ ga), ga.sum(0)]

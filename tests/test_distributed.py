@@ -127,25 +127,51 @@ def test_single_process_defaults():
 
 
 def test_rccl_id_rendezvous_through_files(tmp_path, monkeypatch):
-    """the only host-side exchange of the RCCL path: rank 0 publishes the 128-byte id, the others read it"""
+    """the only host-side exchange of the RCCL path: the others publish a nonce, rank 0 answers with [id | nonces]; a stale
+    answer of an earlier launch under the same key is never accepted; private directory, private files; bounded waits"""
+    import stat
     import threading
     from nif_amd import _lib
     from nif_amd.distributed import RcclComm
 
     class FakeLib(object):
+        def __init__(self, fill):
+            self.fill = fill
+
         def nif_comm_unique_id(self, buf):
-            buf.raw = bytes(range(128))
+            buf.raw = bytes([self.fill]) * 128
             return 0
 
-    a = RcclComm(0, 2, 0, key="k/ey 1", directory=str(tmp_path))
-    b = RcclComm(1, 2, 1, key="k/ey 1", directory=str(tmp_path), timeout=20)
+    d = str(tmp_path / "rdzv")
+    a = RcclComm(0, 3, 0, key="k/ey 1", directory=d)
+    b = RcclComm(1, 3, 1, key="k/ey 1", directory=d, timeout=20)
+    c = RcclComm(2, 3, 2, key="k/ey 1", directory=d, timeout=20)
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    # a crashed earlier launch left an answer behind (other id, other nonces): nobody may take it
+    with open(a._id_path(0), "wb") as f:
+        f.write(bytes([9]) * (128 + 2 * RcclComm.NONCE))
     got = {}
-    th = threading.Thread(target=lambda: got.setdefault("b", b._exchange_id(FakeLib())))
-    th.start()
-    raw, path = a._exchange_id(FakeLib())
-    th.join()
-    assert raw == bytes(range(128)) and got["b"][0] == raw and os.path.dirname(path) == str(tmp_path)
-    assert a._id_path(1) != a._id_path(0)          # one file per communicator
-    c = RcclComm(1, 2, 1, key="nobody", directory=str(tmp_path), timeout=0.05)
+    ths = [threading.Thread(target=lambda q=q, nm=nm: got.setdefault(nm, q._exchange_id(FakeLib(7)))) for q, nm in ((b, "b"), (c, "c"))]
+    for th in ths:
+        th.start()
+    raw, mine = a._exchange_id(FakeLib(7))
+    for th in ths:
+        th.join()
+    assert raw == bytes([7]) * 128 and got["b"][0] == raw and got["c"][0] == raw
+    assert all(os.path.dirname(q) == d for q in mine) and len(mine) == 3      # the answer + two hello files: rank 0 removes them
+    assert stat.S_IMODE(os.stat(a._id_path(0)).st_mode) == 0o600
+    assert a._id_path(1) != a._id_path(0)          # one file set per communicator
+    # bounded waits on both sides
+    lone = RcclComm(1, 2, 1, key="nobody", directory=d, timeout=0.05)
     with pytest.raises(_lib.NifError):
-        c._exchange_id(FakeLib())
+        lone._exchange_id(FakeLib(1))
+    lone0 = RcclComm(0, 2, 0, key="nobody2", directory=d, timeout=0.05)
+    with pytest.raises(_lib.NifError):
+        lone0._exchange_id(FakeLib(1))
+    # no key, no launcher environment, more than one rank: refuse instead of guessing
+    monkeypatch.delenv("NIF_RDZV_KEY", raising=False); monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(_lib.NifError):
+        RcclComm(0, 2, 0, directory=d)
+    monkeypatch.setenv("NIF_COMM_TIMEOUT", "7")
+    monkeypatch.setenv("MASTER_PORT", "1234")
+    assert RcclComm(0, 2, 0, directory=d)._timeout == 7.0

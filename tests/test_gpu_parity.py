@@ -238,14 +238,26 @@ def test_adam_steps_follow_oracle():
     th = O.flatten(ws)
     mm = np.zeros_like(th); vv = np.zeros_like(th)
     losses = []
+    solid = np.ones_like(th, dtype=bool)
     for t in range(1, 4):
         l, g = O.loss_and_grad(spec, O.unflatten(spec, th), x.astype(np.float64), y.astype(np.float64))
         losses.append(l)
+        # entries whose gradient is not small against the tensor's own scale: there the fp32 gradient (2e-4 of the tensor's
+        # norm, test_loss_and_grad_match_oracle) has a small RELATIVE error, and only there is Adam's normalised step
+        # lr * g / |g| insensitive to it
+        off = 0
+        for gt in g:
+            rms = np.sqrt(np.mean(gt ** 2)) + 1e-300
+            solid[off:off + gt.size] &= np.abs(gt.ravel()) > 0.02 * rms
+            off += gt.size
         th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=2e-3)
     got = O.flatten(model.get_weights())
     assert np.allclose(hist.history["loss"], losses, rtol=2e-4)
-    # Adam normalises the step to ~lr, so compare the displacement
-    assert np.abs(got - th).max() < 0.05 * 2e-3 * 3
+    # Adam normalises the step to ~lr, so compare the displacement: 5 % of the three steps where the gradient entry is solid
+    # (the bulk), and nowhere more than a sign flip of one of the three steps would explain
+    assert solid.mean() > 0.8
+    assert np.abs(got - th)[solid].max() < 0.05 * 2e-3 * 3
+    assert np.abs(got - th).max() < 0.4 * 2e-3 * 3
 
 
 def test_fit_batches_partial_last_batch_and_sample_weight():
