@@ -14,6 +14,9 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
 
 #define NCCLCHK(expr)                                                                             \
   do {                                                                                            \
@@ -166,14 +169,30 @@ extern "C" int nif_train_step_multi(nif_ctx** ctxs, int32_t n, const float* xin,
   const int64_t base = B / n, rem = B % n;
   lo[0] = 0;
   for (int i = 0; i < n; ++i) lo[i + 1] = lo[i] + base + (i < rem ? 1 : 0);
+  // One host thread per device stages its shard (the host arrays are pageable: hipMemcpyAsync from them blocks its caller) and
+  // enqueues the shard's step behind the copy on the device's own stream -- n copies and n steps in flight at once, instead of
+  // device i + 1's copy waiting for the host to be done with device i (r2: a serial loop).  The error text of a failing
+  // shard is carried over from its thread (nif_last_error is thread-local).
   int rc = NIF_OK;
-  for (int i = 0; i < n && rc == NIF_OK; ++i) {
+  std::vector<int> rcs(n, NIF_OK);
+  std::vector<std::string> msgs(n);
+  auto shard = [&](int i) {
     nif_ctx* c = ctxs[i];
     const int ncol = c->pi + c->si;
     const int64_t b = lo[i + 1] - lo[i];
-    rc = nif_stage_batch(c, xin + lo[i] * ncol, y + lo[i] * c->so, sw ? sw + lo[i] : nullptr, b, &dx[i], &dy[i], &dsw[i]);
-    if (rc == NIF_OK) rc = nif_loss_grad_dev(c, dx[i], dy[i], sw ? dsw[i] : nullptr, b, B);
+    int r = nif_stage_batch(c, xin + lo[i] * ncol, y + lo[i] * c->so, sw ? sw + lo[i] : nullptr, b, &dx[i], &dy[i], &dsw[i]);
+    if (r == NIF_OK) r = nif_loss_grad_dev(c, dx[i], dy[i], sw ? dsw[i] : nullptr, b, B);
+    rcs[i] = r;
+    if (r != NIF_OK) msgs[i] = nif_last_error();
+  };
+  if (n == 1) shard(0);
+  else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i) th.emplace_back(shard, i);
+    for (auto& t : th) t.join();
   }
+  for (int i = 0; i < n && rc == NIF_OK; ++i)
+    if (rcs[i] != NIF_OK) rc = nif_fail(rcs[i], msgs[i]);
   if (rc == NIF_OK && n > 1) rc = nif_allreduce_grad_multi(ctxs, n);
   for (int i = 0; i < n && rc == NIF_OK; ++i) rc = nif_adam_step_dev(ctxs[i], opt);
   if (rc == NIF_OK && loss_out) rc = nif_last_loss(ctxs[0], loss_out);

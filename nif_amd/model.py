@@ -41,9 +41,13 @@ class Variable(object):
 class Model(object):
     """The subset of tf.keras.Model the reference's README uses (README.md:23-37, :71-117, :179-195)."""
 
-    def __init__(self, owner, role, n_inputs=1):
+    def __init__(self, owner, role, n_inputs=1, jac_reg=0.0):
         self._owner = owner
         self._role = role  # 'full' | 'p_to_lr' | 'p_to_w' | 'lr_to_w' | 'x_to_u_given_w' | 'x_to_phi'
+        # l1 of the latent Jacobian regulariser: only the model build() returns carries it (the reference wraps JacRegLatentLayer
+        # in build() alone, model.py:353-375; .model() and the sub-models train / evaluate without it).  Pushed to the shared
+        # engine whenever THIS model computes a loss.
+        self._jac_reg = float(jac_reg or 0.0)
         self.optimizer = None
         self.loss = None
         self.stop_training = False
@@ -152,12 +156,23 @@ class Model(object):
         self.optimizer = new
         self.loss = "mse"
 
+    _EVAL_CHUNK = 1 << 18
+
     def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
-        u = self.predict(x)
-        per = ((u.astype(np.float64) - np.asarray(y, dtype=np.float64)) ** 2).mean(axis=1)
-        if sample_weight is not None:
-            per = per * np.asarray(sample_weight, dtype=np.float64)
-        return float(per.sum() / u.shape[0])
+        """Keras Model.evaluate: the TOTAL loss -- sample-weighted mse plus every regularisation loss of the model (kernel / bias
+        L1 / L2, the ParameterNet activity regulariser, the latent Jacobian regulariser of build()), as `fit` logs it; evaluated
+        through the engine's loss kernels in chunks, each chunk's loss weighted by its rows (Keras' batch-weighted mean)."""
+        e = self._engine
+        x = np.asarray(x); n = x.shape[0]
+        if n == 0:
+            return 0.0
+        e.set_jac_regularizer(self._jac_reg)
+        tot = 0.0
+        for lo in range(0, n, self._EVAL_CHUNK):
+            hi = min(n, lo + self._EVAL_CHUNK)
+            sw = None if sample_weight is None else np.asarray(sample_weight)[lo:hi]
+            tot += (hi - lo) * e.loss_and_grad(x[lo:hi], np.asarray(y)[lo:hi], sw)[0]
+        return float(tot / n)
 
     # hooks the two-output Sobolev model overrides
     def _targets(self, y, n_rows):
@@ -193,6 +208,7 @@ class Model(object):
                                       % ", ".join(sorted(kwargs)))
         s = self._owner._spec
         e = self._engine
+        e.set_jac_regularizer(self._jac_reg)      # (raises here, not at first engine access, when the shape has no kernel for it)
         self.stop_training = False
         if getattr(self, "_fresh_slots", False):
             z = np.zeros((e.n_params,), dtype=np.float32)
@@ -234,29 +250,44 @@ class Model(object):
         bs = 32 if batch_size is None else int(batch_size)
         callbacks = list(callbacks or [])
         hist = History()
-        for cb in callbacks:
-            if hasattr(cb, "set_model"):
-                cb.set_model(self)
-        for cb in callbacks:
-            if hasattr(cb, "on_train_begin"):
-                cb.on_train_begin({})
         owned = [] if shard is not None else [src_x] + src_t + ([src_sw] if has_sw else [])
-        if shuffle:
-            d_x = e.alloc(N * ncol)
-            d_t = [e.alloc(N * w) for w in widths]
-            d_sw = e.alloc(N) if has_sw else None
-            d_perm = e.alloc(N)
-            owned += [d_x] + d_t + ([d_sw] if has_sw else []) + [d_perm]
-        else:
-            d_x, d_t, d_sw = src_x, src_t, src_sw
-        rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
-        comm = dist.get()
-        world = comm.world if comm is not None else 1
-        # every rank walks its own shard; the global size of every step's batch is agreed ONCE per call, ranks whose
-        # shard is a batch shorter join the last collective with a zero gradient (distributed.plan_steps)
-        sizes, gsizes = dist.plan_steps(N, bs, comm, e)
-        e.reserve(max(sizes) if sizes else 1, self._n_tangents())
         try:
+            for cb in callbacks:
+                if hasattr(cb, "set_model"):
+                    cb.set_model(self)
+            for cb in callbacks:
+                if hasattr(cb, "on_train_begin"):
+                    cb.on_train_begin({})
+            # a shuffled epoch gathers the resident table into a second one on the device (4 bytes of permutation per row
+            # travel); when HBM has no room for the second copy the epoch is permuted on the host and uploaded instead
+            dev_shuffle = bool(shuffle) and N > 0
+            if dev_shuffle:
+                try:
+                    d_x = e.alloc(N * ncol); owned.append(d_x)
+                    d_t = []
+                    for w in widths:
+                        d_t.append(e.alloc(N * w)); owned.append(d_t[-1])
+                    d_sw = None
+                    if has_sw:
+                        d_sw = e.alloc(N); owned.append(d_sw)
+                    d_perm = e.alloc(N); owned.append(d_perm)
+                except _lib.NifError:
+                    if shard is not None:
+                        raise
+                    for arr in owned[1 + len(src_t) + (1 if has_sw else 0):]:
+                        arr.free()
+                    del owned[1 + len(src_t) + (1 if has_sw else 0):]
+                    dev_shuffle = False
+            if not dev_shuffle:
+                d_x, d_t, d_sw = src_x, src_t, src_sw
+            host_shuffle = bool(shuffle) and N > 0 and not dev_shuffle
+            rng = np.random.default_rng(getattr(self, "_shuffle_seed", None))
+            comm = dist.get()
+            world = comm.world if comm is not None else 1
+            # every rank walks its own shard; the global size of every step's batch is agreed ONCE per call, ranks whose
+            # shard is a batch shorter (or empty) join the collectives of the steps they lack with a zero gradient
+            sizes, gsizes = dist.plan_steps(N, bs, comm, e)
+            e.reserve(max(1, max(sizes, default=0)), self._n_tangents())
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
                     break
@@ -264,7 +295,7 @@ class Model(object):
                     if hasattr(cb, "on_epoch_begin"):
                         cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
-                if shuffle:
+                if dev_shuffle:
                     perm = rng.permutation(N).astype(np.int32)
                     d_perm.upload(perm.view(np.float32))
                     e.gather_rows(src_x, d_perm, N, ncol, d_x)
@@ -272,6 +303,14 @@ class Model(object):
                         e.gather_rows(st_, d_perm, N, w, dt)
                     if has_sw:
                         e.gather_rows(src_sw, d_perm, N, 1, d_sw)
+                elif host_shuffle:
+                    perm = rng.permutation(N)
+                    e.sync()                      # the previous epoch's steps have read the table
+                    src_x.upload(x[perm])
+                    for dt, t in zip(src_t, targets):
+                        dt.upload(t[perm])
+                    if has_sw:
+                        src_sw.upload(sw[perm])
                 adam = self.optimizer.as_struct()
                 e.metric_read(reset=True)
                 for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
@@ -464,8 +503,6 @@ class NIF(object):
                 self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
             if self._act_reg != (0.0, 0.0):
                 self.__engine.set_activity_regularizer(*self._act_reg)
-            if isinstance(self.p_jac_reg, (float, int)) and self.p_jac_reg:
-                self.__engine.set_jac_regularizer(self.p_jac_reg)     # build() of the reference wraps the model (model.py:353-375)
         return self.__engine
 
     def call(self, inputs, training=None, mask=None):
@@ -474,8 +511,10 @@ class NIF(object):
 
     def build(self):
         """model.py:345-377: with cfg_parameter_net['jac_reg'] the reference returns the model wrapped in JacRegLatentLayer
-        (same outputs, + l1 * mean((d latent / d parameter)^2) in the loss); here the engine carries the term."""
-        return self.model()
+        (same outputs, + l1 * mean((d latent / d parameter)^2) in the loss); here the returned Model carries l1 and hands it to
+        the engine when it trains or evaluates -- .model() and the sub-models stay without it, as in the reference."""
+        l1 = float(self.p_jac_reg) if isinstance(self.p_jac_reg, (float, int)) and not isinstance(self.p_jac_reg, bool) else 0.0
+        return Model(self, "full", jac_reg=l1)
 
     def model(self):
         """model.py:379-389"""

@@ -77,7 +77,11 @@ class OracleEngine(object):
         pass
 
     def reserve(self, b_max, n_tangents=0):
+        assert b_max >= 1, "nif_reserve rejects B_max <= 0"
         self.calls.append(("reserve", int(b_max)))
+
+    def set_jac_regularizer(self, l1):
+        assert l1 == 0.0, "the double has no latent Jacobian regulariser"
 
     def set_opt_state(self, m, v, step):
         self.m = np.asarray(m, dtype=np.float64).copy(); self.v = np.asarray(v, dtype=np.float64).copy(); self.t = int(step)
@@ -94,6 +98,19 @@ class OracleEngine(object):
         self.grad_buf[:-1] = O.flatten(grads); self.grad_buf[-1] = loss
         self.reg_applied = False
         self.calls.append(("loss_grad", int(b), int(bg)))
+
+    def loss_and_grad(self, inputs, y, sample_weight=None):
+        """nif_loss_and_grad: host arrays in, (loss incl. the weight-regulariser term, flat gradient) out"""
+        x = np.asarray(inputs, dtype=np.float64)[:, :self.o.pi + self.o.si]
+        sw = None if sample_weight is None else np.asarray(sample_weight, dtype=np.float64)
+        loss, grads = O.loss_and_grad(self.o, O.unflatten(self.o, self.theta), x, np.asarray(y, dtype=np.float64), sw)
+        g = O.flatten(grads)
+        l1, l2, lo, hi = self.reg
+        if l1 or l2:
+            w = self.theta[lo:hi]
+            g[lo:hi] += 2.0 * l2 * w + l1 * np.sign(w)
+            loss += l2 * np.sum(w * w) + l1 * np.sum(np.abs(w))
+        return float(loss), g
 
     def zero_grad(self):
         self.grad_buf[:] = 0.0
@@ -122,6 +139,9 @@ class OracleEngine(object):
 
     def sync(self):
         pass
+
+    def last_loss(self):
+        return float(self.grad_buf[-1])
 
 
 class GlooComm(object):
@@ -163,3 +183,24 @@ class GlooComm(object):
 
     def shutdown(self):
         pass
+
+
+def bench_double(points):
+    """NIF_BENCH_ENGINE=tests.doubles:bench_double -- what `bench.py` steps when the launcher / JSON contract is tested on a box
+    without a GPU: the benchmark model on the oracle engine, a gloo communicator when the launcher's environment names more than
+    one rank.  NIF_BENCH_DOUBLE_FAIL_RANK=r makes that rank die before it joins anything (the fast-failure test)."""
+    import os
+    import sys
+    import bench
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("NIF_BENCH_DOUBLE_FAIL_RANK") == str(rank):
+        sys.stderr.write("double: rank %d fails on purpose\n" % rank)
+        sys.exit(3)
+    comm = None
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("gloo")
+        comm = GlooComm()
+    spec = O.Spec("NIFMultiScale", bench.CFG_SHAPE, bench.CFG_PARAM)
+    ws = O.init_weights(spec, np.random.default_rng(1))
+    return OracleEngine(spec, ws), comm, (lambda engine, n: _HostArray(n))

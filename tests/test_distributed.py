@@ -108,6 +108,43 @@ def test_two_rank_fit_equals_global_batch_training(name, tmp_path):
     assert np.allclose(r0["loss"], losses, rtol=1e-9)
 
 
+def _worker_empty(rank, world, port, outdir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    import torch.distributed as td
+    td.init_process_group("gloo")
+    import nif_amd
+    from nif_amd import distributed as dist
+    from nif_amd.model import Model
+    from nif_amd.spec import Spec
+    from tests.doubles import GlooComm, OracleEngine
+    comm = dist.install(GlooComm())
+    kind, cs, cp, spec, ws, x, y, sw, reg = _problem("ms_plain")
+    eng = OracleEngine(spec, ws, reg)
+    model = Model(types.SimpleNamespace(_spec=Spec(kind, cs, cp), _engine=eng), "full")
+    model.compile(nif_amd.Adam(1e-2), "mse")
+    n = 40 if rank == 0 else 0                      # rank 1 has NO rows at all
+    h = model.fit(x[:n], y[:n], sample_weight=sw[:n], batch_size=BS, epochs=1, shuffle=True, verbose=0)
+    steps = [c[0] for c in eng.calls if c[0] in ("loss_grad", "zero_grad")]
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), theta=eng.theta, loss=np.array(h.history["loss"]), nred=comm.n_grad_reduces,
+             steps=np.array(steps), reserve=np.array([c[1] for c in eng.calls if c[0] == "reserve"]))
+    dist.shutdown()
+    td.destroy_process_group()
+
+
+def test_two_rank_fit_with_an_empty_shard(tmp_path):
+    """a rank without rows reserves a 1-row workspace, takes part in every step's all-reduce with a zero gradient
+    (which still carries the weight-regulariser term) and ends with the same replicated weights"""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_empty, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["nred"]) == int(r1["nred"]) == 3
+    assert list(r1["steps"]) == ["zero_grad"] * 3 and list(r0["steps"]) == ["loss_grad"] * 3
+    assert list(r1["reserve"]) == [1] and list(r0["reserve"]) == [16]
+    assert np.array_equal(r0["theta"], r1["theta"]) and np.array_equal(r0["loss"], r1["loss"])
+
+
 def test_plan_steps_single_process_and_shard_bounds():
     from nif_amd import distributed as dist
     assert dist.plan_steps(37, 16) == ([16, 16, 5], [16, 16, 5])
@@ -175,3 +212,44 @@ def test_rccl_id_rendezvous_through_files(tmp_path, monkeypatch):
     monkeypatch.setenv("NIF_COMM_TIMEOUT", "7")
     monkeypatch.setenv("MASTER_PORT", "1234")
     assert RcclComm(0, 2, 0, directory=d)._timeout == 7.0
+
+
+def _run_bench(extra_env, args, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIF_BENCH_ENGINE="tests.doubles:bench_double", PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+
+
+def test_bench_self_launch_two_ranks_prints_one_json_line():
+    """`python bench.py --gpus 2` (how a user, and the driver's N > 1 legs via torchrun, start it): two real processes, the
+    launcher's environment, ONE JSON line from rank 0 with the aggregate over both ranks -- on an engine double (CPU)."""
+    import json
+    pytest.importorskip("torch")
+    r = _run_bench({}, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "48", "--no-cpu-baseline", "--no-extras"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 96 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 96 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_self_launch_fails_fast_when_a_rank_dies_early():
+    """rank 1 exits before the rendezvous: rank 0 (blocked in the process-group handshake) is taken down within seconds and the
+    launcher returns rank 1's exit code, with the rank's stderr passed on under its prefix"""
+    import time
+    pytest.importorskip("torch")
+    t0 = time.time()
+    r = _run_bench({"NIF_BENCH_DOUBLE_FAIL_RANK": "1"},
+                   ["--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "48", "--no-cpu-baseline", "--no-extras"])
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 60
+    assert "[rank 1] double: rank 1 fails on purpose" in r.stderr and "stopping the other ranks" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip()]

@@ -1126,6 +1126,8 @@ def test_jac_reg_matches_oracle(name):
     ws = O.init_weights(spec, rng, dtype=np.float32)
     m = getattr(nif_amd, kind)(cs, cp2)
     model = m.build(); model.set_weights(ws)
+    assert model._jac_reg == l1 and m.model()._jac_reg == 0.0      # only build() wraps the model (model.py:353-375)
+    m._engine.set_jac_regularizer(l1)                              # what model.fit / model.evaluate do before they compute a loss
     ws64 = [w.astype(np.float64) for w in ws]
     for B, bg in ((333, 333), (64, 200)):
         x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
@@ -1150,5 +1152,9 @@ def test_jac_reg_matches_oracle(name):
         dj = (g.astype(np.float64) - gw)[:spec.n_params()]
         npn = sum(int(np.prod(s_)) for nm, s_ in spec.param_shapes() if nm.startswith("pnet_") and not nm.startswith("pnet_last"))
         assert _rel(dj[:npn], O.flatten(gj)[:npn]) < 2e-3 and abs((loss - lw) - lj) < 2e-4 * lj + 1e-7 * l0
+    # evaluate() = the total loss incl. the regulariser for build()'s model, without it for .model() (Keras: model.losses)
+    ev_b, ev_m = model.evaluate(x, y), m.model().evaluate(x, y)
+    lj_e, _ = O.jac_reg_loss_and_grad(spec, ws64, x.astype(np.float64)[:, :spec.pi], l1)
+    assert abs((ev_b - ev_m) - lj_e) < 2e-4 * lj_e + 1e-6 * ev_m
     model.compile(nif_amd.Adam(1e-3), "mse")
     assert np.isfinite(model.fit(x, y, epochs=2, batch_size=32, verbose=0).history["loss"]).all()
