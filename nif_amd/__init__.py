@@ -5,8 +5,8 @@ Drop-in for the point-wise training path of pswpswpsw/nif (`from nif import NIF`
 sub-model extractors, on hand-written HIP kernels behind a C-ABI (include/nif_hip.h)."""
 from .model import (NIF, NIFMultiScale, NIFMultiScaleLastLayerParameterized, Model, JacobianLayer,  # noqa: F401
                     HessianLayer, SobolevModel, set_seed)
-from . import optimizers, callbacks, distributed, data  # noqa: F401
+from . import optimizers, callbacks, distributed, data, layers, demo  # noqa: F401
 from .optimizers import Adam  # noqa: F401
 
 __all__ = ["NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized", "Model", "JacobianLayer", "HessianLayer", "SobolevModel", "Adam", "set_seed",
-           "optimizers", "callbacks", "distributed", "data"]
+           "optimizers", "callbacks", "distributed", "data", "layers", "demo"]

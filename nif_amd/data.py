@@ -340,3 +340,8 @@ class NPZShardDataset(object):
         if not isinstance(batch_file, Shard):
             raise TypeError("expected an element of the meta-dataset")
         return ShardBatches(batch_file, batch_size, shuffle)
+
+
+# `nif.data.TFRDataset` (tfr_dataset.py:22) under its reference name: same workflow, `.npz` column shards instead of TFRecords
+# (`get_tfr_meta_dataset` is kept as an alias of `get_meta_dataset`)
+TFRDataset = NPZShardDataset

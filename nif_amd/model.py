@@ -48,11 +48,26 @@ class Model(object):
         # in build() alone, model.py:353-375; .model() and the sub-models train / evaluate without it).  Pushed to the shared
         # engine whenever THIS model computes a loss.
         self._jac_reg = float(jac_reg or 0.0)
+        self._po_l1 = 0.0      # layers.ParameterOutputL1ActReg: l1 * sum |pnet_output| (un-normalised, regularization.py:28-30)
         self.optimizer = None
         self.loss = None
         self.stop_training = False
         self.history = None
         self._n_inputs = n_inputs
+
+
+    def _push_losses(self, e, bg):
+        """the loss terms THIS model adds on top of its owner's configuration, for a step / evaluation over bg rows"""
+        e.set_jac_regularizer(self._jac_reg)
+        if self._po_l1:
+            a1, a2 = getattr(self._owner, "_act_reg", (0.0, 0.0))
+            if a2:
+                raise NotImplementedError("ParameterOutputL1ActReg on a model configured with act_l2_reg")
+            e.set_activity_regularizer(a1 + self._po_l1 * float(bg), 0.0)     # the engine's term is c / B * sum |out|
+
+    def _pop_losses(self, e):
+        if self._po_l1:
+            e.set_activity_regularizer(*getattr(self._owner, "_act_reg", (0.0, 0.0)))
 
     # ---- weights ---------------------------------------------------------------------------------
     @property
@@ -166,12 +181,15 @@ class Model(object):
         x = np.asarray(x); n = x.shape[0]
         if n == 0:
             return 0.0
-        e.set_jac_regularizer(self._jac_reg)
         tot = 0.0
-        for lo in range(0, n, self._EVAL_CHUNK):
-            hi = min(n, lo + self._EVAL_CHUNK)
-            sw = None if sample_weight is None else np.asarray(sample_weight)[lo:hi]
-            tot += (hi - lo) * e.loss_and_grad(x[lo:hi], np.asarray(y)[lo:hi], sw)[0]
+        try:
+            for lo in range(0, n, self._EVAL_CHUNK):
+                hi = min(n, lo + self._EVAL_CHUNK)
+                sw = None if sample_weight is None else np.asarray(sample_weight)[lo:hi]
+                self._push_losses(e, hi - lo)
+                tot += (hi - lo) * e.loss_and_grad(x[lo:hi], np.asarray(y)[lo:hi], sw)[0]
+        finally:
+            self._pop_losses(e)
         return float(tot / n)
 
     # hooks the two-output Sobolev model overrides
@@ -208,7 +226,7 @@ class Model(object):
                                       % ", ".join(sorted(kwargs)))
         s = self._owner._spec
         e = self._engine
-        e.set_jac_regularizer(self._jac_reg)      # (raises here, not at first engine access, when the shape has no kernel for it)
+        self._push_losses(e, 1)                   # (raises here, not at first engine access, when the shape has no kernel for it)
         self.stop_training = False
         if getattr(self, "_fresh_slots", False):
             z = np.zeros((e.n_params,), dtype=np.float32)
@@ -315,6 +333,8 @@ class Model(object):
                 e.metric_read(reset=True)
                 for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
                     b0 = ib * bs
+                    if self._po_l1:
+                        self._push_losses(e, bg)
                     if b > 0:
                         self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * w) for dt, w in zip(d_t, widths)],
                                             d_sw.at(b0) if d_sw is not None else None, b, bg)
@@ -338,6 +358,7 @@ class Model(object):
                 if verbose:
                     print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
         finally:
+            self._pop_losses(e)
             if shard is not None:
                 shard.release(e)          # the slot's device buffers may be refilled once these steps have run
             e.sync()

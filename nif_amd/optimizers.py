@@ -155,8 +155,18 @@ class LBFGSMinimizer(object):
 
     def run(self, x, max_iter):
         """one tfp.optimizer.lbfgs_minimize call: fresh memory, up to max_iter iterations"""
-        f, g = self.fun(x)
-        S, Y = [], []
+        x, f, _, _ = self.run_resumable(x, max_iter, None)
+        return x, f
+
+    def run_resumable(self, x, max_iter, state):
+        """up to max_iter more iterations of a run whose correction pairs / last evaluation are carried in `state`
+        (lbfgs_minimize(previous_optimizer_results=...)) -> (x, f, state, iterations done)"""
+        if state is None:
+            f, g = self.fun(x)
+            S, Y = [], []
+        else:
+            f, g, S, Y = state
+        done = 0
         for _ in range(max_iter):
             if np.abs(g).max() <= self.TOLERANCE:
                 break
@@ -180,13 +190,14 @@ class LBFGSMinimizer(object):
             s_, y_ = p["a"] * d, p["g"] - g
             fprev = f
             x, f, g = x + s_, p["f"], p["g"]
+            done += 1
             if s_.dot(y_) > 0:
                 S.append(s_); Y.append(y_)
                 if len(S) > self.NUM_CORRECTION_PAIRS:
                     S.pop(0); Y.pop(0)
             if np.abs(s_).max() <= self.TOLERANCE or abs(fprev - f) <= self.TOLERANCE * abs(fprev):
                 break
-        return x, f
+        return x, f, (f, g, S, Y), done
 
 
 class TFPLBFGS(object):
@@ -248,3 +259,54 @@ class TFPLBFGS(object):
             x, _f = LBFGSMinimizer(self._f).run(x0, max_iter)
             e.set_flat(x.astype(np.float32))      # lbfgs.py:120 assign_new_model_parameters(results.position)
         return self.history
+
+
+class MSEClosure(object):
+    """What `LBFGSOptimizer` takes where the reference takes a Python function evaluated under a GradientTape
+    (lbfgs_V2.py:77-85: `loss_closure` = "the model's loss on the training table"): the model, its full-batch table and
+    optional sample weights -- resident in HBM once; calling it returns the current loss like the reference's closure does."""
+
+    def __init__(self, model, x, y, sample_weight=None):
+        self._t = TFPLBFGS(model, "mse", x, y, display_epoch=1 << 62, sample_weight=sample_weight)
+        self.model = model
+
+    def __call__(self):
+        e = self.model._engine
+        return self._t._f(e.get_flat().astype(self._t._np.float64))[0]
+
+
+class LBFGSOptimizer(object):
+    """nif/optimizers/lbfgs_V2.py:77-112: `opt = LBFGSOptimizer(loss_closure, trainable_variables, steps)`; every
+    `opt.minimize()` continues the SAME L-BFGS run for `steps` more iterations (previous_optimizer_results: the correction
+    pairs survive between calls, unlike TFPLBFGS); `.epoch` = iterations so far, `.loss` = the objective there.
+    `loss_closure` is an `MSEClosure`; `trainable_variables` is accepted for signature parity (it is always the model's
+    full variable list, which is what the reference passes)."""
+
+    def __init__(self, loss_closure, trainable_variables=None, steps=1):
+        if not isinstance(loss_closure, MSEClosure):
+            raise TypeError("LBFGSOptimizer(loss_closure=nif_amd.optimizers.MSEClosure(model, x, y), ...): a Python loss function "
+                            "cannot be differentiated here -- the closure names the model and its table, the HIP kernels do the rest")
+        self._c = loss_closure
+        self.steps = int(steps)
+        self._it = 0
+        self._loss = None
+        self._state = None
+
+    @property
+    def epoch(self):
+        return self._it
+
+    @property
+    def loss(self):
+        return self._loss
+
+    def minimize(self):
+        import numpy as np
+        t = self._c._t
+        e = self._c.model._engine
+        mz = LBFGSMinimizer(t._f)
+        x0 = e.get_flat().astype(np.float64)
+        x, f, self._state, done = mz.run_resumable(x0, self.steps, self._state)
+        self._it += done
+        self._loss = float(f)
+        e.set_flat(x.astype(np.float32))           # lbfgs_V2.py:112 assign(results.position)

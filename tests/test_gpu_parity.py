@@ -1101,6 +1101,39 @@ def test_activity_regularisers_match_oracle(name, which):
     assert np.isfinite(h.history["loss"]).all()
 
 
+def test_parameter_output_l1_act_reg_layer_matches_oracle():
+    """nif.layers.ParameterOutputL1ActReg (regularization.py:4-32): loss += l1 * ||pnet_output||_1 over the WHOLE batch tensor --
+    no division by the batch size -- through model.evaluate and one fit step (partial last batch: the term follows the batch)"""
+    import nif_amd
+    from nif_amd.layers import ParameterOutputL1ActReg
+    (kind, cs, cp), B = CONFIGS["ms_cfg2_64x4"]
+    B = 300
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    m = getattr(nif_amd, kind)(cs, cp)
+    base = m.build(); base.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    l1 = 3e-6
+    reg = ParameterOutputL1ActReg(base, l1=l1)
+    po = O.model_lr_to_w(spec, ws64, O.model_p_to_lr(spec, ws64, x[:, :spec.pi].astype(np.float64)))
+    l0 = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64))[0]
+    want = l0 + l1 * np.abs(po).sum()
+    assert l1 * np.abs(po).sum() > 1e-3 * l0
+    assert abs(reg.evaluate(x, y) - want) <= 2e-5 * want and abs(base.evaluate(x, y) - l0) <= 1e-5 * l0
+    # one epoch of two steps (200 + 100 rows) with a vanishing learning rate: the logged loss is the row-weighted mean of the batches' totals
+    reg.compile(nif_amd.Adam(1e-12), "mse")
+    h = reg.fit(x, y, epochs=1, batch_size=200, shuffle=False, verbose=0)
+    parts = []
+    for lo, hi in ((0, 200), (200, 300)):
+        lb = O.loss_and_grad(spec, ws64, x[lo:hi].astype(np.float64), y[lo:hi].astype(np.float64))[0]
+        parts.append((hi - lo) * (lb + l1 * np.abs(po[lo:hi]).sum()))
+    assert abs(h.history["loss"][0] - sum(parts) / B) <= 2e-5 * sum(parts) / B
+    assert abs(base.evaluate(x, y) - l0) <= 1e-5 * l0           # the owner's configuration is restored
+
+
 # ---- latent Jacobian regulariser (N3; reference model.py:353-375, gradient.py:52-127) ------------------------------------------
 JAC = {
     "nif_swish_pi2": _cfg("NIF", 32, 2, 32, 2, 2, 1, 1, 2),
