@@ -987,6 +987,126 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     return loss, core + [g_last_w, gw.sum(0)], u, J
 
 
+def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, rnd=None):
+    """The Sobolev step of NIF / NIFMultiScale with COORDINATE columns in x_index, in the plane formulation the kernel executes
+    (k_sob):  h_q W(a) = sum_k (zt_k h_q) M^(k)  for the primal (q = 0) and every tangent stream.  rnd=None: exact --
+    equal to sobolev_loss_and_grad (tests/test_oracle.py pins 1e-10), a second independent restatement.  rnd=bf16_round: the
+    build's mixed_bfloat16 policy as k_sob<..., BF = 2> applies it: in the forward sweep the operands (zt_k h_q) and (w0 M^(k)) of
+    every hidden n x n product are rounded to bfloat16 -- the latent factor is applied BEFORE the rounding there, unlike the plain
+    step (planes_loss_and_grad), which scales the product; in the data adjoint dL/da (and nu^d = mu^d c) and (w0 M^(k)) are rounded;
+    first / last layer, biases, activations, loss, the dz dot products and the weight-gradient sums stay in full precision.
+    Returns (loss, grads in Keras order, u, dudx)."""
+    assert spec.kind in (KIND_NIF, KIND_MS)
+    R = (lambda a: a) if rnd is None else rnd
+    nif = spec.kind == KIND_NIF
+    B = inputs.shape[0]
+    Bg = B if batch_global is None else batch_global
+    si, so, n = spec.si, spec.so, spec.n
+    om = 1.0 if nif else spec.omega_s
+    f_, df_ = act_fn(spec.s_act if nif else "sine")
+    d2f_ = act_d2(spec.s_act if nif else "sine")
+    x_index = list(x_index)
+    assert all(spec.pi <= j < spec.pi + si for j in x_index), "coordinate columns only"
+    seeds = [j - spec.pi for j in x_index]
+    nx = len(seeds)
+    p = inputs[:, :spec.pi]
+    x = inputs[:, spec.pi:spec.pi + si]
+    _, z, ptape = pnet_forward(spec, ws, p, keep=True)
+    last = _pnet_split(spec, ws)[3]
+    M = np.vstack([last[0], last[1][None, :]])          # [(r+1), po]
+    zt = np.hstack([z, np.ones((B, 1), dtype=z.dtype)])
+    K = spec.r + 1
+    sl = spec.slices()
+    mat = lambda k, ab, shape: M[k, ab[0]:ab[1]].reshape(shape)
+    vec = lambda k, ab: M[k, ab[0]:ab[1]]
+    ztk = lambda k: zt[:, k:k + 1]
+    nh = spec.n_hidden_mats
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    a = sum(ztk(k) * (om * (x @ mat(k, sl["w1"], (si, n))) + vec(k, sl["b1"])[None, :]) for k in range(K))
+    ad = [sum(ztk(k) * (om * mat(k, sl["w1"], (si, n))[sd][None, :]) for k in range(K)) for sd in seeds]
+    tape = []
+
+    def act(a_, ad_):
+        return f_(a_), df_(a_), -d2f_(a_), [df_(a_) * v for v in ad_]
+    t, cs, sn, td = act(a, ad)
+    tape.append((x, None, sn, cs, ad))
+    h, hd = t, td
+    blk = None
+    for l in range(nh):
+        ab = sl["wh"][l]
+        a = sum(R(ztk(k) * h) @ R(om * mat(k, ab, (n, n))) for k in range(K)) + sum(ztk(k) * vec(k, sl["bh"][l])[None, :] for k in range(K))
+        ad = [sum(R(ztk(k) * v) @ R(om * mat(k, ab, (n, n))) for k in range(K)) for v in hd]
+        t, cs, sn, td = act(a, ad)
+        tape.append((h, hd, sn, cs, ad))
+        if nif:
+            h, hd = t + h, [v + u0 for v, u0 in zip(td, hd)]
+        elif spec.s_res:
+            if l % 2 == 0:
+                blk = (h, hd); h, hd = t, td
+            else:
+                h = 0.5 * (blk[0] + t); hd = [0.5 * (u0 + v) for u0, v in zip(blk[1], td)]
+        else:
+            h, hd = t, td
+    u = sum(ztk(k) * (h @ mat(k, sl["wl"], (n, so)) + vec(k, sl["bl"])[None, :]) for k in range(K))
+    ud = [sum(ztk(k) * (v @ mat(k, sl["wl"], (n, so))) for k in range(K)) for v in hd]
+    J = np.stack(ud, axis=2)
+    # ---- loss --------------------------------------------------------------------------------------------------------
+    w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
+    e = u - y
+    ej = J - np.asarray(dydx).reshape(B, so, nx)
+    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
+    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    # ---- adjoint -----------------------------------------------------------------------------------------------------
+    gM = np.zeros_like(M)
+    gzt = np.zeros_like(zt)
+    for k in range(K):
+        Wl = mat(k, sl["wl"], (n, so))
+        gM[k, sl["wl"][0]:sl["wl"][1]] += ((ztk(k) * h).T @ g_u + sum((ztk(k) * v).T @ g for v, g in zip(hd, g_ud))).ravel()
+        gM[k, sl["bl"][0]:sl["bl"][1]] += (ztk(k) * g_u).sum(0)
+        gzt[:, k] += ((h @ Wl + vec(k, sl["bl"])[None, :]) * g_u).sum(1) + sum(((v @ Wl) * g).sum(1) for v, g in zip(hd, g_ud))
+    lam = sum(ztk(k) * (g_u @ mat(k, sl["wl"], (n, so)).T) for k in range(K))
+    mu = [sum(ztk(k) * (g @ mat(k, sl["wl"], (n, so)).T) for k in range(K)) for g in g_ud]
+    skip = None
+    for l in reversed(range(nh)):
+        hin, hdin, sn, cs, ad = tape[l + 1]
+        if spec.s_res and l % 2 == 1:
+            lam = 0.5 * lam; mu = [0.5 * m for m in mu]; skip = (lam, mu)
+        if nif:
+            skip = (lam, mu)
+        nu = [m * cs for m in mu]
+        da = lam * cs
+        for m, v in zip(mu, ad):
+            da = da - m * sn * v
+        ab = sl["wh"][l]
+        for k in range(K):
+            gM[k, ab[0]:ab[1]] += (om * ((ztk(k) * hin).T @ da + sum((ztk(k) * v).T @ g for v, g in zip(hdin, nu)))).ravel()
+            gM[k, sl["bh"][l][0]:sl["bh"][l][1]] += (ztk(k) * da).sum(0)
+            gzt[:, k] += da @ vec(k, sl["bh"][l])
+        U = [[R(v) @ R(om * mat(k, ab, (n, n))).T for k in range(K)] for v in [da] + nu]       # U[q][k]
+        for k in range(K):
+            gzt[:, k] += (hin * U[0][k]).sum(1) + sum((v * U[1 + q][k]).sum(1) for q, v in enumerate(hdin))
+        lam = sum(ztk(k) * U[0][k] for k in range(K))
+        mu = [sum(ztk(k) * U[1 + q][k] for k in range(K)) for q in range(nx)]
+        if nif or (spec.s_res and l % 2 == 0):
+            lam = lam + skip[0]; mu = [m + s_ for m, s_ in zip(mu, skip[1])]
+    _, _, sn, cs, ad = tape[0]
+    nu = [m * cs for m in mu]
+    da = lam * cs
+    for m, v in zip(mu, ad):
+        da = da - m * sn * v
+    for k in range(K):
+        W1 = mat(k, sl["w1"], (si, n))
+        g1 = (ztk(k) * x).T @ da
+        for sd, g in zip(seeds, nu):
+            g1[sd] += (ztk(k) * g).sum(0)
+        gM[k, sl["w1"][0]:sl["w1"][1]] += (om * g1).ravel()
+        gM[k, sl["b1"][0]:sl["b1"][1]] += (ztk(k) * da).sum(0)
+        gzt[:, k] += ((om * (x @ W1) + vec(k, sl["b1"])[None, :]) * da).sum(1) + sum((om * W1[sd][None, :] * g).sum(1) for sd, g in zip(seeds, nu))
+    grads = pnet_backward(spec, ws, ptape, None, g_z_extra=gzt[:, :spec.r], g_last=[gM[:spec.r], gM[spec.r]])
+    return loss, grads, u, J
+
+
 def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
     """Sobolev step of the last-layer-parameterised class (model.py:1044-1068, :1219-1269 under JacobianLayer): the shared
     SIREN ShapeNet x -> phi [B,so,r] carries the coordinate tangents phi'_d (_mlp_tangents), u = Dot(phi, a) + bias and

@@ -63,6 +63,7 @@ CONFIGS = {
     # builds disagreed on the tile stride there and produced wrong ShapeNet weight gradients without any error
     "ms_96x2_r2": (_cfg("NIFMultiScale", 96, 2, 32, 1, 2, 2, 1, 1), 77),
     "ms_res_80x1_so2": (_cfg("NIFMultiScale", 80, 1, 32, 1, 1, 2, 2, 1, s_res=True), 140),
+    "ms_res_64x2": (_cfg("NIFMultiScale", 64, 2, 32, 2, 2, 2, 1, 1, s_res=True), 150),
     "nif_80x2_swish_r2": (_cfg("NIF", 80, 2, 32, 2, 2, 1, 1, 1, act="swish"), 100),
     # whole fp32 planes + the (r+1) copies of the small vectors exceed the LDS: the bf16-split kernel (chunked planes) still takes it
     "ms_res_128x4_r4_so2": (_cfg("NIFMultiScale", 128, 4, 32, 2, 4, 1, 2, 2, s_res=True), 97),
@@ -231,9 +232,13 @@ def test_loss_and_grad_match_oracle(name, weighted):
 
 
 def test_adam_steps_follow_oracle():
+    """three full-batch Adam steps.  lr = 2e-4: with w0 = 30 the loss surface is rough enough that at lr = 2e-3 the SECOND step's
+    gradient already differs by several per cent between an fp32 and an fp64 trajectory (r3: one entry 6 % off after three steps
+    although its first gradient agreed to four digits); the step itself is pinned to 2e-5 by smoke() and the 200-step test"""
     import nif_amd
+    LR = 2e-4
     m, model, spec, ws, x, y, sw = _make("ms_cfg2_64x4")
-    model.compile(nif_amd.Adam(learning_rate=2e-3), loss="mse")
+    model.compile(nif_amd.Adam(learning_rate=LR), loss="mse")
     hist = model.fit(x, y, epochs=3, batch_size=x.shape[0], shuffle=False, verbose=0)
     th = O.flatten(ws)
     mm = np.zeros_like(th); vv = np.zeros_like(th)
@@ -250,14 +255,14 @@ def test_adam_steps_follow_oracle():
             rms = np.sqrt(np.mean(gt ** 2)) + 1e-300
             solid[off:off + gt.size] &= np.abs(gt.ravel()) > 0.02 * rms
             off += gt.size
-        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=2e-3)
+        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=float(np.float32(LR)))
     got = O.flatten(model.get_weights())
     assert np.allclose(hist.history["loss"], losses, rtol=2e-4)
     # Adam normalises the step to ~lr, so compare the displacement: 5 % of the three steps where the gradient entry is solid
     # (the bulk), and nowhere more than a sign flip of one of the three steps would explain
     assert solid.mean() > 0.8
-    assert np.abs(got - th)[solid].max() < 0.05 * 2e-3 * 3
-    assert np.abs(got - th).max() < 0.4 * 2e-3 * 3
+    assert np.abs(got - th)[solid].max() < 0.05 * LR * 3
+    assert np.abs(got - th).max() < 0.4 * LR * 3
 
 
 def test_fit_batches_partial_last_batch_and_sample_weight():
@@ -763,14 +768,18 @@ def test_full_size_shard_sum_other_configs(which):
     assert np.linalg.norm(acc[:-1] - full[:-1]) < 2e-5 * np.linalg.norm(full[:-1])
     ws64 = [w.astype(np.float64) for w in ws]
     n_s = 2048
+    bf = which.endswith("bf16")
     if xi:
-        lref = O.sobolev_loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64),
-                                       gt[:n_s].astype(np.float64), xi, 0.1)[0]
-        got = grad_of(0, n_s, n_s)[-1]
+        # under the policy: the oracle that rounds where k_sob<..., BF = 2> rounds (sobolev_planes_loss_and_grad)
+        lref, gref = O.sobolev_planes_loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64),
+                                                    gt[:n_s].astype(np.float64), xi, 0.1, rnd=O.bf16_round if bf else None)[:2]
     else:
-        lref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))[0]
-        got = grad_of(0, n_s, n_s)[-1]
-    assert abs(got - lref) < (2e-2 if which.endswith("bf16") else 2e-5) * abs(lref), (got, lref)   # bf16 policy: its own distance
+        lref, gref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))
+    sub = grad_of(0, n_s, n_s)
+    assert abs(sub[-1] - lref) < (5e-4 if bf else 2e-5) * abs(lref), (sub[-1], lref)
+    if xi:
+        rel = _per_tensor_rel(spec, sub[:-1], O.flatten(gref))
+        assert max(rel.values()) < (3e-3 if bf else 3e-4), rel
     d_x.free(); d_y.free()
     if d_g is not None:
         d_g.free()
@@ -991,15 +1000,47 @@ def test_mixed_bfloat16_training_and_sobolev_step():
     xi = [1, 2]
     gt = np.random.default_rng(3).uniform(-1, 1, size=(x.shape[0], 1, 2)).astype(np.float32)
     loss, grad = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.05, sw)
-    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), gt.astype(np.float64), xi, 0.05,
-                                             sw.astype(np.float64))
-    assert abs(loss - rl) < 2e-2 * abs(rl), (loss, rl)
-    assert _rel(grad, O.flatten(rg)) < 0.2
+    x64, y64, g64, s64 = x.astype(np.float64), y.astype(np.float64), gt.astype(np.float64), sw.astype(np.float64)
+    # cast for cast: the oracle's plane formulation rounds (zt_k h_q), (w0 M^(k)), dL/da and nu^d where
+    # k_sob<..., BF = 2> rounds them; same bars as the plain step under the policy
+    pl, pg, pu, pJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.05, s64, rnd=O.bf16_round)
+    assert abs(loss - pl) <= 5e-4 * abs(pl), (loss, pl)
+    rel = _per_tensor_rel(spec, grad, O.flatten(pg))
+    assert max(rel.values()) < 3e-3, rel
+    u_p, J_p = m._engine.sobolev_forward(x, xi)
+    # (a 1e-7 difference of an fp32 operand flips a bf16 rounding now and then: 2^-9 of that element)
+    assert _rel(u_p, pu) < 1e-3 and _rel(J_p.reshape(pJ.shape), pJ) < 2e-3, (_rel(u_p, pu), _rel(J_p.reshape(pJ.shape), pJ))
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.05, s64)
+    assert 1e-5 * abs(rl) < abs(pl - rl) < 5e-2 * abs(rl)          # the policy's own distance from exact arithmetic
     m32, model32, *_ = _make_policy("ms_cfg5_64x4_si2", "float32")
     l32, g32 = m32._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.05, sw)
     assert abs(l32 - rl) < 2e-5 * abs(rl) and loss != l32          # the policy really changes the arithmetic
     with pytest.raises(NotImplementedError):
         nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
+
+
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_res_64x2", "ms_64x2_r1_so4", "ll_plain_32x2_r3"])
+def test_sobolev_step_under_the_policy_cast_for_cast(name):
+    """configs[4] beyond its own shape: class NIF (skip connections, swish), a resblock net, several outputs -- the Sobolev
+    step under mixed_bfloat16 against the oracle that rounds where k_sob<..., BF = 2> rounds (5e-4 loss / predictions, 3e-3 per
+    gradient tensor); the last-layer class keeps exact products in k_sob<LL> under the policy: held to the exact
+    oracle at the float32 bars"""
+    (kind, cs, cp), _ = CONFIGS[name]
+    m, model, spec, ws, x, y, sw = _make_policy(name, "mixed_bfloat16")
+    x, y, sw = x[:200], y[:200], sw[:200]
+    xi = list(range(spec.pi, spec.pi + spec.si))[:2]
+    gt = np.random.default_rng(5).uniform(-1, 1, size=(x.shape[0], spec.so, len(xi))).astype(np.float32)
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.1, sw)
+    x64, y64, g64, s64 = x.astype(np.float64), y.astype(np.float64), gt.astype(np.float64), sw.astype(np.float64)
+    if spec.kind == O.KIND_LL:
+        rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.1, s64)
+        bar_l, bar_g = 2e-5, 3e-4
+    else:
+        rl, rg, ru, rJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.1, s64, rnd=O.bf16_round)
+        bar_l, bar_g = 5e-4, 3e-3
+    assert abs(loss - rl) <= bar_l * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, grad, O.flatten(rg))
+    assert max(rel.values()) < bar_g, rel
 
 
 # ---- HessianLayer (N3; reference gradient.py:130-180) ------------------------------------------------------------------------

@@ -287,3 +287,28 @@ def test_activity_regulariser_matches_torch_autograd(name, which):
     assert abs(loss - tl.item()) <= 1e-12 * max(1.0, abs(tl.item()))
     for (nm, _), g, t in zip(spec.param_shapes(), grads, tg):
         assert np.abs(g - t.numpy()).max() / max(np.abs(t.numpy()).max(), 1e-30) < 1e-9, nm
+
+
+@pytest.mark.parametrize("name", [k for k, v in ALL_SMALL.items() if v[0] in ("NIF", "NIFMultiScale")])
+def test_sobolev_plane_formulation_equals_the_materialised_one(name):
+    """sobolev_planes_loss_and_grad (what k_sob executes; carries the mixed_bfloat16 emulation of configs[4]) == the reference
+    formulation sobolev_loss_and_grad to 1e-10 in exact mode, for one and two coordinate columns; under rnd=bf16_round it is a
+    DIFFERENT computation (1e-4 .. 1e-2 away) with a finite, non-degenerate gradient"""
+    kind, cs, cp = ALL_SMALL[name]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng)
+    B = 19
+    x = rng.uniform(-1, 1, (B, spec.pi + spec.si)); y = rng.uniform(-1, 1, (B, spec.so)); sw = rng.uniform(0.5, 1.5, (B,))
+    for xi in ([spec.pi], list(range(spec.pi, spec.pi + spec.si))[:2]):
+        dy = rng.uniform(-1, 1, (B, spec.so, len(xi)))
+        l0, g0, u0, j0 = O.sobolev_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31)
+        l1, g1, u1, j1 = O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31)
+        assert abs(l0 - l1) <= 1e-12 * abs(l0) and np.abs(u0 - u1).max() < 1e-12 and np.abs(j0 - j1).max() < 1e-10
+        f0, f1 = O.flatten(g0), O.flatten(g1)
+        assert np.abs(f0 - f1).max() <= 1e-10 * np.abs(f0).max()
+        l2, g2, _, _ = O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31, rnd=O.bf16_round)
+        d = np.linalg.norm(O.flatten(g2) - f0) / np.linalg.norm(f0)
+        assert 1e-5 < d < 5e-2 and np.isfinite(l2)
+    with pytest.raises(AssertionError):
+        O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, [0], 0.3)        # parameter columns: the materialised form has them
