@@ -216,12 +216,12 @@ int nif_set_regularizer(nif_ctx* ctx, float l1, float l2, int64_t lo, int64_t hi
 /* Latent Jacobian regulariser cfg_parameter_net["jac_reg"] (nif/model.py:353-375 wraps the model in JacRegLatentLayer,
  * nif/layers/gradient.py:52-127): loss += l1 * mean_{a,c,d} (d latent_c / d parameter_d)^2, differentiated through the
  * Jacobian: forward tangents of the ParameterNet + their adjoint (k_pjac), weight gradients by the batch GEMM kernels over
- * tangent pseudo-tiles.  All three classes; ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs. */
+ * tangent pseudo-tiles.  All three classes; at most 3 parameter inputs (pi_dim <= 3). */
 int nif_set_jac_regularizer(nif_ctx* ctx, float l1);
 /* Activity regulariser of cfg_parameter_net["act_l1_reg"/"act_l2_reg"] (nif/model.py:118-125: Keras activity_regularizer
  * L2(l2) or else L1(l1) on the last ParameterNet layer, :226, :659, :731): loss += c / B * sum_a sum_i phi(pnet_out[a, i]),
  * phi = (.)^2 or |.|, Keras dividing the activity loss by the batch size.  pnet_out [B, po] is never materialised: two
- * passes recompute it on the fly (k_actreg_*; latent_dim <= 8).  On the last-layer class pnet_out is the small [B, latent_dim]
+ * passes recompute it on the fly (k_actreg_*; latent_dim <= 64).  On the last-layer class pnet_out is the small [B, latent_dim]
  * tensor itself: one pass (k_ll_actreg). */
 int nif_set_activity_regularizer(nif_ctx* ctx, float l1, float l2);
 /* Keras' epoch loss metric without a host sync per batch: sum += weight * grad[P], count += weight (device side) */

@@ -27,6 +27,10 @@ struct JacArgs {
   float* dydx;                // [B][so][nx_total]
   // HessianLayer launches (k_jac<..., HESS>): seeds 0, 1 = the coordinate pair at x positions (hj, hk); stream 2 -> d2[B][so][nx][nx]
   int hj, hk; float* d2ydx2;
+  // 1: ONE plane buffer in LDS instead of two (shapes whose small hyper-vectors leave no room for the second 64-KB plane of a
+  // 128-wide net: latent_dim >= 4 with many matrices).  The next plane still travels through registers while the current one
+  // is multiplied; it lands after an extra barrier.  Slower, but the derivative layers never refuse a shape the step trains.
+  int one_buf;
 };
 
 // HESS (HessianLayer, gradient.py:130-180, :234-261): streams 0 and 1 are the first-order tangents of two coordinate seeds
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 
   f32x4* planes = reinterpret_cast<f32x4*>(smem);
-  float* sm = smem + 2 * PLANE;
+  const int one_buf = J.one_buf;
+  float* sm = smem + (one_buf ? 1 : 2) * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   float* zs = sm + sm_tot + (long)wid * ((1 + NIF_JAC_MAXSEED) * r * 16);
   float* zds = zs + r * 16;   // [seed][r][16]: dz_k/dp for parameter seeds (0 for coordinate seeds)
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
           for (int q = 0; q < PF4; ++q)
             if (PEXACT || tid + NT * q < PLANE / 4) pre[q] = src[tid + NT * q];
         }
-        const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);
+        const f32x4* cur = planes + (one_buf ? 0 : (gpar & 1)) * (PLANE / 4);
         const float zt = k < r ? zt_base[k * 16] : 1.0f;
         if (anyp && k < r) {
           // parameter seeds need the unscaled partial product T_k = h . M^(k)
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? 2 : 1)) void k_jac(JacArgs J) {
             }
           }
         if (has_next) {
-          f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);
+          if (one_buf) __syncthreads();     // every wave is done with the plane that is about to be overwritten
+          f32x4* dst = planes + (one_buf ? 0 : ((gpar + 1) & 1)) * (PLANE / 4);
 #pragma unroll
           for (int q = 0; q < PF4; ++q)
             if (PEXACT || tid + NT * q < PLANE / 4) dst[tid + NT * q] = pre[q];
@@ -351,6 +357,14 @@ void launch_hess(const SNetArgs& a, int seed_j, int seed_k, int hj, int hk, int 
   J.ZD[0] = seed_j < 0 ? zd_j : nullptr; J.ZD[1] = seed_k < 0 ? zd_k : nullptr; J.ZD[2] = zdd;
   launch_jac_impl(J, true, st);
 }
+// shapes the Jacobian / Hessian kernels take: one 16-point-tile plane (and the small hyper-vectors) must fit the LDS
+bool jac_supported(const SNetArgs& a) {
+  if (a.n > 128) return false;
+  const int NBL = snet3_nbl(a.n);
+  const size_t plane = (size_t)NBL * NBL * 256;
+  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  return (plane + sm_tot + 4 * (size_t)(1 + NIF_JAC_MAXSEED) * a.r * 16 + 8) * sizeof(float) <= 160u * 1024u;
+}
 static void launch_jac_impl(JacArgs& J, bool hess, hipStream_t st) {
   const SNetArgs& a = J.s;
   const int NBL = snet3_nbl(a.n);
@@ -360,7 +374,9 @@ static void launch_jac_impl(JacArgs& J, bool hess, hipStream_t st) {
   dim3 grid((unsigned)(ngroups < cap ? ngroups : cap)), block(256);
   const size_t plane = (size_t)NBL * NBL * 256;
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  const size_t shm = (2 * plane + sm_tot + 4 * (size_t)(1 + NIF_JAC_MAXSEED) * a.r * 16 + 8) * sizeof(float);
+  const size_t rest = sm_tot + 4 * (size_t)(1 + NIF_JAC_MAXSEED) * a.r * 16 + 8;
+  J.one_buf = (2 * plane + rest) * sizeof(float) > 160u * 1024u ? 1 : 0;
+  const size_t shm = ((J.one_buf ? 1 : 2) * plane + rest) * sizeof(float);
 #define JL(NBL_, ACT_, MODE_)                                                                                        \
   {                                                                                                                  \
     if (hess) {                                                                                                      \

@@ -564,28 +564,28 @@ void launch_gather_rows(const float* src, const int* perm, long n, int ncol, flo
 //                     partial[slab][k][i] = sum_{a in slab} phi'(out_ai) zt_k(a)           (-> k_actreg_apply adds c/B * sum)
 // Cost 4 (r+1) po flop per point (67 kflop at 4x64): an optional regulariser, not the benchmark path.
 // ============================================================================================
-#define NIF_ACT_MAXR 8
-template <bool L1>
+// MAXR: register / LDS vectors sized for latent_dim <= 8 (the common case) or <= 64 (everything nif_create accepts; r3)
+template <bool L1, int MAXR>
 __global__ __launch_bounds__(256) void k_actreg_points(const float* __restrict__ theta, long off_W, long off_b, int r, long po,
                                                        const float* __restrict__ Z, long B, float coef, float* __restrict__ DZ,
                                                        float* __restrict__ loss_partial) {
   __shared__ float red[256];
   const long a = (long)blockIdx.x * 256 + threadIdx.x;
-  float zt[NIF_ACT_MAXR], dz[NIF_ACT_MAXR];
+  float zt[MAXR], dz[MAXR];
   const bool ok = a < B;
   const long tile = a >> 5; const int pp = (int)(a & 31);
 #pragma unroll
-  for (int k = 0; k < NIF_ACT_MAXR; ++k) { zt[k] = (ok && k < r) ? Z[(tile * r + k) * 32 + pp] : 0.f; dz[k] = 0.f; }
+  for (int k = 0; k < MAXR; ++k) { zt[k] = (ok && k < r) ? Z[(tile * r + k) * 32 + pp] : 0.f; dz[k] = 0.f; }
   float acc = 0.f;
   for (long i = 0; i < po; ++i) {
     float out = theta[off_b + i];
 #pragma unroll
-    for (int k = 0; k < NIF_ACT_MAXR; ++k)
+    for (int k = 0; k < MAXR; ++k)
       if (k < r) out = fmaf(zt[k], theta[off_W + (long)k * po + i], out);
     const float d = L1 ? (out > 0.f ? 1.f : (out < 0.f ? -1.f : 0.f)) : 2.0f * out;
     acc += L1 ? fabsf(out) : out * out;
 #pragma unroll
-    for (int k = 0; k < NIF_ACT_MAXR; ++k)
+    for (int k = 0; k < MAXR; ++k)
       if (k < r) dz[k] = fmaf(d, theta[off_W + (long)k * po + i], dz[k]);
   }
   if (ok)
@@ -598,19 +598,19 @@ __global__ __launch_bounds__(256) void k_actreg_points(const float* __restrict__
   }
   if (threadIdx.x == 0) loss_partial[blockIdx.x] = coef * red[0];
 }
-template <bool L1>
+template <bool L1, int MAXR>
 __global__ __launch_bounds__(256) void k_actreg_planes(const float* __restrict__ theta, long off_W, long off_b, int r, long po,
                                                        const float* __restrict__ Z, long B, long slab, float* __restrict__ part) {
-  __shared__ float zs[NIF_ACT_MAXR * 256];
+  __shared__ float zs[MAXR * 256];
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long a0 = (long)blockIdx.y * slab, a1 = a0 + slab < B ? a0 + slab : B;
-  float m[NIF_ACT_MAXR + 1], g[NIF_ACT_MAXR + 1];
+  float m[MAXR + 1], g[MAXR + 1];
 #pragma unroll
-  for (int k = 0; k <= NIF_ACT_MAXR; ++k) { m[k] = 0.f; g[k] = 0.f; }
+  for (int k = 0; k <= MAXR; ++k) { m[k] = 0.f; g[k] = 0.f; }
   if (i < po) {
 #pragma unroll
-    for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) m[k] = theta[off_W + (long)k * po + i];
-    m[NIF_ACT_MAXR] = theta[off_b + i];
+    for (int k = 0; k < MAXR; ++k) if (k < r) m[k] = theta[off_W + (long)k * po + i];
+    m[MAXR] = theta[off_b + i];
   }
   for (long c0 = a0; c0 < a1; c0 += 256) {
     __syncthreads();
@@ -619,19 +619,19 @@ __global__ __launch_bounds__(256) void k_actreg_planes(const float* __restrict__
     __syncthreads();
     const int cnt = (int)(a1 - c0 < 256 ? a1 - c0 : 256);
     for (int q = 0; q < cnt; ++q) {
-      float out = m[NIF_ACT_MAXR];
+      float out = m[MAXR];
 #pragma unroll
-      for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) out = fmaf(zs[k * 256 + q], m[k], out);
+      for (int k = 0; k < MAXR; ++k) if (k < r) out = fmaf(zs[k * 256 + q], m[k], out);
       const float d = L1 ? (out > 0.f ? 1.f : (out < 0.f ? -1.f : 0.f)) : 2.0f * out;
 #pragma unroll
-      for (int k = 0; k < NIF_ACT_MAXR; ++k) if (k < r) g[k] = fmaf(d, zs[k * 256 + q], g[k]);
-      g[NIF_ACT_MAXR] += d;
+      for (int k = 0; k < MAXR; ++k) if (k < r) g[k] = fmaf(d, zs[k * 256 + q], g[k]);
+      g[MAXR] += d;
     }
   }
   if (i < po) {
     float* row = part + (long)blockIdx.y * (r + 1) * po;
     for (int k = 0; k < r; ++k) row[(long)k * po + i] = g[k];
-    row[(long)r * po + i] = g[NIF_ACT_MAXR];
+    row[(long)r * po + i] = g[MAXR];
   }
 }
 // g[hyper kernel rows | hyper bias] += coef * sum over slabs (fixed order); g[P] += sum of the loss partials
@@ -658,19 +658,29 @@ __global__ __launch_bounds__(256) void k_actreg_apply(const float* __restrict__ 
     if (threadIdx.x == 0) g[P] += red[0];
   }
 }
-int actreg_max_r() { return NIF_ACT_MAXR; }
+int actreg_max_r() { return 64; }
 void launch_actreg_points(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, float coef,
                           float* DZ, float* loss_partial, hipStream_t st) {
   dim3 grid((unsigned)((B + 255) / 256)), block(256);
-  if (l1) hipLaunchKernelGGL(k_actreg_points<true>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
-  else hipLaunchKernelGGL(k_actreg_points<false>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+  if (r <= 8) {
+    if (l1) hipLaunchKernelGGL((k_actreg_points<true, 8>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+    else hipLaunchKernelGGL((k_actreg_points<false, 8>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+  } else {
+    if (l1) hipLaunchKernelGGL((k_actreg_points<true, 64>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+    else hipLaunchKernelGGL((k_actreg_points<false, 64>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, coef, DZ, loss_partial);
+  }
 }
 void launch_actreg_planes(bool l1, const float* theta, long off_W, long off_b, int r, long po, const float* Z, long B, int nslab,
                           float* part, hipStream_t st) {
   const long slab = ((B + nslab - 1) / nslab + 255) / 256 * 256;
   dim3 grid((unsigned)((po + 255) / 256), (unsigned)nslab), block(256);
-  if (l1) hipLaunchKernelGGL(k_actreg_planes<true>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
-  else hipLaunchKernelGGL(k_actreg_planes<false>, grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+  if (r <= 8) {
+    if (l1) hipLaunchKernelGGL((k_actreg_planes<true, 8>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+    else hipLaunchKernelGGL((k_actreg_planes<false, 8>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+  } else {
+    if (l1) hipLaunchKernelGGL((k_actreg_planes<true, 64>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+    else hipLaunchKernelGGL((k_actreg_planes<false, 64>), grid, block, 0, st, theta, off_W, off_b, r, po, Z, B, slab, part);
+  }
 }
 void launch_actreg_apply(const float* part, int nslab, int r, long po, float coef, long off_W, long off_b, const float* loss_partial,
                          int nloss, float* g, long P, hipStream_t st) {

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
   const long tile = pta >> 5; const int pp = (int)(pta & 31);
   const int pi = A.pi, nst = A.nst, lst = A.lst, r = A.r, res = A.res;
   const int nm = lst * (res ? 2 : 1);
-  const int FP = ((nst + 31) / 32) * 32;
+  const int FP = stash_fp(nst);           // feature rows of a stash tile as the gradient kernels read them (32, 64 or 128)
   const float s = A.siren ? A.omega : 1.0f;
   const int act = A.siren ? ACT_SINE : A.act;
   const float* th = A.theta;
@@ -303,12 +303,15 @@ void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st)
   const long ntiles = (a.B + 31) / 32;
   const int nblk = (int)((ntiles * 32 + 127) / 128);
   if (a.nst <= 32) hipLaunchKernelGGL((k_pjac2<32>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
-  else hipLaunchKernelGGL((k_pjac2<64>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
+  else if (a.nst <= 64) hipLaunchKernelGGL((k_pjac2<64>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
+  else hipLaunchKernelGGL((k_pjac2<128>), dim3(nblk), dim3(128), 0, st, a, cj, ck, ZDD);
 }
 
 bool pjac_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
-  return a.nst <= 64 && nm <= 4 && a.pi <= NIF_PJ_MAXPI;     // (first / hidden / bottleneck only: the same for every class)
+  // (first / hidden / bottleneck only: the same for every class).  r3: every ParameterNet width / depth the engine accepts --
+  // the 128-unit instantiation keeps its per-thread vectors in scratch (a scalar kernel for optional terms: slow, never refused)
+  return a.nst <= 128 && nm <= NIF_MAX_HID && a.pi <= NIF_PJ_MAXPI;
 }
 static int launch_pjac_any(const PJacArgs& J, hipStream_t st);
 int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st) {
@@ -336,6 +339,7 @@ static int launch_pjac_any(const PJacArgs& J, hipStream_t st) {
   const PNetArgs& a = J.p;
   const int nblk = (int)((a.B + 127) / 128);
   if (a.nst <= 32) hipLaunchKernelGGL((k_pjac<32>), dim3(nblk), dim3(128), 0, st, J);
-  else hipLaunchKernelGGL((k_pjac<64>), dim3(nblk), dim3(128), 0, st, J);
+  else if (a.nst <= 64) hipLaunchKernelGGL((k_pjac<64>), dim3(nblk), dim3(128), 0, st, J);
+  else hipLaunchKernelGGL((k_pjac<128>), dim3(nblk), dim3(128), 0, st, J);
   return nblk;
 }

@@ -17,18 +17,22 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const bool two = slim && (NBL <= 2 || ns == 1);
   const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
-  {   // LDS the launch below will ask for (same arithmetic): -1 = does not fit one CU, the caller refuses the shape
+  int one_buf = 0;
+  {   // LDS the launch below will ask for (same arithmetic).  Two plane buffers when they fit, else ONE (r3: the derivative layers
+      // must not refuse a shape the plain step trains); -1 = even that does not fit one CU, the caller refuses the shape
     const bool bfq = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
     const size_t planeq = bfq ? (size_t)(NBL / 2) * NBL * 3 * 64 * 4 : (size_t)NBL * NBL * 256;
     const size_t smq = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
     size_t npwq = 1;
     if (par && !a.ll) for (int d = 0; d < ns; ++d) npwq += par->par[d] >= 0;
-    size_t need = (2 * planeq + smq + 4 * npwq * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
-    if (a.ll) {
-      const size_t llwq = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16;
-      if (need + 4 * llwq * sizeof(float) > 160u * 1024u && 4 * llwq > planeq) need += 4 * llwq * sizeof(float);
+    const size_t restq = (smq + 4 * npwq * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
+    const size_t llwq = a.ll ? (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16 : 0;
+    size_t need = 2 * planeq * sizeof(float) + restq;
+    if (a.ll && need + 4 * llwq * sizeof(float) > 160u * 1024u && 4 * llwq > planeq) need += 4 * llwq * sizeof(float);
+    if (need > 160u * 1024u) {
+      one_buf = 1;      // (the last-layer epilogue's scratch then needs LDS of its own: there is no idle plane buffer)
+      if (planeq * sizeof(float) + restq + 4 * llwq * sizeof(float) > 160u * 1024u) return -1;
     }
-    if (need > 160u * 1024u) return -1;
   }
   if (query_only) return nblk;
   SobArgs J;
@@ -39,7 +43,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     J.par[d] = (par && d < ns) ? par->par[d] : -1;
   }
   J.ZT = par ? par->ZT : nullptr; J.DZT = par ? par->DZT : nullptr;
-  J.npar = 0; J.nx_tot = ns; J.DAT = nullptr; J.ZTL = nullptr; J.zl_rows = 0;
+  J.npar = 0; J.nx_tot = ns; J.DAT = nullptr; J.ZTL = nullptr; J.zl_rows = 0; J.one_buf = one_buf;
   for (int d = 0; d < NIF_SOB_MAXSEED; ++d) { J.parc[d] = 0; J.pcol[d] = 0; }
   if (a.ll && par) {       // last-layer class: parameter columns are heads of the epilogue, not streams
     J.npar = par->npar; J.nx_tot = ns + par->npar; J.DAT = par->DAT; J.ZTL = par->ZTL; J.zl_rows = par->zl_rows;
@@ -54,12 +58,12 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   size_t npw = 1;
   if (any_par) for (int d = 0; d < ns; ++d) npw += J.par[d] >= 0;
-  const size_t shm = (2 * plane + sm_tot + 4 * npw * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
+  const size_t shm = ((one_buf ? 1 : 2) * plane + sm_tot + 4 * npw * (size_t)(a.r * 64 + a.r * 16) + 8) * sizeof(float);
   J.ll_plane = 0;
   if (a.ll) {
     const size_t llw = (size_t)(2 * a.rl + (1 + NIF_SOB_MAXSEED) * (a.so + a.so_u) + NIF_SOB_MAXSEED * (2 * a.rl + a.so_u)) * 16;
     size_t shm_ll = shm + 4 * llw * sizeof(float);
-    if (shm_ll > 160u * 1024u && 4 * llw <= plane) { J.ll_plane = 1; shm_ll = shm; }   // scratch in the idle plane buffer
+    if (!one_buf && shm_ll > 160u * 1024u && 4 * llw <= plane) { J.ll_plane = 1; shm_ll = shm; }   // scratch in the idle plane buffer
     launch_sob_ll(J, train, bf, nblk, shm_ll, st);
     return nblk;
   }

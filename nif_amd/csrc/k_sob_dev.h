@@ -48,6 +48,8 @@ struct SobArgs {
   int pcol[NIF_SOB_MAXSEED];    // column of gt / JU that head e fills
   float* DAT;                   // [npar][tiles][rl][32]
   float* ZTL; int zl_rows;      // [npar][tiles][zl_rows][32]
+  int one_buf;                  // 1: ONE plane buffer in LDS (shapes where two do not fit next to the small hyper-vectors): the next
+                                // plane's DMA starts after the barrier behind the current plane's products, and is waited for
 };
 
 // parameter-seed instantiations (k_sob_par.hip)
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 
   f32x4* planes = reinterpret_cast<f32x4*>(smem);
-  float* sm = smem + 2 * PLANE;
+  const int one_buf = J.one_buf;
+  float* sm = smem + (one_buf ? 1 : 2) * PLANE;
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   // PAR: the per-wave (dL/dzt, zt) block once more per PARAMETER stream (they are the last npar of the ns streams)
   int nsc = ns;
@@ -174,22 +177,26 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
   float* IN0 = A.stash;
   float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
 
-#define SOB_PLANE(...)                                                                        \
-  {                                                                                           \
-    if ((pl + 1 < nplanes) || !last_group) {                                                  \
+#define SOB_DMA_(DST_)                                                                         \
+    {                                                                                         \
       const int nxt_ = pl + 1 < nplanes ? pl + 1 : 0;                                         \
       const f32x4* src = plane_src(nxt_);                                                     \
       const int nu_ = plane_units(nxt_);                                                      \
-      f32x4* dst = planes + ((gpar + 1) & 1) * (PLANE / 4);                                   \
+      f32x4* dst = (DST_);                                                                    \
       _Pragma("unroll") for (int q = 0; q < PF4; ++q)                                         \
         if (wid * 64 + NT * q < nu_)                                                          \
           __builtin_amdgcn_global_load_lds(                                                   \
               (const __attribute__((address_space(1))) void*)(src + tid + NT * q),            \
               (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);  \
-    }                                                                                         \
-    const f32x4* cur = planes + (gpar & 1) * (PLANE / 4);                                     \
+    }
+#define SOB_PLANE(...)                                                                        \
+  {                                                                                           \
+    const bool has_next_ = (pl + 1 < nplanes) || !last_group;                                 \
+    if (has_next_ && !one_buf) SOB_DMA_(planes + ((gpar + 1) & 1) * (PLANE / 4))              \
+    const f32x4* cur = planes + (one_buf ? 0 : (gpar & 1)) * (PLANE / 4);                     \
     __VA_ARGS__                                                                               \
     __syncthreads();                                                                          \
+    if (has_next_ && one_buf) { SOB_DMA_(planes) __syncthreads(); }                           \
     ++gpar; ++pl;                                                                             \
   }
 #define ZERO4(x) { (x)[0] = 0.f; (x)[1] = 0.f; (x)[2] = 0.f; (x)[3] = 0.f; }

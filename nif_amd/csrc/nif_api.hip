@@ -483,12 +483,13 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
 static int ensure_packed32(nif_ctx* c) {
   if (c->packed32 || c->kind == NIF_KIND_LASTLAYER) return NIF_OK;
   ProfScope ps_(c, NIF_PROF_PACK);
-  const long plane_s = c->use_snet3 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
+  const bool fmt16 = c->use_snet3 || c->jac_ok;     // 16-point-tile plane format (k_snet3, k_jac, k_sob) / 32-point (k_snet)
+  const long plane_s = fmt16 ? snet3_plane_floats(c->n) / 4 : (long)c->NB * c->NB * 256;
   for (int j = 0; j < c->nh; ++j) {
     const long slot = (long)c->si * c->n + (long)j * c->n * c->n;
     f32x4* wf = c->sWF + (long)j * (c->r + 1) * plane_s;
     f32x4* wb = c->sWB + (long)j * (c->r + 1) * plane_s;
-    if (c->use_snet3) launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
+    if (fmt16) launch_pack16(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), snet3_nbl(c->n), wf, wb, c->st);
     else launch_pack(c->theta, hyper_ref(c, slot, c->n, c->n, c->n), c->NB, c->NB, wf, wb, c->st);
   }
   HIPCHK(hipGetLastError());
@@ -566,6 +567,7 @@ static int ensure_packed(nif_ctx* c) {
   }
   SNetArgs probe; fill_snet(c, probe, nullptr, 0, 0, 32);
   c->use_snet3 = snet3_supported(probe);
+  c->jac_ok = jac_supported(probe);       // (a superset: one plane buffer when two do not fit)
   // NIF_FP32_MFMA=1 in the environment keeps every product on the f32-input MFMAs (k_snet3) for A/B runs
   const bool fp32_only = c->opt_fp32_mfma;
   // (the bf16-split kernel streams its planes in chunks: it also takes the shapes whose whole fp32 planes do not fit the LDS --
@@ -648,7 +650,7 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   rc = ensure_packed32(c); if (rc) return rc;
   rc = ensure_packed_p32(c); if (rc) return rc;
   const bool ll = c->kind == NIF_KIND_LASTLAYER;
-  if (!ll && !c->use_snet3) return fail(NIF_ERR_INVALID, "JacobianLayer needs the 16-point-tile path (units <= 128, small latent)");
+  if (!ll && !c->jac_ok) return fail(NIF_ERR_INVALID, "JacobianLayer: one weight plane and the small hyper-vectors of this shape exceed the 160 KB LDS of a CU");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   const long ntiles = (B + 31) / 32;
   const int ncol = c->pi + c->si;
@@ -733,7 +735,7 @@ extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_
   float* zdd = nullptr;
   if (anyp) {
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+      return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
     const long need_zt = (long)c->pi * ntl * 32 * c->r, need_dd = ntl * 32 * c->r;
     if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
     if (need_dd > c->dzt_par_cap) { rc = grow(&c->dzt_par, &c->dzt_par_cap, need_dd); if (rc) return rc; }
@@ -824,7 +826,7 @@ extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_
     return NIF_OK;
   }
   rc = ensure_packed32(c); if (rc) return rc;
-  if (!c->use_snet3) return fail(NIF_ERR_INVALID, "HessianLayer needs the 16-point-tile path (units <= 128, small latent)");
+  if (!c->jac_ok) return fail(NIF_ERR_INVALID, "HessianLayer: one weight plane and the small hyper-vectors of this shape exceed the 160 KB LDS of a CU");
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
   rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * c->so * nx * nx); if (rc) return rc;
@@ -1331,15 +1333,15 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   const long ntiles = (B + 31) / 32;
   if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
   if (ns > 0) {
-    if (c->kind != NIF_KIND_LASTLAYER && !c->use_snet3)
-      return fail(NIF_ERR_INVALID, "Sobolev training is built for the 16-point-tile path (units <= 128)");
+    if (c->kind != NIF_KIND_LASTLAYER && !c->jac_ok)
+      return fail(NIF_ERR_INVALID, "Sobolev training: one weight plane and the small hyper-vectors of this shape exceed the 160 KB LDS of a CU");
     if (c->cfg.s_resblock && (c->nh & 1)) return fail(NIF_ERR_INVALID, "resblock ShapeNet with an odd matrix count");
   }
   rc = ensure_capacity(c, ntiles * 32 * (1 + ns), true); if (rc) return rc;
   if (sp && sp->any_par) {   // z' = dz/dp of the parameter columns, in front of the ShapeNet
     PNetArgs pa; fill_pnet(c, pa, xin, B);
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
     const long need_zt = (long)c->pi * ntiles * 32 * c->r, need_dzt = 3 * ntiles * 32 * c->r;
     if (need_zt > c->zt_par_cap || need_dzt > c->dzt_par_cap) HIPCHK(hipStreamSynchronize(c->st));
     if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
@@ -1473,8 +1475,8 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
-  if (c->kind != NIF_KIND_LASTLAYER && !c->use_snet3)
-    return fail(NIF_ERR_INVALID, "Sobolev path is built for the 16-point-tile path (units <= 128)");
+  if (c->kind != NIF_KIND_LASTLAYER && !c->jac_ok)
+    return fail(NIF_ERR_INVALID, "Sobolev path: one weight plane and the small hyper-vectors of this shape exceed the 160 KB LDS of a CU");
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   launch_pnet(pa, c->NSTB, false, c->st);
@@ -1483,7 +1485,7 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   if (c->kind == NIF_KIND_LASTLAYER) {
     if (sp.any_par) {       // parameter columns: heads of the epilogue on z' = dz/dp
       if (!pjac_supported(pa))
-        return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+        return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
       const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
       if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
       launch_pjac_fwd(pa, c->zt_par, c->st);
@@ -1500,7 +1502,7 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   }
   if (sp.any_par) {
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
     const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
     if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
     launch_pjac_fwd(pa, c->zt_par, c->st);
@@ -1530,7 +1532,7 @@ extern "C" int nif_set_jac_regularizer(nif_ctx* c, float l1) {
   if (!c || l1 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
   if (l1 != 0.f) {
     PNetArgs pa; fill_pnet(c, pa, nullptr, 32);
-    if (!pjac_supported(pa)) return fail(NIF_ERR_INVALID, "jac_reg: ParameterNet units <= 64, <= 4 hidden matrices, <= 3 parameter inputs");
+    if (!pjac_supported(pa)) return fail(NIF_ERR_INVALID, "jac_reg: at most 3 parameter inputs (pi_dim <= 3)");
   }
   c->jac_l1 = l1;
   return NIF_OK;
@@ -1639,7 +1641,7 @@ static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const Sob
 // Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)
 extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
   if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
-  if ((l1 != 0.f || l2 != 0.f) && c->kind != NIF_KIND_LASTLAYER && c->r > actreg_max_r()) return fail(NIF_ERR_INVALID, "activity regularisers: latent_dim <= 8");
+  if ((l1 != 0.f || l2 != 0.f) && c->kind != NIF_KIND_LASTLAYER && c->r > actreg_max_r()) return fail(NIF_ERR_INVALID, "activity regularisers: latent_dim <= 64");
   c->act_l1 = l2 != 0.f ? 0.f : l1; c->act_l2 = l2;
   return NIF_OK;
 }

@@ -179,6 +179,7 @@ int snet3_nbl(int n);
 int snet3_nsm(int si, int so, int nh, int n);
 long snet3_plane_floats(int n);
 long snet3_ring_floats_per_wave(int n, int nh);
+bool jac_supported(const SNetArgs& a);      // JacobianLayer / HessianLayer: wider than snet3_supported (single plane buffer when needed)
 void launch_jac(const SNetArgs& a, int ns, const int* seeds, const float* const* zd, int nx_total, int x0, float* dydx,
                 hipStream_t st);
 // seed_j / seed_k: coordinate index, or -1 for a parameter column (then zd_j / zd_k = dz/dp of that column [tiles][r][32], and

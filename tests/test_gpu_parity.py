@@ -1043,6 +1043,90 @@ def test_sobolev_step_under_the_policy_cast_for_cast(name):
     assert max(rel.values()) < bar_g, rel
 
 
+# ---- round 3: the derivative layers and the optional regularisers take every shape the plain step trains ----------------------
+WIDE = {
+    # 128 units, 6 matrices, latent_dim 5: two fp32 planes + the small hyper-vectors exceed 160 KB of LDS -> single plane buffer
+    "ms_128x6_r5_si2": _cfg("NIFMultiScale", 128, 6, 32, 2, 5, 2, 1, 1),
+    # ParameterNet 96 units / 5 hidden matrices, two parameter inputs: k_pjac<128>, nm > 4
+    "ms_64x2_pnet96x5_pi2": _cfg("NIFMultiScale", 64, 2, 96, 5, 2, 1, 1, 2, p_act="tanh"),
+}
+
+
+def test_derivative_layers_take_wide_nets_with_larger_latents():
+    """JacobianLayer / HessianLayer / the Sobolev step on a shape whose two weight-plane buffers do not fit
+    the LDS next to the small hyper-vectors (r2: refused) -- one plane buffer instead; against the oracle at the usual bars"""
+    import nif_amd
+    kind, cs, cp = WIDE["ms_128x6_r5_si2"]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    m = getattr(nif_amd, kind)(cs, cp)
+    model = m.build(); model.set_weights(ws)
+    ws64 = [w.astype(np.float64) for w in ws]
+    B = 150
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    xi = [1, 2]
+    yv, J = nif_amd.JacobianLayer(model, [0], xi)(x)
+    ur, Jr = O.jacobian_analytic(spec, ws64, x64, [0], xi)
+    assert _rel(yv, ur) < 1e-5 and _rel(J, Jr) < 2e-5, (_rel(yv, ur), _rel(J, Jr))
+    yv, J2, H = nif_amd.HessianLayer(model, [0], xi)(x)
+    _, _, Hr = O.hessian_analytic(spec, ws64, x64, [0], xi)
+    assert _rel(H, Hr) < 1e-4, _rel(H, Hr)
+    gt = rng.uniform(-1, 1, size=(B, 1, 2)).astype(np.float32)
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.1, None)
+    rl, rg, _, _ = O.sobolev_loss_and_grad(spec, ws64, x64, y.astype(np.float64), gt.astype(np.float64), xi, 0.1)
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, grad, O.flatten(rg))
+    assert max(rel.values()) < 3e-4, rel
+
+
+def test_parameter_column_terms_take_wide_deep_parameter_nets():
+    """k_pjac / k_pjac2 beyond 64 units and 4 hidden matrices (r2: refused): latent Jacobian regulariser, Hessian and Sobolev
+    step with parameter columns on a 96 x 5 ParameterNet with two inputs; activity regulariser at latent_dim 12"""
+    import nif_amd
+    kind, cs, cp = WIDE["ms_64x2_pnet96x5_pi2"]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(1)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    l1 = 0.05
+    m = getattr(nif_amd, kind)(cs, dict(cp, jac_reg=l1))
+    model = m.build(); model.set_weights(ws)
+    B = 130
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    m._engine.set_jac_regularizer(l1)
+    loss, g = m._engine.loss_and_grad(x, y)
+    l0, g0 = O.loss_and_grad(spec, ws64, x64, y64)
+    lj, gj = O.jac_reg_loss_and_grad(spec, ws64, x64[:, :spec.pi], l1)
+    assert lj > 1e-6 * l0 and abs(loss - (l0 + lj)) <= 1e-5 * (l0 + lj), (loss, l0, lj)
+    rel = _per_tensor_rel(spec, g, O.flatten(g0) + O.flatten(gj))
+    assert max(rel.values()) < 3e-4, rel
+    m._engine.set_jac_regularizer(0.0)
+    xa = [0, 1, 2]                                     # both parameter columns and the coordinate
+    yv, J, H = nif_amd.HessianLayer(model, [0], xa)(x)
+    ur, Jr, Hr = O.hessian_analytic(spec, ws64, x64, [0], xa)
+    assert _rel(J, Jr) < 2e-5 and _rel(H, Hr) < 1e-4, (_rel(J, Jr), _rel(H, Hr))
+    gt = rng.uniform(-1, 1, size=(B, 1, 2)).astype(np.float32)
+    ls, gs = m._engine.sobolev_loss_and_grad(x, y, gt, [0, 2], 0.1, None)
+    rl, rg, _, _ = O.sobolev_loss_and_grad(spec, ws64, x64, y64, gt.astype(np.float64), [0, 2], 0.1)
+    assert abs(ls - rl) <= 2e-5 * abs(rl)
+    assert max(_per_tensor_rel(spec, gs, O.flatten(rg)).values()) < 3e-4
+    # activity regulariser at latent_dim 12 (r2: <= 8)
+    kind2, cs2, cp2 = _cfg("NIFMultiScale", 32, 2, 32, 1, 12, 1, 1, 1)
+    spec2 = O.Spec(kind2, cs2, cp2)
+    ws2 = O.init_weights(spec2, rng, dtype=np.float32)
+    m2 = getattr(nif_amd, kind2)(cs2, dict(cp2, act_l2_reg=2e-3))
+    model2 = m2.build(); model2.set_weights(ws2)
+    x2 = rng.uniform(-1, 1, size=(B, spec2.pi + spec2.si)).astype(np.float32)
+    l2, g2 = m2._engine.loss_and_grad(x2, y)
+    r2l, r2g = O.loss_and_grad(spec2, [w.astype(np.float64) for w in ws2], x2.astype(np.float64), y64, act_reg=(0.0, 2e-3))
+    assert abs(l2 - r2l) <= 1e-5 * abs(r2l) and max(_per_tensor_rel(spec2, g2, O.flatten(r2g)).values()) < 3e-4
+
+
 # ---- HessianLayer (N3; reference gradient.py:130-180) ------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["nif_cfg1_32x2", "nif_pad_n30_tanh_r2_so2", "ms_cfg2_64x4", "ms_64x2_mlp_pnet_r3", "ms_res_48x2_pres",
                                   "ms_cfg5_64x4_si2", "ms_cfg3_128x3", "ms_32x2_r7_si3", "ms_96x2_r2", "ll_plain_32x2_r3",

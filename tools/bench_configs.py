@@ -42,6 +42,32 @@ WORK = {
 }
 
 
+def roofline(s, B, ns, policy, snet_ms):
+    """the bench line's roofline block for any config (bench.py): the fused ShapeNet kernel's own algorithmic HBM bytes (stash rows
+    written + re-read, x (1 + ns) streams for a Sobolev step), the bf16 flops it executes, fractions of 8 TB/s / 2.5 PFLOP/s, and
+    SURVEY 8d's fp32-equivalent figure against the 157.3 TF peak as a secondary key"""
+    if snet_ms <= 0:
+        return None
+    n, nh = s.n_sx, s.n_hidden_mats
+    planes = 1 if s.connectivity == "last_layer" else s.pi_hidden + 1
+    fp = 32 if n <= 32 else (64 if n <= 64 else 128)
+    stash = 4.0 * fp * (2 * (nh + 1) + nh) * (1 + ns) * B
+    so_eff = s.so_dim * (s.pi_hidden if s.connectivity == "last_layer" else 1)
+    n_w = s.si_dim * n + nh * n * n + n * so_eff
+    flop32 = 4.0 * planes * n_w * (1 + ns) * B                     # forward + data adjoint, fp32-equivalent
+    prod = 2.0 if policy == "mixed_bfloat16" else 9.0              # bf16 products per fp32 product: 6 forward + 3 adjoint (1 + 1)
+    nbl_even = (((n + 15) // 16) % 2) == 0 and n > 16
+    exec16 = prod * 2.0 * planes * nh * n * n * (1 + ns) * B if nbl_even else 0.0
+    t = snet_ms * 1e-3
+    hbm, mf = stash / t / 1e9, exec16 / t / 1e12
+    bound = "hbm" if hbm / 8000.0 >= mf / 2500.0 else "mfma"
+    return {"kernel": "fused ShapeNet kernel (k_snet4 / k_sob)", "bound": bound, "achieved": round(hbm if bound == "hbm" else mf, 2),
+            "peak": 8000.0 if bound == "hbm" else 2500.0, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": round(max(hbm / 8000.0, mf / 2500.0), 4), "avg_ms": snet_ms, "stash_GBs": round(hbm, 1),
+            "executed_bf16_TFLOPs": round(mf, 1), "fp32_equiv_TFLOPs": round(flop32 / t / 1e12, 1),
+            "frac_of_fp32_mfma_peak_157": round(flop32 / t / 1e12 / 157.3, 4), "traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -95,6 +121,7 @@ def main():
         rec = {"points": B, "ms_per_step": round(msstep, 4), "Mpts_per_s": round(B / msstep / 1e3, 2),
                "params": int(e.n_params),
                "kernel_ms": {k: round(v[0] / a.steps, 4) for k, v in prof.items() if v[1] > 0}}
+        rec["roofline"] = roofline(m._spec, B, len(xi) if xi else 0, policy, rec["kernel_ms"].get("snet", 0.0))
         if name.startswith("cfg2"):
             # the same step when the boundary hands over HOST buffers (nif_train_step: H2D of x, y + step + loss readback)
             import time
@@ -112,6 +139,30 @@ def main():
         if d_g is not None:
             d_g.free()
         e.close()
+    if not a.only or "cfg0" in a.only:
+        # configs[0]: tutorial 1 -- NIF 2x32 + 2x32, the 10k-point lattice of SURVEY 8d, Model.fit with batch 512, 20 steps per epoch
+        import time
+        nif_amd.set_seed(0)
+        cs = {"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+        cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+        m = nif_amd.NIF(cs, cp)
+        model = m.build()
+        model.compile(nif_amd.Adam(1e-3), "mse")
+        t = np.repeat(np.linspace(0, 90, 50), 200); xx = np.tile(np.arange(200) * 0.005, 50)
+        raw = np.stack([t, xx, nif_amd.data.traveling_wave(t, xx, 4.0)], axis=1)
+        data, _, _ = nif_amd.data.PointWiseData.standard_normalize(raw)
+        x0, y0 = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
+        model.fit(x0, y0, epochs=2, batch_size=512, verbose=0)
+        t0 = time.perf_counter()
+        ep = 10
+        model.fit(x0, y0, epochs=ep, batch_size=512, verbose=0)
+        dt = time.perf_counter() - t0
+        nsteps = ep * ((x0.shape[0] + 511) // 512)
+        rec = {"points": int(x0.shape[0]), "batch": 512, "us_per_step": round(dt / nsteps * 1e6, 1), "Mpts_per_s": round(ep * x0.shape[0] / dt / 1e6, 2),
+               "params": int(m._engine.n_params), "roofline": None,
+               "note": "launch-bound (13 kernels x 4-8 us of launch-and-drain per step, DESIGN 5.2): no roofline applies at 512 points per step"}
+        out["cfg0_tutorial1_fit_10k_b512"] = rec
+        print("cfg0_tutorial1_fit_10k_b512", json.dumps(rec), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -15,11 +15,11 @@ from tests.test_gpu_parity import _cfg, _rel      # noqa: E402
 def draw(rng):
     kind = rng.choice(["NIF", "NIFMultiScale", "LL"], p=[0.25, 0.45, 0.3])
     n = int(rng.choice([8, 16, 24, 30, 32, 40, 48, 56, 64, 72, 80, 96, 100, 112, 128]))
-    L = int(rng.integers(1, 5))
-    nst = int(rng.choice([6, 16, 20, 32, 40, 64]))
-    lst = int(rng.integers(1, 3))
-    r = int(rng.integers(1, 5)) if kind != "LL" else int(rng.integers(1, 9))
-    si = int(rng.integers(1, 4)); so = int(rng.integers(1, 4)); pi = int(rng.integers(1, 3))
+    L = int(rng.integers(1, 7))
+    nst = int(rng.choice([6, 16, 20, 32, 40, 64, 96, 128]))
+    lst = int(rng.integers(1, 6))
+    r = int(rng.integers(1, 9))       # (r3: latent_dim up to 8 on every class -- with 128 units the single-plane-buffer kernels)
+    si = int(rng.integers(1, 4)); so = int(rng.integers(1, 4)); pi = int(rng.integers(1, 4))
     s_res = bool(rng.integers(0, 2)) and kind != "NIF"
     p_res = bool(rng.integers(0, 2)) and kind != "NIF"
     p_act = str(rng.choice(["sine", "swish", "tanh"]))
@@ -27,6 +27,9 @@ def draw(rng):
     if kind == "LL" and so * r > 32:
         r = max(1, 32 // so)
     B = int(rng.choice([1, 31, 33, 64, 97, 130, 257, 515, 1031, 4099]))
+    po = (L * (2 if s_res else 1)) * n * n + (si + so + 1 + L * (2 if s_res else 1)) * n + so
+    if kind != "LL":
+        B = max(1, min(B, int(3e7 // po)))          # the oracle materialises [B, po] tensors
     if kind == "NIF":
         cfg = _cfg("NIF", n, L, nst, lst, r, si, so, pi, act=act)
     else:
