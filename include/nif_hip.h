@@ -172,6 +172,12 @@ int nif_jacobian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* 
  * parameter derivatives. */
 int nif_hessian(nif_ctx* ctx, const float* xin_host, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
                 int32_t nx, float* y_out, float* dydx_out, float* d2ydx2_out);
+/* The same with device pointers (inputs [B, pi+si] and the three outputs resident in HBM; y_idx / x_idx are host arrays): the
+ * row gather and, for the last-layer class, the contraction with the ParameterNet output run in kernels on the context's stream;
+ * nothing is copied to the host and no host loop runs over the points (a PDE residual over 10^6 collocation points,
+ * gradient.py:234-261).  Asynchronous: nif_sync() before the results are read by anyone else.  ny <= 16. */
+int nif_hessian_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
+                    int32_t nx, float* y_dev, float* dydx_dev, float* d2ydx2_dev);
 
 /* ---- training ------------------------------------------------------------------------- */
 /* Keras train_step body without the update: loss = mse(y, model(x), sample_weight) and

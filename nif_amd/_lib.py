@@ -83,6 +83,7 @@ SIGNATURES = {
     "nif_x_to_phi": (C.c_int, [_CTX, _VP, C.c_int64, _VP]),
     "nif_jacobian": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_hessian": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _VP, _VP, _VP]),
+    "nif_hessian_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _VP, _VP, _VP]),
     "nif_latent_to_w": (C.c_int, [_CTX, _VP, C.c_int64, _VP]),
     "nif_latent_to_w_dev": (C.c_int, [_CTX, _VP, C.c_int64, _VP]),
     "nif_shapenet_given_w": (C.c_int, [_CTX, _VP, _VP, C.c_int64, _VP]),

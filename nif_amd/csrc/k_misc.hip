@@ -749,3 +749,95 @@ __global__ void k_axpy_cols(float* __restrict__ g, const float* __restrict__ tmp
 void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st) {
   hipLaunchKernelGGL(k_axpy_cols, dim3((unsigned)((ncols + 1 + 255) / 256)), dim3(256), 0, st, g, tmp, ncols, P);
 }
+
+// ============================================================================================
+// HessianLayer epilogues on the device (r3; r2 gathered / contracted on the host).
+//   k_hess_gather   NIF / NIFMultiScale: rows y_idx of the kernels' [B][so][nx] / [B][so][nx][nx] results -> [B][ny][nx] / [B][ny][nx][nx]
+//   k_through_lw    last-layer class: a' = z' last_w for a stack of latent-layout vectors (z' = dz/dp_j, z'' = d2z/dp_j dp_k)
+//   k_ll_hess       last-layer class: u = phi.a + bias; the coordinates only move phi, the parameters only move a:
+//                   du/dx = phi'_x.a, du/dp = phi.a'_p, d2u/dx dx' = phi''.a, d2u/dx dp = phi'_x.a'_p, d2u/dp dp' = phi.a''
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_hess_gather(const float* __restrict__ fj, const float* __restrict__ fh, long B, int so, int nx,
+                                                     HessIdx I, float* __restrict__ dydx, float* __restrict__ d2) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;      // (point, i)
+  if (e >= B * I.ny) return;
+  const long a = e / I.ny; const int i = (int)(e - a * I.ny);
+  const long src = a * so + I.y_idx[i];
+  for (int j = 0; j < nx; ++j) {
+    dydx[e * nx + j] = fj[src * nx + j];
+    for (int k = 0; k < nx; ++k) d2[(e * nx + j) * nx + k] = fh[(src * nx + j) * nx + k];
+  }
+}
+void launch_hess_gather(const float* fj, const float* fh, long B, int so, int nx, const HessIdx& I, float* dydx, float* d2, hipStream_t st) {
+  hipLaunchKernelGGL(k_hess_gather, dim3((unsigned)((B * I.ny + 255) / 256)), dim3(256), 0, st, fj, fh, B, so, nx, I, dydx, d2);
+}
+__global__ __launch_bounds__(256) void k_through_lw(const float* __restrict__ SRC, const long* __restrict__ src_off, int nvec, const float* __restrict__ lw,
+                                                    int rl, long npts, float* __restrict__ DST) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;      // (vector, padded point)
+  if (e >= (long)nvec * npts) return;
+  const int v = (int)(e / npts); const long a = e - (long)v * npts;
+  const long zoff = (a >> 5) * rl * 32 + (a & 31);
+  const float* z = SRC + src_off[v];
+  float* d = DST + (long)v * npts * rl;
+  for (int cc = 0; cc < rl; ++cc) {
+    float t = 0.f;
+    for (int c2 = 0; c2 < rl; ++c2) t = fmaf(z[zoff + (long)c2 * 32], lw[c2 * rl + cc], t);
+    d[zoff + (long)cc * 32] = t;
+  }
+}
+void launch_through_lw(const float* SRC, const long* src_off_dev, int nvec, const float* lw, int rl, long npts, float* DST, hipStream_t st) {
+  hipLaunchKernelGGL(k_through_lw, dim3((unsigned)(((long)nvec * npts + 255) / 256)), dim3(256), 0, st, SRC, src_off_dev, nvec, lw, rl, npts, DST);
+}
+__global__ __launch_bounds__(256) void k_ll_hess(HessLLArgs H) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;      // (point, i)
+  const int ny = H.I.ny, nx = H.nx, rl = H.rl, so = H.so, nxc = H.nxc > 0 ? H.nxc : 1, np = H.np;
+  if (e >= H.B * ny) return;
+  const long a = e / ny; const int i = (int)(e - a * ny);
+  const long zoff = (a >> 5) * rl * 32 + (a & 31);
+  const long npts = H.npts;
+  const long sop = (long)so * rl;
+  auto av = [&](int c) { return H.Za[zoff + (long)c * 32]; };
+  auto ap = [&](int j, int c) { return H.AP[((long)j * npts) * rl + zoff + (long)c * 32]; };           // a'_j
+  auto app = [&](int j, int k, int c) {                                                                // a''_{jk} (stored for j <= k)
+    const int lo = j < k ? j : k, hi = j < k ? k : j;
+    return H.AP[((long)(np + lo * np + hi) * npts) * rl + zoff + (long)c * 32];
+  };
+  if (i == 0)
+    for (int o = 0; o < so; ++o) {
+      float t = H.bias[o];
+      for (int c = 0; c < rl; ++c) t = fmaf(H.f0[a * sop + (long)o * rl + c], av(c), t);
+      H.y[a * so + o] = t;
+    }
+  const long src = a * sop + (long)H.I.y_idx[i] * rl;        // phi[a, y_i, 0]
+  float* dy = H.dydx + e * nx;
+  float* h = H.d2 + e * nx * nx;
+  for (int j = 0; j < H.nxc; ++j) {
+    float t = 0.f;
+    for (int c = 0; c < rl; ++c) t = fmaf(H.fj[(src + c) * nxc + j], av(c), t);
+    dy[H.xc[j]] = t;
+    for (int k = 0; k < H.nxc; ++k) {
+      float t2 = 0.f;
+      for (int c = 0; c < rl; ++c) t2 = fmaf(H.fh[((src + c) * nxc + j) * nxc + k], av(c), t2);
+      h[H.xc[j] * nx + H.xc[k]] = t2;
+    }
+    for (int k = 0; k < np; ++k) {
+      float t2 = 0.f;
+      for (int c = 0; c < rl; ++c) t2 = fmaf(H.fj[(src + c) * nxc + j], ap(k, c), t2);
+      h[H.xc[j] * nx + H.xp[k]] = t2; h[H.xp[k] * nx + H.xc[j]] = t2;
+    }
+  }
+  for (int j = 0; j < np; ++j) {
+    float t = 0.f;
+    for (int c = 0; c < rl; ++c) t = fmaf(H.f0[src + c], ap(j, c), t);
+    dy[H.xp[j]] = t;
+    for (int k = 0; k < np; ++k) {
+      float t2 = 0.f;
+      for (int c = 0; c < rl; ++c) t2 = fmaf(H.f0[src + c], app(j, k, c), t2);
+      h[H.xp[j] * nx + H.xp[k]] = t2;
+    }
+  }
+}
+void launch_ll_hess(const HessLLArgs& H, hipStream_t st) {
+  hipLaunchKernelGGL(k_ll_hess, dim3((unsigned)((H.B * H.I.ny + 255) / 256)), dim3(256), 0, st, H);
+}
+

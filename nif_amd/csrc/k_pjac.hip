@@ -41,7 +41,7 @@ __device__ __forceinline__ void pj_act(int act, float a, float* f0, float* f1, f
     case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-a)); *f0 = s; *f1 = s * (1.0f - s); *f2 = s * (1.0f - s) * (1.0f - 2.0f * s); } break;
     case ACT_ELU: { const float e = expf(fminf(a, 0.f)); *f0 = a > 0.f ? a : e - 1.0f; *f1 = a > 0.f ? 1.0f : e; *f2 = a > 0.f ? 0.f : e; } break;
     case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); *f0 = fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))); *f1 = s; *f2 = s * (1.0f - s); } break;
-    case ACT_GELU: { const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f)), pdf = 0.3989422804014327f * expf(-0.5f * a * a);
+    case ACT_GELU: { const float cdf = 0.5f * (1.0f + nif_erff(a * 0.70710678118654752440f)), pdf = 0.3989422804014327f * expf(-0.5f * a * a);
                      *f0 = a * cdf; *f1 = cdf + a * pdf; *f2 = pdf * (2.0f - a * a); } break;
     default: *f0 = a; *f1 = 1.0f; *f2 = 0.f; break;
   }

@@ -709,151 +709,141 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   return NIF_OK;
 }
 
-// HessianLayer (gradient.py:130-180, :234-261): y [B, so], dy/dx [B, ny, nx] and d2y/dx2 [B, ny, nx, nx] for COORDINATE
-// columns x_idx of NIF / NIFMultiScale: one launch of the second-order tangent kernel per coordinate pair (j <= k).
-extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
-                           int32_t nx, float* y_out, float* dydx_out, float* d2_out) {
-  if (!c || !xin || !y_idx || !x_idx || !y_out || !dydx_out || !d2_out || B <= 0 || ny <= 0 || nx <= 0)
-    return fail(NIF_ERR_INVALID, "bad argument");
-  for (int i = 0; i < ny; ++i)
-    if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
+// HessianLayer (gradient.py:130-180, :234-261): y [B, so], dy/dx [B, ny, nx] and d2y/dx2 [B, ny, nx, nx] for ANY input columns
+// x_idx: one launch of the second-order tangent kernel per column pair (j <= k), then the gather of the rows y_idx -- and, for the
+// last-layer class, the contraction with the ParameterNet output -- ON THE DEVICE (r3; r2 did both in host loops).  Everything is
+// enqueued on the context's stream; the outputs are device pointers.
+static int hessian_core(nif_ctx* c, const float* xin_dev, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
+                        int32_t nx, float* y_dev, float* dydx_dev, float* d2_dev) {
   bool anyp = false;
-  for (int j = 0; j < nx; ++j) {
-    if (x_idx[j] < 0 || x_idx[j] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "x_index out of range (0 <= i < pi_dim + si_dim)");
-    anyp = anyp || x_idx[j] < c->pi;
-  }
-  HIPCHK(hipSetDevice(c->dev));
-  HIPCHK(hipStreamSynchronize(c->st));
+  for (int j = 0; j < nx; ++j) anyp = anyp || x_idx[j] < c->pi;
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   const int ncol = c->pi + c->si;
   const long ntl = (B + 31) / 32;
-  rc = stage(c, &c->d_a, &c->cap_a, xin, B * ncol); if (rc) return rc;
-  PNetArgs pa; fill_pnet(c, pa, c->d_a, B);
+  HessIdx I; I.ny = ny;
+  for (int i = 0; i < 16; ++i) I.y_idx[i] = i < ny ? y_idx[i] : 0;
+  PNetArgs pa; fill_pnet(c, pa, xin_dev, B);
   launch_pnet(pa, c->NSTB, false, c->st);
   // parameter columns: z' = dz/dp of every parameter column once (k_pjac, forward mode), z'' per pair of them (k_pjac2)
-  float* zdd = nullptr;
+  std::vector<int> xc, xp;                         // positions (in x_idx) of the coordinate / parameter columns
+  for (int j = 0; j < nx; ++j) (x_idx[j] >= c->pi ? xc : xp).push_back(j);
+  const int np_ = (int)xp.size();
+  if (xc.size() > 16 || np_ > 4) return fail(NIF_ERR_INVALID, "HessianLayer: at most 16 coordinate and 4 parameter columns in x_index");
+  const long blk = ntl * 32 * c->r;                // floats of one latent-layout vector
   if (anyp) {
     if (!pjac_supported(pa))
       return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
-    const long need_zt = (long)c->pi * ntl * 32 * c->r, need_dd = ntl * 32 * c->r;
+    const long need_zt = (long)c->pi * blk, need_dd = (long)np_ * np_ * blk;
+    if (need_zt > c->zt_par_cap || need_dd > c->dzt_par_cap) HIPCHK(hipStreamSynchronize(c->st));
     if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
     if (need_dd > c->dzt_par_cap) { rc = grow(&c->dzt_par, &c->dzt_par_cap, need_dd); if (rc) return rc; }
     launch_pjac_fwd(pa, c->zt_par, c->st);
-    zdd = c->dzt_par;
   }
-  auto zt_of = [&](int col) -> const float* { return c->zt_par + (long)col * ntl * 32 * c->r; };
+  auto zt_of = [&](int col) -> const float* { return c->zt_par + (long)col * blk; };
+  auto zdd_of = [&](int j, int k) -> float* { return c->dzt_par + (long)(j * np_ + k) * blk; };   // pair of xp positions, j <= k
   if (c->kind == NIF_KIND_LASTLAYER) {
     // u_i = sum_c phi[i,c](x) a_c(p) + bias_i: the coordinates only move phi (second-order tangents of the shared SIREN ShapeNet,
-    // the r = 0 case of the same kernel with so * latent_dim outputs), the parameters only move a = latent last_w + last_b:
-    //   d2u/dx dx' = phi''.a ,  d2u/dx dp = phi'_x.a'_p ,  d2u/dp dp' = phi.a''   -- contracted on the host (this entry point
-    // takes and returns host arrays)
+    // the r = 0 case of the same kernel with so * latent_dim outputs), the parameters only move a = latent last_w + last_b
     const int rl = c->r, sop = c->so * c->r;
-    std::vector<int> xc, xp;                         // positions (in x_idx) of the coordinate / parameter columns
-    for (int j = 0; j < nx; ++j) (x_idx[j] >= c->pi ? xc : xp).push_back(j);
     const int nxc = xc.empty() ? 1 : (int)xc.size();
     rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * sop); if (rc) return rc;
     rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * sop * nxc); if (rc) return rc;
     rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * sop * nxc * nxc); if (rc) return rc;
-    SNetArgs sa; rc = fill_snet_ll_sob(c, sa, c->d_a, B, true); if (rc) return rc;
+    SNetArgs sa; rc = fill_snet_ll_sob(c, sa, xin_dev, B, true); if (rc) return rc;
     if (xc.empty()) { sa.u_out = c->d_d; launch_hess(sa, 0, 0, 0, 0, 1, c->d_b, c->d_c, c->st); }     // phi alone
     for (size_t j = 0; j < xc.size(); ++j)
       for (size_t k = j; k < xc.size(); ++k) {
         sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
         launch_hess(sa, x_idx[xc[j]] - c->pi, x_idx[xc[k]] - c->pi, (int)j, (int)k, nxc, c->d_b, c->d_c, c->st);
       }
-    HIPCHK(hipGetLastError());
-    std::vector<float> f0((size_t)B * sop), fj((size_t)B * sop * nxc), fh((size_t)B * sop * nxc * nxc), za((size_t)ntl * rl * 32),
-        bias(c->so), lw((size_t)rl * rl), zt1(anyp ? (size_t)c->pi * ntl * 32 * rl : 0);
-    HIPCHK(hipMemcpyAsync(f0.data(), c->d_d, sizeof(float) * f0.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(fj.data(), c->d_b, sizeof(float) * fj.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(fh.data(), c->d_c, sizeof(float) * fh.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(za.data(), c->Z, sizeof(float) * za.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(bias.data(), c->theta + c->ll_bias, sizeof(float) * bias.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(lw.data(), c->theta + c->last_w, sizeof(float) * lw.size(), hipMemcpyDeviceToHost, c->st));
-    if (anyp) HIPCHK(hipMemcpyAsync(zt1.data(), c->zt_par, sizeof(float) * zt1.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    // a''_{jk} for the parameter pairs: one k_pjac2 launch + copy each
-    const size_t np_ = xp.size();
-    std::vector<std::vector<float>> zt2(np_ * np_);
-    for (size_t j = 0; j < np_; ++j)
-      for (size_t k = j; k < np_; ++k) {
-        launch_pjac2(pa, x_idx[xp[j]], x_idx[xp[k]], zdd, c->st);
-        zt2[j * np_ + k].resize((size_t)ntl * rl * 32);
-        HIPCHK(hipMemcpyAsync(zt2[j * np_ + k].data(), zdd, sizeof(float) * zt2[j * np_ + k].size(), hipMemcpyDeviceToHost, c->st));
-        HIPCHK(hipStreamSynchronize(c->st));
-        zt2[k * np_ + j] = zt2[j * np_ + k];
-      }
-    std::vector<double> av(rl), ad((size_t)(np_ ? np_ : 1) * rl), add((size_t)(np_ ? np_ * np_ : 1) * rl);
-    for (int64_t a_ = 0; a_ < B; ++a_) {
-      const size_t zoff = (size_t)(a_ >> 5) * rl * 32 + (a_ & 31);       // latent-layout arrays: element c at [zoff + c * 32]
-      for (int cc = 0; cc < rl; ++cc) av[cc] = za[zoff + (size_t)cc * 32];
-      auto through_lw = [&](const float* zsrc, double* dst) {            // a' = z' last_w (no bias)
-        for (int cc = 0; cc < rl; ++cc) {
-          double t = 0.0;
-          for (int c2 = 0; c2 < rl; ++c2) t += (double)zsrc[zoff + (size_t)c2 * 32] * lw[(size_t)c2 * rl + cc];
-          dst[cc] = t;
-        }
-      };
-      for (size_t j = 0; j < np_; ++j) {
-        through_lw(zt1.data() + (size_t)x_idx[xp[j]] * ntl * 32 * rl, &ad[j * rl]);
-        for (size_t k = 0; k < np_; ++k) through_lw(zt2[j * np_ + k].data(), &add[(j * np_ + k) * rl]);
-      }
-      auto dot = [&](const float* ph, size_t stride, const double* v) {  // sum_c ph[c * stride] v[c]
-        double t = 0.0;
-        for (int cc = 0; cc < rl; ++cc) t += (double)ph[(size_t)cc * stride] * v[cc];
-        return t;
-      };
-      for (int i = 0; i < c->so; ++i) y_out[a_ * c->so + i] = (float)(dot(&f0[(size_t)a_ * sop + (size_t)i * rl], 1, av.data()) + bias[i]);
-      for (int i = 0; i < ny; ++i) {
-        const size_t src = (size_t)a_ * sop + (size_t)y_idx[i] * rl;      // phi[a, y_i, 0]
-        auto phi1 = [&](int jc) { return &fj[src * nxc + jc]; };          // phi'_{jc}[c] at stride nxc
-        auto phi2 = [&](int jc, int kc) { return &fh[(src * nxc + jc) * nxc + kc]; };
-        for (size_t j = 0; j < xc.size(); ++j) dydx_out[(a_ * ny + i) * nx + xc[j]] = (float)dot(phi1((int)j), nxc, av.data());
-        for (size_t j = 0; j < np_; ++j) dydx_out[(a_ * ny + i) * nx + xp[j]] = (float)dot(&f0[src], 1, &ad[j * rl]);
-        float* h = d2_out + (size_t)(a_ * ny + i) * nx * nx;
-        for (size_t j = 0; j < xc.size(); ++j) {
-          for (size_t k = 0; k < xc.size(); ++k) h[xc[j] * nx + xc[k]] = (float)dot(phi2((int)j, (int)k), (size_t)nxc * nxc, av.data());
-          for (size_t k = 0; k < np_; ++k) {
-            const float v = (float)dot(phi1((int)j), nxc, &ad[k * rl]);
-            h[xc[j] * nx + xp[k]] = v; h[xp[k] * nx + xc[j]] = v;
-          }
-        }
-        for (size_t j = 0; j < np_; ++j)
-          for (size_t k = 0; k < np_; ++k) h[xp[j] * nx + xp[k]] = (float)dot(&f0[src], 1, &add[(j * np_ + k) * rl]);
-      }
+    // a'_j = z'_j last_w and a''_jk = z''_jk last_w: one k_pjac2 launch per parameter pair, ONE k_through_lw over all of them
+    const int nvec = np_ + np_ * np_;
+    float* ap = nullptr;
+    if (nvec > 0) {
+      const long need = (long)nvec * blk + 64;        // + the source offsets (as raw bytes behind the vectors)
+      if (need > c->jac_mu_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->jac_mu, &c->jac_mu_cap, need); if (rc) return rc; }
+      ap = c->jac_mu;
+      for (int j = 0; j < np_; ++j)
+        for (int k = j; k < np_; ++k) launch_pjac2(pa, x_idx[xp[j]], x_idx[xp[k]], zdd_of(j, k), c->st);
+      // source of vector v: z'_j inside zt_par, z''_jk inside dzt_par -- addressed relative to zt_par (both are hipMalloc'ed floats)
+      std::vector<long> off(nvec, 0);
+      for (int j = 0; j < np_; ++j) off[j] = (long)(zt_of(x_idx[xp[j]]) - c->zt_par);
+      for (int j = 0; j < np_; ++j)
+        for (int k = 0; k < np_; ++k) off[np_ + j * np_ + k] = (long)(zdd_of(j < k ? j : k, j < k ? k : j) - c->zt_par);
+      long* off_dev = reinterpret_cast<long*>(ap + (long)nvec * blk);
+      HIPCHK(hipMemcpyAsync(off_dev, off.data(), sizeof(long) * nvec, hipMemcpyHostToDevice, c->st));
+      HIPCHK(hipStreamSynchronize(c->st));            // (off is a host temporary)
+      launch_through_lw(c->zt_par, off_dev, nvec, c->theta + c->last_w, rl, ntl * 32, ap, c->st);
     }
+    HessLLArgs H;
+    memset(&H, 0, sizeof(H));
+    H.f0 = c->d_d; H.fj = c->d_b; H.fh = c->d_c; H.Za = c->Z; H.AP = ap; H.bias = c->theta + c->ll_bias;
+    H.B = B; H.npts = ntl * 32; H.so = c->so; H.rl = rl; H.nxc = (int)xc.size(); H.np = np_; H.nx = nx; H.I = I;
+    for (size_t j = 0; j < xc.size(); ++j) H.xc[j] = xc[j];
+    for (int j = 0; j < np_; ++j) H.xp[j] = xp[j];
+    H.y = y_dev; H.dydx = dydx_dev; H.d2 = d2_dev;
+    launch_ll_hess(H, c->st);
+    HIPCHK(hipGetLastError());
     return NIF_OK;
   }
   rc = ensure_packed32(c); if (rc) return rc;
   if (!c->jac_ok) return fail(NIF_ERR_INVALID, "HessianLayer: one weight plane and the small hyper-vectors of this shape exceed the 160 KB LDS of a CU");
-  rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->so * nx); if (rc) return rc;
   rc = stage(c, &c->d_c, &c->cap_c, nullptr, B * c->so * nx * nx); if (rc) return rc;
-  SNetArgs sa; fill_snet(c, sa, c->d_a, ncol, c->pi, B);
+  SNetArgs sa; fill_snet(c, sa, xin_dev, ncol, c->pi, B);
+  std::vector<int> ppos(nx, -1);                    // position among the parameter columns of x_idx
+  for (int j = 0; j < np_; ++j) ppos[xp[j]] = j;
   for (int j = 0; j < nx; ++j)
     for (int k = j; k < nx; ++k) {
-      sa.u_out = (j == 0 && k == 0) ? c->d_d : nullptr;
+      sa.u_out = (j == 0 && k == 0) ? y_dev : nullptr;
       const bool pj = x_idx[j] < c->pi, pk = x_idx[k] < c->pi;
+      float* zdd = (pj && pk) ? zdd_of(ppos[j], ppos[k]) : nullptr;
       if (pj && pk) launch_pjac2(pa, x_idx[j], x_idx[k], zdd, c->st);
       launch_hess(sa, pj ? -1 : x_idx[j] - c->pi, pk ? -1 : x_idx[k] - c->pi, j, k, nx, c->d_b, c->d_c, c->st,
-                  pj ? zt_of(x_idx[j]) : nullptr, pk ? zt_of(x_idx[k]) : nullptr, (pj && pk) ? zdd : nullptr);
+                  pj ? zt_of(x_idx[j]) : nullptr, pk ? zt_of(x_idx[k]) : nullptr, zdd);
     }
+  launch_hess_gather(c->d_b, c->d_c, B, c->so, nx, I, dydx_dev, d2_dev, c->st);
   HIPCHK(hipGetLastError());
-  std::vector<float> fj((size_t)B * c->so * nx), fh((size_t)B * c->so * nx * nx);
-  HIPCHK(hipMemcpyAsync(y_out, c->d_d, sizeof(float) * (size_t)(B * c->so), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(hipMemcpyAsync(fj.data(), c->d_b, sizeof(float) * fj.size(), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(hipMemcpyAsync(fh.data(), c->d_c, sizeof(float) * fh.size(), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(hipStreamSynchronize(c->st));
-  for (int64_t a_ = 0; a_ < B; ++a_)
-    for (int i = 0; i < ny; ++i) {
-      const size_t src = (size_t)a_ * c->so + y_idx[i];
-      for (int j = 0; j < nx; ++j) {
-        dydx_out[(a_ * ny + i) * nx + j] = fj[src * nx + j];
-        for (int k = 0; k < nx; ++k) d2_out[((a_ * ny + i) * nx + j) * nx + k] = fh[(src * nx + j) * nx + k];
-      }
-    }
   return NIF_OK;
+}
+
+static int hessian_check(nif_ctx* c, const void* xin, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx, int32_t nx,
+                         const void* y_out, const void* dydx_out, const void* d2_out) {
+  if (!c || !xin || !y_idx || !x_idx || !y_out || !dydx_out || !d2_out || B <= 0 || ny <= 0 || nx <= 0)
+    return fail(NIF_ERR_INVALID, "bad argument");
+  if (ny > 16) return fail(NIF_ERR_INVALID, "y_index: at most 16 entries");
+  for (int i = 0; i < ny; ++i)
+    if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "y_index out of range");
+  for (int j = 0; j < nx; ++j)
+    if (x_idx[j] < 0 || x_idx[j] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "x_index out of range (0 <= i < pi_dim + si_dim)");
+  return NIF_OK;
+}
+extern "C" int nif_hessian_dev(nif_ctx* c, const float* xin_dev, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
+                               int32_t nx, float* y_dev, float* dydx_dev, float* d2_dev) {
+  int rc = hessian_check(c, xin_dev, B, y_idx, ny, x_idx, nx, y_dev, dydx_dev, d2_dev); if (rc) return rc;
+  HIPCHK(hipSetDevice(c->dev));
+  return hessian_core(c, xin_dev, B, y_idx, ny, x_idx, nx, y_dev, dydx_dev, d2_dev);
+}
+extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
+                           int32_t nx, float* y_out, float* dydx_out, float* d2_out) {
+  int rc = hessian_check(c, xin, B, y_idx, ny, x_idx, nx, y_out, dydx_out, d2_out); if (rc) return rc;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));
+  rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
+  const size_t n_y = (size_t)B * c->so, n_d = (size_t)B * ny * nx, n_h = n_d * nx;
+  float* out = nullptr;
+  HIPCHK(hipMalloc(&out, sizeof(float) * (n_y + n_d + n_h)));
+  rc = hessian_core(c, c->d_a, B, y_idx, ny, x_idx, nx, out, out + n_y, out + n_y + n_d);
+  if (rc == NIF_OK) {
+    hipError_t e = hipMemcpyAsync(y_out, out, sizeof(float) * n_y, hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dydx_out, out + n_y, sizeof(float) * n_d, hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2_out, out + n_y + n_d, sizeof(float) * n_h, hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+    if (e != hipSuccess) rc = fail(NIF_ERR_HIP, hipGetErrorString(e));
+  } else (void)hipStreamSynchronize(c->st);
+  (void)hipFree(out);
+  return rc;
 }
 
 extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr) {

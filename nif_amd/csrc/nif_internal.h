@@ -237,6 +237,18 @@ void launch_actreg_planes(bool l1, const float* theta, long off_W, long off_b, i
                           float* part, hipStream_t st);
 void launch_actreg_apply(const float* part, int nslab, int r, long po, float coef, long off_W, long off_b, const float* loss_partial,
                          int nloss, float* g, long P, hipStream_t st);
+// HessianLayer epilogues on the device (k_misc.hip)
+struct HessIdx { int ny; int y_idx[16]; };
+struct HessLLArgs {
+  const float *f0, *fj, *fh;      // phi [B][so*rl], phi' [B][so*rl][nxc], phi'' [B][so*rl][nxc][nxc]
+  const float *Za, *AP, *bias;    // a [tiles][rl][32]; AP: [np + np*np][npts][rl] blocks in latent layout: a'_j, then a''_{jk} at np + j*np + k (j <= k)
+  long B, npts; int so, rl, nxc, np, nx;
+  HessIdx I; int xc[16], xp[4];   // positions (in x_index) of the coordinate / parameter columns
+  float *y, *dydx, *d2;
+};
+void launch_hess_gather(const float* fj, const float* fh, long B, int so, int nx, const HessIdx& I, float* dydx, float* d2, hipStream_t st);
+void launch_through_lw(const float* SRC, const long* src_off_dev, int nvec, const float* lw, int rl, long npts, float* DST, hipStream_t st);
+void launch_ll_hess(const HessLLArgs& H, hipStream_t st);
 void launch_gather_rows(const float* src, const int* perm, long n, int ncol, float* dst, hipStream_t st);
 void launch_rows_to_tiles(const float* rows, long B, int c, float* tiles, hipStream_t st);
 void launch_tiles_to_rows(const float* tiles, long B, int c, float* rows, hipStream_t st);
@@ -312,6 +324,30 @@ __device__ __forceinline__ void nif_sincosf(float x, float* sp, float* cp) {
   else nif_sincosf_core(x, sp, cp);
 }
 
+// erf, branch free (both ranges evaluated, one select): 1-ulp minimax forms for |x| <= 0.9277 (x P(x^2)) and beyond
+// (1 - exp(Q(|x|))), max abs error 5.8e-8 against fp64 over [-6, 6] (checked on 2e6 points).  r3: ocml's erff is a branchy
+// routine; inlined 64 times into the 128-unit k_mlp_jac instantiation (1100 spilled registers) it produced WRONG tangents for
+// gelu ParameterNets of 65-128 units (tools/fuzz_parity.py over the wider shapes; every other activation was right)
+__device__ __forceinline__ float nif_erff(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float big = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float small = fmaf(q, a, a);
+  return t > 0.927734375f ? big : small;
+}
+
 // h = f(a), d = f'(a) for the Keras activation ACT (compile time)
 template <int ACT>
 __device__ __forceinline__ void act_eval(float a, float* h, float* d) {
@@ -333,7 +369,7 @@ __device__ __forceinline__ void act_eval(float a, float* h, float* d) {
     *h = fmaxf(a, 0.f) + log1pf(expf(-fabsf(a)));
     *d = 1.0f / (1.0f + expf(-a));
   } else if (ACT == ACT_GELU) {
-    const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + nif_erff(a * 0.70710678118654752440f));
     *h = a * cdf; *d = cdf + a * 0.3989422804014327f * expf(-0.5f * a * a);
   } else {
     *h = a; *d = 1.0f;

@@ -225,6 +225,14 @@ class Engine(object):
                                    xi.ctypes.data_as(C.POINTER(C.c_int32)), xi.size, ptr(y), ptr(d), ptr(h)))
         return y, d, h
 
+    def hessian_dev(self, d_x, b, y_index, x_index, d_y, d_dydx, d_d2):
+        """HessianLayer on device-resident inputs / outputs (nif_hessian_dev): [b, pi+si] -> y [b, so], dydx [b, ny, nx],
+        d2 [b, ny, nx, nx]; asynchronous on the context's stream"""
+        yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
+        xi = np.ascontiguousarray(list(x_index), dtype=np.int32)
+        check(self.lib.nif_hessian_dev(self.ctx, d_x, int(b), yi.ctypes.data_as(C.POINTER(C.c_int32)), yi.size,
+                                       xi.ctypes.data_as(C.POINTER(C.c_int32)), xi.size, d_y, d_dydx, d_d2))
+
     def x_to_phi(self, x):
         x = self._rows(x, self.spec.si_dim, "coordinates")
         s = self.spec

@@ -140,6 +140,7 @@ def run_case(cfg, B, seed):
         cpr = dict(cp, l2_reg=l2w, jac_reg=ljac); cpr[which] = lact
         mr = getattr(nif_amd, kind)(cs, cpr)
         modelr = mr.build(); modelr.set_weights(ws)
+        mr._engine.set_jac_regularizer(modelr._jac_reg)      # (what build()'s model does before it computes a loss; r3)
         lr_, gr_ = mr._engine.loss_and_grad(x, y, sw)
         act = (0.0, lact) if which == "act_l2_reg" else (lact, 0.0)
         l0, g0 = O.loss_and_grad(spec, ws64, x64, y64, sw64, act_reg=act)
