@@ -297,8 +297,13 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 #endif
   float loss_lane = 0.f;
   float* dring = (TRAIN && !SGN) ? A.dring + ((long)blockIdx.x * WAVES + wid) * (long)(nh + 1) * (NBL * 256) : nullptr;
+#ifdef NIF_ABL_INTERLEAVE     // measurement builds: the ten slots of a tile next to each other (the consumers then read garbage)
+  const long sstride = (long)FP * 32, tstride = (long)(2 * (nh + 1)) * FP * 32;
+#else
+  const long sstride = A.slot_stride, tstride = (long)FP * 32;
+#endif
   float* IN0 = A.stash;
-  float* DA0 = A.stash + (long)(nh + 1) * A.slot_stride;
+  float* DA0 = A.stash + (long)(nh + 1) * sstride;
 
 // one chunk step: start the DMA of chunk c + DIST into the buffer that chunk c - 1 left, multiply chunk c, then wait until
 // chunk c + 1 has landed -- i.e. until at most the vm_y1 instructions issued after ITS DMA are outstanding -- and meet the
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 #ifdef NIF_ABL_STASHMASK      // measurement builds: the stash traffic folded onto a cache-resident window (results are wrong)
     const long row0 = (tile32 & NIF_ABL_STASHMASK) * (long)FP * 32 + poff;
 #else
-    const long row0 = tile32 * (long)FP * 32 + poff;
+    const long row0 = tile32 * tstride + poff;
 #endif
     if (TRAIN)
       for (int k = 0; k < r; ++k) dzs[k * 64 + lane] = 0.f;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     // ---- hidden hyper-matrices: a = b^(r) + h (w0 M^(r)) + sum_{k<r} zt_k (b^(k) + h (w0 M^(k))) -------------------
     f32x4 ublk[MODE == 1 ? NBL : 1];
     for (int j = 0; j < nh; ++j) {
-      if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * A.slot_stride, row0, h, g); vm_note(4 * NBL); }
+      if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); vm_note(4 * NBL); }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
       NIF_TL(10 + j);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     }
     NIF_TL(3);
     // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------
-    if (TRAIN && active) { st_store16<NBL>(IN0 + (long)nh * A.slot_stride, row0, h, g); vm_note(4 * NBL); }
+    if (TRAIN && active) { st_store16<NBL>(IN0 + (long)nh * sstride, row0, h, g); vm_note(4 * NBL); }
     f32x4 gh[NBL];
     ZERO_T(gh)
     const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         f32x4 ga[NBL];
         if (SGN) {
           tag_cos<NBL>(hin, dnext);
-          st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
+          st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
         } else {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane];
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
           }
         }
-        if (active) { st_store16<NBL>(DA0 + (long)(j + 1) * A.slot_stride, row0, ga, g); vm_note(4 * NBL); }
+        if (active) { st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g); vm_note(4 * NBL); }
         // <dL/da, b^(k)> now, so that dL/da is dead once it is split and stashed (16 registers less across the planes)
         for (int k = 0; k < r; ++k) {
           const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             if (ks == 0) {
               NIF_CHUNK({
                 mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], U, lane);
-                if (!SGN) st_load16<NBL>(IN0 + (long)j * A.slot_stride, row0, hin, g);
+                if (!SGN) st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
               })
             } else NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane); })
           }
