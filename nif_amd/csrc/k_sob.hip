@@ -14,7 +14,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const bool bf_ = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
   const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par && !a.ll;     // the 1- / 2-seed instantiations: two workgroups per CU
   // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
-  const bool two = slim && (NBL <= 2 || ns == 1);
+  const bool two = slim && (NBL <= 2 || ns == 1 || (NIF_SOB_TWO_BF2 && ns == 2 && a.prec == 1));
   const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   int one_buf = 0;

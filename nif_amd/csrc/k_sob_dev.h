@@ -79,6 +79,9 @@ __device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&
   }
 }
 
+#ifndef NIF_SOB_TWO_BF2
+#define NIF_SOB_TWO_BF2 1   // two seeds under mixed_bfloat16 at two workgroups per CU (256 registers: 17 spilled; the fp32 form spills 94 there)
+#endif
 // BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
 // NSD: seed streams the instantiation carries (register arrays and loops are sized by it): 1 or 2 seeds at n <= 64 leave room
 // for TWO workgroups per CU (256 registers), the 3-seed form needs all 512
@@ -87,7 +90,7 @@ __device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&
 // u_i = sum_c phi[i*rl+c] a_c + bias_i and du_i/dx_d = sum_c phi'_d[i*rl+c] a_c; the adjoint starts from dphi = du (x) a,
 // dphi'_d = du'_d (x) a and also yields dL/da (and dL/dlatent through the rl x rl map of the ParameterNet's last layer).
 template <int NBL, int MODE, bool TRAIN, int BF, bool SGN, int NSD = NIF_SOB_MAXSEED, bool PAR = false, bool LL = false>
-__global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD == 1)) ? 2 : (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
+__global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD == 1) || (NBL <= 4 && NSD == 2 && BF == 2 && NIF_SOB_TWO_BF2)) ? 2 : (NBL <= 4 ? NIF_SOB_OCC : 1)) void k_sob(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
   constexpr int NT = 256, WAVES = 4, NS = NSD, NQ = 1 + NS;

@@ -120,7 +120,7 @@ def run_case(cfg, B, seed):
         bad.append(("hessian refused", str(ex)[:80]))
     # three Adam steps through fit() against the oracle's trajectory
     try:
-        model.compile(nif_amd.Adam(1e-3), "mse")
+        model.compile(nif_amd.Adam(1e-4), "mse")     # (r3: 1e-4 -- at 1e-3 deep SIREN nets leave the linear regime within three steps)
         h = model.fit(x, y, epochs=3, batch_size=B, shuffle=False, verbose=0, sample_weight=sw)
         th = O.flatten(ws64); mm = np.zeros_like(th); vv = np.zeros_like(th)
         f32 = lambda a: float(np.float32(a))
@@ -128,7 +128,7 @@ def run_case(cfg, B, seed):
         for t in range(1, 4):
             l_, g_ = O.loss_and_grad(spec, O.unflatten(spec, th), x64, y64, sw64)
             ls.append(l_)
-            th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+            th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-4), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
         if not np.allclose(h.history["loss"], ls, rtol=2e-3 if B >= 8 else 5e-2):      # (Adam's first steps are +-lr per weight: sign flips of ~0 gradients)
             bad.append(("fit trajectory", h.history["loss"], ls))
     except nif_amd._lib.NifError as ex:
