@@ -80,7 +80,7 @@ __device__ __forceinline__ void sob_act(int act, const f32x4 (&a)[NBL], f32x4 (&
 }
 
 #ifndef NIF_SOB_TWO_BF2
-#define NIF_SOB_TWO_BF2 1   // two seeds under mixed_bfloat16 at two workgroups per CU (256 registers: 17 spilled; the fp32 form spills 94 there)
+#define NIF_SOB_TWO_BF2 0   // two seeds under mixed_bfloat16 at two workgroups per CU (256 registers, 17 spilled): measured 4.09 -> 4.40 ms, off
 #endif
 // BF: 0 = f32-input MFMA planes, 1 = exact bf16 splits, 2 = one bf16 product (mixed_bfloat16 policy)
 // NSD: seed streams the instantiation carries (register arrays and loops are sized by it): 1 or 2 seeds at n <= 64 leave room
