@@ -10,12 +10,14 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   if (par) for (int d = 0; d < ns; ++d) any_par = any_par || par->par[d] >= 0;
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
-  const long ngroups = (nt16 + 3) / 4;
+  long ngroups = (nt16 + 3) / 4;
   const bool bf_ = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
   const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par && !a.ll;     // the 1- / 2-seed instantiations: two workgroups per CU
   // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
   const bool two = slim && (NBL <= 2 || ns == 1 || (NIF_SOB_TWO_BF2 && ns == 2 && a.prec == 1));
-  const long cap = two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256);
+  const bool wav = train && sobw_supported(a, ns, any_par);      // k_sobw.hip: one 12-wave workgroup per CU
+  if (wav) ngroups = (nt16 + sobw_tiles_per_group() - 1) / sobw_tiles_per_group();
+  const long cap = wav ? sobw_grid_cap() : (two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256));
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   int one_buf = 0;
   {   // LDS the launch below will ask for (same arithmetic).  Two plane buffers when they fit, else ONE (r3: the derivative layers
@@ -51,6 +53,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.par[d] = -1;
     any_par = false;
   }
+  if (wav) { launch_sobw(J, nblk, st); return nblk; }
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
   const bool sgn = !a.res && !a.nif_skip && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register (SIREN only)
