@@ -16,7 +16,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
   const bool two = slim && (NBL <= 2 || ns == 1 || (NIF_SOB_TWO_BF2 && ns == 2 && a.prec == 1));
   const bool wav = train && sobw_supported(a, ns, any_par);      // k_sobw.hip: one 12-wave workgroup per CU
-  if (wav) ngroups = (nt16 + sobw_tiles_per_group() - 1) / sobw_tiles_per_group();
+  if (wav) ngroups = (nt16 + sobw_tiles_per_group(ns) - 1) / sobw_tiles_per_group(ns);
   const long cap = wav ? sobw_grid_cap() : (two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256));
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   int one_buf = 0;

@@ -57,7 +57,7 @@ void launch_sob_par(const SobArgs& J, bool train, bool bf, int nblk, size_t shm,
 // two coordinate seeds of a plain SIREN net, the streams on separate waves (k_sobw.hip)
 bool sobw_supported(const SNetArgs& a, int ns, bool any_par);
 void launch_sobw(const SobArgs& J, int nblk, hipStream_t st);
-int sobw_tiles_per_group();
+int sobw_tiles_per_group(int ns);
 int sobw_grid_cap();
 // last-layer class (k_sob_ll.hip)
 void launch_sob_ll(const SobArgs& J, bool train, bool bf, int nblk, size_t shm, hipStream_t st);
@@ -286,11 +286,31 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ZERO4(aq[q][b]);
+      // mixed_bfloat16 (BF = 2): every stream's tile is rounded ONCE per layer and the latent factor scales the product -- the cast
+      // points of the plain step (k_snet4<PR>) and of k_sobw<PR>; streams with parameter seeds keep the combined operand below
+      bf16x8 hb[(BF == 2 && !PAR) ? NQ : 1][(BF == 2 && !PAR) ? NCH : 1];
+      if constexpr (BF == 2 && !PAR) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int ks = 0; ks < NCH; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) hb[q][ks][t] = (__bf16)hq[q][2 * ks + (t >> 2)][t & 3];
+      }
       for (int k = 0; k <= r; ++k) {
         SOB_PLANE({
           const float zt = k < r ? zt_base[k * 16] : 1.0f;
           _Pragma("unroll") for (int q = 0; q < NQ; ++q)
             if (q <= ns) {
+              if constexpr (BF == 2 && !PAR) {
+                f32x4 T[NBL];
+                _Pragma("unroll") for (int ks = 0; ks < NCH; ++ks) {
+                  if (ks == 0) mfma_x6<NBL, true, true>(reinterpret_cast<const bf16x8*>(cur), hb[q][0], hb[q][0], hb[q][0], T, lane);
+                  else mfma_x6<NBL, true>(reinterpret_cast<const bf16x8*>(cur) + ks * CF, hb[q][ks], hb[q][ks], hb[q][ks], T, lane);
+                }
+                _Pragma("unroll") for (int b = 0; b < NBL; ++b) aq[q][b] += zt * T[b];
+                continue;
+              }
               f32x4 hz[NBL];
               _Pragma("unroll") for (int b = 0; b < NBL; ++b) hz[b] = zt * hq[q][b];
               if (PAR && q > 0 && k < r && ispar[q > 0 ? q - 1 : 0]) {

@@ -12,7 +12,7 @@
 // (formulas: k_sob_dev.h).  The tangent pre-activations a'_d wait in a global ring (one tile per hidden layer and tangent
 // wave; the first layer's is recomputed), the cosine of the adjoint is rebuilt from the tagged sine (k_snet4).
 // PR: the mixed_bfloat16 policy -- one bf16 product per operand pair, the stream's tile rounded once per layer, the latent
-// factor applied to the product (k_snet4<PR>'s cast points; k_sob<BF = 2> rounds zt_k h instead; tests/test_gpu_parity.py pins either cast for cast).
+// factor applied to the product (k_snet4<PR>'s cast points, k_sob<BF = 2>'s too).
 #include "k_sob_dev.h"
 
 template <int NBL>
@@ -51,16 +51,16 @@ __device__ __forceinline__ void sine16_tagc(const f32x4 (&a)[NBL], f32x4 (&h)[NB
 #ifndef NIF_SOBW_OCC
 #define NIF_SOBW_OCC 3      // waves per SIMD the register budget allows (hipcc: the second __launch_bounds__ argument is waves per EU)
 #endif
-#ifndef NIF_SOBW_TPG
-#define NIF_SOBW_TPG 4      // tiles per workgroup: 4 = one 12-wave workgroup per CU, 2 = two 6-wave workgroups
-#endif
+// tiles per workgroup: 12 waves / (1 + seeds) streams = one 12-wave workgroup per CU (two 6-wave workgroups of 2 tiles with two
+// seeds: 4.6 instead of 3.4 ms)
+#define NIF_SOBW_TPG(NS_) (12 / (1 + (NS_)))
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
-template <int NBL, bool PR>
-__global__ __launch_bounds__(192 * NIF_SOBW_TPG, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
+template <int NBL, bool PR, int NS>
+__global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
-  constexpr int NS = 2, NQ = 1 + NS, TPG = NIF_SOBW_TPG, WAVES = TPG * NQ, NT = 64 * WAVES;
+  constexpr int NQ = 1 + NS, TPG = NIF_SOBW_TPG(NS), WAVES = TPG * NQ, NT = 64 * WAVES;
   constexpr int NCH = NBL / 2;
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;
   constexpr int QF = (CF + NT - 1) / NT;
@@ -372,7 +372,12 @@ __global__ __launch_bounds__(192 * NIF_SOBW_TPG, NIF_SOBW_OCC) void k_sobw(SobAr
       SW_MEET()
       if (q == 0) {      // hin still holds sin(a)
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) ga[b] = gh[b] * ex[b] - hin[b] * (xch[(1 * NBL + b) * 64 + lane] + xch[(2 * NBL + b) * 64 + lane]);
+        for (int b = 0; b < NBL; ++b) {
+          f32x4 w = xch[(1 * NBL + b) * 64 + lane];
+#pragma unroll
+          for (int d = 1; d < NS; ++d) w += xch[((1 + d) * NBL + b) * 64 + lane];
+          ga[b] = gh[b] * ex[b] - hin[b] * w;
+        }
       } else {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ga[b] = gh[b] * xc[b * 64];
@@ -436,7 +441,12 @@ __global__ __launch_bounds__(192 * NIF_SOBW_TPG, NIF_SOBW_OCC) void k_sobw(SobAr
       SW_MEET()
       if (q == 0) {
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) ga[b] = gh[b] * ex[b] - hin[b] * (xch[(1 * NBL + b) * 64 + lane] + xch[(2 * NBL + b) * 64 + lane]);
+        for (int b = 0; b < NBL; ++b) {
+          f32x4 w = xch[(1 * NBL + b) * 64 + lane];
+#pragma unroll
+          for (int d = 1; d < NS; ++d) w += xch[((1 + d) * NBL + b) * 64 + lane];
+          ga[b] = gh[b] * ex[b] - hin[b] * w;
+        }
       } else {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ga[b] = gh[b] * xc[b * 64];
@@ -462,7 +472,12 @@ __global__ __launch_bounds__(192 * NIF_SOBW_TPG, NIF_SOBW_OCC) void k_sobw(SobAr
       SW_MEET()
       if (q == 0 && active && g == 0)
         for (int k = 0; k < r; ++k)
-          A.DZ[(tile32 * r + k) * 32 + poff] = dzx[(tl * r + k) * 16 + p] + dzx[((TPG + tl) * r + k) * 16 + p] + dzx[((2 * TPG + tl) * r + k) * 16 + p];
+        {
+          float t = dzx[(tl * r + k) * 16 + p];
+#pragma unroll
+          for (int d = 1; d < NQ; ++d) t += dzx[((d * TPG + tl) * r + k) * 16 + p];
+          A.DZ[(tile32 * r + k) * 32 + poff] = t;
+        }
     }
   }
 #undef SW_CHUNK
@@ -478,34 +493,36 @@ __global__ __launch_bounds__(192 * NIF_SOBW_TPG, NIF_SOBW_OCC) void k_sobw(SobAr
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static size_t sobw_shmem(const SNetArgs& a, int NBL) {
+static size_t sobw_shmem(const SNetArgs& a, int NBL, int ns) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  const size_t T = NIF_SOBW_TPG;
-  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + 3 * T * pw + T * 3 * NBL * 256 + 3 * T * a.r * 16 + 16) * sizeof(float);
+  const size_t W = 12;      // waves = tiles per group x streams, whatever the seed count
+  return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + W * pw + W * NBL * 256 + W * a.r * 16 + 16) * sizeof(float);
 }
-// two coordinate seeds of a plain SIREN NIFMultiScale net on the packed bf16 planes, n <= 64, training
+// coordinate seeds of a plain SIREN NIFMultiScale net on the packed bf16 planes, n <= 64, training
 bool sobw_supported(const SNetArgs& a, int ns, bool any_par) {
   static const int on = [] { const char* e = getenv("NIF_SOBW"); return e ? atoi(e) : 1; }();
   const int NBL = snet3_nbl(a.n);
-  if (!on || ns != 2 || any_par || a.ll || a.res || a.nif_skip || !a.WF4 || !a.WB4) return false;
+  if (!on || ns < 1 || ns > 3 || any_par || a.ll || a.res || a.nif_skip || !a.WF4 || !a.WB4) return false;
   if ((NBL != 2 && NBL != 4) || a.nh < 1 || a.r < 1) return false;
-  return sobw_shmem(a, NBL) <= 160u * 1024u;
+  return sobw_shmem(a, NBL, ns) <= 160u * 1024u;
 }
-int sobw_tiles_per_group() { return NIF_SOBW_TPG; }
-int sobw_grid_cap() { return 256 * ((4 * NIF_SOBW_OCC) / (3 * NIF_SOBW_TPG)); }   // resident workgroups of the chip
+int sobw_tiles_per_group(int ns) { return NIF_SOBW_TPG(ns); }
+int sobw_grid_cap() { return 256; }       // one workgroup per CU
 void launch_sobw(const SobArgs& J, int nblk, hipStream_t st) {
   const SNetArgs& a = J.s;
   const int NBL = snet3_nbl(a.n);
-  const size_t shm = sobw_shmem(a, NBL);
-  dim3 grid(nblk), block(192 * NIF_SOBW_TPG);
-#define SWL(NBL_, PR_)                                                                                               \
-  {                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_sobw<NBL_, PR_>), grid, block, shm, st, J);                                                \
+  const size_t shm = sobw_shmem(a, NBL, J.ns);
+  dim3 grid(nblk), block(768);
+#define SWL(NBL_, PR_, NS_)                                                                                               \
+  {                                                                                                                      \
+    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_sobw<NBL_, PR_, NS_>), grid, block, shm, st, J);                                                \
   }
-  if (NBL == 4) { if (a.prec == 1) SWL(4, true) else SWL(4, false) }
-  else { if (a.prec == 1) SWL(2, true) else SWL(2, false) }
+#define SWN(NBL_, PR_) { if (J.ns == 1) SWL(NBL_, PR_, 1) else if (J.ns == 2) SWL(NBL_, PR_, 2) else SWL(NBL_, PR_, 3) }
+  if (NBL == 4) { if (a.prec == 1) SWN(4, true) else SWN(4, false) }
+  else { if (a.prec == 1) SWN(2, true) else SWN(2, false) }
+#undef SWN
 #undef SWL
 }

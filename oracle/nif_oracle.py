@@ -987,17 +987,14 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     return loss, core + [g_last_w, gw.sum(0)], u, J
 
 
-def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, rnd=None,
-                                 scaled=True):
+def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, rnd=None):
     """The Sobolev step of NIF / NIFMultiScale with COORDINATE columns in x_index, in the plane formulation the kernel executes
-    (k_sob):  h_q W(a) = sum_k (zt_k h_q) M^(k)  for the primal (q = 0) and every tangent stream.  rnd=None: exact --
-    equal to sobolev_loss_and_grad (tests/test_oracle.py pins 1e-10), a second independent restatement.  rnd=bf16_round: the
-    build's mixed_bfloat16 policy as k_sob<..., BF = 2> applies it: in the forward sweep the operands (zt_k h_q) and (w0 M^(k)) of
-    every hidden n x n product are rounded to bfloat16 -- the latent factor is applied BEFORE the rounding there, unlike the plain
-    step (planes_loss_and_grad), which scales the product; in the data adjoint dL/da (and nu^d = mu^d c) and (w0 M^(k)) are rounded;
-    first / last layer, biases, activations, loss, the dz dot products and the weight-gradient sums stay in full precision.
-    scaled=False: the cast points of k_sobw (two seeds of a plain SIREN net, one wave per stream) -- those of the plain step: the
-    stream's tile h_q is rounded once per layer and the latent factor scales the PRODUCT,  sum_k zt_k (R(h_q) R(w0 M^(k))).
+    (k_sob / k_sobw):  h_q W(a) = sum_k zt_k (h_q M^(k))  for the primal (q = 0) and every tangent stream.  rnd=None:
+    exact -- equal to sobolev_loss_and_grad (tests/test_oracle.py pins 1e-10), a second independent restatement.  rnd=bf16_round:
+    the build's mixed_bfloat16 policy with the cast points of the kernels (the plain step's, planes_loss_and_grad): in the forward
+    sweep the operands h_q and (w0 M^(k)) of every hidden n x n product are rounded to bfloat16 and the latent factor scales the
+    product; in the data adjoint dL/da (and nu^d = mu^d c) and (w0 M^(k)) are rounded; first / last layer, biases, activations,
+    loss, the dz dot products and the weight-gradient sums stay in full precision.
     Returns (loss, grads in Keras order, u, dudx)."""
     assert spec.kind in (KIND_NIF, KIND_MS)
     R = (lambda a: a) if rnd is None else rnd
@@ -1037,10 +1034,7 @@ def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, samp
     blk = None
     for l in range(nh):
         ab = sl["wh"][l]
-        if scaled:
-            prod = lambda v, k: R(ztk(k) * v) @ R(om * mat(k, ab, (n, n)))
-        else:
-            prod = lambda v, k: ztk(k) * (R(v) @ R(om * mat(k, ab, (n, n))))
+        prod = lambda v, k: ztk(k) * (R(v) @ R(om * mat(k, ab, (n, n))))
         a = sum(prod(h, k) for k in range(K)) + sum(ztk(k) * vec(k, sl["bh"][l])[None, :] for k in range(K))
         ad = [sum(prod(v, k) for k in range(K)) for v in hd]
         t, cs, sn, td = act(a, ad)

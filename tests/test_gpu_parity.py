@@ -774,8 +774,7 @@ def test_full_size_shard_sum_other_configs(which):
     if xi:
         # under the policy: the oracle that rounds where k_sob<..., BF = 2> rounds (sobolev_planes_loss_and_grad)
         lref, gref = O.sobolev_planes_loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64),
-                                                    gt[:n_s].astype(np.float64), xi, 0.1, rnd=O.bf16_round if bf else None,
-                                                    scaled=_sob_scaled(spec, xi))[:2]
+                                                    gt[:n_s].astype(np.float64), xi, 0.1, rnd=O.bf16_round if bf else None)[:2]
     else:
         lref, gref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))
     sub = grad_of(0, n_s, n_s)
@@ -1004,15 +1003,12 @@ def test_mixed_bfloat16_training_and_sobolev_step():
     gt = np.random.default_rng(3).uniform(-1, 1, size=(x.shape[0], 1, 2)).astype(np.float32)
     loss, grad = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.05, sw)
     x64, y64, g64, s64 = x.astype(np.float64), y.astype(np.float64), gt.astype(np.float64), sw.astype(np.float64)
-    # cast for cast: the oracle's plane formulation rounds h_q, (w0 M^(k)), dL/da and nu^d where the training
-    # kernel of this shape (two seeds of a plain SIREN net: k_sobw<PR>) rounds them; same bars as the plain step under the policy
-    assert not _sob_scaled(spec, xi)
-    pl, pg, _, _ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.05, s64, rnd=O.bf16_round, scaled=False)
+    # cast for cast: the oracle's plane formulation rounds h_q, (w0 M^(k)), dL/da and nu^d where the kernels
+    # (training: k_sobw<PR>, one wave per stream; predictions: k_sob<TRAIN = false, BF = 2>) round them; same bars as the plain step
+    pl, pg, pu, pJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.05, s64, rnd=O.bf16_round)
     assert abs(loss - pl) <= 5e-4 * abs(pl), (loss, pl)
     rel = _per_tensor_rel(spec, grad, O.flatten(pg))
     assert max(rel.values()) < 3e-3, rel
-    # predictions: k_sob<TRAIN = false, BF = 2>, which rounds (zt_k h_q)
-    _, _, pu, pJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.05, s64, rnd=O.bf16_round)
     u_p, J_p = m._engine.sobolev_forward(x, xi)
     # (a 1e-7 difference of an fp32 operand flips a bf16 rounding now and then: 2^-9 of that element)
     assert _rel(u_p, pu) < 1e-3 and _rel(J_p.reshape(pJ.shape), pJ) < 2e-3, (_rel(u_p, pu), _rel(J_p.reshape(pJ.shape), pJ))
@@ -1025,19 +1021,10 @@ def test_mixed_bfloat16_training_and_sobolev_step():
         nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
 
 
-def _sob_scaled(spec, xi):
-    """which cast points the Sobolev TRAINING kernel of this shape has under mixed_bfloat16: two coordinate seeds of a plain SIREN
-    NIFMultiScale net up to 64 units run in k_sobw (one wave per stream: h_q rounded, the latent factor on the product -> False),
-    everything else in k_sob<BF = 2> (zt_k h_q rounded -> True)"""
-    wav = (spec.kind == O.KIND_MS and not spec.s_res and len(xi) == 2 and all(j >= spec.pi for j in xi) and spec.n <= 64
-           and spec.r >= 1 and ((spec.n + 15) // 16) % 2 == 0)
-    return not wav
-
-
 @pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_res_64x2", "ms_64x2_r1_so4", "ll_plain_32x2_r3", "ms_cfg5_64x4_si2"])
 def test_sobolev_step_under_the_policy_cast_for_cast(name):
     """configs[4] beyond its own shape: class NIF (skip connections, swish), a resblock net, several outputs -- the Sobolev
-    step under mixed_bfloat16 against the oracle that rounds where k_sob<..., BF = 2> rounds (5e-4 loss / predictions, 3e-3 per
+    step under mixed_bfloat16 against the oracle that rounds where k_sob<..., BF = 2> and k_sobw<PR> round (5e-4 loss / predictions, 3e-3 per
     gradient tensor); the last-layer class keeps exact products in k_sob<LL> under the policy: held to the exact
     oracle at the float32 bars"""
     (kind, cs, cp), _ = CONFIGS[name]
@@ -1051,8 +1038,7 @@ def test_sobolev_step_under_the_policy_cast_for_cast(name):
         rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.1, s64)
         bar_l, bar_g = 2e-5, 3e-4
     else:
-        rl, rg, ru, rJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.1, s64, rnd=O.bf16_round,
-                                                        scaled=_sob_scaled(spec, xi))
+        rl, rg, ru, rJ = O.sobolev_planes_loss_and_grad(spec, ws, x64, y64, g64, xi, 0.1, s64, rnd=O.bf16_round)
         bar_l, bar_g = 5e-4, 3e-3
     assert abs(loss - rl) <= bar_l * abs(rl), (loss, rl)
     rel = _per_tensor_rel(spec, grad, O.flatten(rg))
