@@ -72,7 +72,7 @@ CONFIGS = {
 
 def _make(name, seed=0, boost=2.0):
     import nif_amd
-    (kind, cs, cp), B = CONFIGS[name]
+    (kind, cs, cp), B = CONFIGS[name] if isinstance(name, str) else name
     spec = O.Spec(kind, cs, cp)
     rng = np.random.default_rng(seed)
     ws = O.init_weights(spec, rng, dtype=np.float32)
@@ -466,6 +466,55 @@ def test_sobolev_loss_and_grad_match_oracle(name, weighted):
     u, J = sm.predict(x)
     assert u.shape == (B, spec.so) and J.shape == (B, spec.so, len(xi))
     assert _rel(u, ru) < 1e-5 and _rel(J, rJ) < 2e-5, (_rel(u, ru), _rel(J, rJ))
+
+
+# shapes of k_sobw (plain SIREN NIFMultiScale, <= 64 units, coordinate seeds: one wave per stream): two- and four-block widths,
+# 1..3 seeds in any order, several outputs, latent dims up to 4, one hidden matrix, ragged batches
+SOBW = {
+    "n20_L1_r1_si2": (_cfg("NIFMultiScale", 20, 1, 16, 1, 1, 2, 1, 1), 97),
+    "n32_L3_r4_si3_so2": (_cfg("NIFMultiScale", 32, 3, 24, 2, 4, 3, 2, 2), 1031),
+    "n50_L2_r2_si2_so3": (_cfg("NIFMultiScale", 50, 2, 32, 2, 2, 2, 3, 1), 515),
+    "n64_L5_r3_si3": (_cfg("NIFMultiScale", 64, 5, 32, 2, 3, 3, 1, 2), 4099),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SOBW))
+@pytest.mark.parametrize("ns", [1, 2, 3])
+def test_sobolev_streams_on_waves_shapes(name, ns):
+    m, model, spec, ws, x, y, sw = _make(SOBW[name])
+    if ns > spec.si:
+        pytest.skip("fewer coordinates than seeds")
+    B = x.shape[0]
+    xi = list(range(spec.pi, spec.pi + spec.si))[::-1][:ns]          # descending columns: the streams are not in x_index order
+    g = np.random.default_rng(13).uniform(-1, 1, size=(B, spec.so, ns)).astype(np.float32)
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.3, sw)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, 0.3,
+                                             sw.astype(np.float64))
+    assert abs(loss - rl) <= 2e-5 * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, grad, O.flatten(rg))
+    assert max(rel.values()) < 3e-4, rel
+    # without sample weights, five points fewer (another ragged tail)
+    l2, g2 = m._engine.sobolev_loss_and_grad(x[:B - 5], y[:B - 5], g[:B - 5], xi, 0.3, None)
+    rl2, rg2 = O.sobolev_loss_and_grad(spec, ws, x[:B - 5].astype(np.float64), y[:B - 5].astype(np.float64),
+                                       g[:B - 5].astype(np.float64), xi, 0.3, None)[:2]
+    assert abs(l2 - rl2) <= 2e-5 * abs(rl2) and _rel(g2, O.flatten(rg2)) < 3e-4
+
+
+def test_sobolev_streams_on_waves_many_tile_groups():
+    """70 001 points = 1094 tile groups on 256 workgroups (the chunk stream wraps, the input rows of the next group are
+    prefetched, the last group is ragged) against the oracle's plane formulation, float32 and under the policy"""
+    cfg = (_cfg("NIFMultiScale", 64, 2, 32, 2, 2, 2, 1, 1), 70001)
+    for policy, rnd, bl, bg in (("float32", None, 2e-5, 3e-4), ("mixed_bfloat16", O.bf16_round, 5e-4, 3e-3)):
+        m, model, spec, ws, x, y, sw = _make_policy(cfg, policy)
+        xi = [spec.pi, spec.pi + 1]
+        g = np.random.default_rng(17).uniform(-1, 1, size=(x.shape[0], spec.so, 2)).astype(np.float32)
+        loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.1, sw)
+        rl, rg = O.sobolev_planes_loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, 0.1,
+                                                sw.astype(np.float64), rnd=rnd)[:2]
+        assert abs(loss - rl) <= bl * abs(rl), (policy, loss, rl)
+        rel = _per_tensor_rel(spec, grad, O.flatten(rg))
+        assert max(rel.values()) < bg, (policy, rel)
+
 
 
 def test_sobolev_single_seed_and_zero_weight_degenerates():
@@ -914,7 +963,7 @@ BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_s
 
 def _make_policy(name, policy, boost=1.0):
     import nif_amd
-    (kind, cs, cp), B = CONFIGS[name]
+    (kind, cs, cp), B = CONFIGS[name] if isinstance(name, str) else name
     spec = O.Spec(kind, cs, cp)
     rng = np.random.default_rng(0)
     ws = O.init_weights(spec, rng, dtype=np.float32)
