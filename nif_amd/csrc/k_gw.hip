@@ -276,19 +276,29 @@ __global__ __launch_bounds__(64 * WV) void k_gw_mfma(GwArgs A, int NBO) {
 // at 5 TB/s the kernel sits at the read bandwidth this access pattern reaches (k_gw_out_lds, no arithmetic: 5.3 TB/s).
 // NBUF = 1 (128-wide layers: 256 accumulator registers and a 24-KiB tile per wave): one buffer, refilled as soon as the
 // tile sits in registers -- the DMA of tile t+1 still overlaps the whole split + MFMA phase of tile t.
-template <int NBI, int OBC, int NBUF>   // KC = 2, 4 waves; grid = (rows, planes / 2, NBO / OBC)
+// DAB (mixed_bfloat16, r3): the dL/da stash holds bf16 rows [tile][feature][32 points] of 64 B (k_snet4<PR> / k_sobw<PR> write them:
+// half the bytes of this operand) and the products are the policy's: ONE bf16 product per operand pair, bf16(zt_k h_in) x dL/da.
+// A 1-KiB DMA chunk is then 16 rows of 4 pieces; piece c of row r goes to slot 4 r + (c ^ (r >> 2)) -- the 16 lanes of a
+// ds_read_b128 pass (rows 0..15, same piece) hit 16 distinct 4-bank groups.
+template <int NBI, int OBC, int NBUF, bool DAB = false>   // KC = 2, 4 waves; grid = (rows, planes / 2, NBO / OBC)
 __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   constexpr int KC = 2, WV = 4;
-  constexpr int TFI = NBI * 1024, TFB = OBC * 1024;   // floats of the operand tiles held by this workgroup
+  constexpr int TFI = NBI * 1024, TFB = OBC * (DAB ? 512 : 1024);   // floats of the operand tiles held by this workgroup
   constexpr int BUF = TFI + TFB + 64;                 // IN | DA | Z rows (2 x 32)
   const int ob0 = blockIdx.z * OBC;
-  const long TFO = (long)NBO * 1024;
+  const long TFO = (long)NBO * (DAB ? 512 : 1024);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, hf = lane >> 5;
   const int k0 = blockIdx.y * KC;
   const long nwaves = (long)gridDim.x * WV;
   float* wbuf = gsm + (long)wid * NBUF * BUF;
+  // bf16 dL/da rows: DMA source of this lane inside a chunk (row lane >> 2, piece (lane & 3) ^ (row >> 2)), reader offsets of
+  // lane (i, hf) for the two K halves (row i, piece 2 hf + hh = points 16 hf + 8 hh ..)
+  const int bsrc = (lane >> 2) * 16 + (((lane & 3) ^ (lane >> 4)) & 3) * 4;
+  int boff[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) boff[hh] = (i >> 4) * 256 + ((i & 15) * 4 + (((2 * hf + hh) ^ ((i & 15) >> 2)) & 3)) * 4;
 
   f32x16 acc[KC][NBI][OBC];
   float bacc[KC][OBC];
@@ -312,15 +322,22 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
   auto dma_tile = [&](long t, int set) {
     float* dst = wbuf + set * BUF;
     const float* in = A.IN + t * TFI;
-    const float* da = A.DA + t * TFO + (long)ob0 * 1024;
+    const float* da = A.DA + t * TFO + (long)ob0 * (DAB ? 512 : 1024);
 #pragma unroll
     for (int j = 0; j < NBI * 4; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + j * 256 + ((j & 1) ? src1 : src0)),
                                        (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+    if constexpr (DAB) {
 #pragma unroll
-    for (int j = 0; j < OBC * 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + ((j & 1) ? src1 : src0)),
-                                       (__attribute__((address_space(3))) void*)(dst + TFI + j * 256), 16, 0, 0);
+      for (int j = 0; j < OBC * 2; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + bsrc),
+                                         (__attribute__((address_space(3))) void*)(dst + TFI + j * 256), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < OBC * 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + j * 256 + ((j & 1) ? src1 : src0)),
+                                         (__attribute__((address_space(3))) void*)(dst + TFI + j * 256), 16, 0, 0);
+    }
     const int ti = __builtin_amdgcn_readfirstlane((int)t);
     const int tz = zt_mod >= nt_all ? ti : ti % zt_mod;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + ((long)tz * A.r + kz) * 32 + i),
@@ -338,7 +355,8 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
   if (t < A.ntiles) dma_tile(t, 0);
   for (; t < A.ntiles; t += nwaves, set ^= (NBUF - 1)) {
     const float* buf = wbuf + set * BUF;
-    f32x4 af[NBI][4], bf[OBC][4], zq[KC][4];
+    f32x4 af[NBI][4], bf[DAB ? 1 : OBC][4], zq[KC][4];
+    bf16x8 bq[DAB ? OBC : 1][2];       // DAB: the tile's dL/da operands as they are
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // operands of the tile's quads [q0, q1) from LDS into registers
     auto read_quads = [&](int q0, int q1) {
@@ -346,10 +364,17 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
       for (int ib = 0; ib < NBI; ++ib)
 #pragma unroll
         for (int q = q0; q < q1; ++q) af[ib][q] = *reinterpret_cast<const f32x4*>(buf + ib * 1024 + roff[q]);
+      if constexpr (DAB) {
 #pragma unroll
-      for (int ob = 0; ob < OBC; ++ob)
+        for (int ob = 0; ob < OBC; ++ob)
 #pragma unroll
-        for (int q = q0; q < q1; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TFI + ob * 1024 + roff[q]);
+          for (int hh = q0 / 2; hh < q1 / 2; ++hh) bq[ob][hh] = *reinterpret_cast<const bf16x8*>(buf + TFI + ob * 512 + boff[hh]);
+      } else {
+#pragma unroll
+        for (int ob = 0; ob < OBC; ++ob)
+#pragma unroll
+          for (int q = q0; q < q1; ++q) bf[ob][q] = *reinterpret_cast<const f32x4*>(buf + TFI + ob * 1024 + roff[q]);
+      }
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
@@ -373,15 +398,19 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
           dma_tile(t1 < last ? t1 : last, set);
         }
       }
-      bf16x8 bh[OBC], bl[OBC];
+      bf16x8 bh[OBC], bl[DAB ? 1 : OBC];
 #pragma unroll
-      for (int ob = 0; ob < OBC; ++ob)
+      for (int ob = 0; ob < OBC; ++ob) {
+        if constexpr (DAB) bh[ob] = bq[ob][hh];
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
-          const __bf16 x0 = (__bf16)x;
-          bh[ob][e] = x0; bl[ob][e] = (__bf16)(x - (float)x0);
+          for (int e = 0; e < 8; ++e) {
+            const float x = bf[ob][2 * hh + (e >> 2)][e & 3];
+            const __bf16 x0 = (__bf16)x;
+            bh[ob][e] = x0; bl[ob][e] = (__bf16)(x - (float)x0);
+          }
         }
+      }
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk) {
         if (k0 + kk > A.r) break;
@@ -392,12 +421,15 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
           for (int e = 0; e < 8; ++e) {
             const float x = af[ib][2 * hh + (e >> 2)][e & 3] * (k0 + kk < A.r ? zq[kk][2 * hh + (e >> 2)][e & 3] : 1.0f);
             const __bf16 x0 = (__bf16)x;
-            ah[e] = x0; al[e] = (__bf16)(x - (float)x0);
+            ah[e] = x0;
+            if (!DAB) al[e] = (__bf16)(x - (float)x0);
           }
 #pragma unroll
           for (int ob = 0; ob < OBC; ++ob) {
-            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ob], acc[kk][ib][ob], 0, 0, 0);
-            acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+            if constexpr (!DAB) {
+              acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ob], acc[kk][ib][ob], 0, 0, 0);
+              acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ob], acc[kk][ib][ob], 0, 0, 0);
+            }
             acc[kk][ib][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ob], acc[kk][ib][ob], 0, 0, 0);
           }
         }
@@ -407,7 +439,8 @@ __global__ __launch_bounds__(256) void k_gw_lds(GwArgs A, int NBO) {
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int ob = 0; ob < OBC; ++ob)
-              bacc[kk][ob] = fmaf(wbias ? (k0 + kk < A.r ? zq[kk][q][c] : 1.0f) : 0.f, bf[ob][q][c], bacc[kk][ob]);
+              bacc[kk][ob] = fmaf(wbias ? (k0 + kk < A.r ? zq[kk][q][c] : 1.0f) : 0.f,
+                                  DAB ? (float)bh[ob][4 * (q - 2 * hh) + c] : bf[DAB ? 0 : ob][q][c], bacc[kk][ob]);
       }
     }
   }
@@ -462,26 +495,33 @@ static GwArgs gw_fix(const GwArgs& in) {
 #define NIF_GW_WAVES 4   // 8 = two waves per SIMD, single-buffered: spills at 256 registers, slower
 #endif
 bool gw8_supported(const GwArgs& a, int NBI, int NBO);
+static bool gw_use_lds() { static const bool v = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }(); return v; }
+// may the producers of this context write their hidden-layer dL/da stash rows in bf16 (mixed_bfloat16)?  Only k_gw_lds reads them
+bool gw_da_bf16_ok(int NBI, int NBO) {
+  static const bool on = [] { const char* e = getenv("NIF_DA_BF16"); return !(e && e[0] == '0'); }();
+  return on && gw_use_lds() && NBI == NBO && NBI <= 2;
+}
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st);
 void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
   constexpr int WV = NIF_GW_WAVES;
   dim3 block(64 * WV);
-  static const bool use_lds = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }();
+  const bool use_lds = gw_use_lds();
   // 128-wide layers: the 8-wave shared-tile kernel reads every stash tile once (k_gw8.hip); NIF_GW8=0: the r1 kernels (A/B)
   static const bool use_gw8 = [] { const char* e = getenv("NIF_GW8"); return !(e && e[0] == '0'); }();
   if (use_gw8 && gw8_supported(a, NBI, NBO)) { launch_gw8(a, rows, st); return; }
   if (use_lds && NBI == NBO && (NBI <= 2 || NBI == 4)) {
-#define NIF_GWL(NBI_, OBC_, NBUF_)                                                                                         \
+#define NIF_GWL(NBI_, OBC_, NBUF_, DAB_)                                                                                   \
   do {                                                                                                                     \
     const size_t shm = sizeof(float) * (size_t)(4 * NBUF_ * ((NBI_ + OBC_) * 1024 + 64));                                  \
     dim3 grid(rows, (a.r + 1 + 1) / 2, NBI_ / OBC_);                                                                       \
-    (void)hipFuncSetAttribute((const void*)k_gw_lds<NBI_, OBC_, NBUF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_gw_lds<NBI_, OBC_, NBUF_>), grid, dim3(256), shm, st, a, NBO);                                   \
+    (void)hipFuncSetAttribute((const void*)k_gw_lds<NBI_, OBC_, NBUF_, DAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_gw_lds<NBI_, OBC_, NBUF_, DAB_>), grid, dim3(256), shm, st, a, NBO);                             \
   } while (0)
-    if (NBI == 1) NIF_GWL(1, 1, 2);
-    else if (NBI == 2) NIF_GWL(2, 2, 2);
-    else NIF_GWL(4, 2, 1);
+    if (a.da_bf16) { if (NBI == 1) NIF_GWL(1, 1, 2, true); else NIF_GWL(2, 2, 2, true); }      // (gw_da_bf16_ok: NBI <= 2)
+    else if (NBI == 1) NIF_GWL(1, 1, 2, false);
+    else if (NBI == 2) NIF_GWL(2, 2, 2, false);
+    else NIF_GWL(4, 2, 1, false);
 #undef NIF_GWL
     return;
   }

@@ -60,6 +60,21 @@ __device__ __forceinline__ void st_store16(float* __restrict__ slot, long row0, 
       for (int v = 0; v < 4; ++v) q[(16 * bb + v) * 32] = h[b + bb][v];
   }
 }
+// the same tile as bf16 rows [tile32][feature][32 points] of 64 B (dL/da under mixed_bfloat16): same element index, half the bytes
+template <int NBL>
+__device__ __forceinline__ void st_store16_bf(float* __restrict__ slot, long row0, const f32x4 (&h)[NBL], int g) {
+#ifdef NIF_ABL_NOSTORE
+  if (h[0][0] != 12345.678f) return;
+#endif
+#pragma unroll
+  for (int b = 0; b < NBL; b += 2) {
+    __bf16* q = reinterpret_cast<__bf16*>(slot) + (row0 + (long)(16 * b + 4 * g) * 32);
+#pragma unroll
+    for (int bb = 0; bb < 2 && b + bb < NBL; ++bb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) q[(16 * bb + v) * 32] = (__bf16)h[b + bb][v];
+  }
+}
 template <int NBL>
 __device__ __forceinline__ void st_load16(const float* __restrict__ slot, long row0, f32x4 (&h)[NBL], int g) {
 #ifdef NIF_ABL_NOLOAD      // measurement builds: how much of the kernel is the stash round trip (results are wrong)

@@ -577,7 +577,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             for (int b = 0; b < NBL; ++b) skip[b] = gh[b];
           }
         }
-        if (active) { st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g); vm_note(4 * NBL); }
+        if (active) {
+          if (PR && NBL <= 4 && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+          else st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+          vm_note(4 * NBL);
+        }
         // <dL/da, b^(k)> now, so that dL/da is dead once it is split and stashed (16 registers less across the planes)
         for (int k = 0; k < r; ++k) {
           const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;

@@ -383,7 +383,10 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
         for (int b = 0; b < NBL; ++b) ga[b] = gh[b] * xc[b * 64];
       }
       st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);     // the stream's input of this layer (dz) -- primal: also sin(a) of layer j-1
-      if (active) { st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g); }
+      if (active) {
+        if (PR && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+        else st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+      }
       if (q == 0)
         for (int k = 0; k < r; ++k) {
           const float* sb = sm + k * nsm + o_bh + j * NP + 4 * g;

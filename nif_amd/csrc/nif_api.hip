@@ -1218,6 +1218,14 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   int nloss = (int)((ntiles + 3) / 4);
   rc = snet_plan(c, sa, ns, seeds, &nloss, sp ? sp->par : nullptr); if (rc) return rc;
   *nloss_out = nloss;
+  {   // mixed_bfloat16: the hidden layers' dL/da stash rows in bf16 when both the producer of this step (k_snet4<PR> / k_sobw<PR>)
+      // and the consumer (k_gw_lds) have the form -- half the bytes of that operand on either side
+    const int nbl = snet3_nbl(c->n);
+    bool dab = sa.prec == 1 && (nbl == 2 || nbl == 4) && gw_da_bf16_ok(c->NB, c->NB);
+    if (ns > 0) dab = dab && sobw_supported(sa, ns, sp && sp->any_par);
+    else dab = dab && c->use_snet4;
+    sa.da_bf16 = dab ? 1 : 0;
+  }
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) {
@@ -1278,6 +1286,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   // ShapeNet hidden matrices
   for (int j = 0; j < c->nh; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
+    g.da_bf16 = sa.da_bf16;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
     g.W = hyper_ref(c, wslot, c->n, c->n, c->n);

@@ -91,6 +91,7 @@ struct SNetArgs {
   float* DA_ll;                           // [tiles][rl][32]   dL/da
   float* DZL;                             // [tiles][rl][32]   dL/d latent (through the rl x rl map of the ParameterNet)
   int prec;                               // 0: fp32-exact products; 1: mixed_bfloat16 policy (operands of the n x n products rounded to bf16)
+  int da_bf16;                            // prec == 1: the hidden layers' dL/da stash rows in bf16 (the consumer is k_gw_lds<.., DAB>; nif_api decides)
   int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
@@ -137,7 +138,10 @@ struct GwArgs {
   // gradient and (first layer) use the one-hot input e_seed[t / zt_mod - 1].  0 = plain batch (launchers fix up).
   long zt_mod, bias_ntiles;
   int seed[3];
+  int da_bf16;          // DA holds bf16 rows (mixed_bfloat16: k_snet4<PR> / k_sobw<PR> wrote them); k_gw_lds only (gw_da_bf16_ok)
 };
+bool gw_da_bf16_ok(int NBI, int NBO);
+bool sobw_supported(const SNetArgs& a, int ns, bool any_par);      // k_sobw.hip takes this Sobolev training step
 
 // launchers (implemented in the .hip files); all enqueue on `st`
 void launch_pack(const float* theta, const MatRef& m, int NBI, int NBO, f32x4* WF, f32x4* WB, hipStream_t st);

@@ -533,9 +533,11 @@ def bf16_round(a):
     return r.view(np.float32).astype(np.float64).reshape(a32.shape)
 
 
-def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None):
+def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False):
     """loss, grads (Keras order) and predictions of NIF / NIFMultiScale in the plane formulation.
-    rnd=None: exact; rnd=bf16_round: the build's mixed_bfloat16 policy."""
+    rnd=None: exact; rnd=bf16_round: the build's mixed_bfloat16 policy.  stash_bf16 (with rnd): the hidden layers' weight-gradient
+    sums take dL/da as the bf16 rows the fused kernel stashed and bf16(zt_k h_in) as the other operand, one product each
+    (k_gw_lds<.., DAB>: nets of 17..32 / 49..64 units on the bf16 kernels); biases sum the same bf16 dL/da."""
     assert spec.kind in (KIND_NIF, KIND_MS)
     R = (lambda a: a) if rnd is None else rnd
     B = inputs.shape[0]
@@ -601,10 +603,17 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
         for k in range(K):
             gM[k, ab[0]:ab[1]] += scale * ((zt[:, k:k + 1] * hin).T @ ga).ravel()
 
-    def bgrad(ab, ga):
+    def bgrad(ab, ga, hidden=False):
+        gs = R(ga) if (hidden and stash_bf16) else ga
         for k in range(K):
-            gM[k, ab[0]:ab[1]] += (zt[:, k:k + 1] * ga).sum(0)
+            gM[k, ab[0]:ab[1]] += (zt[:, k:k + 1] * gs).sum(0)
             gzt[:, k] += ga @ vec(k, ab)
+
+    def wgrad_h(ab, hin, ga, scale):      # hidden matrices
+        if not stash_bf16:
+            return wgrad(ab, hin, ga, scale)
+        for k in range(K):
+            gM[k, ab[0]:ab[1]] += scale * (R(zt[:, k:k + 1] * hin).T @ R(ga)).ravel()
 
     def back(ab, shape, ga, hin, scale, rounded):     # dL/dh_in and the latent part through the matrix
         if rounded:                                   # hidden matrices: the adjoint planes hold scale * M_k as well
@@ -622,22 +631,22 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
         for i in reversed(range(nh)):
             hin, a = acts[i]
             ga = gh * df(a)
-            wgrad(sl["wh"][i], hin, ga, 1.0); bgrad(sl["bh"][i], ga)
+            wgrad_h(sl["wh"][i], hin, ga, 1.0); bgrad(sl["bh"][i], ga, True)
             gh = back(sl["wh"][i], (n, n), ga, hin, 1.0, True) + gh
     elif spec.s_res:
         for i in reversed(range(spec.L)):
             hin, a1, t, a2 = acts[i]
             ga2 = 0.5 * gh * np.cos(a2)
-            wgrad(sl["wh"][2 * i + 1], t, ga2, om); bgrad(sl["bh"][2 * i + 1], ga2)
+            wgrad_h(sl["wh"][2 * i + 1], t, ga2, om); bgrad(sl["bh"][2 * i + 1], ga2, True)
             gt = back(sl["wh"][2 * i + 1], (n, n), ga2, t, om, True)
             ga1 = gt * np.cos(a1)
-            wgrad(sl["wh"][2 * i], hin, ga1, om); bgrad(sl["bh"][2 * i], ga1)
+            wgrad_h(sl["wh"][2 * i], hin, ga1, om); bgrad(sl["bh"][2 * i], ga1, True)
             gh = 0.5 * gh + back(sl["wh"][2 * i], (n, n), ga1, hin, om, True)
     else:
         for i in reversed(range(nh)):
             hin, a = acts[i]
             ga = gh * np.cos(a)
-            wgrad(sl["wh"][i], hin, ga, om); bgrad(sl["bh"][i], ga)
+            wgrad_h(sl["wh"][i], hin, ga, om); bgrad(sl["bh"][i], ga, True)
             gh = back(sl["wh"][i], (n, n), ga, hin, om, True)
     ga0 = gh * df(a0)
     wgrad(sl["w1"], x, ga0, om); bgrad(sl["b1"], ga0)
@@ -987,14 +996,16 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     return loss, core + [g_last_w, gw.sum(0)], u, J
 
 
-def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, rnd=None):
+def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, rnd=None,
+                                 stash_bf16=False):
     """The Sobolev step of NIF / NIFMultiScale with COORDINATE columns in x_index, in the plane formulation the kernel executes
     (k_sob / k_sobw):  h_q W(a) = sum_k zt_k (h_q M^(k))  for the primal (q = 0) and every tangent stream.  rnd=None:
     exact -- equal to sobolev_loss_and_grad (tests/test_oracle.py pins 1e-10), a second independent restatement.  rnd=bf16_round:
     the build's mixed_bfloat16 policy with the cast points of the kernels (the plain step's, planes_loss_and_grad): in the forward
     sweep the operands h_q and (w0 M^(k)) of every hidden n x n product are rounded to bfloat16 and the latent factor scales the
     product; in the data adjoint dL/da (and nu^d = mu^d c) and (w0 M^(k)) are rounded; first / last layer, biases, activations,
-    loss, the dz dot products and the weight-gradient sums stay in full precision.
+    loss, the dz dot products and the weight-gradient sums stay in full precision -- except with stash_bf16 (k_sobw<PR>: nets the
+    bf16 kernels take), where the hidden layers' weight-gradient sums are bf16(zt_k h_in)^T bf16(dL/da) per stream, one product.
     Returns (loss, grads in Keras order, u, dudx)."""
     assert spec.kind in (KIND_NIF, KIND_MS)
     R = (lambda a: a) if rnd is None else rnd
@@ -1081,8 +1092,12 @@ def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, samp
             da = da - m * sn * v
         ab = sl["wh"][l]
         for k in range(K):
-            gM[k, ab[0]:ab[1]] += (om * ((ztk(k) * hin).T @ da + sum((ztk(k) * v).T @ g for v, g in zip(hdin, nu)))).ravel()
-            gM[k, sl["bh"][l][0]:sl["bh"][l][1]] += (ztk(k) * da).sum(0)
+            if stash_bf16:
+                gM[k, ab[0]:ab[1]] += (om * (R(ztk(k) * hin).T @ R(da) + sum(R(ztk(k) * v).T @ R(g) for v, g in zip(hdin, nu)))).ravel()
+                gM[k, sl["bh"][l][0]:sl["bh"][l][1]] += (ztk(k) * R(da)).sum(0)
+            else:
+                gM[k, ab[0]:ab[1]] += (om * ((ztk(k) * hin).T @ da + sum((ztk(k) * v).T @ g for v, g in zip(hdin, nu)))).ravel()
+                gM[k, sl["bh"][l][0]:sl["bh"][l][1]] += (ztk(k) * da).sum(0)
             gzt[:, k] += da @ vec(k, sl["bh"][l])
         U = [[R(v) @ R(om * mat(k, ab, (n, n))).T for k in range(K)] for v in [da] + nu]       # U[q][k]
         for k in range(K):

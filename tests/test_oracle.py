@@ -310,5 +310,19 @@ def test_sobolev_plane_formulation_equals_the_materialised_one(name):
         l2, g2, _, _ = O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31, rnd=O.bf16_round)
         d = np.linalg.norm(O.flatten(g2) - f0) / np.linalg.norm(f0)
         assert 1e-5 < d < 5e-2 and np.isfinite(l2)
+        # the bf16 dL/da stash form (k_sobw<PR> / k_gw_lds<DAB>): the same sums without rounding, other weight gradients with it
+        l3, g3, _, _ = O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31, stash_bf16=True)
+        assert l3 == l1 and np.abs(O.flatten(g3) - f1).max() <= 1e-12 * np.abs(f1).max()
+        l4, g4, _, _ = O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, xi, 0.3, sw, batch_global=31, rnd=O.bf16_round, stash_bf16=True)
+        d4 = np.linalg.norm(O.flatten(g4) - O.flatten(g2)) / np.linalg.norm(f0)
+        assert l4 == l2 and 1e-6 < d4 < 2e-2
+    # and of the plain step
+    l5, g5, _ = O.planes_loss_and_grad(spec, ws, x, y, sw, batch_global=31)
+    l6, g6, _ = O.planes_loss_and_grad(spec, ws, x, y, sw, batch_global=31, stash_bf16=True)
+    assert l5 == l6 and np.abs(O.flatten(g5) - O.flatten(g6)).max() <= 1e-12 * np.abs(O.flatten(g5)).max()
+    l7, g7, _ = O.planes_loss_and_grad(spec, ws, x, y, sw, batch_global=31, rnd=O.bf16_round)
+    l8, g8, _ = O.planes_loss_and_grad(spec, ws, x, y, sw, batch_global=31, rnd=O.bf16_round, stash_bf16=True)
+    d8 = np.linalg.norm(O.flatten(g8) - O.flatten(g7)) / np.linalg.norm(O.flatten(g7))
+    assert l7 == l8 and 1e-6 < d8 < 2e-2
     with pytest.raises(AssertionError):
         O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, [0], 0.3)        # parameter columns: the materialised form has them
