@@ -286,10 +286,12 @@ __device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL /
 // back to back) and one LDS round trip feeds 12 MFMAs
 // PR (the mixed_bfloat16 policy of the build): operands rounded to bf16, ONE product a0*b0 instead of the exact split
 // ZI: the chains start from zero (the first MFMA of every chain takes the inline constant 0 as C: no v_mov zeroing)
-template <int NBL, bool PR = false, bool ZI = false>
-__device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T)[NBL], int lane) {
+// NT / OB0: the chunk holds NBL of the NT output blocks of T, starting at block OB0 (128-wide nets stream half chunks)
+template <int NBL, bool PR = false, bool ZI = false, int NT = NBL, int OB0 = 0>
+__device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4* T = T_ + OB0;
 #pragma unroll
   for (int ob = 0; ob < NBL; ob += 2) {
     if (PR) {
@@ -316,10 +318,11 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
-template <int NBL, bool PR = false, bool ZI = false>
-__device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
+template <int NBL, bool PR = false, bool ZI = false, int NT = NBL, int OB0 = 0>
+__device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4* T = T_ + OB0;
 #pragma unroll
   for (int ib = 0; ib < NBL; ib += 2) {
     if (PR) {

@@ -26,6 +26,19 @@
 #ifndef NIF_S4_NBUF
 #define NIF_S4_NBUF 2     // LDS chunk buffers of the <= 64-wide instantiations (the DMA runs NBUF - 1 chunk steps ahead)
 #endif
+#ifndef NIF_S4_SPLIT8
+#define NIF_S4_SPLIT8 2     // 128-wide nets of the last-layer class: a K-step's chunk streams in this many pieces (output-block halves),
+#endif                      // 2 x 12 KB of LDS per workgroup instead of 2 x 24: cfg-4 3.67 -> 2.64 ms (128 x 6: 7.80 -> 6.42); the
+                            // hypernetwork classes (r + 1 planes per layer) lose with it: cfg-3 2.25 -> 2.38 ms, resblocks 3.01 -> 4.17
+#ifndef NIF_S4_SPLIT4
+#define NIF_S4_SPLIT4 1
+#endif
+#ifndef NIF_S4_NBUF_LL8
+#define NIF_S4_NBUF_LL8 2
+#endif
+#ifndef NIF_S4_OCC_LL8
+#define NIF_S4_OCC_LL8 2    // workgroups per CU of the 128-wide last-layer-class training kernel (168 registers: 3 would fit)
+#endif
 #ifndef NIF_S4_OCC_WIDE
 #define NIF_S4_OCC_WIDE 2   // workgroups per CU of the 96- and 128-wide instantiations: 2 x 256 registers with ~200 spilled beat 1 x 512 (cfg-3: 3.45 -> 2.79 ms)
 #endif
@@ -132,18 +145,19 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
 // per-plane biases start the MFMA accumulators (no bias FMAs, no zeroing: acc = b^(r) + sum_k zt_k (b^(k) + h (w0 M^(k)))),
 // zero-started chains take the inline constant as C, the chunk stream is a running pointer with a phase counter.
 template <int NBL, bool TRAIN, int ACT, int MODE, bool SGN, bool LL, bool PR = false>
-__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) void k_snet4(SNetArgs A) {
+__global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && TRAIN && MODE == 0) ? NIF_S4_OCC_LL8 : NIF_S4_OCC_WIDE))) void k_snet4(SNetArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 256, WAVES = 4;
   constexpr int NCH = NBL / 2;                      // K-step chunks per plane
-  constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  constexpr int SPL = (NBL == 8 && LL) ? NIF_S4_SPLIT8 : (NBL == 4 ? NIF_S4_SPLIT4 : 1), NBS = NBL / SPL;   // chunk pieces per K-step, output (input) blocks per piece
+  constexpr int CF = NBS * 3 * 64, CB = NBS * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr int QF = (CF + NT - 1) / NT;
   // LDS ring of the chunk stream: NBUF buffers, the DMA runs DIST = NBUF - 1 chunk steps ahead of the MFMAs.  r2 had two buffers
   // and drained vmcnt(0) in front of every barrier: the L2 -> LDS latency of a chunk (~1.5-2 k cycles) had to hide behind ONE
   // chunk's 24 MFMAs (384 cycles) -- the s_memtime timeline showed ~1.3 k ticks per chunk step, i.e. the kernel was bound by
   // that latency, not by VALU issue (r3: the VALU diet alone moved it 1.10 -> 1.03 ms).  Three buffers for the <= 64-wide nets
   // (36 KB), two for the 96/128-wide ones (their chunks carry 4x the MFMAs and 2 x 24 KB is what fits twice per CU)
-  constexpr int NBUF = NBL <= 4 ? NIF_S4_NBUF : 2, DIST = NBUF - 1;
+  constexpr int NBUF = NBL <= 4 ? NIF_S4_NBUF : ((NBL == 8 && LL) ? NIF_S4_NBUF_LL8 : 2), DIST = NBUF - 1;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, r = LL ? 0 : A.r, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
   // cs_next() issues the DMA of the next chunk of the stream into LDS buffer `buf` and steps the state; behind the last
   // phase the stream wraps to the next tile group's phase 0, or ends (cs_left < 0) when this workgroup has no further group.
   constexpr int PHF = 2 * 3 * 64;                       // units of a phi-layer forward chunk (LL)
-  const int NPC = (r + 1) * NCH;                        // chunks of one hidden matrix
+  const int NPC = (r + 1) * NCH * SPL;                  // chunks of one hidden matrix
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
   int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;      // tile groups of this workgroup behind the current one
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     for (;;) {
       ++cs_phase;
       if (cs_phase == 1) { if (LL) { cs_src = reinterpret_cast<const bf16x8*>(A.WPF); cs_units = PHF; cs_left = NCH; return; } }
-      else if (cs_phase == 2) { if (LL && TRAIN) { cs_src = reinterpret_cast<const bf16x8*>(A.WPB); cs_units = CB; cs_left = 1; return; } }
+      else if (cs_phase == 2) { if (LL && TRAIN) { cs_src = reinterpret_cast<const bf16x8*>(A.WPB); cs_units = CB; cs_left = SPL; return; } }
       else if (TRAIN && cs_phase < 3 + nh) {
         cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 3)) * NPC * CB; cs_units = CB; cs_left = NPC; return;
       } else {
@@ -326,6 +340,22 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;                                   \
   }
 
+// the SPL pieces of K-step ks_: forward (6-product) into T_, adjoint (3-product) into U_; ZI_: the chains start from zero
+#define NIF_FWD_STEP(KS_, T_)                                                                                          \
+  _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
+    if (sp_ == 0) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, 0>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); })            \
+    else if (sp_ == 1) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 1 ? NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    else if (sp_ == 2) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 2 ? 2 * NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    else NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 3 ? 3 * NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+  }
+#define NIF_BWD_STEP(B0_, B1_, U_, ZI_, PR_, ...)                                                                      \
+  _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
+    if (sp_ == 0) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, 0>(cur, B0_, B1_, U_, lane); __VA_ARGS__ })                  \
+    else if (sp_ == 1) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 1 ? NBS : 0)>(cur, B0_, B1_, U_, lane); })       \
+    else if (sp_ == 2) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 2 ? 2 * NBS : 0)>(cur, B0_, B1_, U_, lane); })   \
+    else NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 3 ? 3 * NBS : 0)>(cur, B0_, B1_, U_, lane); })                 \
+  }
+
   int iset = 0;
   for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
     const long t16_raw = tg * WAVES + wid;
@@ -400,13 +430,13 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
+        for (int ks = 0; ks < NCH; ++ks) NIF_FWD_STEP(ks, T)
         const float zt = zt_base[k * 16];
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
 #pragma unroll
-      for (int ks = 0; ks < NCH; ++ks) NIF_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+      for (int ks = 0; ks < NCH; ++ks) NIF_FWD_STEP(ks, acc)
       NIF_TL(30 + j);
       if (TRAIN && SGN) sine16_tag<NBL>(acc, acc);
       else {
@@ -507,7 +537,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
             }
           bf16x8 d0[1], d1[1];
           split2<2>(dq2, d0, d1);
-          NIF_CHUNK({ mfma_x3<NBL>(cur, d0[0], d1[0], gh, lane); })
+          NIF_BWD_STEP(d0[0], d1[0], gh, false, false)
         }
       }
     } else
@@ -600,12 +630,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
           f32x4 U[NBL];
 #pragma unroll
           for (int ks = 0; ks < NCH; ++ks) {
-            if (ks == 0) {
-              NIF_CHUNK({
-                mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], U, lane);
-                if (!SGN) st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
-              })
-            } else NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane); })
+            if (ks == 0) { NIF_BWD_STEP(b0[0], b1[0], U, true, PR, if (!SGN) st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);) }
+            else { NIF_BWD_STEP(b0[ks], b1[ks], U, false, PR) }
           }
           const float zt = zt_base[k * 16];
           float s = 0.f;
@@ -624,8 +650,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
         }
 #pragma unroll
         for (int ks = 0; ks < NCH; ++ks) {
-          if (LL && ks == 0) NIF_CHUNK({ mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], gh, lane); })   // r = 0: the chain starts here
-          else NIF_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
+          if (LL && ks == 0) { NIF_BWD_STEP(b0[0], b1[0], gh, true, PR) }   // r = 0: the chain starts here
+          else { NIF_BWD_STEP(b0[ks], b1[ks], gh, false, PR) }
         }
         NIF_TL(70 + j);
         if (MODE == 2 || (MODE == 1 && !(j & 1))) {
@@ -663,6 +689,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : NIF_S4_OCC_WIDE)) voi
       }
     }
   }
+#undef NIF_BWD_STEP
+#undef NIF_FWD_STEP
 #undef NIF_CHUNK
   if (TRAIN) {
     for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
@@ -678,7 +706,7 @@ static size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const int nz = a.ll ? a.rl : a.r, sou = a.ll ? a.so_u : a.so;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((nz + 3) & ~3) + ((sou + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni;
-  return (size_t)(NBL <= 4 ? NIF_S4_NBUF : 2) * NBL * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);   // NBUF chunk buffers
+  return (size_t)(NBL <= 4 ? NIF_S4_NBUF : ((NBL == 8 && a.ll) ? NIF_S4_NBUF_LL8 : 2)) * ((NBL == 8 && a.ll) ? NBL / NIF_S4_SPLIT8 : (NBL == 4 ? NBL / NIF_S4_SPLIT4 : NBL)) * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);   // NBUF chunk buffers
 }
 // floats per k of the LDS small-vector image (last-layer class: + last_layer_bias and the rl x rl map)
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl) {
@@ -709,6 +737,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   const long nt16 = 2 * ((a.B + 31) / 32);
   const long ngroups = (nt16 + 3) / 4;
   long cap = NBL <= 4 ? 256 * NIF_S4_OCC : 256 * NIF_S4_OCC_WIDE;
+  if (NBL == 8 && a.ll && train && !a.res) cap = 256 * NIF_S4_OCC_LL8;
   if (a.wg_cap > 0 && a.wg_cap < cap) cap = a.wg_cap;
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   if (query_only) return nblk;
