@@ -460,6 +460,13 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
         } else {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) h[b] = 0.5f * (ublk[b] + acc[b]);
+          if (TRAIN && SGN) {     // the block output carries the sign tag of cos(a2): sin(a2) itself is rebuilt as 2 h - u in the adjoint
+#pragma unroll
+            for (int b = 0; b < NBL; ++b)
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                h[b][v] = __uint_as_float((__float_as_uint(h[b][v]) & ~1u) | (__float_as_uint(acc[b][v]) & 1u));
+          }
         }
       }
     }
@@ -590,7 +597,19 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       for (int j = nh - 1; j >= 0; --j) {
         f32x4 ga[NBL];
         if (SGN) {
-          tag_cos<NBL>(hin, dnext);
+          if (MODE == 1 && (j & 1)) {
+            // second matrix of a resblock: hin is the block output 0.5 (u + sin(a2)) with the tag of cos(a2); u = the block input
+            f32x4 ub[NBL];
+            st_load16<NBL>(IN0 + (long)(j - 1) * sstride, row0, ub, g);
+#pragma unroll
+            for (int b = 0; b < NBL; ++b)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float t = fmaf(2.0f, hin[b][v], -ub[b][v]);
+                ub[b][v] = __uint_as_float((__float_as_uint(t) & ~1u) | (__float_as_uint(hin[b][v]) & 1u));
+              }
+            tag_cos<NBL>(ub, dnext);
+          } else tag_cos<NBL>(hin, dnext);
           st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
         } else {
 #pragma unroll
@@ -731,7 +750,7 @@ long snet4_fwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)
 long snet4_bwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)(NBL / 2) * NBL * 2 * 64 * 8 * (r + 1); }
 
 // plain SIREN: the act'(a) ring is not needed (the cosine's sign rides in the stashed sine, any depth / width)
-bool snet4_sign_ring(const SNetArgs& a) { return !a.nif_skip && !a.res; }
+bool snet4_sign_ring(const SNetArgs& a) { return !a.nif_skip; }
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st) {
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);
@@ -753,11 +772,11 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
 // PR_: the mixed_bfloat16 policy (ONE bf16 product per n x n operand pair); plain SIREN training always takes the tagged-sine form
 #define S4M(NBL_, LL_, PR_)                                                                                         \
   if (a.nif_skip) { if (train) S4L(NBL_, true, -1, 2, false, LL_, PR_) else S4L(NBL_, false, -1, 2, false, LL_, PR_) }    \
-  else if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
+  else if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, true, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
   else if (train) S4L(NBL_, true, ACT_SINE, 0, true, LL_, PR_)                                                      \
   else S4L(NBL_, false, ACT_SINE, 0, false, LL_, PR_)
 #define S4N(NBL_, LL_, PR_)   /* last-layer class: no NIF skip form */                                              \
-  if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, false, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
+  if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, true, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
   else if (train) S4L(NBL_, true, ACT_SINE, 0, true, LL_, PR_)                                                      \
   else S4L(NBL_, false, ACT_SINE, 0, false, LL_, PR_)
 #define S4(NBL_)                                                            \
