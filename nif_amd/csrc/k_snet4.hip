@@ -132,11 +132,13 @@ void launch_pack_phi(const float* theta, long w_off, int n, int sop, void* WPF, 
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
 // MODE: 0 = plain (NIFMultiScale without resblock), 1 = SIREN resblock, 2 = NIF skip connection
-// SGN (plain SIREN only): no act'(a) ring.  The next layer's stashed input IS sin(a), so cos(a) = +-sqrt(1 - sin^2): only the
+// SGN (SIREN nets, with or without resblocks): no act'(a) ring.  The next layer's stashed input IS sin(a), so cos(a) = +-sqrt(1 - sin^2): only the
 // SIGN of cos(a) is kept -- as the least significant mantissa bit of the stashed sine itself (sine16_tag / tag_cos in
 // k_snet3_dev.h; r3 -- r2 kept a 128-bit shift register per lane, which cost 3 pack instructions per element and limited the
 // form to (nh + 1) * 4 * NBL <= 128 bits).  |error| of the rebuilt cosine <= 2.4e-4 in the measure-zero neighbourhood of
 // cos = 0, ~1e-7 typically: gradient-path only; the forward activations move by at most one ulp.
+// Resblocks (MODE 1): the first sine of a block is the second matrix's stashed input (as above); the block output
+// 0.5 (u + sin(a2)) takes the tag of cos(a2), and the adjoint rebuilds sin(a2) = 2 h - u from the two stash rows (|error| ~2e-7).
 // LL: last-layer-parameterised class (model.py:1044-1068, :1219-1269): the ShapeNet is a shared-weight dense SIREN
 // (r = 0, one plane per layer) whose last layer emits phi [so_u x rl]; u = Dot(phi, a) + bias with the ParameterNet
 // output a; the adjoint starts from dphi = du (x) a and also yields dL/da (and dL/dlatent through the rl x rl map).
