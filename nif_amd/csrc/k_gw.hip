@@ -1099,8 +1099,31 @@ __global__ __launch_bounds__(256) void k_gw_out_lds(GwArgs A) {
   }
 }
 
+// bias only (W.nin = 0, r = 0: last_layer_bias of the last-layer class): column sums of the small per-point vectors
+// SM [tiles][nc][32] -- 4 nc bytes per point instead of a whole layer-input tile (r3: the call went through k_gw_out_lds, which
+// streamed the 512 B / point of the 128-wide stash tile only to ignore it: 0.195 ms of cfg-4's step).  grid = (rows)
+__global__ __launch_bounds__(256) void k_gw_bias(GwArgs A) {
+  __shared__ float red[8 * 32];
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;       // 8 tiles in flight per workgroup, lane = point of the tile
+  float* prow = A.partial + (long)blockIdx.x * A.pstride;
+  for (int c = 0; c < A.nc; ++c) {
+    float s = 0.f;
+    for (long t = (long)blockIdx.x * 8 + sub; t < A.bias_ntiles; t += (long)gridDim.x * 8) s += A.SM[(t * A.nc + c) * 32 + lane];
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+    if (lane == 0) red[sub * 32 + c % 32] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = 0.f;
+      for (int w = 0; w < 8; ++w) v += red[w * 32 + c % 32];
+      if (c < A.Bv.nout) prow[matref_index(A.Bv, 0, 0, c)] = v;
+    }
+    __syncthreads();
+  }
+}
+
 void launch_gw_out(const GwArgs& a_, int NBI, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  if (a.W.nin == 0 && a.r == 0 && a.has_bias) { hipLaunchKernelGGL(k_gw_bias, dim3(rows), dim3(256), 0, st, a); return; }
   // few columns (e.g. so = 1, r = 1): the VALU kernel below is as fast; from 8 columns on the MFMA form wins big
   if (NIF_GW_EDGE_MFMA && (a.r + 1) * a.nc <= 32 && (a.r + 1) * a.nc >= 8) {
     dim3 grid(rows), block(256);
