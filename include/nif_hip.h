@@ -55,7 +55,7 @@ typedef enum {
  * both.  NIF_POLICY_MIXED_BF16: the operands of the ShapeNet's hidden n x n products (activations, hyper-planes, dL/da in
  * the data adjoint) are rounded to bfloat16, accumulation in fp32; biases, activations, first/last layer, loss, the
  * ParameterNet and the weight-gradient sums stay fp32 (strictly more accurate than Keras' policy, which also stores
- * every layer output in bf16).  Nets of 17..32 / 49..64 units also keep the hidden layers' dL/da stash rows in bf16 and form
+ * every layer output in bf16).  Nets of 17..32 / 49..64 units (and 113..128 with at most two planes per layer) also keep the hidden layers' dL/da stash rows in bf16 and form
  * the weight-gradient sums of those layers as one bf16 product.  Kernels without a bf16 path (odd 16-feature block
  * counts, 128-wide Sobolev) keep fp32. */
 typedef enum { NIF_POLICY_FLOAT32 = 0, NIF_POLICY_MIXED_BF16 = 1 } nif_policy;

@@ -496,10 +496,13 @@ static GwArgs gw_fix(const GwArgs& in) {
 #endif
 bool gw8_supported(const GwArgs& a, int NBI, int NBO);
 static bool gw_use_lds() { static const bool v = [] { const char* e = getenv("NIF_GW_LDS"); return !(e && e[0] == '0'); }(); return v; }
-// may the producers of this context write their hidden-layer dL/da stash rows in bf16 (mixed_bfloat16)?  Only k_gw_lds reads them
-bool gw_da_bf16_ok(int NBI, int NBO) {
+// may the producers of this context write their hidden-layer dL/da stash rows in bf16 (mixed_bfloat16)?  k_gw_lds / k_gw8 read them
+bool gw_da_bf16_ok(int NBI, int NBO, int r) {
   static const bool on = [] { const char* e = getenv("NIF_DA_BF16"); return !(e && e[0] == '0'); }();
-  return on && gw_use_lds() && NBI == NBO && NBI <= 2;
+  static const bool use_gw8 = [] { const char* e = getenv("NIF_GW8"); return !(e && e[0] == '0'); }();
+  if (!on || NBI != NBO) return false;
+  if (NBI == 4) return use_gw8 && (r == 0 || r == 1);      // k_gw8<R, DAB>
+  return gw_use_lds() && NBI <= 2;                         // k_gw_lds<.., DAB>
 }
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st);
 void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
@@ -1103,19 +1106,29 @@ __global__ __launch_bounds__(256) void k_gw_out_lds(GwArgs A) {
 // SM [tiles][nc][32] -- 4 nc bytes per point instead of a whole layer-input tile (r3: the call went through k_gw_out_lds, which
 // streamed the 512 B / point of the 128-wide stash tile only to ignore it: 0.195 ms of cfg-4's step).  grid = (rows)
 __global__ __launch_bounds__(256) void k_gw_bias(GwArgs A) {
-  __shared__ float red[8 * 32];
+  __shared__ float red[8 * 8];
   const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;       // 8 tiles in flight per workgroup, lane = point of the tile
   float* prow = A.partial + (long)blockIdx.x * A.pstride;
-  for (int c = 0; c < A.nc; ++c) {
-    float s = 0.f;
-    for (long t = (long)blockIdx.x * 8 + sub; t < A.bias_ntiles; t += (long)gridDim.x * 8) s += A.SM[(t * A.nc + c) * 32 + lane];
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
-    if (lane == 0) red[sub * 32 + c % 32] = s;
+  for (int c0 = 0; c0 < A.nc; c0 += 8) {                           // eight columns at a time: their loads are independent
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (long t = (long)blockIdx.x * 8 + sub; t < A.bias_ntiles; t += (long)gridDim.x * 8) {
+      const float* q = A.SM + (t * A.nc + c0) * 32 + lane;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < A.nc) s[e] += q[e * 32];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      for (int off = 16; off > 0; off >>= 1) s[e] += __shfl_down(s[e], off, 32);
+      if (lane == 0) red[sub * 8 + e] = s[e];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 8 && c0 + (int)threadIdx.x < A.nc) {
       float v = 0.f;
-      for (int w = 0; w < 8; ++w) v += red[w * 32 + c % 32];
-      if (c < A.Bv.nout) prow[matref_index(A.Bv, 0, 0, c)] = v;
+      for (int w = 0; w < 8; ++w) v += red[w * 8 + threadIdx.x];
+      if (c0 + (int)threadIdx.x < A.Bv.nout) prow[matref_index(A.Bv, 0, 0, c0 + threadIdx.x)] = v;
     }
     __syncthreads();
   }

@@ -28,7 +28,9 @@ typedef float g8_f32x16 __attribute__((ext_vector_type(16)));
 // now 8e3 -- the kernel's time did not move, 1.12 -> 1.09 ms on cfg-3: it is not LDS-bound either)
 __device__ __forceinline__ int g8_off(int f, int p0) { return f * 64 + ((((p0 >> 3) ^ (f >> 2)) & 3) << 4) + ((p0 & 7) << 1); }
 
-template <int R>   // R = 1: planes k = 0 (x zt), 1; R = 0: one plane
+// DAB (mixed_bfloat16, r3): the dL/da stash holds bf16 rows (k_snet4<8, .., PR> writes them) and the sums are the policy's: one
+// product bf16(zt_k h_in) x dL/da per operand pair -- the dL/da pieces go to the operand plane as they are, no lo planes
+template <int R, bool DAB = false>   // R = 1: planes k = 0 (x zt), 1; R = 0: one plane
 __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   extern __shared__ __attribute__((aligned(16))) char g8sm[];
   constexpr int NPL = R + 1;
@@ -57,15 +59,22 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   const long nt = A.ntiles;
   // two register sets: while tile t is split and multiplied, tiles t+1 and t+2 (64 KB per CU) are in flight -- one tile
   // (32 KB) does not cover the HBM latency at 5 TB/s (measured 3.8 TB/s)
-  f32x4 rin[2][2], rda[2][2], rz[2];
+  f32x4 rin[2][2], rda[DAB ? 1 : 2][2], rz[2];
+  g8_bf16x4 rdb[DAB ? 2 : 1][2];
 #define G8_LOAD(SET_, T_)                                                                          \
   {                                                                                                \
     const float* in_ = A.IN + (T_) * (128 * 32);                                                   \
     const float* da_ = A.DA + (T_) * (128 * 32);                                                   \
     rin[SET_][0] = *reinterpret_cast<const f32x4*>(in_ + f0 * 32 + p0);                            \
     rin[SET_][1] = *reinterpret_cast<const f32x4*>(in_ + f1 * 32 + p0);                            \
-    rda[SET_][0] = *reinterpret_cast<const f32x4*>(da_ + f0 * 32 + p0);                            \
-    rda[SET_][1] = *reinterpret_cast<const f32x4*>(da_ + f1 * 32 + p0);                            \
+    if (DAB) {                                                                                     \
+      const __bf16* db_ = reinterpret_cast<const __bf16*>(A.DA) + (T_) * (128 * 32);               \
+      rdb[DAB ? SET_ : 0][0] = *reinterpret_cast<const g8_bf16x4*>(db_ + f0 * 32 + p0);            \
+      rdb[DAB ? SET_ : 0][1] = *reinterpret_cast<const g8_bf16x4*>(db_ + f1 * 32 + p0);            \
+    } else {                                                                                       \
+      rda[DAB ? 0 : SET_][0] = *reinterpret_cast<const f32x4*>(da_ + f0 * 32 + p0);                \
+      rda[DAB ? 0 : SET_][1] = *reinterpret_cast<const f32x4*>(da_ + f1 * 32 + p0);                \
+    }                                                                                              \
     if (R) {                                                                                       \
       const long tz_ = zt_mod >= nt ? (T_) : (T_) % zt_mod;                                        \
       rz[SET_] = *reinterpret_cast<const f32x4*>(A.Z + tz_ * 32 + p0);   /* r = 1: one latent row per tile */ \
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
     for (int e = 0; e < 4; ++e) { const __bf16 h = (__bf16)v[e]; hi[e] = h; lo[e] = (__bf16)(v[e] - (float)h); }
     const int o = g8_off(f, p0);
     *reinterpret_cast<g8_bf16x4*>(plane_hi + o) = hi;
-    *reinterpret_cast<g8_bf16x4*>(plane_lo + o) = lo;
+    if (!DAB) *reinterpret_cast<g8_bf16x4*>(plane_lo + o) = lo;
   };
   // one tile: split register set RS into operand buffer `set`, barrier, refill RS with tile t + 2 grid, products
 #define G8_TILE(RS)                                                                                                    \
@@ -86,19 +95,23 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
     const bool wbias = t < A.bias_ntiles;                                                                              \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
       const int f = j ? f1 : f0;                                                                                       \
+      f32x4 dav;                                                                                                       \
+      if (DAB) { _Pragma("unroll") for (int e = 0; e < 4; ++e) dav[e] = (float)rdb[DAB ? RS : 0][j][e]; }              \
+      else dav = rda[DAB ? 0 : RS][j];                                                                                 \
       if (R) {                                                                                                         \
         const f32x4 zin = {rin[RS][j][0] * rz[RS][0], rin[RS][j][1] * rz[RS][1], rin[RS][j][2] * rz[RS][2], rin[RS][j][3] * rz[RS][3]}; \
         split_store(S + 0 * PLANE, S + 1 * PLANE, f, zin);              /* plane 0: zt h */                            \
         split_store(S + 2 * PLANE, S + 3 * PLANE, f, rin[RS][j]);       /* plane 1: h */                               \
         if (wbias) {                                                                                                   \
-          bsum[j][0] += (rda[RS][j][0] * rz[RS][0] + rda[RS][j][1] * rz[RS][1]) + (rda[RS][j][2] * rz[RS][2] + rda[RS][j][3] * rz[RS][3]); \
-          bsum[j][1] += (rda[RS][j][0] + rda[RS][j][1]) + (rda[RS][j][2] + rda[RS][j][3]);                             \
+          bsum[j][0] += (dav[0] * rz[RS][0] + dav[1] * rz[RS][1]) + (dav[2] * rz[RS][2] + dav[3] * rz[RS][3]);         \
+          bsum[j][1] += (dav[0] + dav[1]) + (dav[2] + dav[3]);                                                         \
         }                                                                                                              \
       } else {                                                                                                         \
         split_store(S + 0 * PLANE, S + 1 * PLANE, f, rin[RS][j]);                                                      \
-        if (wbias) bsum[j][0] += (rda[RS][j][0] + rda[RS][j][1]) + (rda[RS][j][2] + rda[RS][j][3]);                    \
+        if (wbias) bsum[j][0] += (dav[0] + dav[1]) + (dav[2] + dav[3]);                                                \
       }                                                                                                                \
-      split_store(S + 2 * NPL * PLANE, S + (2 * NPL + 1) * PLANE, f, rda[RS][j]);                                      \
+      if (DAB) *reinterpret_cast<g8_bf16x4*>(S + 2 * NPL * PLANE + g8_off(f, p0)) = rdb[DAB ? RS : 0][j];              \
+      else split_store(S + 2 * NPL * PLANE, S + (2 * NPL + 1) * PLANE, f, dav);                                        \
     }                                                                                                                  \
     __syncthreads();   /* planes of `set` complete; the other buffer's readers finished before the previous barrier */ \
     const long tn = t + 2 * (long)gridDim.x;                                                                           \
@@ -115,8 +128,10 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
         const int cb = ((((2 * hh + kg) ^ (fb >> 2)) & 3) << 4);                                                       \
         const g8_bf16x8 bh = *reinterpret_cast<const g8_bf16x8*>(Bhi + fb * 64 + cb);                                  \
         const g8_bf16x8 bl = *reinterpret_cast<const g8_bf16x8*>(Blo + fb * 64 + cb);                                  \
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[o], 0, 0, 0);                                     \
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[o], 0, 0, 0);                                     \
+        if (!DAB) {                                                                                                    \
+          acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[o], 0, 0, 0);                                   \
+          acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[o], 0, 0, 0);                                   \
+        }                                                                                                              \
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[o], 0, 0, 0);                                     \
       }                                                                                                                \
     }                                                                                                                  \
@@ -168,6 +183,17 @@ bool gw8_supported(const GwArgs& a, int NBI, int NBO) {
   return NBI == 4 && NBO == 4 && (a.r == 0 || a.r == 1);
 }
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st) {
+  if (a.da_bf16) {
+    const size_t shm = (size_t)2 * (2 * (a.r + 1) + 2) * 128 * 64;
+    if (a.r == 1) {
+      (void)hipFuncSetAttribute((const void*)k_gw8<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_gw8<1, true>), dim3(rows), dim3(512), shm, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gw8<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_gw8<0, true>), dim3(rows), dim3(512), shm, st, a);
+    }
+    return;
+  }
   if (a.r == 1) {
     const size_t shm = (size_t)2 * (2 * 2 + 2) * 128 * 64;
     (void)hipFuncSetAttribute((const void*)k_gw8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

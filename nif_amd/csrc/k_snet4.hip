@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
           }
         }
         if (active) {
-          if (PR && NBL <= 4 && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+          if (PR && NBL != 6 && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
           else st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
           vm_note(4 * NBL);
         }

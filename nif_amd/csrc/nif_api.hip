@@ -978,6 +978,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   int nloss = (int)((ntiles * 32 + 255) / 256);
+  bool ll_dab = false;
   if (ns > 0) {   // Sobolev: primal + tangents + their adjoint on k_sob<.., LL>; stashes and DPHI hold (1 + ns) blocks of tiles
     SNetArgs sa; int rc = fill_snet_ll_sob(c, sa, xin, B); if (rc) return rc;
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
@@ -1004,6 +1005,11 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   } else if (c->use_ll4) {
     SNetArgs sa; fill_snet_ll(c, sa, xin, ncol, c->pi, B);
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+    {   // mixed_bfloat16: bf16 dL/da stash rows of the shared hidden layers (step_chunk has the hypernetwork classes' rule)
+      const int nbl = snet3_nbl(c->n);
+      ll_dab = sa.prec == 1 && (nbl == 2 || nbl == 4 || nbl == 8) && gw_da_bf16_ok(c->NB, c->NB, 0);
+      sa.da_bf16 = ll_dab ? 1 : 0;
+    }
     nloss = launch_snet4(sa, true, true, c->st);
     const long need = (long)nloss * 4 * snet3_ring_floats_per_wave(c->n, c->nh);
     if (need > c->dring_cap) {
@@ -1058,6 +1064,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
       if (!c->cfg.s_resblock) { w_off = c->s_hid_w[mi]; b_off = c->s_hid_b[mi]; }
       else { const int i = mi / 2; w_off = (mi & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (mi & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
       g.W = dense_ref(w_off, c->n, c->n); g.Bv = vec_ref(b_off, c->n);
+      g.da_bf16 = ll_dab ? 1 : 0;
       launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
     }
     sbase(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
@@ -1221,7 +1228,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   {   // mixed_bfloat16: the hidden layers' dL/da stash rows in bf16 when both the producer of this step (k_snet4<PR> / k_sobw<PR>)
       // and the consumer (k_gw_lds) have the form -- half the bytes of that operand on either side
     const int nbl = snet3_nbl(c->n);
-    bool dab = sa.prec == 1 && (nbl == 2 || nbl == 4) && gw_da_bf16_ok(c->NB, c->NB);
+    bool dab = sa.prec == 1 && (nbl == 2 || nbl == 4 || nbl == 8) && gw_da_bf16_ok(c->NB, c->NB, c->r);
     if (ns > 0) dab = dab && sobw_supported(sa, ns, sp && sp->any_par);
     else dab = dab && c->use_snet4;
     sa.da_bf16 = dab ? 1 : 0;

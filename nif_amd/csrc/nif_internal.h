@@ -138,9 +138,9 @@ struct GwArgs {
   // gradient and (first layer) use the one-hot input e_seed[t / zt_mod - 1].  0 = plain batch (launchers fix up).
   long zt_mod, bias_ntiles;
   int seed[3];
-  int da_bf16;          // DA holds bf16 rows (mixed_bfloat16: k_snet4<PR> / k_sobw<PR> wrote them); k_gw_lds only (gw_da_bf16_ok)
+  int da_bf16;          // DA holds bf16 rows (mixed_bfloat16: k_snet4<PR> / k_sobw<PR> wrote them); k_gw_lds / k_gw8 (gw_da_bf16_ok)
 };
-bool gw_da_bf16_ok(int NBI, int NBO);
+bool gw_da_bf16_ok(int NBI, int NBO, int r);
 bool sobw_supported(const SNetArgs& a, int ns, bool any_par);      // k_sobw.hip takes this Sobolev training step
 
 // launchers (implemented in the .hip files); all enqueue on `st`

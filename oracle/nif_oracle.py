@@ -701,10 +701,11 @@ def snet_phi(spec, ws, x, keep=False, rnd=None):
     return phi
 
 
-def _snet_backward(spec, ws, tape_h, g_phi, rnd=None):
+def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
     *_, rest = _pnet_split(spec, ws)
     first, hidden, bott, _ = _snet_split(spec, rest)
     R = (lambda a_: a_) if rnd is None else rnd      # policy: dL/da and the weights rounded in the data adjoint; weight gradients fp32
+    S = R if stash_bf16 else (lambda a_: a_)         # ... unless the dL/da stash rows are bf16: hidden sums bf16(h_in)^T bf16(dL/da)
     tape, hL = tape_h
     om = spec.omega_s
     g = g_phi.reshape(g_phi.shape[0], -1)
@@ -715,16 +716,16 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None):
         if rec[0] == "sres":
             _, hin, a1, t, a2 = rec
             ga2 = 0.5 * gh * np.cos(a2)
-            gw2 = om * (t.T @ ga2); gb2 = ga2.sum(0)
+            gw2 = om * (S(t).T @ S(ga2)); gb2 = S(ga2).sum(0)
             gt = R(ga2) @ R(om * lay[2]).T
             ga1 = gt * np.cos(a1)
-            gw1 = om * (hin.T @ ga1); gb1 = ga1.sum(0)
+            gw1 = om * (S(hin).T @ S(ga1)); gb1 = S(ga1).sum(0)
             gh = 0.5 * gh + R(ga1) @ R(om * lay[0]).T
             g_hidden.append([gw1, gb1, gw2, gb2])
         else:
             _, hin, a1 = rec
             ga1 = gh * np.cos(a1)
-            g_hidden.append([om * (hin.T @ ga1), ga1.sum(0)])
+            g_hidden.append([om * (S(hin).T @ S(ga1)), S(ga1).sum(0)])
             gh = R(ga1) @ R(om * lay[0]).T
     _, x, a = tape[0]
     ga = gh * np.cos(a)
@@ -780,7 +781,7 @@ def mse_loss(u, y, sample_weight=None):
     return per.sum() / u.shape[0]
 
 
-def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None):
+def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False):
     """last-layer class under the build's mixed_bfloat16 policy (rnd=bf16_round): -> (loss, grads, u), the counterpart of
     planes_loss_and_grad for the shared dense ShapeNet (hidden n x n products on rounded operands, everything else fp32)"""
     assert spec.kind == KIND_LL
@@ -796,7 +797,7 @@ def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_globa
     loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg
     g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
     g_pout = np.einsum("bsj,bs->bj", phi, g_u)
-    g_snet = _snet_backward(spec, ws, stape, g_u[:, :, None] * pout[:, None, :], rnd=rnd)
+    g_snet = _snet_backward(spec, ws, stape, g_u[:, :, None] * pout[:, None, :], rnd=rnd, stash_bf16=stash_bf16 and rnd is not None)
     return loss, pnet_backward(spec, ws, ptape, g_pout) + g_snet + [g_u.sum(0)], u
 
 

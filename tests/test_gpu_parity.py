@@ -963,13 +963,18 @@ BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_s
 
 
 def _stash_bf16(spec, xi=None):
-    """does the step of this shape keep its hidden-layer dL/da stash rows in bf16 under mixed_bfloat16?  The bf16 kernels' widths
-    (two or four 16-feature blocks), plain step: k_snet4<PR>; Sobolev step: only k_sobw<PR> (plain SIREN, coordinate seeds)"""
-    if spec.kind not in (O.KIND_NIF, O.KIND_MS) or (spec.n + 15) // 16 not in (2, 4):
+    """does the step of this shape keep its hidden-layer dL/da stash rows in bf16 under mixed_bfloat16?  The bf16 kernels' widths:
+    two or four 16-feature blocks (k_gw_lds<DAB>), eight with at most two planes per layer (k_gw8<R, DAB>: the last-layer class,
+    latent_dim 1); plain step: k_snet4<PR>; Sobolev step: only k_sobw<PR> (plain SIREN, coordinate seeds, <= 64 units)"""
+    nbl = (spec.n + 15) // 16
+    if spec.kind == O.KIND_LL:
+        return xi is None and nbl in (2, 4, 8)
+    if not (nbl in (2, 4) or (nbl == 8 and spec.r <= 1)):
         return False
     if xi is None:
         return True
-    return spec.kind == O.KIND_MS and not spec.s_res and 1 <= len(xi) <= 3 and all(j >= spec.pi for j in xi) and spec.r >= 1
+    return (spec.kind == O.KIND_MS and not spec.s_res and nbl in (2, 4) and 1 <= len(xi) <= 3 and all(j >= spec.pi for j in xi)
+            and spec.r >= 1)
 
 
 def _make_policy(name, policy, boost=1.0):
@@ -1033,13 +1038,16 @@ def test_mixed_bfloat16_policy_on_the_last_layer_class(name):
     ws = [w.astype(np.float32).astype(np.float64) for w in ws]
     assert m.compute_Dtype == "bfloat16"
     x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
-    rl, rg, ru = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round)
+    rl, rg, ru = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec))
     u = model.predict(x)
     assert _rel(u, ru) < 5e-4, _rel(u, ru)
     loss, g = m._engine.loss_and_grad(x, y, sw)
     assert abs(loss - rl) <= 5e-4 * abs(rl), (loss, rl)
     rel = _per_tensor_rel(spec, g, O.flatten(rg))
     assert max(rel.values()) < 3e-3, rel
+    if _stash_bf16(spec):      # the bf16 dL/da stash (k_gw_lds<DAB> / k_gw8<0, DAB>) is what the hidden sums took
+        rg0 = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=False)[1]
+        assert _rel(g, O.flatten(rg)) < 0.7 * _rel(g, O.flatten(rg0)), (_rel(g, O.flatten(rg)), _rel(g, O.flatten(rg0)))
     d_u = _rel(u, O.forward(spec, ws, x64))
     assert 1e-6 < d_u < 5e-2, d_u                     # the policy IS a different computation
     m32, model32, *_ = _make_policy(name, "float32")

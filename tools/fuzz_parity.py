@@ -164,10 +164,12 @@ def run_case(cfg, B, seed):
             mb = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_bfloat16")
             modelb = mb.build(); modelb.set_weights(ws)
             if ll:
-                rlb, rgb, rub = O.ll_policy_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round)
+                rlb, rgb, rub = O.ll_policy_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round,
+                                                          stash_bf16=(spec.n + 15) // 16 in (2, 4, 8))
             else:       # two / four 16-feature blocks: the dL/da stash rows are bf16 too (k_gw_lds<DAB>)
                 rlb, rgb, rub = O.planes_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round,
-                                                       stash_bf16=(spec.n + 15) // 16 in (2, 4))
+                                                       stash_bf16=((spec.n + 15) // 16 in (2, 4)
+                                                                   or ((spec.n + 15) // 16 == 8 and spec.r <= 1)))
             lb, gb = mb._engine.loss_and_grad(x, y, sw)
             if abs(lb - rlb) > 1e-3 * abs(rlb) or _rel(gb, O.flatten(rgb)) > 5e-3:
                 bad.append(("bf16 policy", lb, rlb, _rel(gb, O.flatten(rgb))))
