@@ -34,6 +34,7 @@ WORK = {
     # configs[4] names bf16: the mixed_bfloat16 policy of the build (single bf16 product per n x n operand pair)
     "cfg5_sobolev_2d_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1, 2], "mixed_bfloat16"),
     "cfg2_wave_4x64_bf16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 1, 1, 1), 1 << 20, None, "mixed_bfloat16"),
+    "cfg3_ms_6x128_2d_bf16": ("NIFMultiScale", ms(128, 6, 64, 2, 1, 2, 1, 1), 1 << 19, None, "mixed_bfloat16"),
     "cfg4_linear_nif_3d_128x6": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
     "cfg4_linear_nif_3d_128x6_bf16": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None,
                                       "mixed_bfloat16"),
