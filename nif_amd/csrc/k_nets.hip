@@ -89,11 +89,20 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   const PSmall S = psmall_stage<NB>(A, pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0), threadIdx.x, 256);
   // one 32-feature block: the hidden products run as exact bf16 splits (k_pnet_bf16.h), forward planes built here
   pbf16x8* bpl = reinterpret_cast<pbf16x8*>(pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0) + ((psmall_floats(A, NB) + 3) & ~3));
+  // two blocks (33..64 units, r3): the same when the launcher found room for the planes (A.pbf2: 24 KB per matrix), else the
+  // f32-input MFMAs on the packed planes in global memory
+  const bool bf2 = NB == 2 && A.pbf2;
   if constexpr (NB == 1) {
     for (int m = 0; m < nm; ++m) {
       const long w_off = A.res ? ((m & 1) ? A.hid_w2[m >> 1] : A.hid_w[m >> 1]) : A.hid_w[m];
       pbf_build(bpl + m * PBF_FWD_U4, nullptr, A.theta, w_off, A.nst, threadIdx.x, 256);
     }
+  } else if constexpr (NB == 2) {
+    if (bf2)
+      for (int m = 0; m < nm; ++m) {
+        const long w_off = A.res ? ((m & 1) ? A.hid_w2[m >> 1] : A.hid_w[m >> 1]) : A.hid_w[m];
+        pbfn_build_fwd<2>(bpl + m * 4 * PBF_FWD_U4, A.theta, w_off, A.nst, threadIdx.x, 256);
+      }
   }
   __syncthreads();
   for (long tile = (long)blockIdx.x * 4 + wid; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       // MLP_SimpleShortCut: h + act(hK+b)   |   SIREN hidden: sin(w0 hW + b)
       if (TRAIN) stash_store<NB>(A.stash + (long)i * A.slot_stride, tile, h, p, hf);
       if constexpr (NB == 1) pbf_dense_fwd(bpl + i * PBF_FWD_U4, h[0], T[0], lane);
+      else if (NB == 2 && bf2) pbfn_dense_fwd<NB>(bpl + i * (NB * NB * PBF_FWD_U4), h, T, lane);
       else dense_mfma<NB, NB>(A.WF + (long)i * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       f32x16 t[NB];
       if (TRAIN) stash_store<NB>(A.stash + (long)(2 * i) * A.slot_stride, tile, h, p, hf);
       if constexpr (NB == 1) pbf_dense_fwd(bpl + (2 * i) * PBF_FWD_U4, h[0], T[0], lane);
+      else if (NB == 2 && bf2) pbfn_dense_fwd<NB>(bpl + (2 * i) * (NB * NB * PBF_FWD_U4), h, T, lane);
       else dense_mfma<NB, NB>(A.WF + (long)(2 * i) * plane, h, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) T[b] = A.omega * T[b] + psmall_get(S.hb + i * NB * 32, b, hf);
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
         stash_store<NB>(A.stash + (long)(2 * i + 1) * A.slot_stride, tile, t, p, hf);
       }
       if constexpr (NB == 1) pbf_dense_fwd(bpl + (2 * i + 1) * PBF_FWD_U4, t[0], T[0], lane);
+      else if (NB == 2 && bf2) pbfn_dense_fwd<NB>(bpl + (2 * i + 1) * (NB * NB * PBF_FWD_U4), t, T, lane);
       else dense_mfma<NB, NB>(A.WF + (long)(2 * i + 1) * plane, t, T, lane);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -249,14 +261,18 @@ __global__ __launch_bounds__(256) void k_pnet_bwd(PNetArgs A) {
   stash_store<NB>(da0, tile, ga, p, hf);
 }
 
-void launch_pnet(const PNetArgs& a, int NSTB, bool train, hipStream_t st) {
+void launch_pnet(const PNetArgs& a_, int NSTB, bool train, hipStream_t st) {
+  PNetArgs a = a_;
   const long ntiles = (a.B + 31) / 32;
   long nblk = (ntiles + 3) / 4;
   if (nblk > 2048) nblk = 2048;          // persistent: the small vectors are staged in LDS once per workgroup
-  dim3 grid((unsigned)nblk), block(256);
   const int nmat = a.lst * (a.res ? 2 : 1);
-  const size_t shm = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)((psmall_floats(a, NSTB) + 3) & ~3) +
-                      (NSTB == 1 ? (size_t)nmat * PBF_FWD_U4 * 4 : 0)) * sizeof(float);
+  const size_t shm0 = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)((psmall_floats(a, NSTB) + 3) & ~3)) * sizeof(float);
+  static const bool bf2_on = [] { const char* e = getenv("NIF_PNET_BF2"); return !(e && e[0] == '0'); }();
+  a.pbf2 = (NSTB == 2 && bf2_on && shm0 + (size_t)nmat * 4 * PBF_FWD_U4 * 16 <= 64u * 1024u) ? 1 : 0;   // two workgroups per CU keep their planes
+  if (a.pbf2 && nblk > 512) nblk = 512;  // the planes are built once per workgroup: fewer, longer-lived workgroups
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t shm = shm0 + (NSTB == 1 ? (size_t)nmat * PBF_FWD_U4 * 16 : (a.pbf2 ? (size_t)nmat * 4 * PBF_FWD_U4 * 16 : 0));
 #define PNL(NB_, TR_, ACT_)                                                                                             \
   {                                                                                                                     \
     if (shm > 48 * 1024)                                                                                                \

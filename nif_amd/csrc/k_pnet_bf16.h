@@ -102,3 +102,65 @@ __device__ __forceinline__ void pbf_dense_bwd(const pbf16x8* bwd, const f32x16& 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b, x0[1], acc, 0, 0, 0);
   U = acc;
 }
+
+// ---- wider ParameterNets (nst <= 32 NB, r3): the same scheme per pair of 32-feature blocks.  fwd: [ob][ib] plane sets of
+// PBF_FWD_U4 units.  An activation block is split once and used against every output block.
+template <int NB>
+__device__ __forceinline__ void pbfn_build_fwd(pbf16x8* fwd, const float* __restrict__ theta, long w_off, int nst, int tid, int nthreads) {
+  __bf16* f16 = reinterpret_cast<__bf16*>(fwd);
+  for (int e = tid; e < NB * NB * 1024; e += nthreads) {
+    const int t = e & 7, lane = (e >> 3) & 63, m = (e >> 9) & 1, blk = e >> 10;
+    const int ob = blk / NB, ib = blk - ob * NB;
+    const int row = 32 * ob + (lane & 31), kf = 32 * ib + pbf_feat(m, lane >> 5, t);
+    const float w = (kf < nst && row < nst) ? theta[w_off + (long)kf * nst + row] : 0.f;
+    const __bf16 w0 = (__bf16)w;
+    const float r1 = w - (float)w0;
+    const __bf16 w1 = (__bf16)r1;
+    __bf16* q = f16 + (long)blk * PBF_FWD_U4 * 8;
+    q[((0 * 2 + m) * 64 + lane) * 8 + t] = w0;
+    q[((1 * 2 + m) * 64 + lane) * 8 + t] = w1;
+    q[((2 * 2 + m) * 64 + lane) * 8 + t] = (__bf16)(r1 - (float)w1);
+  }
+}
+template <int NB>
+__device__ __forceinline__ void pbfn_dense_fwd(const pbf16x8* fwd, const f32x16 (&h)[NB], f32x16 (&T)[NB], int lane) {
+  pbf16x8 x0[NB][2], x1[NB][2], x2[NB][2];
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float x = h[ib][8 * m + t];
+        const __bf16 a = (__bf16)x;
+        const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1;
+        x0[ib][m][t] = a; x1[ib][m][t] = b; x2[ib][m][t] = (__bf16)(r1 - (float)b);
+      }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+      const pbf16x8* q = fwd + (long)(ob * NB + ib) * PBF_FWD_U4;
+      const pbf16x8 w0a = q[(0 * 2 + 0) * 64 + lane], w0b = q[(0 * 2 + 1) * 64 + lane];
+      const pbf16x8 w1a = q[(1 * 2 + 0) * 64 + lane], w1b = q[(1 * 2 + 1) * 64 + lane];
+      const pbf16x8 w2a = q[(2 * 2 + 0) * 64 + lane], w2b = q[(2 * 2 + 1) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, x1[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1b, x1[ib][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2a, x0[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2b, x0[ib][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0a, x2[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b, x2[ib][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, x0[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1b, x0[ib][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0a, x1[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b, x1[ib][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0a, x0[ib][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b, x0[ib][1], acc, 0, 0, 0);
+    }
+    T[ob] = acc;
+  }
+}

@@ -50,6 +50,7 @@ struct PNetArgs {
   long hid_w[NIF_MAX_HID], hid_b[NIF_MAX_HID], hid_w2[NIF_MAX_HID], hid_b2[NIF_MAX_HID];
   long bott_w, bott_b;
   int ll_kind; long last_w, last_b;       // last-layer class: pnet_out = z @ W[r,r] + b
+  int pbf2;                               // k_pnet<2>: hidden products as bf16 splits from LDS planes (set by launch_pnet)
   const f32x4* WF; const f32x4* WB;       // packed MFMA operands, mat m at m*NSTB*NSTB*256 f32x4
   float* stash; long slot_stride;         // slot s at stash + s*slot_stride  (floats)
   float* Z;                               // out: [tiles][r][32]
