@@ -761,7 +761,8 @@ def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
     assert np.array_equal(model2.predict(x), model.predict(x))
 
 
-@pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev", "cfg5_sobolev_bf16"])
+@pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev", "cfg5_sobolev_bf16", "cfg3_ms_128_bf16",
+                                   "cfg4_last_layer_bf16"])
 def test_full_size_shard_sum_other_configs(which):
     """The same size-independent properties at the TRUE per-GPU shard sizes and shapes of BASELINE configs[2..4]: the sum over 8
     contiguous shards of [grad | loss] equals the full-batch result, a repeated launch is bit-identical, and the
@@ -771,10 +772,10 @@ def test_full_size_shard_sum_other_configs(which):
     from nif_amd import distributed as dist
     rng = np.random.default_rng(4)
     xi = None
-    if which == "cfg3_ms_128":          # configs[2]: NIFMultiScale 6x128, 4M points / 8 GPUs
+    if which.startswith("cfg3_ms_128"):          # configs[2]: NIFMultiScale 6x128, 4M points / 8 GPUs
         kind, cs, cp = _cfg("NIFMultiScale", 128, 6, 32, 2, 1, 2, 1, 1, p_act="swish")
         B = 1 << 19
-    elif which == "cfg4_last_layer":    # configs[3]: last-layer class 128x6, 16M points / 8 GPUs
+    elif which.startswith("cfg4_last_layer"):    # configs[3]: last-layer class 128x6, 16M points / 8 GPUs
         kind, cs, cp = _cfg("LL", 128, 6, 32, 2, 10, 3, 3, 1, p_act="swish")
         B = 1 << 21
     else:                               # configs[4]: Sobolev, 64x4 with two coordinates, 8M points / 8 GPUs
@@ -825,13 +826,20 @@ def test_full_size_shard_sum_other_configs(which):
         lref, gref = O.sobolev_planes_loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64),
                                                     gt[:n_s].astype(np.float64), xi, 0.1, rnd=O.bf16_round if bf else None,
                                                     stash_bf16=bf and _stash_bf16(spec, xi))[:2]
+    elif bf:      # the policy on the 128-wide nets: bf16 dL/da stash rows through k_gw8<R, DAB> (r3)
+        fn = O.ll_policy_loss_and_grad if spec.kind == O.KIND_LL else O.planes_loss_and_grad
+        lref, gref = fn(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64), rnd=O.bf16_round,
+                        stash_bf16=_stash_bf16(spec))[:2]
     else:
         lref, gref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))
     sub = grad_of(0, n_s, n_s)
     assert abs(sub[-1] - lref) < (5e-4 if bf else 2e-5) * abs(lref), (sub[-1], lref)
-    if xi:
+    if xi or bf:
         rel = _per_tensor_rel(spec, sub[:-1], O.flatten(gref))
-        assert max(rel.values()) < (3e-3 if bf else 3e-4), rel
+        # (6 x 128 under the policy, this draw: the policy itself sits 9 % from exact arithmetic -- a flipped bf16 rounding of one
+        # activation then moves the gradient by 4e-3 of its norm; another draw of the same net: 3.5e-4)
+        bar = (6e-3 if spec.n > 64 else 3e-3) if bf else 3e-4
+        assert max(rel.values()) < bar, rel
     d_x.free(); d_y.free()
     if d_g is not None:
         d_g.free()
