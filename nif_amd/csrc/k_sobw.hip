@@ -1,18 +1,19 @@
-// k_sobw.hip -- the Sobolev training step of the plain SIREN ShapeNet with TWO coordinate seeds (BASELINE configs[4]:
-// u, du/dx, du/dy; reference nif/layers/gradient.py:36-49 + the two-output mse of the Keras model), the three streams of a
-// tile on three WAVES.
+// k_sobw.hip -- the Sobolev training step of the plain SIREN ShapeNet with one to three coordinate seeds (BASELINE configs[4]:
+// u, du/dx, du/dy; reference nif/layers/gradient.py:36-49 + the two-output mse of the Keras model), the streams of a tile on
+// separate WAVES.
 //
-// k_sob (k_sob_dev.h) carries the primal and both tangent streams of a 16-point tile in ONE wave: 370 registers, one wave per
-// SIMD, every dependent latency exposed -- 3.99 ms of arithmetic where three k_snet4 passes take 2.1.  Here a
-// workgroup is twelve waves = 4 tiles x (primal, d/dx_a, d/dx_b); each wave is a k_snet4 wave (same chunk stream, same
-// bf16-split MFMA forms, same stash layout -- stream q of tile32 t is pseudo-tile q * nt32 + t, as k_sob writes them), three
+// k_sob (k_sob_dev.h) carries the primal and all tangent streams of a 16-point tile in ONE wave: 370 registers with two seeds, one
+// wave per SIMD, every dependent latency exposed -- 3.99 ms of arithmetic where three k_snet4 passes take 2.1.
+// Here a workgroup is twelve waves = 12 / (1 + ns) tiles x (primal, tangent 0, ..); each wave is a k_snet4 wave (same chunk stream,
+// same bf16-split MFMA forms, same stash layout -- stream q of tile32 t is pseudo-tile q * nt32 + t, as k_sob writes them), three
 // per SIMD, and the streams meet in LDS twice per layer:
 //   forward :  primal  -> c = cos(a)                      -> tangents: h' = c a'
-//   adjoint :  primal  -> c ;  tangent d -> w_d = mu_d a'_d   -> primal: da = lambda c - sin(a) (w_0 + w_1) ; tangents: nu_d = mu_d c
+//   adjoint :  primal  -> c ;  tangent d -> w_d = mu_d a'_d   -> primal: da = lambda c - sin(a) sum_d w_d ; tangents: nu_d = mu_d c
 // (formulas: k_sob_dev.h).  The tangent pre-activations a'_d wait in a global ring (one tile per hidden layer and tangent
 // wave; the first layer's is recomputed), the cosine of the adjoint is rebuilt from the tagged sine (k_snet4).
 // PR: the mixed_bfloat16 policy -- one bf16 product per operand pair, the stream's tile rounded once per layer, the latent
-// factor applied to the product (k_snet4<PR>'s cast points, k_sob<BF = 2>'s too).
+// factor applied to the product (k_snet4<PR>'s cast points, k_sob<BF = 2>'s too); with SNetArgs.da_bf16 the hidden layers'
+// dL/da stash rows are bf16 (k_gw_lds<.., DAB> reads them).
 #include "k_sob_dev.h"
 
 template <int NBL>
