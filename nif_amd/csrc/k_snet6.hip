@@ -1,0 +1,546 @@
+// k_snet6.hip -- the plain-SIREN training kernel (k_snet4<NBL, TRAIN, SINE, 0, SGN>) with EVERY ShapeNet weight gradient fused in:
+// no dL/da stash, no weight-gradient launches (k_gw_first_lds, 4 x k_gw_lds, k_gw_out_lds), one partial-gradient row per workgroup.
+//
+// Why: k_snet4 writes 2.5 KB/point of h / dL/da rows that exist only so that the K = batch reductions
+//     dL/dM_j^(k)[in][out] = w0 sum_p zt_k(p) h_j[in][p] dL/da_{j+1}[out][p]
+// can run as separate HBM-bound kernels (0.54 ms of the 1.76 ms step, next to a 1.02 ms kernel whose arithmetic side is 0.71 ms).
+// Here they are accumulated where both operands are live:
+//   * ONE workgroup of 8 waves per CU (2 per SIMD, 256 registers), wave = one 16-point tile as in k_snet4;
+//   * the accumulators of all hidden matrices and planes (nh (r+1) n^2 = 128 KB at 4 x 64, r = 1) live in the 8 waves' registers:
+//     wave (k, I, J) = (wid >> 2, (wid >> 1) & 1, wid & 1) owns the 32 x 32 block (plane k, input block I, output block J) of EVERY
+//     hidden matrix: 16 accumulator registers per matrix;
+//   * at the end of adjoint layer j every wave DEPOSITS its tile's operands in LDS as bf16 (hi, lo) planes in the form it holds them
+//     anyway (the MFMA B operands of the data adjoint: dL/da split for the M dL/da product, h_j re-split, zt dL/da split): 24
+//     ds_write_b64 per layer and tile, no packing arithmetic beyond the splits; during the chunk steps of layer j-1 every wave runs
+//     ITS block over the 8 deposited tiles: ds_read_b64_tr_b16 hands the operands over with features on lanes (k_fuse_dev.h) --
+//     8 transpose reads + 3 v_mfma_f32_32x32x16_bf16 (hi.lo + lo.hi + hi.hi, K = the tile's 16 points) per tile, no VALU work;
+//     the chunk barriers that exist anyway order deposit and consumption (two extra barriers per tile round around the first layer);
+//   * biases, the first layer (K = si) and the last layer (N = so) are v_dot2_f32_bf16 sums over the same transposed operands
+//     (the lane already holds 8 points of its feature): 8 / 12 VALU instructions per tile and wave role;
+//   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
+// Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
+// Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
+#include "k_fuse_dev.h"
+
+#define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
+
+struct S6Args {
+  SNetArgs s;
+  float* partial; long pstride;     // partial-gradient rows [gridDim.x][pstride] (the ShapeNet = hypernetwork columns of them)
+};
+
+template <int NBL>
+__global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
+  extern __shared__ __attribute__((aligned(256))) char smem6[];
+  const SNetArgs& A = F.s;
+  constexpr int NT = 512, WAVES = 8, r = 1;
+  constexpr int NCH = NBL / 2;
+  constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  constexpr int QF = (CF + NT - 1) / NT;
+  constexpr int NBUF = 2;
+  constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt dL/da (hi, lo), dL/da (hi, lo)
+  constexpr int EXT = NPL * FUSE_PLANE_BYTES;
+  constexpr int NVEC = 6, WVT = NVEC * 64;              // per-tile weight vectors of the skinny layers: [vec][hi 16 | lo 16] bf16
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
+  const int FP = stash_fp(n);
+  const long nt16 = 2 * ((A.B + 31) / 32);
+  const long ngroups = (nt16 + WAVES - 1) / WAVES;
+  // wave role in the weight-gradient products
+  const int kk = wid >> 2, bI = (wid >> 1) & 1, bJ = wid & 1;
+
+  char* EX = smem6;                                     // [tile 8][plane 6][2 KB]
+  char* WVL = EX + WAVES * EXT;                         // last layer: zt_k du_o   [tile][k * so + o][32 bf16]
+  char* WVF = WVL + WAVES * WVT;                        // first layer: x_c        [tile][c][32 bf16]
+  bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVT);
+  float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
+  const int sm_tot = ((r + 1) * nsm + 3) & ~3;
+  const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
+  const int NI = (CX + CZ + CY + 4) * 16;
+  const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats
+  float* dzs = sm + sm_tot + (long)wid * pw;
+  float* sks = dzs + r * 64;
+  float* inp = sks + r * 64;
+  float* lsum = sm + sm_tot + (long)WAVES * pw;
+  constexpr int NP = 16 * NBL;
+  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
+
+  // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
+  const int NPC = (r + 1) * NCH;
+  const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
+  int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
+  long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
+  auto cs_phase_step = [&]() {
+    ++cs_phase;
+    if (cs_phase < 1 + nh) {
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CB; cs_units = CB; cs_left = NPC; return;
+    }
+    if (cs_groups <= 0) { cs_left = -1; return; }
+    --cs_groups; cs_phase = 0;
+    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CF; cs_left = nh * NPC;
+  };
+  auto cs_next = [&](int buf) {
+    if (cs_left < 0) return;
+    bf16x8* dst = chunks + buf * CF;
+#pragma unroll
+    for (int q = 0; q < QF; ++q)
+      if (wid * 64 + NT * q < cs_units)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + tid + NT * q),
+                                         (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
+    asm volatile("" ::: "memory");
+    cs_src += cs_units;
+    if (--cs_left == 0) cs_phase_step();
+  };
+  auto prefetch_inputs = [&](long tgn, int set) {
+    long t16n = tgn * WAVES + wid;
+    if (t16n >= nt16) t16n = nt16 - 1;
+    const long tile32n = t16n >> 1;
+    const int poffn = 16 * (int)(t16n & 1) + p;
+    long ptn = t16n * 16 + p;
+    if (ptn >= A.B) ptn = A.B - 1;
+    float* dst = inp + set * NI;
+    for (int i0 = 0; i0 < CX; i0 += 4) {
+      const int c = i0 + g < si ? i0 + g : si - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.xin + ptn * A.ncol + A.col0 + c),
+                                       (__attribute__((address_space(3))) void*)(dst + i0 * 16), 4, 0, 0);
+    }
+    for (int i0 = 0; i0 < CZ; i0 += 4) {
+      const int c = i0 + g < r ? i0 + g : r - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (tile32n * r + c) * 32 + poffn),
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + i0) * 16), 4, 0, 0);
+    }
+    for (int i0 = 0; i0 < CY; i0 += 4) {
+      const int c = i0 + g < so ? i0 + g : so - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.y + ptn * so + c),
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
+    }
+    const float* swp = A.sw ? A.sw + ptn : A.y + ptn * so;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
+                                     (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
+  };
+  {
+    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    prefetch_inputs(blockIdx.x, 0);
+    for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
+      const int k = idx / nsm, e = idx - k * nsm;
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
+    }
+    // the exchange images start as zeros: the first tile round consumes a first-layer deposit that nobody made
+    for (int idx = tid; idx < (WAVES * (EXT + 2 * WVT)) / 16; idx += NT) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cs_left <= 0) cs_left = -1;
+    cs_next(0);
+  }
+  __syncthreads();
+  int cbuf = 0, nbuf = 1;
+  float loss_lane = 0.f;
+  const long sstride = A.slot_stride, tstride = (long)FP * 32;
+  float* IN0 = A.stash;
+
+  // persistent gradient accumulators of this wave's block (plane kk, inputs 32 bI .., outputs 32 bJ ..)
+  f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
+  float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f, bacc3 = 0.f;      // hidden biases (k, J) -- kept by the I = 0 waves
+  float facc[3] = {0.f, 0.f, 0.f}, fbacc = 0.f;                     // first layer (k, J), tiles 4 bI .. 4 bI + 3
+  float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};      // last layer (k, I), tiles 4 bJ .. 4 bJ + 3; its bias
+  const FuseDep dep = fuse_dep_addr(p, g);
+  FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;          // this lane's transpose reads of the wave's A block / B block of a tile image
+  rdA.a0 += 256 * bI; rdA.a1 += 256 * bI;
+  rdB.a0 += (2 + 2 * kk) * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += (2 + 2 * kk) * FUSE_PLANE_BYTES + 256 * bJ;
+  char* exw = EX + wid * EXT;                            // this wave's tile images
+  const int hf = lane >> 5;
+
+#define S6_CHUNK(...)                                                         \
+  {                                                                           \
+    cs_next(nbuf);                                                            \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    __VA_ARGS__                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed; deposits are visible, transpose reads back */ \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    cbuf ^= 1; nbuf ^= 1;                                                     \
+  }
+  // hidden matrix: this wave's block over the deposited tiles [T0_, T1_)
+#define S6_HID_TILES(ACC_, BACC_, T0_, T1_)                                                                 \
+  _Pragma("unroll") for (int t_ = T0_; t_ < T1_; ++t_) {                                                    \
+    const char* img_ = EX + t_ * EXT;                                                                       \
+    const bf16x8 ah_ = fuse_read_op(img_, rdA, 0), al_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdA, 0);     \
+    const bf16x8 bh_ = fuse_read_op(img_, rdB, 0), bl_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdB, 0);     \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, ACC_, 0, 0, 0);                                \
+    if (bI == 0) BACC_ = fuse_sum8(bh_, bl_, BACC_);                                                        \
+  }
+  // the 8 tiles of a deposit are taken in three parts, next to chunk steps 2, 3 and 4 of the following layer
+#define S6_HID_PART(ACC_, BACC_)                                                                            \
+  { if (part == 1) { S6_HID_TILES(ACC_, BACC_, 0, 3) } else if (part == 2) { S6_HID_TILES(ACC_, BACC_, 3, 6) } else { S6_HID_TILES(ACC_, BACC_, 6, 8) } }
+  // last layer (h_nh deposited as the A planes, zt_k du_o as vectors): rows 32 bI .. of plane kk over tiles 4 bJ ..
+  auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t) {
+      const int tt = 4 * bJ + t;
+      const char* img = EX + tt * EXT;
+      const bf16x8 ah = fuse_read_op(img, rdA, 0), al = fuse_read_op(img + FUSE_PLANE_BYTES, rdA, 0);
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+        if (o < so) {
+          const char* w = WVL + tt * WVT + (kk * so + o) * 64 + 16 * hf;
+          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
+          lacc[o] = fuse_dot8(ah, al, whi, wlo, lacc[o]);
+          if (bI == 0) blacc[o] = fuse_sum8(whi, wlo, blacc[o]);
+        }
+    }
+  };
+  // first layer (dL/da_0 deposited as the B planes, x_c as vectors): columns 32 bJ .. of plane kk over tiles 4 bI ..
+  auto consume_first = [&](int t0, int t1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t) {
+      const int tt = 4 * bI + t;
+      const char* img = EX + tt * EXT;
+      const bf16x8 bh = fuse_read_op(img, rdB, 0), bl = fuse_read_op(img + FUSE_PLANE_BYTES, rdB, 0);
+      fbacc = fuse_sum8(bh, bl, fbacc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < si) {
+          const char* w = WVF + tt * WVT + c * 64 + 16 * hf;
+          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
+          facc[c] = fuse_dot8(bh, bl, whi, wlo, facc[c]);
+        }
+    }
+  };
+  // the consumption that belongs to chunk step 1 + `part` (part = 1..3) of the layer after deposit `dj` (nh = the last layer's)
+  auto consume_part = [&](int dj, int part) __attribute__((always_inline)) {
+    if (dj == nh) {       // 4 tiles per wave: two next to step 2, two next to step 3
+      if (part == 1) consume_last(0, 2); else if (part == 2) consume_last(2, 4);
+      return;
+    }
+    switch (dj) {
+      case 0: S6_HID_PART(acc0, bacc0) break;
+      case 1: S6_HID_PART(acc1, bacc1) break;
+      case 2: S6_HID_PART(acc2, bacc2) break;
+      default: S6_HID_PART(acc3, bacc3) break;
+    }
+  };
+
+  int iset = 0;
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
+    const long t16_raw = tg * WAVES + wid;
+    const bool active = t16_raw < nt16;
+    const long t16 = active ? t16_raw : nt16 - 1;
+    const long tile32 = t16 >> 1;
+    const int poff = 16 * (int)(t16 & 1) + p;
+    const long pt = t16 * 16 + p;
+    const bool valid = active && pt < A.B;
+    const float* xs = inp + (iset & 1) * NI + p;
+    const float* zs = inp + (iset & 1) * NI + CX * 16;
+    const float* ys = zs + CZ * 16 + p;
+    const float* wsp = zs + (CZ + CY) * 16 + p;
+    const float* zt_base = zs + p;
+    const long row0 = tile32 * tstride + poff;
+    dzs[lane] = 0.f;
+
+    f32x4 h[NBL], acc[NBL];
+    // ---- first layer ----------------------------------------------------------------------------------------------------
+    {
+      const float* s0 = sm + r * nsm + 4 * g;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] = s;
+      }
+    }
+    {
+      const float zt = zt_base[0];
+      const float* s0 = sm + 4 * g;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        acc[b] += zt * s;
+      }
+    }
+    sine16_tag<NBL>(acc, h);
+    prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
+    // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
+    for (int j = 0; j < nh; ++j) {
+      if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
+      bf16x8 b0[NCH], b1[NCH], b2[NCH];
+      split3<NBL>(h, b0, b1, b2);
+      {
+        const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+      }
+      {
+        f32x4 T[NBL];
+        const float* sb = sm + o_bh + j * NP + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+        S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+        // (the first-layer deposit of the previous tile round is consumed next to the first hidden matrix's steps 2 and 3)
+        S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], T, lane); if (j == 0) consume_first(0, 2); })
+        const float zt = zt_base[0];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
+      }
+      S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], acc, lane); if (j == 0) consume_first(2, 4); })
+      S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], acc, lane); })
+      sine16_tag<NBL>(acc, acc);
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) h[b] = acc[b];
+    }
+    // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------------------------------------
+    f32x4 gh[NBL];
+    ZERO_T6(gh)
+    const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
+    const float zt0 = zt_base[0];
+    float se = 0.f;
+    for (int o = 0; o < so; ++o) {
+      f32x4 wg[NBL];
+      ZERO_T6(wg)
+      float part = 0.f, bias = 0.f;
+#pragma unroll
+      for (int k = 0; k <= r; ++k) {
+        const float zt = k < r ? zt0 : 1.0f;
+        const float* s0 = sm + k * nsm;
+        float sk = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          wg[b] += zt * w;
+        }
+        part = fmaf(zt, sk, part);
+        bias = fmaf(zt, s0[o_bl + o], bias);
+        if (k < r) sks[k * 64 + lane] = sk;
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      const float uo = part + bias;
+      const float e = uo - ys[o * 16];
+      se = fmaf(e, e, se);
+      const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
+      {
+        float t = du * sks[lane];
+        if (g == 0) t = fmaf(du, sm[o_bl + o], t);
+        dzs[lane] += t;
+      }
+      if (g == 0) {     // zt_k du_o of the tile's 16 points as bf16 (hi | lo) rows: the last layer's weight-gradient vectors
+        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVT);
+        const float w0 = zt0 * du;
+        const __bf16 a0 = (__bf16)w0, d0 = (__bf16)du;
+        wv[o * 32 + p] = a0; wv[o * 32 + 16 + p] = (__bf16)(w0 - (float)a0);
+        wv[(so + o) * 32 + p] = d0; wv[(so + o) * 32 + 16 + p] = (__bf16)(du - (float)d0);
+      }
+    }
+    {   // deposit "nh": the last layer's input h_nh as the A planes
+      bf16x8 a0[NCH], a1[NCH];
+      split2<NBL>(h, a0, a1);
+      fuse_deposit4(exw, dep, a0);
+      fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
+    }
+    if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+    // ---- adjoint through the hidden hyper-matrices ---------------------------------------------------------------------------
+    f32x4 dnext[NBL], hin[NBL];
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) hin[b] = h[b];
+    for (int j = nh - 1; j >= 0; --j) {
+      f32x4 ga[NBL];
+      tag_cos<NBL>(hin, dnext);
+      st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);      // h_j: dz dot product and this layer's A planes
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+      {
+        const float* sb = sm + o_bh + j * NP + 4 * g;
+        float sbv = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+          sbv += (ga[b][0] * bb[0] + ga[b][1] * bb[1]) + (ga[b][2] * bb[2] + ga[b][3] * bb[3]);
+        }
+        dzs[lane] += sbv;
+      }
+      bf16x8 b0[NCH], b1[NCH], c0[NCH], c1[NCH];
+      split2<NBL>(ga, b0, b1);
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ga[b] = zt0 * ga[b];
+      split2<NBL>(ga, c0, c1);                                     // zt dL/da: the B operand of plane 0's gradient
+      {
+        f32x4 U[NBL];
+        S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], U, lane); consume_part(j + 1, 1); })
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) gh[b] = zt0 * U[b];
+        dzs[lane] += s;
+      }
+      S6_CHUNK({ mfma_x3<NBL>(cur, b0[0], b1[0], gh, lane); consume_part(j + 1, 2); })
+      S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], gh, lane); consume_part(j + 1, 3); })
+      {   // deposit j: (h_j ; zt dL/da ; dL/da) of this tile -- consumed during the chunk steps of layer j - 1
+        bf16x8 a0[NCH], a1[NCH];
+        split2<NBL>(hin, a0, a1);
+        fuse_deposit4(exw, dep, a0);
+        fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
+        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, c0);
+        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, c1);
+        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
+        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    consume_part(0, 1); consume_part(0, 2); consume_part(0, 3);
+    // ---- first layer ---------------------------------------------------------------------------------------------------------
+    {
+      f32x4 ga[NBL];
+      tag_cos<NBL>(hin, dnext);
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+      {
+        const float* s0 = sm + 4 * g;
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+          for (int dd = 0; dd < si; ++dd) t += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
+        }
+        float tot = dzs[lane] + s;
+        tot += __shfl_xor(tot, 16);
+        tot += __shfl_xor(tot, 32);
+        if (active && g == 0) A.DZ[(tile32 * r) * 32 + poff] = tot;
+      }
+      bf16x8 b0[NCH], b1[NCH], c0[NCH], c1[NCH];
+      split2<NBL>(ga, b0, b1);
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) ga[b] = zt0 * ga[b];
+      split2<NBL>(ga, c0, c1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);    // (the transpose reads of deposit 0 have returned)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, c0);
+      fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, c1);
+      fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
+      fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
+      if (g < si && g < 3) {      // x_c of the tile's 16 points as bf16 (hi | lo) rows
+        __bf16* wv = reinterpret_cast<__bf16*>(WVF + wid * WVT);
+        const float x = xs[g * 16];
+        const __bf16 x0 = (__bf16)x;
+        wv[g * 32 + p] = x0; wv[g * 32 + 16 + p] = (__bf16)(x - (float)x0);
+      }
+    }
+  }
+#undef S6_CHUNK
+#undef S6_HID_PART
+#undef S6_HID_TILES
+  // ---- the last round's first-layer deposit, then this workgroup's partial-gradient row --------------------------------------------
+  __syncthreads();
+  consume_first(0, 4);
+  __syncthreads();          // the exchange images become the reduction scratch
+  {
+    float* prow = F.partial + (long)blockIdx.x * F.pstride;
+    const int i = lane & 31;
+    const float om = A.omega;
+    auto gidx = [&](int k, long slot) -> long { return (k < r ? A.off_Wh + (long)k * A.po : A.off_bh) + slot; };
+    // hidden matrices: no reduction -- every block of the row belongs to exactly one wave
+#define S6_WRITE(J_, ACC_, BACC_)                                                                            \
+    if (J_ < nh) {                                                                                           \
+      const long ws_ = slot_wh(A, J_), bs_ = slot_bh(A, J_);                                                 \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
+        const int in_ = 32 * bI + fmap(e, hf), out_ = 32 * bJ + i;                                           \
+        if (in_ < n && out_ < n) prow[gidx(kk, ws_ + (long)in_ * n + out_)] = om * ACC_[e];                  \
+      }                                                                                                      \
+      if (bI == 0) {                                                                                         \
+        float v_ = BACC_; v_ += __shfl_xor(v_, 32);                                                          \
+        const int out_ = 32 * bJ + i;                                                                        \
+        if (hf == 0 && out_ < n) prow[gidx(kk, bs_ + out_)] = v_;                                            \
+      }                                                                                                      \
+    }
+    S6_WRITE(0, acc0, bacc0) S6_WRITE(1, acc1, bacc1) S6_WRITE(2, acc2, bacc2) S6_WRITE(3, acc3, bacc3)
+#undef S6_WRITE
+    // skinny layers: halves of the tile range (and of K) meet in LDS
+    float* red = reinterpret_cast<float*>(EX);        // [wave][10][64]
+    float vals[10] = {facc[0], facc[1], facc[2], fbacc, lacc[0], lacc[1], lacc[2], blacc[0], blacc[1], blacc[2]};
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      float v = vals[q];
+      v += __shfl_xor(v, 32);
+      red[(wid * 10 + q) * 64 + lane] = v;
+    }
+    __syncthreads();
+    if (hf == 0) {
+      if (bI == 0) {        // first layer (kk, bJ): this wave's tiles + those of wave (kk, 1, bJ)
+        const int out = 32 * bJ + i;
+        if (out < n) {
+          for (int c = 0; c < si && c < 3; ++c)
+            prow[gidx(kk, (long)c * n + out)] = om * (red[(wid * 10 + c) * 64 + lane] + red[((wid + 2) * 10 + c) * 64 + lane]);
+          prow[gidx(kk, slot_b1(A) + out)] = red[(wid * 10 + 3) * 64 + lane] + red[((wid + 2) * 10 + 3) * 64 + lane];
+        }
+      }
+      if (bJ == 0) {        // last layer (kk, bI): this wave's tiles + those of wave (kk, bI, 1)
+        const int in = 32 * bI + i;
+        if (in < n)
+          for (int o = 0; o < so && o < 3; ++o)
+            prow[gidx(kk, slot_wl(A) + (long)in * so + o)] = red[(wid * 10 + 4 + o) * 64 + lane] + red[((wid + 1) * 10 + 4 + o) * 64 + lane];
+      }
+      if (bI == 0 && bJ == 0 && lane == 0)     // last layer's bias (kk): every lane of the I = 0 waves holds the same sum of its tiles
+        for (int o = 0; o < so && o < 3; ++o)
+          prow[gidx(kk, slot_bl(A) + o)] = red[(wid * 10 + 7 + o) * 64] + red[((wid + 1) * 10 + 7 + o) * 64];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
+  if (lane == 0) lsum[wid] = loss_lane;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < WAVES; ++w) s += lsum[w];
+    A.loss_partial[blockIdx.x] = s;
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static size_t snet6_shmem(const SNetArgs& a, int NBL) {
+  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
+  const size_t pw = 2 * a.r * 64 + 2 * ni;
+  return 8 * (6 * FUSE_PLANE_BYTES + 2 * 6 * 64) + 2 * (size_t)NBL * 3 * 64 * 16 + (sm_tot + 8 * pw + 16) * sizeof(float);
+}
+// the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
+bool snet6_supported(const SNetArgs& a) {
+  if (a.ll || a.res || a.nif_skip || a.prec != 0) return false;
+  if (snet3_nbl(a.n) != 4 || a.r != 1 || a.nh < 1 || a.nh > 4 || a.si > 3 || a.so > 3) return false;
+  return snet6_shmem(a, 4) <= 160u * 1024u;
+}
+// workgroups = partial-gradient rows = loss partials of the launch
+int snet6_rows(const SNetArgs& a) {
+  const long nt16 = 2 * ((a.B + 31) / 32);
+  const long ngroups = (nt16 + 7) / 8;
+  return (int)(ngroups < 256 ? ngroups : 256);
+}
+int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st) {
+  const int nblk = snet6_rows(a);
+  S6Args f; f.s = a; f.partial = partial; f.pstride = pstride;
+  const size_t shm = snet6_shmem(a, 4);
+  (void)hipFuncSetAttribute((const void*)k_snet6<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((k_snet6<4>), dim3(nblk), dim3(512), shm, st, f);
+  return nblk;
+}

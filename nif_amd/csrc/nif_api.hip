@@ -120,6 +120,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   nif_ctx* c = new nif_ctx();
   c->cfg = *cfg;
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
+  { const char* e = getenv("NIF_FUSE_GW"); c->opt_fuse_gw = !(e && e[0] == '0'); }
   { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
   { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
@@ -1224,6 +1225,11 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   if (!whole) sa.wg_cap = c->opt_pipe_wgs;        // leave room on every CU for the reductions of the previous chunk
   int nloss = (int)((ntiles + 3) / 4);
   rc = snet_plan(c, sa, ns, seeds, &nloss, sp ? sp->par : nullptr); if (rc) return rc;
+  // plain SIREN step on the bf16-split kernel: every ShapeNet weight gradient inside the training kernel (k_snet6) -- its workgroups
+  // are the partial-gradient rows, so the row count of this step has to be the kernel's grid
+  const bool fused_gw = ns == 0 && whole && c->use_snet4 && c->opt_fuse_gw && snet6_supported(sa) &&
+                        snet6_rows(sa) == rows_for(c, ntiles);
+  if (fused_gw) nloss = snet6_rows(sa);
   *nloss_out = nloss;
   {   // mixed_bfloat16: the hidden layers' dL/da stash rows in bf16 when both the producer of this step (k_snet4<PR> / k_sobw<PR>)
       // and the consumer (k_gw_lds) have the form -- half the bytes of that operand on either side
@@ -1246,6 +1252,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
       }
       launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st, sparp);
     }
+    else if (fused_gw) launch_snet6(sa, partial, c->pstride, sa_st);
     else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
     else launch_snet(sa, c->NB, true, sa_st);
@@ -1268,7 +1275,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     // the compute-bound adjoint also pulls the first gradient kernel's stash slot (dL/da of the first layer) through
     // the cache hierarchy -- see PbwArgs::touch.  NIF_PBW_TOUCH=0 turns it off (A/B)
     static const bool touch_on = [] { const char* e = getenv("NIF_PBW_TOUCH"); return !(e && e[0] == '0'); }();
-    const float* touch = (touch_on && whole && pb_st == sb_st) ? sa.stash + (long)(c->nh + 1) * c->slot_s : nullptr;
+    const float* touch = (touch_on && whole && pb_st == sb_st && !fused_gw) ? sa.stash + (long)(c->nh + 1) * c->slot_s : nullptr;
     if (fused_p) launch_pnet_bwg(pa, partial, c->pstride, rows, pb_st, touch, (long)c->NB * 1024);
     else launch_pnet_bwd(pa, c->NSTB, pb_st); }
   ProfScope pgw(c, NIF_PROF_GW, sb_st);
@@ -1284,6 +1291,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   };
   const float om_s = sa.omega, om_p = pa.omega;
   float* sIN = sa.stash; float* sDA = sa.stash + (long)(c->nh + 1) * c->slot_s;
+  if (!fused_gw) {
   // ShapeNet first layer
   sbase(g); g.DA = sDA; g.xin = xin; g.ncol = ncol; g.col0 = c->pi; g.nd = c->si; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
   g.W = hyper_ref(c, 0, c->n, c->si, c->n);
@@ -1308,6 +1316,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     g.W = hyper_ref(c, wslot, c->so, c->n, c->so);
     g.Bv = hyper_ref(c, bslot, 0, 1, c->so);
     launch_gw_out(g, c->NB, rows, sb_st);
+  }
   }
   // ParameterNet: first, hidden matrices, bottleneck
   float* pST = pa.stash;
@@ -1701,6 +1710,7 @@ extern "C" int nif_zero_grad(nif_ctx* c) {
 // A/B switches (measurement and tests; the defaults are the product path)
 extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
   if (!c || !key) return fail(NIF_ERR_INVALID, "null");
+  if (strcmp(key, "fuse_gw") == 0) { c->opt_fuse_gw = value != 0; return NIF_OK; }   // 0: k_snet4 + k_gw_* instead of the fused-gradient kernel
   if (strcmp(key, "fp32_mfma") == 0) {      // 1: every product on the f32-input MFMAs (k_snet3) instead of the bf16 splits
     c->opt_fp32_mfma = value != 0;
     c->packed = false; c->packed32 = false; c->packed_p32 = false;

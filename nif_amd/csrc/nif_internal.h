@@ -166,6 +166,11 @@ void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, float scale, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+// k_snet4's plain-SIREN training step with every ShapeNet weight gradient fused in (k_snet6.hip): one partial-gradient row and one
+// loss partial per workgroup; no dL/da stash, no k_gw_* launches
+bool snet6_supported(const SNetArgs& a);
+int snet6_rows(const SNetArgs& a);
+int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st);
 int snet4_nsm_ll(int si, int sop, int nh, int n, int sou, int rl);
 // Sobolev step (k_sob.hip): primal + tangents w.r.t. `ns` coordinate seeds, loss mse(u,y) + wj*mse(du/dx,gt), adjoint
 long sob_ring_floats_per_wave(int n, int nh);
