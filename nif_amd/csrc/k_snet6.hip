@@ -9,20 +9,53 @@
 //   * the accumulators of all hidden matrices and planes (nh (r+1) n^2 = 128 KB at 4 x 64, r = 1) live in the 8 waves' registers:
 //     wave (k, I, J) = (wid >> 2, (wid >> 1) & 1, wid & 1) owns the 32 x 32 block (plane k, input block I, output block J) of EVERY
 //     hidden matrix: 16 accumulator registers per matrix;
-//   * at the end of adjoint layer j every wave DEPOSITS its tile's operands in LDS as bf16 (hi, lo) planes in the form it holds them
-//     anyway (the MFMA B operands of the data adjoint: dL/da split for the M dL/da product, h_j re-split, zt dL/da split): 24
-//     ds_write_b64 per layer and tile, no packing arithmetic beyond the splits; during the chunk steps of layer j-1 every wave runs
+//   * at the end of adjoint layer j every wave DEPOSITS its tile's operands in LDS as bf16 (hi, lo) planes in the form it holds
+//     MFMA B operands anyway (dL/da: the split of the data adjoint's own product; h_j and zt h_j: split when the row comes back from
+//     the stash -- nothing is held across the layer for it): 24 ds_write_b64 per layer and tile, no packing arithmetic beyond the
+//     splits; during the chunk steps of layer j-1 every wave runs
 //     ITS block over the 8 deposited tiles: ds_read_b64_tr_b16 hands the operands over with features on lanes (k_fuse_dev.h) --
 //     8 transpose reads + 3 v_mfma_f32_32x32x16_bf16 (hi.lo + lo.hi + hi.hi, K = the tile's 16 points) per tile, no VALU work;
 //     the chunk barriers that exist anyway order deposit and consumption (two extra barriers per tile round around the first layer);
-//   * biases, the first layer (K = si) and the last layer (N = so) are v_dot2_f32_bf16 sums over the same transposed operands
-//     (the lane already holds 8 points of its feature): 8 / 12 VALU instructions per tile and wave role;
+//   * biases, the first layer (K = si) and the last layer (N = so) are v_dot2_f32_bf16 sums of the same transposed operands against
+//     per-tile weight vectors (zt, 1, x_c, zt x_c, du_o as bf16 hi | lo rows of 16 points): the lane already holds 8 points of its
+//     feature -- 12 VALU instructions per tile, vector and wave role;
 //   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
 // Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
 // Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
 #include "k_fuse_dev.h"
 
 #define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
+
+#ifndef NIF_S6_RING
+#define NIF_S6_RING 1       // 1: the h_j rows of a wave's tile in a private ring [matrix j][feature][16 points] that stays cache resident; 0: the [tile32][feature][32] stash
+#endif
+// private ring of a wave: feature f of the tile at f * 16 + p
+template <int NBL>
+__device__ __forceinline__ void ring_store16(float* __restrict__ slot, const f32x4 (&h)[NBL], int g, int p) {
+#ifdef NIF_ABL_NOSTORE
+  if (h[0][0] != 12345.678f) return;
+#endif
+  float* q = slot + 4 * g * 16 + p;
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) q[(16 * b + v) * 16] = h[b][v];
+}
+template <int NBL>
+__device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x4 (&h)[NBL], int g, int p) {
+#ifdef NIF_ABL_NOLOAD
+  if (p != -12345) {
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) { h[b][0] = 0.5f; h[b][1] = 0.25f; h[b][2] = 0.125f; h[b][3] = 0.75f; }
+    return;
+  }
+#endif
+  const float* q = slot + 4 * g * 16 + p;
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) h[b][v] = q[(16 * b + v) * 16];
+}
 
 struct S6Args {
   SNetArgs s;
@@ -38,9 +71,11 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr int QF = (CF + NT - 1) / NT;
   constexpr int NBUF = 2;
-  constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt dL/da (hi, lo), dL/da (hi, lo)
+  constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
   constexpr int EXT = NPL * FUSE_PLANE_BYTES;
-  constexpr int NVEC = 6, WVT = NVEC * 64;              // per-tile weight vectors of the skinny layers: [vec][hi 16 | lo 16] bf16
+  // per-tile weight vectors [hi 16 | lo 16] bf16 = 64 B.  Last layer (WVL): du_o (o < 3), zt, ones.  First layer (WVF), per plane k:
+  // k * 4 + c = (zt | 1) x_c, k * 4 + 3 = (zt | 1)
+  constexpr int NVL = 5, NVF = 8, WVLT = NVL * 64, WVFT = NVF * 64;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
@@ -51,9 +86,9 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   const int kk = wid >> 2, bI = (wid >> 1) & 1, bJ = wid & 1;
 
   char* EX = smem6;                                     // [tile 8][plane 6][2 KB]
-  char* WVL = EX + WAVES * EXT;                         // last layer: zt_k du_o   [tile][k * so + o][32 bf16]
-  char* WVF = WVL + WAVES * WVT;                        // first layer: x_c        [tile][c][32 bf16]
-  bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVT);
+  char* WVL = EX + WAVES * EXT;
+  char* WVF = WVL + WAVES * WVLT;
+  bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);
   float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
@@ -134,15 +169,22 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
       sm[idx] = v;
     }
     // the exchange images start as zeros: the first tile round consumes a first-layer deposit that nobody made
-    for (int idx = tid; idx < (WAVES * (EXT + 2 * WVT)) / 16; idx += NT) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += NT) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (cs_left <= 0) cs_left = -1;
     cs_next(0);
   }
   __syncthreads();
+  if (tid < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
+    const int t = tid >> 4, q = tid & 15;
+    reinterpret_cast<__bf16*>(WVL + t * WVLT)[4 * 32 + q] = (__bf16)1.0f;
+    reinterpret_cast<__bf16*>(WVF + t * WVFT)[7 * 32 + q] = (__bf16)1.0f;
+  }
   int cbuf = 0, nbuf = 1;
   float loss_lane = 0.f;
   const long sstride = A.slot_stride, tstride = (long)FP * 32;
   float* IN0 = A.stash;
+  float* ring = A.stash + ((long)blockIdx.x * WAVES + wid) * (long)nh * (NP * 16);    // NIF_S6_RING: [matrix][NP features][16 points]
+  (void)ring; (void)IN0; (void)sstride;
 
   // persistent gradient accumulators of this wave's block (plane kk, inputs 32 bI .., outputs 32 bJ ..)
   f32x16 acc0, acc1, acc2, acc3;
@@ -153,10 +195,10 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};      // last layer (k, I), tiles 4 bJ .. 4 bJ + 3; its bias
   const FuseDep dep = fuse_dep_addr(p, g);
   FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;          // this lane's transpose reads of the wave's A block / B block of a tile image
-  rdA.a0 += 256 * bI; rdA.a1 += 256 * bI;
-  rdB.a0 += (2 + 2 * kk) * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += (2 + 2 * kk) * FUSE_PLANE_BYTES + 256 * bJ;
+  rdA.a0 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI; rdA.a1 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI;   // plane 0: zt h, plane 1 (= r): h
+  rdB.a0 += 4 * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += 4 * FUSE_PLANE_BYTES + 256 * bJ;
+  const int wofs = 16 * (lane >> 5);                    // this lane's 8 points inside a weight vector (bytes)
   char* exw = EX + wid * EXT;                            // this wave's tile images
-  const int hf = lane >> 5;
 
 #define S6_CHUNK(...)                                                         \
   {                                                                           \
@@ -178,12 +220,15 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, ACC_, 0, 0, 0);                                \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, ACC_, 0, 0, 0);                                \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, ACC_, 0, 0, 0);                                \
-    if (bI == 0) BACC_ = fuse_sum8(bh_, bl_, BACC_);                                                        \
+    if (bI == 0) {                                                                                          \
+      const char* w_ = WVL + t_ * WVLT + (3 + kk) * 64 + wofs;                                              \
+      BACC_ = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), BACC_); \
+    }                                                                                                       \
   }
   // the 8 tiles of a deposit are taken in three parts, next to chunk steps 2, 3 and 4 of the following layer
 #define S6_HID_PART(ACC_, BACC_)                                                                            \
   { if (part == 1) { S6_HID_TILES(ACC_, BACC_, 0, 3) } else if (part == 2) { S6_HID_TILES(ACC_, BACC_, 3, 6) } else { S6_HID_TILES(ACC_, BACC_, 6, 8) } }
-  // last layer (h_nh deposited as the A planes, zt_k du_o as vectors): rows 32 bI .. of plane kk over tiles 4 bJ ..
+  // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors): rows 32 bI .. of plane kk over tiles 4 bJ ..
   auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = t0; t < t1; ++t) {
@@ -193,25 +238,31 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
 #pragma unroll
       for (int o = 0; o < 3; ++o)
         if (o < so) {
-          const char* w = WVL + tt * WVT + (kk * so + o) * 64 + 16 * hf;
+          const char* w = WVL + tt * WVLT + o * 64 + wofs;
           const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
           lacc[o] = fuse_dot8(ah, al, whi, wlo, lacc[o]);
-          if (bI == 0) blacc[o] = fuse_sum8(whi, wlo, blacc[o]);
+          if (bI == 0) {
+            const char* z = WVL + tt * WVLT + (3 + kk) * 64 + wofs;
+            blacc[o] = fuse_dot8(whi, wlo, *reinterpret_cast<const bf16x8*>(z), *reinterpret_cast<const bf16x8*>(z + 32), blacc[o]);
+          }
         }
     }
   };
-  // first layer (dL/da_0 deposited as the B planes, x_c as vectors): columns 32 bJ .. of plane kk over tiles 4 bI ..
+  // first layer (dL/da_0 deposited as the B planes, (zt | 1) x_c and (zt | 1) as vectors): columns 32 bJ .. of plane kk over tiles 4 bI ..
   auto consume_first = [&](int t0, int t1) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = t0; t < t1; ++t) {
       const int tt = 4 * bI + t;
       const char* img = EX + tt * EXT;
       const bf16x8 bh = fuse_read_op(img, rdB, 0), bl = fuse_read_op(img + FUSE_PLANE_BYTES, rdB, 0);
-      fbacc = fuse_sum8(bh, bl, fbacc);
+      {
+        const char* w = WVF + tt * WVFT + (kk * 4 + 3) * 64 + wofs;
+        fbacc = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), fbacc);
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         if (c < si) {
-          const char* w = WVF + tt * WVT + c * 64 + 16 * hf;
+          const char* w = WVF + tt * WVFT + (kk * 4 + c) * 64 + wofs;
           const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
           facc[c] = fuse_dot8(bh, bl, whi, wlo, facc[c]);
         }
@@ -219,6 +270,9 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   };
   // the consumption that belongs to chunk step 1 + `part` (part = 1..3) of the layer after deposit `dj` (nh = the last layer's)
   auto consume_part = [&](int dj, int part) __attribute__((always_inline)) {
+#ifdef NIF_S6_NOCONS
+    return;
+#endif
     if (dj == nh) {       // 4 tiles per wave: two next to step 2, two next to step 3
       if (part == 1) consume_last(0, 2); else if (part == 2) consume_last(2, 4);
       return;
@@ -273,7 +327,11 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
     for (int j = 0; j < nh; ++j) {
+#if NIF_S6_RING
+      ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
+#else
       if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
+#endif
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
       {
@@ -337,19 +395,28 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
         if (g == 0) t = fmaf(du, sm[o_bl + o], t);
         dzs[lane] += t;
       }
-      if (g == 0) {     // zt_k du_o of the tile's 16 points as bf16 (hi | lo) rows: the last layer's weight-gradient vectors
-        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVT);
-        const float w0 = zt0 * du;
-        const __bf16 a0 = (__bf16)w0, d0 = (__bf16)du;
-        wv[o * 32 + p] = a0; wv[o * 32 + 16 + p] = (__bf16)(w0 - (float)a0);
-        wv[(so + o) * 32 + p] = d0; wv[(so + o) * 32 + 16 + p] = (__bf16)(du - (float)d0);
+      if (g == 0 && o < 3) {     // du_o of the tile's 16 points as a bf16 (hi | lo) row: the last layer's weight-gradient vector
+        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
+        const __bf16 d0 = (__bf16)du;
+        wv[o * 32 + p] = d0; wv[o * 32 + 16 + p] = (__bf16)(du - (float)d0);
       }
     }
-    {   // deposit "nh": the last layer's input h_nh as the A planes
+    if (g == 1) {     // zt of the tile (the hidden layers' plane-0 bias sums use it too)
+      __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
+      const __bf16 z0 = (__bf16)zt0;
+      wv[3 * 32 + p] = z0; wv[3 * 32 + 16 + p] = (__bf16)(zt0 - (float)z0);
+    }
+    {   // deposit "nh": the last layer's input h_nh (and zt h_nh) as the A planes
       bf16x8 a0[NCH], a1[NCH];
       split2<NBL>(h, a0, a1);
       fuse_deposit4(exw, dep, a0);
       fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
+      f32x4 zh[NBL];
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) zh[b] = zt0 * h[b];
+      split2<NBL>(zh, a0, a1);
+      fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
+      fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
     }
     if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
     // ---- adjoint through the hidden hyper-matrices ---------------------------------------------------------------------------
@@ -359,7 +426,11 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     for (int j = nh - 1; j >= 0; --j) {
       f32x4 ga[NBL];
       tag_cos<NBL>(hin, dnext);
-      st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);      // h_j: dz dot product and this layer's A planes
+#if NIF_S6_RING
+      ring_load16<NBL>(ring + j * (NP * 16), hin, g, p);           // h_j: dz dot product and this layer's A planes
+#else
+      st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
+#endif
 #pragma unroll
       for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
       {
@@ -372,11 +443,8 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
         }
         dzs[lane] += sbv;
       }
-      bf16x8 b0[NCH], b1[NCH], c0[NCH], c1[NCH];
+      bf16x8 b0[NCH], b1[NCH];
       split2<NBL>(ga, b0, b1);
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) ga[b] = zt0 * ga[b];
-      split2<NBL>(ga, c0, c1);                                     // zt dL/da: the B operand of plane 0's gradient
       {
         f32x4 U[NBL];
         S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
@@ -392,15 +460,19 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
       }
       S6_CHUNK({ mfma_x3<NBL>(cur, b0[0], b1[0], gh, lane); consume_part(j + 1, 2); })
       S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], gh, lane); consume_part(j + 1, 3); })
-      {   // deposit j: (h_j ; zt dL/da ; dL/da) of this tile -- consumed during the chunk steps of layer j - 1
+      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- consumed during the chunk steps of layer j - 1
+        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
+        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
         bf16x8 a0[NCH], a1[NCH];
         split2<NBL>(hin, a0, a1);
         fuse_deposit4(exw, dep, a0);
         fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
-        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, c0);
-        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, c1);
-        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
+        f32x4 zh[NBL];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * hin[b];
+        split2<NBL>(zh, a0, a1);
+        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
+        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
       }
     }
     asm volatile("" ::: "memory");
@@ -428,24 +500,21 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
         tot += __shfl_xor(tot, 32);
         if (active && g == 0) A.DZ[(tile32 * r) * 32 + poff] = tot;
       }
-      bf16x8 b0[NCH], b1[NCH], c0[NCH], c1[NCH];
+      bf16x8 b0[NCH], b1[NCH];
       split2<NBL>(ga, b0, b1);
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) ga[b] = zt0 * ga[b];
-      split2<NBL>(ga, c0, c1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);    // (the transpose reads of deposit 0 have returned)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, c0);
-      fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, c1);
       fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
       fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
-      if (g < si && g < 3) {      // x_c of the tile's 16 points as bf16 (hi | lo) rows
-        __bf16* wv = reinterpret_cast<__bf16*>(WVF + wid * WVT);
-        const float x = xs[g * 16];
-        const __bf16 x0 = (__bf16)x;
-        wv[g * 32 + p] = x0; wv[g * 32 + 16 + p] = (__bf16)(x - (float)x0);
+      {      // lane group g < si: x_g and zt x_g of the tile's 16 points as bf16 (hi | lo) rows; group 3: zt
+        __bf16* wv = reinterpret_cast<__bf16*>(WVF + wid * WVFT);
+        const float x = g < si ? xs[g * 16] : 1.0f;
+        const float zx = zt0 * x;
+        const __bf16 x0 = (__bf16)x, z0 = (__bf16)zx;
+        if (g < si || g == 3) { wv[g * 32 + p] = z0; wv[g * 32 + 16 + p] = (__bf16)(zx - (float)z0); }
+        if (g < si && g < 3) { wv[(4 + g) * 32 + p] = x0; wv[(4 + g) * 32 + 16 + p] = (__bf16)(x - (float)x0); }
       }
     }
   }
@@ -458,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   __syncthreads();          // the exchange images become the reduction scratch
   {
     float* prow = F.partial + (long)blockIdx.x * F.pstride;
-    const int i = lane & 31;
+    const int i = lane & 31, hf = lane >> 5;
     const float om = A.omega;
     auto gidx = [&](int k, long slot) -> long { return (k < r ? A.off_Wh + (long)k * A.po : A.off_bh) + slot; };
     // hidden matrices: no reduction -- every block of the row belongs to exactly one wave
@@ -522,7 +591,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + 2 * 6 * 64) + 2 * (size_t)NBL * 3 * 64 * 16 + (sm_tot + 8 * pw + 16) * sizeof(float);
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * 3 * 64 * 16 + (sm_tot + 8 * pw + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {
