@@ -62,11 +62,15 @@ struct S6Args {
   float* partial; long pstride;     // partial-gradient rows [gridDim.x][pstride] (the ShapeNet = hypernetwork columns of them)
 };
 
+#ifndef NIF_S6_CONS_PRIO
+#define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
+#endif
+
 template <int NBL>
-__global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
+__global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   extern __shared__ __attribute__((aligned(256))) char smem6[];
   const SNetArgs& A = F.s;
-  constexpr int NT = 512, WAVES = 8, r = 1;
+  constexpr int NT = 512, WAVES = 8, r = 1;             // producer threads / waves (= tiles per round); 8 consumer waves behind them
   constexpr int NCH = NBL / 2;
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr int QF = (CF + NT - 1) / NT;
@@ -79,11 +83,8 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
-  const int FP = stash_fp(n);
   const long nt16 = 2 * ((A.B + 31) / 32);
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
-  // wave role in the weight-gradient products
-  const int kk = wid >> 2, bI = (wid >> 1) & 1, bJ = wid & 1;
 
   char* EX = smem6;                                     // [tile 8][plane 6][2 KB]
   char* WVL = EX + WAVES * EXT;
@@ -93,14 +94,223 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
   const int NI = (CX + CZ + CY + 4) * 16;
-  const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats
-  float* dzs = sm + sm_tot + (long)wid * pw;
-  float* sks = dzs + r * 64;
-  float* inp = sks + r * 64;
+  const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
+  {   // prologue, all 12 waves: LDS image of the small hyper-vectors; the exchange images start as zeros (the first tile round
+      // consumes a first-layer deposit that nobody made)
+    const long s_wl = (long)si * n + (long)nh * n * n;
+    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
+    for (int idx = tid; idx < (r + 1) * nsm; idx += 1024) {
+      const int k = idx / nsm, e = idx - k * nsm;
+      float v = 0.f;
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
+      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
+      sm[idx] = v;
+    }
+    for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += 1024) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  if (wid >= WAVES) {
+    // =====================================================================================================================
+    // consumer wave (plane kk, input block bI, output block bJ): the 32 x 32 block (kk, bI, bJ) of every hidden matrix; the
+    // bI = 1 waves also the hidden biases (kk, bJ) (sums of the B operands they hold anyway), the bI = 0 waves columns 32 bJ .. of
+    // the first layer, the bJ = 0 waves rows 32 bI .. of the last layer, wave (kk, 1, 1) the last layer's bias
+    // =====================================================================================================================
+    const int cw = wid - WAVES, kk = cw >> 2, bI = (cw >> 1) & 1, bJ = cw & 1;
+    __syncthreads();
+    if (tid - NT < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
+      const int t = (tid - NT) >> 4, q = (tid - NT) & 15;
+      reinterpret_cast<__bf16*>(WVL + t * WVLT)[4 * 32 + q] = (__bf16)1.0f;
+      reinterpret_cast<__bf16*>(WVF + t * WVFT)[7 * 32 + q] = (__bf16)1.0f;
+    }
+    __builtin_amdgcn_s_setprio(NIF_S6_CONS_PRIO);
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float bacc[4] = {0.f, 0.f, 0.f, 0.f};                         // hidden biases (kk, bJ) -- bI = 1 waves
+    float facc[3] = {0.f, 0.f, 0.f}, fbacc = 0.f;                  // first layer (kk, columns 32 bJ ..) -- bI = 0 waves
+    float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};   // last layer (kk, rows 32 bI ..) -- bJ = 0 waves; its bias -- wave (kk, 1, 1)
+    FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;
+    rdA.a0 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI; rdA.a1 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI;   // plane 0: zt h, plane 1 (= r): h
+    rdB.a0 += 4 * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += 4 * FUSE_PLANE_BYTES + 256 * bJ;                         // dL/da
+    const int wofs = 16 * (lane >> 5);                  // this lane's 8 points inside a weight vector (bytes)
+
+#define S6_CBAR()                                                             \
+  {                                                                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): the transpose reads are back */ \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+  }
+    // hidden matrix J_: this wave's block over the deposited tiles [T0_, T1_).  One tile's operands ahead of the MFMAs (the
+    // transpose reads of tile t + 1 are in flight while tile t multiplies), never more: 64 accumulator + 2 x 16 operand registers
+#define S6_HID_LOAD(T_, AH_, AL_, BH_, BL_)                                                                 \
+  {                                                                                                         \
+    const char* img_ = EX + (T_) * EXT;                                                                     \
+    AH_ = fuse_read_op(img_, rdA, 0); AL_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdA, 0);                  \
+    BH_ = fuse_read_op(img_, rdB, 0); BL_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdB, 0);                  \
+  }
+#define S6_HID_TILES(J_, T0_, T1_)                                                                          \
+  {                                                                                                         \
+    bf16x8 ah_, al_, bh_, bl_, ah2_, al2_, bh2_, bl2_;                                                      \
+    S6_HID_LOAD(T0_, ah_, al_, bh_, bl_)                                                                    \
+    _Pragma("unroll") for (int t_ = T0_; t_ < T1_; ++t_) {                                                  \
+      if (t_ + 1 < T1_) S6_HID_LOAD(t_ + 1, ah2_, al2_, bh2_, bl2_)                                         \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, acc[J_], 0, 0, 0);                        \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, acc[J_], 0, 0, 0);                        \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, acc[J_], 0, 0, 0);                        \
+      if (bI == 1) {                                                                                        \
+        const char* w_ = WVL + t_ * WVLT + (3 + kk) * 64 + wofs;                                            \
+        bacc[J_] = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), bacc[J_]); \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      ah_ = ah2_; al_ = al2_; bh_ = bh2_; bl_ = bl2_;                                                       \
+    }                                                                                                       \
+  }
+    // the four chunk steps of an adjoint layer with the consumption of hidden deposit DJ_ (a compile-time index: the accumulators
+    // are never selected at run time -- a switch over them made hipcc copy and spill whole accumulators around every call)
+#define S6_HID_LAYER(DJ_)                                                                                   \
+  if (DJ_ < nh) {                                                                                           \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, 0, 3))                                                                          \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, 3, 6))                                                                          \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                          \
+    S6_CBAR()                                                                                               \
+  }
+    // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors).  The skinny sums run as ROLLED loops over the tiles:
+    // unrolled, hipcc fetched the weight vectors of all tiles first and spilled the accumulators to make room
+    auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
+      if (bJ == 0) {
+#pragma clang loop unroll(disable)
+        for (int t = t0; t < t1; ++t) {
+          const char* img = EX + t * EXT;
+          const bf16x8 ah = fuse_read_op(img, rdA, 0), al = fuse_read_op(img + FUSE_PLANE_BYTES, rdA, 0);
+          const char* w = WVL + t * WVLT + wofs;
+          lacc[0] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), lacc[0]);
+          if (so > 1) lacc[1] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), lacc[1]);
+          if (so > 2) lacc[2] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), lacc[2]);
+        }
+      } else if (bI == 1) {
+#pragma clang loop unroll(disable)
+        for (int t = t0; t < t1; ++t) {
+          const char* w = WVL + t * WVLT + wofs;
+          const char* z = w + (3 + kk) * 64;
+          const bf16x8 zhi = *reinterpret_cast<const bf16x8*>(z), zlo = *reinterpret_cast<const bf16x8*>(z + 32);
+          blacc[0] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), zhi, zlo, blacc[0]);
+          if (so > 1) blacc[1] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), zhi, zlo, blacc[1]);
+          if (so > 2) blacc[2] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), zhi, zlo, blacc[2]);
+        }
+      }
+    };
+    // first layer (dL/da_0 deposited as the B planes, (zt | 1) x_c and (zt | 1) as vectors)
+    auto consume_first = [&](int t0, int t1) __attribute__((always_inline)) {
+      if (bI == 0) {
+#pragma clang loop unroll(disable)
+        for (int t = t0; t < t1; ++t) {
+          const char* img = EX + t * EXT;
+          const bf16x8 bh = fuse_read_op(img, rdB, 0), bl = fuse_read_op(img + FUSE_PLANE_BYTES, rdB, 0);
+          const char* w = WVF + t * WVFT + kk * 256 + wofs;
+          fbacc = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 192), *reinterpret_cast<const bf16x8*>(w + 224), fbacc);
+          facc[0] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), facc[0]);
+          if (si > 1) facc[1] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), facc[1]);
+          if (si > 2) facc[2] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), facc[2]);
+        }
+      }
+    };
+#ifdef NIF_S6_NOCONS
+#define S6_DO(...)
+#else
+#define S6_DO(...) __VA_ARGS__
+#endif
+    // the barrier sequence of the producers' tile program, with this wave's share of the products between the barriers
+    for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+      for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
+        S6_CBAR()
+        if (j == 0) { S6_DO(consume_first(0, 4);) }
+        S6_CBAR()
+        if (j == 0) { S6_DO(consume_first(4, 8);) }
+        S6_CBAR()
+        S6_CBAR()
+      }
+      // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
+      S6_CBAR()
+      S6_DO(consume_last(0, 3);)
+      S6_CBAR()
+      S6_DO(consume_last(3, 6);)
+      S6_CBAR()
+      S6_DO(consume_last(6, 8);)
+      S6_CBAR()
+      S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
+      S6_CBAR()                              // deposit 0 next to the first layer's adjoint
+      S6_DO(S6_HID_TILES(0, 0, 8))
+      S6_CBAR()
+    }
+    __syncthreads();
+    S6_DO(consume_first(0, 8);)
+    __syncthreads();
+#undef S6_DO
+#undef S6_HID_LAYER
+#undef S6_HID_TILES
+#undef S6_HID_LOAD
+#undef S6_CBAR
+    // ---- this wave's entries of the workgroup's partial-gradient row (no reduction: every entry belongs to one wave) ---------------
+    float* prow = F.partial + (long)blockIdx.x * F.pstride;
+    const int i = lane & 31, hf = lane >> 5;
+    const float om = A.omega;
+    auto gidx = [&](long slot) -> long { return (kk < r ? A.off_Wh + (long)kk * A.po : A.off_bh) + slot; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nh) {
+        const long ws = slot_wh(A, j);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int in = 32 * bI + fmap(e, hf), out = 32 * bJ + i;
+          if (in < n && out < n) prow[gidx(ws + (long)in * n + out)] = om * acc[j][e];
+          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (hipcc would form all 64 addresses first: 128 registers next to the accumulators)
+        }
+        float v = bacc[j];
+        v += __shfl_xor(v, 32);
+        if (bI == 1 && hf == 0 && 32 * bJ + i < n) prow[gidx(slot_bh(A, j) + 32 * bJ + i)] = v;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = facc[c];
+      v += __shfl_xor(v, 32);
+      if (c < si && bI == 0 && hf == 0 && 32 * bJ + i < n) prow[gidx((long)c * n + 32 * bJ + i)] = om * v;
+    }
+    {
+      float v = fbacc;
+      v += __shfl_xor(v, 32);
+      if (bI == 0 && hf == 0 && 32 * bJ + i < n) prow[gidx(slot_b1(A) + 32 * bJ + i)] = v;
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = lacc[o], w = blacc[o];
+      v += __shfl_xor(v, 32);
+      w += __shfl_xor(w, 32);
+      if (o < so && bJ == 0 && hf == 0 && 32 * bI + i < n) prow[gidx(slot_wl(A) + (long)(32 * bI + i) * so + o)] = v;
+      if (o < so && bJ == 1 && bI == 1 && lane == 0) prow[gidx(slot_bl(A) + o)] = w;
+    }
+    __syncthreads();          // (the producers' loss reduction)
+    return;
+  }
+
+  // =======================================================================================================================
+  // producer wave = one 16-point tile per round: k_snet4's tile program + the deposits
+  // =======================================================================================================================
+  float* dzs = sm + sm_tot + (long)wid * pw;
+  float* sks = dzs + r * 64;
+  float* inp = sks + r * 64;
   // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
   const int NPC = (r + 1) * NCH;
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
@@ -154,50 +364,17 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
                                      (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
   };
-  {
-    const long s_wl = (long)si * n + (long)nh * n * n;
-    const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
-    prefetch_inputs(blockIdx.x, 0);
-    for (int idx = tid; idx < (r + 1) * nsm; idx += NT) {
-      const int k = idx / nsm, e = idx - k * nsm;
-      float v = 0.f;
-      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
-      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
-      else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
-      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
-      else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
-      sm[idx] = v;
-    }
-    // the exchange images start as zeros: the first tile round consumes a first-layer deposit that nobody made
-    for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += NT) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cs_left <= 0) cs_left = -1;
-    cs_next(0);
-  }
+  prefetch_inputs(blockIdx.x, 0);
+  if (cs_left <= 0) cs_left = -1;
+  cs_next(0);
   __syncthreads();
-  if (tid < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
-    const int t = tid >> 4, q = tid & 15;
-    reinterpret_cast<__bf16*>(WVL + t * WVLT)[4 * 32 + q] = (__bf16)1.0f;
-    reinterpret_cast<__bf16*>(WVF + t * WVFT)[7 * 32 + q] = (__bf16)1.0f;
-  }
   int cbuf = 0, nbuf = 1;
   float loss_lane = 0.f;
-  const long sstride = A.slot_stride, tstride = (long)FP * 32;
+  const long sstride = A.slot_stride, tstride = (long)stash_fp(n) * 32;
   float* IN0 = A.stash;
   float* ring = A.stash + ((long)blockIdx.x * WAVES + wid) * (long)nh * (NP * 16);    // NIF_S6_RING: [matrix][NP features][16 points]
-  (void)ring; (void)IN0; (void)sstride;
-
-  // persistent gradient accumulators of this wave's block (plane kk, inputs 32 bI .., outputs 32 bJ ..)
-  f32x16 acc0, acc1, acc2, acc3;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
-  float bacc0 = 0.f, bacc1 = 0.f, bacc2 = 0.f, bacc3 = 0.f;      // hidden biases (k, J) -- kept by the I = 0 waves
-  float facc[3] = {0.f, 0.f, 0.f}, fbacc = 0.f;                     // first layer (k, J), tiles 4 bI .. 4 bI + 3
-  float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};      // last layer (k, I), tiles 4 bJ .. 4 bJ + 3; its bias
+  (void)ring; (void)IN0; (void)sstride; (void)tstride;
   const FuseDep dep = fuse_dep_addr(p, g);
-  FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;          // this lane's transpose reads of the wave's A block / B block of a tile image
-  rdA.a0 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI; rdA.a1 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI;   // plane 0: zt h, plane 1 (= r): h
-  rdB.a0 += 4 * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += 4 * FUSE_PLANE_BYTES + 256 * bJ;
-  const int wofs = 16 * (lane >> 5);                    // this lane's 8 points inside a weight vector (bytes)
   char* exw = EX + wid * EXT;                            // this wave's tile images
 
 #define S6_CHUNK(...)                                                         \
@@ -205,85 +382,12 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     cs_next(nbuf);                                                            \
     const bf16x8* cur = chunks + cbuf * CF;                                   \
     __VA_ARGS__                                                               \
-    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed; deposits are visible, transpose reads back */ \
+    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
     cbuf ^= 1; nbuf ^= 1;                                                     \
   }
-  // hidden matrix: this wave's block over the deposited tiles [T0_, T1_)
-#define S6_HID_TILES(ACC_, BACC_, T0_, T1_)                                                                 \
-  _Pragma("unroll") for (int t_ = T0_; t_ < T1_; ++t_) {                                                    \
-    const char* img_ = EX + t_ * EXT;                                                                       \
-    const bf16x8 ah_ = fuse_read_op(img_, rdA, 0), al_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdA, 0);     \
-    const bf16x8 bh_ = fuse_read_op(img_, rdB, 0), bl_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdB, 0);     \
-    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, ACC_, 0, 0, 0);                                \
-    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, ACC_, 0, 0, 0);                                \
-    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, ACC_, 0, 0, 0);                                \
-    if (bI == 0) {                                                                                          \
-      const char* w_ = WVL + t_ * WVLT + (3 + kk) * 64 + wofs;                                              \
-      BACC_ = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), BACC_); \
-    }                                                                                                       \
-  }
-  // the 8 tiles of a deposit are taken in three parts, next to chunk steps 2, 3 and 4 of the following layer
-#define S6_HID_PART(ACC_, BACC_)                                                                            \
-  { if (part == 1) { S6_HID_TILES(ACC_, BACC_, 0, 3) } else if (part == 2) { S6_HID_TILES(ACC_, BACC_, 3, 6) } else { S6_HID_TILES(ACC_, BACC_, 6, 8) } }
-  // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors): rows 32 bI .. of plane kk over tiles 4 bJ ..
-  auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = t0; t < t1; ++t) {
-      const int tt = 4 * bJ + t;
-      const char* img = EX + tt * EXT;
-      const bf16x8 ah = fuse_read_op(img, rdA, 0), al = fuse_read_op(img + FUSE_PLANE_BYTES, rdA, 0);
-#pragma unroll
-      for (int o = 0; o < 3; ++o)
-        if (o < so) {
-          const char* w = WVL + tt * WVLT + o * 64 + wofs;
-          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
-          lacc[o] = fuse_dot8(ah, al, whi, wlo, lacc[o]);
-          if (bI == 0) {
-            const char* z = WVL + tt * WVLT + (3 + kk) * 64 + wofs;
-            blacc[o] = fuse_dot8(whi, wlo, *reinterpret_cast<const bf16x8*>(z), *reinterpret_cast<const bf16x8*>(z + 32), blacc[o]);
-          }
-        }
-    }
-  };
-  // first layer (dL/da_0 deposited as the B planes, (zt | 1) x_c and (zt | 1) as vectors): columns 32 bJ .. of plane kk over tiles 4 bI ..
-  auto consume_first = [&](int t0, int t1) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = t0; t < t1; ++t) {
-      const int tt = 4 * bI + t;
-      const char* img = EX + tt * EXT;
-      const bf16x8 bh = fuse_read_op(img, rdB, 0), bl = fuse_read_op(img + FUSE_PLANE_BYTES, rdB, 0);
-      {
-        const char* w = WVF + tt * WVFT + (kk * 4 + 3) * 64 + wofs;
-        fbacc = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), fbacc);
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (c < si) {
-          const char* w = WVF + tt * WVFT + (kk * 4 + c) * 64 + wofs;
-          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(w), wlo = *reinterpret_cast<const bf16x8*>(w + 32);
-          facc[c] = fuse_dot8(bh, bl, whi, wlo, facc[c]);
-        }
-    }
-  };
-  // the consumption that belongs to chunk step 1 + `part` (part = 1..3) of the layer after deposit `dj` (nh = the last layer's)
-  auto consume_part = [&](int dj, int part) __attribute__((always_inline)) {
-#ifdef NIF_S6_NOCONS
-    return;
-#endif
-    if (dj == nh) {       // 4 tiles per wave: two next to step 2, two next to step 3
-      if (part == 1) consume_last(0, 2); else if (part == 2) consume_last(2, 4);
-      return;
-    }
-    switch (dj) {
-      case 0: S6_HID_PART(acc0, bacc0) break;
-      case 1: S6_HID_PART(acc1, bacc1) break;
-      case 2: S6_HID_PART(acc2, bacc2) break;
-      default: S6_HID_PART(acc3, bacc3) break;
-    }
-  };
 
   int iset = 0;
   for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
@@ -300,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     const float* wsp = zs + (CZ + CY) * 16 + p;
     const float* zt_base = zs + p;
     const long row0 = tile32 * tstride + poff;
+    (void)row0;
     dzs[lane] = 0.f;
 
     f32x4 h[NBL], acc[NBL];
@@ -345,13 +450,12 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
         S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
-        // (the first-layer deposit of the previous tile round is consumed next to the first hidden matrix's steps 2 and 3)
-        S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], T, lane); if (j == 0) consume_first(0, 2); })
+        S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], T, lane); })
         const float zt = zt_base[0];
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], acc, lane); if (j == 0) consume_first(2, 4); })
+      S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], acc, lane); })
       S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], acc, lane); })
       sine16_tag<NBL>(acc, acc);
 #pragma unroll
@@ -448,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
       {
         f32x4 U[NBL];
         S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
-        S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], U, lane); consume_part(j + 1, 1); })
+        S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], U, lane); })
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
@@ -458,9 +562,9 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
         for (int b = 0; b < NBL; ++b) gh[b] = zt0 * U[b];
         dzs[lane] += s;
       }
-      S6_CHUNK({ mfma_x3<NBL>(cur, b0[0], b1[0], gh, lane); consume_part(j + 1, 2); })
-      S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], gh, lane); consume_part(j + 1, 3); })
-      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- consumed during the chunk steps of layer j - 1
+      S6_CHUNK({ mfma_x3<NBL>(cur, b0[0], b1[0], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], gh, lane); })
+      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
         fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
         fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
         bf16x8 a0[NCH], a1[NCH];
@@ -479,8 +583,7 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    consume_part(0, 1); consume_part(0, 2); consume_part(0, 3);
-    // ---- first layer ---------------------------------------------------------------------------------------------------------
+    // ---- first layer (the consumer waves take deposit 0 meanwhile) ------------------------------------------------------------
     {
       f32x4 ga[NBL];
       tag_cos<NBL>(hin, dnext);
@@ -503,8 +606,8 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
       bf16x8 b0[NCH], b1[NCH];
       split2<NBL>(ga, b0, b1);
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xC07F);    // (the transpose reads of deposit 0 have returned)
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();          // deposit 0 has been consumed
       asm volatile("" ::: "memory");
       fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
       fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
@@ -519,63 +622,8 @@ __global__ __launch_bounds__(512, 2) void k_snet6(S6Args F) {
     }
   }
 #undef S6_CHUNK
-#undef S6_HID_PART
-#undef S6_HID_TILES
-  // ---- the last round's first-layer deposit, then this workgroup's partial-gradient row --------------------------------------------
-  __syncthreads();
-  consume_first(0, 4);
-  __syncthreads();          // the exchange images become the reduction scratch
-  {
-    float* prow = F.partial + (long)blockIdx.x * F.pstride;
-    const int i = lane & 31, hf = lane >> 5;
-    const float om = A.omega;
-    auto gidx = [&](int k, long slot) -> long { return (k < r ? A.off_Wh + (long)k * A.po : A.off_bh) + slot; };
-    // hidden matrices: no reduction -- every block of the row belongs to exactly one wave
-#define S6_WRITE(J_, ACC_, BACC_)                                                                            \
-    if (J_ < nh) {                                                                                           \
-      const long ws_ = slot_wh(A, J_), bs_ = slot_bh(A, J_);                                                 \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
-        const int in_ = 32 * bI + fmap(e, hf), out_ = 32 * bJ + i;                                           \
-        if (in_ < n && out_ < n) prow[gidx(kk, ws_ + (long)in_ * n + out_)] = om * ACC_[e];                  \
-      }                                                                                                      \
-      if (bI == 0) {                                                                                         \
-        float v_ = BACC_; v_ += __shfl_xor(v_, 32);                                                          \
-        const int out_ = 32 * bJ + i;                                                                        \
-        if (hf == 0 && out_ < n) prow[gidx(kk, bs_ + out_)] = v_;                                            \
-      }                                                                                                      \
-    }
-    S6_WRITE(0, acc0, bacc0) S6_WRITE(1, acc1, bacc1) S6_WRITE(2, acc2, bacc2) S6_WRITE(3, acc3, bacc3)
-#undef S6_WRITE
-    // skinny layers: halves of the tile range (and of K) meet in LDS
-    float* red = reinterpret_cast<float*>(EX);        // [wave][10][64]
-    float vals[10] = {facc[0], facc[1], facc[2], fbacc, lacc[0], lacc[1], lacc[2], blacc[0], blacc[1], blacc[2]};
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      float v = vals[q];
-      v += __shfl_xor(v, 32);
-      red[(wid * 10 + q) * 64 + lane] = v;
-    }
-    __syncthreads();
-    if (hf == 0) {
-      if (bI == 0) {        // first layer (kk, bJ): this wave's tiles + those of wave (kk, 1, bJ)
-        const int out = 32 * bJ + i;
-        if (out < n) {
-          for (int c = 0; c < si && c < 3; ++c)
-            prow[gidx(kk, (long)c * n + out)] = om * (red[(wid * 10 + c) * 64 + lane] + red[((wid + 2) * 10 + c) * 64 + lane]);
-          prow[gidx(kk, slot_b1(A) + out)] = red[(wid * 10 + 3) * 64 + lane] + red[((wid + 2) * 10 + 3) * 64 + lane];
-        }
-      }
-      if (bJ == 0) {        // last layer (kk, bI): this wave's tiles + those of wave (kk, bI, 1)
-        const int in = 32 * bI + i;
-        if (in < n)
-          for (int o = 0; o < so && o < 3; ++o)
-            prow[gidx(kk, slot_wl(A) + (long)in * so + o)] = red[(wid * 10 + 4 + o) * 64 + lane] + red[((wid + 1) * 10 + 4 + o) * 64 + lane];
-      }
-      if (bI == 0 && bJ == 0 && lane == 0)     // last layer's bias (kk): every lane of the I = 0 waves holds the same sum of its tiles
-        for (int o = 0; o < so && o < 3; ++o)
-          prow[gidx(kk, slot_bl(A) + o)] = red[(wid * 10 + 7 + o) * 64] + red[((wid + 1) * 10 + 7 + o) * 64];
-    }
-  }
+  __syncthreads();          // the last round's first-layer deposit is visible ...
+  __syncthreads();          // ... and consumed
   for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
   if (lane == 0) lsum[wid] = loss_lane;
   __syncthreads();
@@ -610,6 +658,6 @@ int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st
   S6Args f; f.s = a; f.partial = partial; f.pstride = pstride;
   const size_t shm = snet6_shmem(a, 4);
   (void)hipFuncSetAttribute((const void*)k_snet6<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL((k_snet6<4>), dim3(nblk), dim3(512), shm, st, f);
+  hipLaunchKernelGGL((k_snet6<4>), dim3(nblk), dim3(1024), shm, st, f);
   return nblk;
 }
