@@ -29,17 +29,36 @@
 #ifndef NIF_S6_RING
 #define NIF_S6_RING 1       // 1: the h_j rows of a wave's tile in a private ring [matrix j][feature][16 points] that stays cache resident; 0: the [tile32][feature][32] stash
 #endif
-// private ring of a wave: feature f of the tile at f * 16 + p
+// private ring of a wave, point-major: the 4 features of (block b, lane group g) of point p are ONE 16-byte piece at
+// p * NP + 16 b + 4 g -- 4 store / load instructions per layer instead of 16 (NIF_S6_RING_V4 = 0: feature-major rows f * 16 + p)
+#ifndef NIF_S6_RING_NT
+#define NIF_S6_RING_NT 0      // bit 0: non-temporal ring stores, bit 1: non-temporal ring loads (measured: see DESIGN)
+#endif
+#ifndef NIF_S6_RING_V4
+#define NIF_S6_RING_V4 0
+#endif
 template <int NBL>
 __device__ __forceinline__ void ring_store16(float* __restrict__ slot, const f32x4 (&h)[NBL], int g, int p) {
 #ifdef NIF_ABL_NOSTORE
   if (h[0][0] != 12345.678f) return;
 #endif
+#if NIF_S6_RING_V4
+  f32x4* q = reinterpret_cast<f32x4*>(slot + p * (16 * NBL) + 4 * g);
+#pragma unroll
+  for (int b = 0; b < NBL; ++b) q[4 * b] = h[b];
+#else
   float* q = slot + 4 * g * 16 + p;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) q[(16 * b + v) * 16] = h[b][v];
+    for (int v = 0; v < 4; ++v) {
+#if NIF_S6_RING_NT & 1
+      __builtin_nontemporal_store(h[b][v], q + (16 * b + v) * 16);
+#else
+      q[(16 * b + v) * 16] = h[b][v];
+#endif
+    }
+#endif
 }
 template <int NBL>
 __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x4 (&h)[NBL], int g, int p) {
@@ -50,11 +69,23 @@ __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x
     return;
   }
 #endif
+#if NIF_S6_RING_V4
+  const f32x4* q = reinterpret_cast<const f32x4*>(slot + p * (16 * NBL) + 4 * g);
+#pragma unroll
+  for (int b = 0; b < NBL; ++b) h[b] = q[4 * b];
+#else
   const float* q = slot + 4 * g * 16 + p;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) h[b][v] = q[(16 * b + v) * 16];
+    for (int v = 0; v < 4; ++v) {
+#if NIF_S6_RING_NT & 2
+      h[b][v] = __builtin_nontemporal_load(q + (16 * b + v) * 16);
+#else
+      h[b][v] = q[(16 * b + v) * 16];
+#endif
+    }
+#endif
 }
 
 struct S6Args {
