@@ -29,9 +29,80 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 HBM_PEAK_GBS = 8000.0        # spec; 6290 measured-achievable
 
 
-def STASH_BYTES_PER_POINT(s):
-    """h and dL/da stash rows the fused kernel writes, h re-read in the adjoint"""
-    return 4.0 * 32 * ((s.n_sx + 31) // 32) * (2 * (s.n_hidden_mats + 1) + s.n_hidden_mats)
+BF16_PEAK_TFLOPS = 2500.0    # dense v_mfma_*_bf16 peak
+HBM_MEASURED_GBS = 6290.0    # measured-achievable (MI355X_MICROARCH.md)
+
+
+def csrc_sha():
+    """content hash of the HIP sources the library is built from: ties profiles/traffic.json to the code that produced the timing"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nif_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def roofline_block(dims, B, snet_ms, fused, traffic_json, sha):
+    """The bench line's `roofline` object for the dominant kernel (pure function: tests/test_host_logic.py checks the stale path).
+    dims = (pi, si, so, n, nh, r).  All three fractions are always present; `bound` names the larger of the two pipes the kernel
+    really uses (HBM, bf16 matrix cores) and achieved / peak / unit / frac follow it.  SURVEY 8d-ii's figure -- algorithmic fp32
+    flops against the 157.3 TF fp32-MFMA peak, a pipe the kernel does not run on -- is `frac_fp32_equiv`.
+    `traffic` = HBM bytes per launch from the committed PMC passes, dropped (traffic_stale) when profiles/traffic.json was measured
+    on other sources than the ones this run was built from."""
+    pi, si, so, n, nh, r = dims
+    n_w = si * n + nh * n * n + n * so
+    sn_s = snet_ms * 1e-3
+    alg_bytes = 4.0 * (pi + si + so)                            # SURVEY 8d-ii: what a training step must read per point
+    nblk = (n + 31) // 32
+    if fused:     # k_snet6: forward + data adjoint + weight gradients; h_j through the private ring (write + read), latent in, dL/dz out
+        alg_flop = 6.0 * (r + 1) * n_w
+        exec_bf16 = (6.0 + 3.0 + 3.0) * 2.0 * (r + 1) * nh * n * n
+        design_bytes = 4.0 * 32 * nblk * 2 * nh + 4.0 * (si + so + 1) + 8.0 * r
+        kernel = ("k_snet6<4> (ShapeNet forward + MSE + data adjoint + every ShapeNet weight gradient; fp32 products as bf16 splits on "
+                  "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, 8 producer + 8 consumer waves per workgroup)")
+    else:         # k_snet4: forward + data adjoint; h and dL/da stash rows written, h re-read
+        alg_flop = 4.0 * (r + 1) * n_w
+        exec_bf16 = (6.0 + 3.0) * 2.0 * (r + 1) * nh * n * n if (((n + 15) // 16) % 2) == 0 else 0.0
+        design_bytes = 4.0 * 32 * nblk * (2 * (nh + 1) + nh)
+        kernel = "k_snet4<4,true,SINE,0,tagged-sine> (ShapeNet forward + MSE + data adjoint; k_gw_* reduce the stash rows)"
+    traffic, stale, tnote = None, None, None
+    if traffic_json is not None:
+        tj = traffic_json
+        want = "snet6" if fused else "snet"
+        if tj.get("csrc_sha") == sha and want in tj:
+            traffic = (2.0 * tj[want]["FETCH_SIZE_KB"] + tj[want]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["points"]
+            tnote = tj.get("source", "") + "; " + tj.get("calibration", "")
+            stale = False
+        else:
+            stale = True
+            tnote = "profiles/traffic.json was measured on csrc %s (head %s), this run is built from csrc %s: traffic dropped" % (
+                tj.get("csrc_sha"), tj.get("head"), sha)
+    hbm_bytes = traffic if traffic is not None else design_bytes * B
+    hbm_gbs = hbm_bytes / sn_s / 1e9 if sn_s > 0 else 0.0
+    bf16_tf = exec_bf16 * B / sn_s / 1e12 if sn_s > 0 else 0.0
+    f32_tf = alg_flop * B / sn_s / 1e12 if sn_s > 0 else 0.0
+    frac_hbm, frac_bf16, frac_f32 = hbm_gbs / HBM_PEAK_GBS, bf16_tf / BF16_PEAK_TFLOPS, f32_tf / FP32_PEAK_TFLOPS
+    hbm_bound = frac_hbm >= frac_bf16
+    return {"kernel": kernel, "bound": "hbm" if hbm_bound else "mfma",
+            "achieved": hbm_gbs if hbm_bound else bf16_tf, "peak": HBM_PEAK_GBS if hbm_bound else BF16_PEAK_TFLOPS,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_bf16,
+            "frac_hbm": frac_hbm, "frac_bf16_pipe": frac_bf16, "frac_fp32_equiv": frac_f32,
+            "frac_hbm_of_measured_6290": hbm_gbs / HBM_MEASURED_GBS,
+            "hbm_GBs": hbm_gbs, "hbm_bytes_source": "pmc" if traffic is not None else "design_bytes_per_point",
+            "executed_bf16_TFLOPs": bf16_tf, "fp32_equiv_TFLOPs": f32_tf,
+            "algorithmic_bytes_per_point": alg_bytes, "design_bytes_per_point": design_bytes,
+            "algorithmic_flop_per_point": alg_flop, "executed_bf16_flop_per_point": exec_bf16,
+            "traffic": traffic, "traffic_stale": stale,
+            "traffic_ratio": (traffic / (alg_bytes * B)) if traffic is not None else None,
+            "design_traffic_ratio": design_bytes / alg_bytes,
+            "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled to this batch)",
+            "traffic_note": tnote, "csrc_sha": sha, "avg_ms": snet_ms,
+            "avg_ms_note": "HIP events on the library's stream in a separate instrumented leg after the timed region "
+                           "(events between the kernels: the groups do not overlap there, so their sum exceeds ms_per_step)"}
 
 
 def cpu_baseline(sample_points=1 << 20, micro=4096, probe_points=65536):
@@ -106,7 +177,7 @@ def self_launch(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), NIF_RDZV_KEY="bench_%d_%d" % (os.getpid(), port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("NIF_COMM_TIMEOUT", "120")
+        env.setdefault("NIF_COMM_TIMEOUT", "300")     # counted from the rank's first rendezvous call (after the library and the engine exist), not from process start
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                              stdout=None if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
         threading.Thread(target=pump, args=(r, p.stderr), daemon=True).start()
@@ -195,6 +266,7 @@ def main():
             rank, world = dist.init()
             comm = dist.get()
     assert world == args.gpus, "launch with one rank per GPU: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    numa_node = dist.pin_to_device_numa() if (double is None and use_dist) else None     # this rank's cores = its GPU's socket
 
     if double is None:
         nif_amd.set_seed(1)  # identical initial weights on every rank (mirrored variables)
@@ -220,9 +292,17 @@ def main():
         else:
             e.sync()
 
+    comm_build_s, ranks_seen = None, 1
     if use_dist:
+        t_c = time.perf_counter()
+        comm.attach(e)    # id rendezvous + ncclCommInitRank (RCCL loads its code object here: seconds per process)
         fence()   # the first collective builds RCCL's channels (~10 ms of idle GPU): pay that before the warm-up, not
                   # between the warm-up and the timed region, where the idle gap lets the clocks drop
+        comm_build_s = time.perf_counter() - t_c
+        # the first multi-GPU run is also the first test of the collective: rank + 1 through the step's own all-reduce (same buffer,
+        # count, stream) must sum to N (N + 1) / 2 on every rank, or the run stops here
+        ranks_seen = comm.selftest(e)
+        assert ranks_seen == world, "all-reduce self-check accounts for %d ranks, WORLD_SIZE is %d" % (ranks_seen, world)
     for _ in range(args.warmup):
         step()
     fence()
@@ -231,9 +311,16 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    dt_min = dt_max = dt
     if use_dist:
-        dt = comm.all_reduce_float(e, dt, op="max")
+        dt_min = comm.all_reduce_float(e, dt, op="min")
+        dt_max = dt = comm.all_reduce_float(e, dt, op="max")
+        comm_build_s = comm.all_reduce_float(e, comm_build_s, op="max")
     loss = e.last_loss()
+    dist_info = {"rccl_ranks_seen": ranks_seen, "world": world, "comm_build_s": comm_build_s,
+                 "ms_per_step_rank_min": dt_min / args.steps * 1e3, "ms_per_step_rank_max": dt_max / args.steps * 1e3,
+                 "numa_node_rank0": numa_node,
+                 "selftest": "rank + 1 through nif_allreduce_grad's buffer / stream before the warm-up: N (N + 1) / 2 on every rank" if use_dist else None}
 
     # SURVEY 8d's statistic next to the contract's: median of host-synchronised single steps (all ranks in lock step)
     per = []
@@ -255,7 +342,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "ENGINE DOUBLE (%s): launcher / contract test, not a measurement" % os.environ["NIF_BENCH_ENGINE"],
                           "global_batch": Bg, "parallelism": "dp%d" % world, "final_loss": loss},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": None, "cpu_baseline": None, "dist": dist_info}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     elif rank == 0:
         # ---- per-kernel durations, live, with HIP events on the library's stream -------------
@@ -268,49 +355,18 @@ def main():
         e.profile_enable(False)
         kern_ms = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in prof.items()}
         s = m._spec
-        n_w = s.si_dim * s.n_sx + s.n_hidden_mats * s.n_sx ** 2 + s.n_sx * s.so_dim
-        flops_snet = 4.0 * (s.pi_hidden + 1) * n_w * B          # fwd + data-adjoint GEMMs of the fused kernel
-        ach = flops_snet / (kern_ms["snet"] * 1e-3) / 1e12 if kern_ms["snet"] > 0 else 0.0
-        traffic, traffic_gw, tnote = None, None, None
+        tj, traffic_gw = None, None
+        sha = csrc_sha()
         try:  # HBM traffic of the same kernels from the committed PMC run (bench.py cannot run rocprofv3 on itself)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = (2.0 * tj["snet"]["FETCH_SIZE_KB"] + tj["snet"]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["points"]
-            traffic_gw = (2.0 * tj["k_given_w"]["FETCH_SIZE_KB"] + tj["k_given_w"]["WRITE_SIZE_KB"]) * 1024.0 \
-                * args.given_w_points / tj["k_given_w"]["points"]
-            tnote = tj["source"] + "; " + tj["calibration"]
+            if tj.get("csrc_sha") == sha:
+                traffic_gw = (2.0 * tj["k_given_w"]["FETCH_SIZE_KB"] + tj["k_given_w"]["WRITE_SIZE_KB"]) * 1024.0 \
+                    * args.given_w_points / tj["k_given_w"]["points"]
         except Exception:
-            pass
-        # the fused kernel's n x n products run on the bf16 matrix cores as exact 3-way splits of the fp32 operands
-        # (k_snet4.hip: 6 bf16 products per fp32 product forward, 3 in the adjoint): `achieved` is the ALGORITHMIC
-        # fp32 work per second, priced against the fp32 MFMA peak as the survey prescribes; the bf16
-        # flops actually executed and the stash traffic are given next to it
-        nbl_even = (((s.n_sx + 15) // 16) % 2) == 0
-        exec_bf16 = (6.0 + 3.0) * 2.0 * (s.pi_hidden + 1) * (s.n_hidden_mats * s.n_sx ** 2) * B if nbl_even else 0.0
-        stash_bytes = STASH_BYTES_PER_POINT(s) * B
-        sn_s = kern_ms["snet"] * 1e-3
-        # What binds the fused kernel: neither matrix pipe nor VALU issue -- the HBM write path of the h / dL/da stash
-        # rows (no-stash build: 0.71 ms, with: 1.03; the same store pattern alone streams at 6.6 TB/s).  Primary figure = the
-        # larger of its HBM fraction (this design's own algorithmic bytes: the stash rows it must write and re-read)
-        # and its bf16-matrix-pipe fraction; SURVEY 8d-ii's fp32-equivalent figure is kept as a secondary key.
-        hbm_gbs = stash_bytes / sn_s / 1e9 if sn_s > 0 else 0.0
-        bf16_frac = exec_bf16 / sn_s / 1e12 / 2500.0 if sn_s > 0 else 0.0
-        hbm_bound = hbm_gbs / HBM_PEAK_GBS >= bf16_frac
-        roofline = {"kernel": "k_snet4<4,true,SINE,0,tagged-sine> (ShapeNet fwd + MSE + data adjoint; fp32 products as bf16 splits on "
-                              "v_mfma_f32_16x16x32_bf16)" if nbl_even else "k_snet3 (16x16x4 fp32 MFMA)",
-                    "bound": "hbm" if hbm_bound else "mfma",
-                    "achieved": hbm_gbs if hbm_bound else exec_bf16 / sn_s / 1e12,
-                    "peak": HBM_PEAK_GBS if hbm_bound else 2500.0, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": hbm_gbs / HBM_PEAK_GBS if hbm_bound else bf16_frac,
-                    "algorithmic_bytes_per_point": STASH_BYTES_PER_POINT(s),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, scaled to this batch)",
-                    "traffic_note": tnote, "avg_ms": kern_ms["snet"],
-                    "avg_ms_note": "HIP events on the library's stream in a separate instrumented leg after the timed region "
-                                   "(events between the kernels: the groups do not overlap there, so their sum exceeds ms_per_step)",
-                    "frac_of_measured_hbm_6290": hbm_gbs / 6290.0,
-                    "fp32_equiv_TFLOPs": ach, "flop_per_point": 4.0 * (s.pi_hidden + 1) * n_w,
-                    "frac_of_fp32_mfma_peak_157": ach / FP32_PEAK_TFLOPS,
-                    "executed_bf16_TFLOPs": exec_bf16 / sn_s / 1e12 if sn_s > 0 else 0.0,
-                    "frac_of_bf16_mfma_peak_2500": bf16_frac}
+            tj = None
+        # the weight-gradient group is empty when the fused-gradient kernel (k_snet6) took the step
+        fused = os.environ.get("NIF_FUSE_GW", "1") != "0" and kern_ms.get("gw", 0.0) < 0.05 * kern_ms["snet"]
+        roofline = roofline_block((s.pi_dim, s.si_dim, s.so_dim, s.n_sx, s.n_hidden_mats, s.pi_hidden), B, kern_ms["snet"], fused, tj, sha)
         # ---- A/B: the same step with every ShapeNet product on the f32-input MFMAs (no bf16 splits) -----------
         fp32_ms = None
         if not args.no_extras:
@@ -366,10 +422,12 @@ def main():
             "median_ms_per_step_host_synced": med_ms,
             "value_from_median": (Bg / (med_ms * 1e-3)) if med_ms else None,
             "grad_products": "forward: fp32-exact 6-product bf16 split; data adjoint: 3-product bf16 split; weight gradients: "
-                             "2-way hi/lo bf16 split; fp32 accumulation everywhere",
+                             "2-way hi/lo bf16 split (3 products); fp32 accumulation everywhere",
+            "fused_weight_gradients": fused,
             "ms_per_step_fp32_mfma": fp32_ms,
             "roofline": roofline,
             "roofline_given_w": roofline_given_w,
+            "dist": dist_info,
             "kernel_ms": kern_ms,
         }
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle in the fence)

@@ -221,6 +221,11 @@ int nif_train_step(nif_ctx* ctx, const float* xin_host, const float* y_host, con
  * every ParameterNet kernel and bias): loss += l2*sum(w^2) + l1*sum(|w|) over theta[lo, hi); the gradient
  * term is added once, after the cross-rank all-reduce, inside nif_adam_step_dev / nif_loss_and_grad. */
 int nif_set_regularizer(nif_ctx* ctx, float l1, float l2, int64_t lo, int64_t hi);
+/* cfg_shape_net["l1_reg"/"l2_reg"] of NIFMultiScaleLastLayerParameterized (nif/model.py:1028-1039; added by every SIREN /
+ * SIREN_ResNet layer of the shared ShapeNet for kernels and biases, nif/layers/siren.py:266-269, :393-398): the same term over
+ * the ShapeNet's first / hidden / bottleneck variables (not last_layer_bias).  The caller passes the coefficient the reference
+ * ends up with (it reads cfg_parameter_net's number there, model.py:1031-1036).  Other classes: NIF_ERR_INVALID unless 0, 0. */
+int nif_set_shapenet_regularizer(nif_ctx* ctx, float l1, float l2);
 /* Latent Jacobian regulariser cfg_parameter_net["jac_reg"] (nif/model.py:353-375 wraps the model in JacRegLatentLayer,
  * nif/layers/gradient.py:52-127): loss += l1 * mean_{a,c,d} (d latent_c / d parameter_d)^2, differentiated through the
  * Jacobian: forward tangents of the ParameterNet + their adjoint (k_pjac), weight gradients by the batch GEMM kernels over
@@ -254,6 +259,7 @@ typedef enum { NIF_DT_F32 = 0, NIF_DT_F64 = 1, NIF_DT_I64 = 2 } nif_dtype;
 typedef enum { NIF_OP_SUM = 0, NIF_OP_MAX = 1, NIF_OP_MIN = 2 } nif_redop;
 /* one process per GPU: rank 0 creates the id (ncclGetUniqueId), the host side carries the 128 bytes to the other
  * processes, every rank joins (ncclCommInitRank on ctx's device; collective: returns when all `world` ranks called) */
+int nif_device_pci_bus_id(int32_t device_id, char* out, int32_t capacity);   /* "0000:c1:00.0": NUMA placement of the rank's process */
 int nif_comm_unique_id(void* id_out_128_bytes);
 int nif_comm_init_rank(nif_ctx* ctx, const void* id_128_bytes, int32_t rank, int32_t world);
 /* one process driving n GPUs: ncclCommInitAll over the contexts' devices (rank i = ctxs[i]) */
@@ -263,6 +269,7 @@ int nif_comm_info(nif_ctx* ctx, int32_t* rank_out, int32_t* world_out);   /* (0,
 /* THE collective of the training step: ncclAllReduce(sum, f32, P+1) in place on nif_grad_dev(), on ctx's stream.
  * No-op for a context without communicator (world size 1). */
 int nif_allreduce_grad(nif_ctx* ctx);
+int nif_comm_selftest(nif_ctx* ctx, int32_t* ranks_seen_out);   /* rank + 1 through nif_allreduce_grad's own buffer / stream: sum must be N (N + 1) / 2 */
 int nif_allreduce_grad_multi(nif_ctx** ctxs, int32_t n);  /* the n contexts of nif_comm_init_all, one RCCL group call */
 /* plumbing: in-place all-reduce of a caller-owned device buffer on ctx's stream (Model.fit: every step's global
  * batch size, agreed once per call; bench.py: max-over-ranks wall time) */

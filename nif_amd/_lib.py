@@ -95,12 +95,14 @@ SIGNATURES = {
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
     "nif_zero_grad": (C.c_int, [_CTX]),
     "nif_reserve": (C.c_int, [_CTX, C.c_int64, C.c_int32]),
+    "nif_device_pci_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "nif_comm_unique_id": (C.c_int, [_VP]),
     "nif_comm_init_rank": (C.c_int, [_CTX, _VP, C.c_int32, C.c_int32]),
     "nif_comm_init_all": (C.c_int, [C.POINTER(_CTX), C.c_int32]),
     "nif_comm_destroy": (C.c_int, [_CTX]),
     "nif_comm_info": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "nif_allreduce_grad": (C.c_int, [_CTX]),
+    "nif_comm_selftest": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
     "nif_allreduce_grad_multi": (C.c_int, [C.POINTER(_CTX), C.c_int32]),
     "nif_comm_allreduce": (C.c_int, [_CTX, _VP, C.c_int64, C.c_int32, C.c_int32]),
     "nif_comm_barrier": (C.c_int, [_CTX]),
@@ -108,6 +110,7 @@ SIGNATURES = {
     "nif_loss_and_grad": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, _FP, _VP]),
     "nif_train_step": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.POINTER(nif_adam), _FP]),
     "nif_set_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float, C.c_int64, C.c_int64]),
+    "nif_set_shapenet_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float]),
     "nif_set_jac_regularizer": (C.c_int, [_CTX, C.c_float]),
     "nif_set_activity_regularizer": (C.c_int, [_CTX, C.c_float, C.c_float]),
     "nif_metric_accumulate": (C.c_int, [_CTX, C.c_float]),

@@ -1532,10 +1532,23 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
 }
 
 static void apply_reg(nif_ctx* c) {
-  if ((c->reg_l1 != 0.f || c->reg_l2 != 0.f) && c->reg_hi > c->reg_lo && !c->reg_applied) {
+  if (c->reg_applied) return;
+  if ((c->reg_l1 != 0.f || c->reg_l2 != 0.f) && c->reg_hi > c->reg_lo)
     launch_reg(c->theta, c->grad, c->reg_lo, c->reg_hi, c->P, c->reg_l1, c->reg_l2, c->st);
-    c->reg_applied = true;
-  }
+  if ((c->sreg_l1 != 0.f || c->sreg_l2 != 0.f) && c->kind == NIF_KIND_LASTLAYER)
+    launch_reg(c->theta, c->grad, c->s_first_w, c->ll_bias, c->P, c->sreg_l1, c->sreg_l2, c->st);
+  c->reg_applied = true;
+}
+// cfg_shape_net["l1_reg" / "l2_reg"] of the last-layer class (nif/model.py:1028-1039, handed to every SIREN / SIREN_ResNet of the
+// shared ShapeNet at :1168-1211; siren.py:266-269, :393-398 add them for kernels AND biases): theta[s_first_w, ll_bias) -- first,
+// hidden and bottleneck layers, not last_layer_bias (BiasAddLayer has no regulariser, mlp.py:245-262)
+extern "C" int nif_set_shapenet_regularizer(nif_ctx* c, float l1, float l2) {
+  if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
+  if ((l1 != 0.f || l2 != 0.f) && c->kind != NIF_KIND_LASTLAYER)
+    return fail(NIF_ERR_INVALID, "ShapeNet weight regularisers exist for the last-layer-parameterised class only (the other classes' ShapeNet weights are ParameterNet outputs)");
+  if (c->kind == NIF_KIND_LASTLAYER && !(c->s_first_w < c->ll_bias && c->ll_bias <= c->P)) return fail(NIF_ERR_STATE, "ShapeNet parameter range");
+  c->sreg_l1 = l1; c->sreg_l2 = l2;
+  return NIF_OK;
 }
 extern "C" int nif_set_regularizer(nif_ctx* c, float l1, float l2, int64_t lo, int64_t hi) {
   if (!c || lo < 0 || hi > c->P || lo > hi || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");
@@ -1708,6 +1721,14 @@ extern "C" int nif_zero_grad(nif_ctx* c) {
 }
 
 // A/B switches (measurement and tests; the defaults are the product path)
+// PCI bus id ("0000:c1:00.0") of HIP device `dev`: the host side looks up the device's NUMA node under /sys/bus/pci/devices/ and
+// pins the rank's process to that node's cores (the reference leaves placement to TensorFlow's runtime)
+extern "C" int nif_device_pci_bus_id(int32_t dev, char* out, int32_t cap) {
+  if (!out || cap < 16) return fail(NIF_ERR_INVALID, "bad argument");
+  HIPCHK(hipDeviceGetPCIBusId(out, cap, dev));
+  return NIF_OK;
+}
+
 extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
   if (!c || !key) return fail(NIF_ERR_INVALID, "null");
   if (strcmp(key, "fuse_gw") == 0) { c->opt_fuse_gw = value != 0; return NIF_OK; }   // 0: k_snet4 + k_gw_* instead of the fused-gradient kernel

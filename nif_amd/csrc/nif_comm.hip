@@ -121,6 +121,35 @@ extern "C" int nif_allreduce_grad(nif_ctx* c) {
   return NIF_OK;
 }
 
+// Self-check of the training collective, for the first run on a new node (bench.py calls it before the warm-up): every rank fills
+// THE all-reduce buffer [grad | loss] with rank + 1, nif_allreduce_grad() -- the step's own call, same buffer, count, stream --
+// sums it, and first / middle / last element must read world (world + 1) / 2 on every rank.  ranks_seen = the n that solves
+// n (n + 1) / 2 = the sum found.  The buffer is zeroed afterwards (the next loss / gradient overwrites it anyway).
+__global__ void k_fill_f32(float* __restrict__ p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int nif_comm_selftest(nif_ctx* c, int32_t* ranks_seen) {
+  if (!c || !ranks_seen) return fail(NIF_ERR_INVALID, "null");
+  if (!c->grad) return fail(NIF_ERR_STATE, "no gradient buffer");
+  HIPCHK(hipSetDevice(c->dev));
+  const long n = c->P + 1;
+  hipLaunchKernelGGL(k_fill_f32, dim3(64), dim3(256), 0, c->st, c->grad, n, (float)(c->comm_rank + 1));
+  int rc = nif_allreduce_grad(c); if (rc) return rc;
+  float got[3] = {0.f, 0.f, 0.f};
+  const long at[3] = {0, n / 2, n - 1};
+  for (int i = 0; i < 3; ++i) HIPCHK(hipMemcpyAsync(&got[i], c->grad + at[i], sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemsetAsync(c->grad, 0, sizeof(float) * (size_t)n, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  const int w = c->comm ? c->comm_world : 1;
+  const float want = 0.5f * (float)w * (float)(w + 1);
+  *ranks_seen = (int32_t)lroundf(0.5f * (sqrtf(8.f * got[0] + 1.f) - 1.f));
+  for (int i = 0; i < 3; ++i)
+    if (got[i] != want)
+      return fail(NIF_ERR_COMM, "all-reduce self-check: element " + std::to_string(at[i]) + " of [grad | loss] sums to " + std::to_string(got[i]) +
+                                    ", expected " + std::to_string(want) + " for " + std::to_string(w) + " ranks");
+  return NIF_OK;
+}
+
 // same, for the n contexts one process drives: one group call, so RCCL launches all ranks' kernels together
 extern "C" int nif_allreduce_grad_multi(nif_ctx** ctxs, int32_t n) {
   if (!ctxs || n < 1) return fail(NIF_ERR_INVALID, "bad argument");

@@ -49,6 +49,7 @@ struct nif_ctx {
   float* dring = nullptr; long dring_cap = 0;
   long long* tl = nullptr;   // timeline stamps (measurement builds)
   float reg_l1 = 0.f, reg_l2 = 0.f; long reg_lo = 0, reg_hi = 0; bool reg_applied = false;
+  float sreg_l1 = 0.f, sreg_l2 = 0.f;   // last-layer class: cfg_shape_net l1_reg / l2_reg over the shared ShapeNet's kernels and biases [s_first_w, ll_bias)
   double* metric = nullptr;  // device {sum, count}
   // activity regulariser of the ParameterNet output (nif_set_activity_regularizer): L2 wins over L1 like in the reference
   bool ll_packed32 = false;     // last-layer class under k_sob at n > 96: f32-input MFMA planes of the shared hidden matrices in sWF / sWB

@@ -10,10 +10,10 @@ Process model: RANK / WORLD_SIZE / LOCAL_RANK from the environment (what the usu
 --gpus N` launches its own ranks the same way).  The only thing that has to travel between the processes on
 the host is RCCL's 128-byte unique id (single node, like the reference's MirroredStrategy): a handshake through files in a
 PRIVATE directory (mode 0700, files 0600) named after NIF_RDZV_KEY, else MASTER_ADDR / MASTER_PORT -- what all ranks of one
-launch share, whatever wrapper shells sit between the launcher and the ranks.  Every other rank first publishes a random
-nonce, rank 0 answers with [id | the nonces it saw]: a reader only accepts an answer that carries ITS nonce, so a file a
-crashed earlier launch left behind under the same key can never be taken for this launch's id; rank 0 removes everything
-it wrote in a `finally`.  NIF_COMM_TIMEOUT (seconds, default 300) bounds every wait.
+launch share, whatever wrapper shells sit between the launcher and the ranks.  Rank 0 publishes a per-launch token, every other
+rank answers with [token | a random nonce], rank 0 answers with [id | the nonces of THIS launch's hellos]: a reader only accepts an
+answer that carries ITS nonce and rank 0 only a hello that carries ITS token, so no file a crashed earlier launch left behind under
+the same key can be taken for this launch's; every rank removes what it wrote when it fails, rank 0 everything in a `finally`.  NIF_COMM_TIMEOUT (seconds, default 300) bounds every wait.
 
 The communicator object is pluggable (`install`): the CPU tests put a gloo-backed double with the same methods here to
 run `Model.fit`'s real sharding logic on two processes without a GPU."""
@@ -87,41 +87,69 @@ class RcclComm(object):
     NONCE = 16
 
     def _exchange_id(self, lib):
-        """-> (id, files_to_remove).  Collective over the ranks of the job."""
+        """-> (id, files_to_remove).  Collective over the ranks of the job.
+        Rank 0 first publishes a random per-launch TOKEN (`open` file); every other rank answers with hello = [token | its own nonce]
+        and rank 0 keeps re-reading a hello until it carries the CURRENT token -- a hello file a killed earlier launch left behind
+        under the same key (torchrun's default port gives every launch the same key) is never taken for this launch's.
+        The id file is [id | nonces]: a reader only accepts an answer that carries ITS nonce.  Every rank removes what it wrote
+        when it fails; rank 0 removes everything in attach()'s finally."""
         seq = self._seq
         self._seq += 1
-        idp = self._path("id", seq)
+        idp, openp = self._path("id", seq), self._path("open", seq)
         nb = _lib.COMM_ID_BYTES + (self.world - 1) * self.NONCE
         if self.rank == 0:
-            mine = [idp]
+            mine = [idp, openp] + [self._path("hello", seq, r) for r in range(1, self.world)]
             try:
-                os.remove(idp)    # whatever a crashed launch left under this key
-            except OSError:
-                pass
-            nonces = []
-            t0 = time.time()
-            for r in range(1, self.world):
-                hp = self._path("hello", seq, r)
-                mine.append(hp)
-                while True:
-                    n = self._read(hp, self.NONCE)
-                    if n is not None:
-                        nonces.append(n)
-                        break
-                    self._expired(t0, "no hello from rank %d at %s" % (r, hp))
-            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-            check(lib.nif_comm_unique_id(buf))
-            self._publish(idp, buf.raw + b"".join(nonces))
-            return buf.raw, mine
+                for q in (idp, openp):
+                    try:
+                        os.remove(q)    # whatever a crashed launch left under this key
+                    except OSError:
+                        pass
+                token = os.urandom(self.NONCE)
+                self._publish(openp, token)
+                nonces = []
+                t0 = time.time()
+                for r in range(1, self.world):
+                    hp = self._path("hello", seq, r)
+                    while True:
+                        n = self._read(hp, 2 * self.NONCE)
+                        if n is not None and n[:self.NONCE] == token:
+                            nonces.append(n[self.NONCE:])
+                            break
+                        self._expired(t0, "no hello of this launch from rank %d at %s" % (r, hp))
+                buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+                check(lib.nif_comm_unique_id(buf))
+                self._publish(idp, buf.raw + b"".join(nonces))
+                return buf.raw, mine
+            except BaseException:
+                self._remove(mine)
+                raise
         nonce = os.urandom(self.NONCE)
-        self._publish(self._path("hello", seq, self.rank), nonce)
+        hp = self._path("hello", seq, self.rank)
         lo = _lib.COMM_ID_BYTES + (self.rank - 1) * self.NONCE
         t0 = time.time()
-        while True:
-            raw = self._read(idp, nb)
-            if raw is not None and raw[lo:lo + self.NONCE] == nonce:
-                return raw[:_lib.COMM_ID_BYTES], []
-            self._expired(t0, "no RCCL id from rank 0 at %s" % idp)
+        said = None
+        try:
+            while True:
+                token = self._read(openp, self.NONCE)
+                if token is not None and token != said:      # rank 0 of THIS launch is (now) listening: (re-)introduce ourselves
+                    self._publish(hp, token + nonce)
+                    said = token
+                raw = self._read(idp, nb)
+                if raw is not None and raw[lo:lo + self.NONCE] == nonce:
+                    return raw[:_lib.COMM_ID_BYTES], []
+                self._expired(t0, "no RCCL id from rank 0 at %s" % idp)
+        except BaseException:
+            self._remove([hp])
+            raise
+
+    @staticmethod
+    def _remove(paths):
+        for q in paths:
+            try:
+                os.remove(q)
+            except OSError:
+                pass
 
     def attach(self, engine):
         """Join `engine`'s context to a fresh communicator of all ranks (collective)."""
@@ -132,11 +160,7 @@ class RcclComm(object):
             try:
                 check(engine.lib.nif_comm_init_rank(engine.ctx, raw, self.rank, self.world))
             finally:                  # ncclCommInitRank returned (every rank has read the id) or failed: nothing stays behind
-                for q in mine:
-                    try:
-                        os.remove(q)
-                    except OSError:
-                        pass
+                self._remove(mine)
         engine._comm_joined = True
 
     # ---- collectives ---------------------------------------------------------------------------
@@ -144,6 +168,14 @@ class RcclComm(object):
         """THE collective of the training step: SUM over ranks of [grad | loss], in place, on the engine's stream."""
         self.attach(engine)
         check(engine.lib.nif_allreduce_grad(engine.ctx))
+
+    def selftest(self, engine):
+        """rank + 1 through the training collective's own buffer and stream; raises unless every rank reads N (N + 1) / 2.
+        Returns the number of ranks the sum accounts for."""
+        self.attach(engine)
+        n = C.c_int32(0)
+        check(engine.lib.nif_comm_selftest(engine.ctx, C.byref(n)))
+        return int(n.value)
 
     def zero_grad(self, engine):
         check(engine.lib.nif_zero_grad(engine.ctx))
@@ -217,6 +249,45 @@ def rank():
 def local_device():
     """HIP device of this process: LOCAL_RANK of the job, else 0."""
     return _comm[0].local_rank if _comm[0] is not None else 0
+
+
+def cpus_of_numa_node(node, sysfs="/sys/devices/system/node"):
+    """CPU ids of a NUMA node from its sysfs cpulist ("0-31,128-159"); [] when unknown"""
+    try:
+        txt = open(os.path.join(sysfs, "node%d" % node, "cpulist")).read().strip()
+    except OSError:
+        return []
+    cpus = []
+    for part in txt.split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_device_numa(device_id=None, lib=None, sysfs_pci="/sys/bus/pci/devices"):
+    """Pin this process to the cores of the NUMA node its GPU hangs off (one process per GPU: host-side launches and the staging
+    copies then stay on the socket next to the device).  Returns the node, or None when it cannot be determined (no GPU, no
+    NUMA information, a container without sysfs): nothing is changed then."""
+    try:
+        lib = lib or _lib.load()
+        dev = local_device() if device_id is None else int(device_id)
+        buf = C.create_string_buffer(64)
+        if lib.nif_device_pci_bus_id(dev, buf, 64) != 0:
+            return None
+        bdf = buf.value.decode().strip().lower()
+        node = int(open(os.path.join(sysfs_pci, bdf, "numa_node")).read().strip())
+        if node < 0:
+            return None
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus_of_numa_node(node) if c in allowed]
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
 
 
 def shutdown():

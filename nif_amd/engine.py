@@ -353,6 +353,10 @@ class Engine(object):
     def set_regularizer(self, l1, l2, lo, hi):
         check(self.lib.nif_set_regularizer(self.ctx, float(l1), float(l2), int(lo), int(hi)))
 
+    def set_shapenet_regularizer(self, l1, l2):
+        """last-layer class: cfg_shape_net l1_reg / l2_reg over the shared ShapeNet's kernels and biases (model.py:1028-1039)"""
+        check(self.lib.nif_set_shapenet_regularizer(self.ctx, float(l1), float(l2)))
+
     def set_jac_regularizer(self, l1):
         check(self.lib.nif_set_jac_regularizer(self.ctx, float(l1)))
 

@@ -474,6 +474,20 @@ class SobolevModel(Model):
         e.sobolev_loss_grad_dev(d_x, d_targets[0], d_targets[1], d_sw, b, bg, self.x_index, w1 / w0)
 
 
+def _is_number(v):
+    return isinstance(v, (float, int))        # the reference's test (model.py:109, :1031): True / False count as numbers there too
+
+
+def shapenet_regularizer_coefficients(s_l1, s_l2, p_l1, p_l2):
+    """(l1, l2) of the last-layer class's ShapeNet regulariser as the reference builds it (model.py:1031-1039)"""
+    keras_default = 0.01
+    if _is_number(s_l2):
+        return (0.0, float(p_l2) if p_l2 is not None else keras_default)
+    if _is_number(s_l1):
+        return (float(p_l1) if p_l1 is not None else keras_default, 0.0)
+    return (0.0, 0.0)
+
+
 class NIF(object):
     """reference nif/model.py:48 `class NIF(object)`: a factory of Keras-like models that share one set
     of variables."""
@@ -504,6 +518,8 @@ class NIF(object):
             self._reg = (0.0, float(self.p_l2_reg))
         elif isinstance(self.p_l1_reg, (float, int)):
             self._reg = (float(self.p_l1_reg), 0.0)
+        # last-layer class only: cfg_shape_net['l2_reg' / 'l1_reg'] (model.py:1028-1039) -- read by the subclass constructor
+        self._sreg = (0.0, 0.0)
         self.mixed_policy_name = mixed_policy
         self.variable_Dtype = "float32"
         self.compute_Dtype = "bfloat16" if mixed_policy == "mixed_bfloat16" else "float32"
@@ -524,6 +540,8 @@ class NIF(object):
                 self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
             if self._act_reg != (0.0, 0.0):
                 self.__engine.set_activity_regularizer(*self._act_reg)
+            if self._sreg != (0.0, 0.0):
+                self.__engine.set_shapenet_regularizer(*self._sreg)
         return self.__engine
 
     def call(self, inputs, training=None, mask=None):
@@ -576,6 +594,16 @@ class NIFMultiScale(NIF):
 class NIFMultiScaleLastLayerParameterized(NIFMultiScale):
     """reference nif/model.py:989"""
     _KIND = "NIFMultiScaleLastLayerParameterized"
+
+    def __init__(self, cfg_shape_net, cfg_parameter_net, mixed_policy="float32"):
+        super(NIFMultiScaleLastLayerParameterized, self).__init__(cfg_shape_net, cfg_parameter_net, mixed_policy)
+        # model.py:1028-1039: kernel AND bias regulariser of every layer of the shared ShapeNet (siren.py:266-269, :393-398).
+        # WHICH one is chosen by cfg_shape_net's keys (L2 wins over L1); its COEFFICIENT is the reference's quirk: it passes
+        # self.p_l2_reg / self.p_l1_reg -- cfg_parameter_net's number -- to regularizers.L2 / L1, and Keras 2.11 turns a None
+        # there into its default 0.01 (keras/regularizers.py: `l2 = 0.01 if l2 is None else l2`).  Restated as is.
+        self.s_l1_reg = cfg_shape_net.get("l1_reg", None)
+        self.s_l2_reg = cfg_shape_net.get("l2_reg", None)
+        self._sreg = shapenet_regularizer_coefficients(self.s_l1_reg, self.s_l2_reg, self.p_l1_reg, self.p_l2_reg)
 
     def model_lr_to_w(self):
         """model.py:1106-1115"""

@@ -801,6 +801,37 @@ def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_globa
     return loss, pnet_backward(spec, ws, ptape, g_pout) + g_snet + [g_u.sum(0)], u
 
 
+def weight_regularizer_coefficients(cfg_shape_net, cfg_parameter_net, kind):
+    """((p_l1, p_l2), (s_l1, s_l2)): the Keras kernel / bias regularisers the reference attaches.
+    ParameterNet layers (model.py:109-117): L2(l2_reg) if cfg_parameter_net['l2_reg'] is a number, else L1(l1_reg) if that is.
+    Shared ShapeNet of the last-layer class (model.py:1028-1039): L2 if cfg_shape_net['l2_reg'] is a number, else L1 if
+    cfg_shape_net['l1_reg'] is -- but the coefficient handed to regularizers.L2 / L1 there is self.p_l2_reg / self.p_l1_reg, the
+    PARAMETER net's value (:1032-1036), and Keras 2.11 replaces a None by its default 0.01 (keras/regularizers.py L1 / L2 __init__)."""
+    num = lambda v: isinstance(v, (float, int))
+    p_l1, p_l2 = cfg_parameter_net.get("l1_reg", None), cfg_parameter_net.get("l2_reg", None)
+    preg = (0.0, float(p_l2)) if num(p_l2) else ((float(p_l1), 0.0) if num(p_l1) else (0.0, 0.0))
+    sreg = (0.0, 0.0)
+    if kind == KIND_LL:
+        s_l1, s_l2 = cfg_shape_net.get("l1_reg", None), cfg_shape_net.get("l2_reg", None)
+        if num(s_l2):
+            sreg = (0.0, float(p_l2) if p_l2 is not None else 0.01)
+        elif num(s_l1):
+            sreg = (float(p_l1) if p_l1 is not None else 0.01, 0.0)
+    return preg, sreg
+
+
+def weight_regularizer_term(spec, ws, preg, sreg=(0.0, 0.0)):
+    """loss term and per-variable gradient of the kernel / bias regularisers: Keras L2 = l2 * sum(w^2), L1 = l1 * sum(|w|), added
+    once per layer variable (siren.py:266-269, :393-398; mlp.py Dense regularisers): every 'pnet_*' variable with `preg`, every
+    'snet_*' variable (last-layer class: first / hidden / bottleneck kernels and biases) with `sreg`; last_layer_bias has none."""
+    loss, grads = 0.0, []
+    for (nm, _), w in zip(spec.param_shapes(), ws):
+        l1, l2 = preg if nm.startswith("pnet_") else (sreg if nm.startswith("snet_") else (0.0, 0.0))
+        loss += l2 * float((w ** 2).sum()) + l1 * float(np.abs(w).sum())
+        grads.append(2.0 * l2 * w + l1 * np.sign(w))
+    return loss, grads
+
+
 def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, act_reg=None):
     """MSE loss and gradient w.r.t. every variable (Keras order), hand-derived adjoint
     (SURVEY a-10).  `batch_global` lets a shard compute its share of a larger batch's

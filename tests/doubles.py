@@ -166,6 +166,18 @@ class GlooComm(object):
     def zero_grad(self, engine):
         engine.zero_grad()
 
+    def selftest(self, engine):
+        """RcclComm.selftest on the double: rank + 1 through all_reduce_grad's buffer"""
+        engine.grad_buf[:] = self.rank + 1
+        self.all_reduce_grad(engine)
+        self.n_grad_reduces -= 1
+        s = float(engine.grad_buf[0])
+        ok = np.all(engine.grad_buf == 0.5 * self.world * (self.world + 1))
+        engine.grad_buf[:] = 0.0
+        if not ok:
+            raise RuntimeError("all-reduce self-check failed: %r" % s)
+        return int(round(0.5 * (np.sqrt(8.0 * s + 1.0) - 1.0)))
+
     def all_reduce_ints(self, engine, values, op="sum"):
         import torch
         t = torch.tensor([int(v) for v in values], dtype=torch.int64)

@@ -195,7 +195,7 @@ def test_rccl_id_rendezvous_through_files(tmp_path, monkeypatch):
     for th in ths:
         th.join()
     assert raw == bytes([7]) * 128 and got["b"][0] == raw and got["c"][0] == raw
-    assert all(os.path.dirname(q) == d for q in mine) and len(mine) == 3      # the answer + two hello files: rank 0 removes them
+    assert all(os.path.dirname(q) == d for q in mine) and len(mine) == 4      # the answer, the token, two hello files: rank 0 removes them
     assert stat.S_IMODE(os.stat(a._id_path(0)).st_mode) == 0o600
     assert a._id_path(1) != a._id_path(0)          # one file set per communicator
     # bounded waits on both sides
@@ -205,6 +205,25 @@ def test_rccl_id_rendezvous_through_files(tmp_path, monkeypatch):
     lone0 = RcclComm(0, 2, 0, key="nobody2", directory=d, timeout=0.05)
     with pytest.raises(_lib.NifError):
         lone0._exchange_id(FakeLib(1))
+    assert not [f for f in os.listdir(d) if "nobody" in f]       # a rank that gives up removes what it wrote
+    # a killed earlier launch left a HELLO behind under the same key (torchrun's default port = the same key for every launch) and
+    # rank 1 of this launch starts late: rank 0 must not answer the stale nonce (r3: rank 1 then never saw its own and timed out)
+    k0 = RcclComm(0, 2, 0, key="again", directory=d, timeout=20)
+    k1 = RcclComm(1, 2, 1, key="again", directory=d, timeout=20)
+    with open(k0._path("hello", 0, 1), "wb") as f:
+        f.write(bytes([5]) * (2 * RcclComm.NONCE))
+    with open(k0._path("open", 0), "wb") as f:
+        f.write(bytes([6]) * RcclComm.NONCE)                     # ... and its token
+    late = {}
+
+    def late_rank():
+        import time as _t
+        _t.sleep(0.2)
+        late["r"] = k1._exchange_id(FakeLib(3))
+    th = threading.Thread(target=late_rank); th.start()
+    raw0, mine0 = k0._exchange_id(FakeLib(3))
+    th.join()
+    assert raw0 == bytes([3]) * 128 and late["r"][0] == raw0
     # no key, no launcher environment, more than one rank: refuse instead of guessing
     monkeypatch.delenv("NIF_RDZV_KEY", raising=False); monkeypatch.delenv("MASTER_PORT", raising=False)
     with pytest.raises(_lib.NifError):
@@ -239,6 +258,39 @@ def test_bench_self_launch_two_ranks_prints_one_json_line():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 96 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 96 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_self_launch_eight_ranks_self_check_fields():
+    """world 8 -- the size of the driver's scaling run -- on the engine double: the all-reduce self-check (rank + 1 through the step's
+    own collective: 36 on every rank) runs before the warm-up and the line carries what lets the driver see that N ranks took part"""
+    import json
+    pytest.importorskip("torch")
+    r = _run_bench({}, ["--gpus", "8", "--steps", "2", "--warmup", "1", "--points", "32", "--no-cpu-baseline", "--no-extras"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 256
+    di = d["dist"]
+    assert di["rccl_ranks_seen"] == 8 and di["world"] == 8
+    assert di["comm_build_s"] is not None and di["comm_build_s"] >= 0.0
+    assert 0 < di["ms_per_step_rank_min"] <= di["ms_per_step_rank_max"] == pytest.approx(d["ms_per_step"])
+
+
+def test_numa_cpulist_parsing(tmp_path):
+    from nif_amd import distributed as dist
+    (tmp_path / "node1").mkdir()
+    (tmp_path / "node1" / "cpulist").write_text("32-35,160-161\n")
+    assert dist.cpus_of_numa_node(1, sysfs=str(tmp_path)) == [32, 33, 34, 35, 160, 161]
+    assert dist.cpus_of_numa_node(7, sysfs=str(tmp_path)) == []
+    # no GPU / no library symbol / no sysfs entry: nothing is pinned, no exception
+
+    class NoLib(object):
+        def nif_device_pci_bus_id(self, dev, buf, n):
+            return -1
+    before = os.sched_getaffinity(0)
+    assert dist.pin_to_device_numa(0, lib=NoLib()) is None
+    assert os.sched_getaffinity(0) == before
 
 
 def test_bench_self_launch_fails_fast_when_a_rank_dies_early():

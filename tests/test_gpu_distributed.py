@@ -169,6 +169,37 @@ def test_bench_under_the_drivers_launcher_single_rank():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _one_json_line(r.stdout)      # the contract: ONE line on stdout
     assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d and "RCCL" in d["config"]["collective"]
+    # r4: the run checks its own collective (rank + 1 through nif_allreduce_grad's buffer and stream) and says so
+    di = d["dist"]
+    assert di["rccl_ranks_seen"] == 1 and di["world"] == 1 and di["comm_build_s"] > 0 and di["selftest"]
+    assert 0 < di["ms_per_step_rank_min"] <= di["ms_per_step_rank_max"]
+    ro = d["roofline"]
+    for k in ("frac_hbm", "frac_bf16_pipe", "frac_fp32_equiv", "algorithmic_bytes_per_point", "design_bytes_per_point", "traffic_stale",
+              "csrc_sha", "bound"):
+        assert k in ro, k
+    assert ro["algorithmic_bytes_per_point"] == 12.0
+
+
+def test_comm_selftest_world1_and_pci_bus_id():
+    """nif_comm_selftest with one real RCCL rank: the sum accounts for one rank, the buffer is left zeroed; the PCI bus id of the
+    device (NUMA placement of a rank's process) has the sysfs form"""
+    import ctypes as C
+    import nif_amd
+    from nif_amd import distributed as dist
+    from nif_amd._lib import check
+    m, _ = _model()
+    e = m._engine
+    comm = dist.RcclComm(0, 1, 0, key="selftest_%d" % os.getpid())
+    os.environ["NIF_FORCE_RCCL"] = "1"
+    try:
+        assert comm.selftest(e) == 1
+    finally:
+        os.environ.pop("NIF_FORCE_RCCL", None)
+    buf = C.create_string_buffer(64)
+    check(e.lib.nif_device_pci_bus_id(0, buf, 64))
+    bdf = buf.value.decode()
+    assert len(bdf.split(":")) == 3 and "." in bdf, bdf
+    check(e.lib.nif_comm_destroy(e.ctx))
 
 
 def test_bench_plain_invocation():

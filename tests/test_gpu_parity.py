@@ -409,6 +409,55 @@ def test_weight_regularisers_l2_and_l1():
         assert _rel(g, gref) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_res_48x2_r4", "ll_cfg4_128x2_r10_so3"])
+@pytest.mark.parametrize("case", ["s_l2_p_l2", "s_l1_p_l1", "s_l2_only", "s_l1_p_l2"])
+def test_last_layer_class_shapenet_regularisers(name, case):
+    """cfg_shape_net l2_reg / l1_reg of the last-layer class (model.py:1028-1039): kernel and bias regulariser of every layer of the
+    shared ShapeNet, with the reference's coefficient quirk (it hands cfg_parameter_net's number, or Keras' default 0.01 for None,
+    to regularizers.L2 / L1).  r3 ignored these keys silently."""
+    import nif_amd
+    (kind, cs, cp), B = CONFIGS[name]
+    cs2, cp2 = dict(cs), dict(cp)
+    if case == "s_l2_p_l2": cs2["l2_reg"] = 5e-4; cp2["l2_reg"] = 2e-3          # ShapeNet L2 with the ParameterNet's 2e-3
+    elif case == "s_l1_p_l1": cs2["l1_reg"] = 7e-4; cp2["l1_reg"] = 1e-4        # ShapeNet L1 with 1e-4
+    elif case == "s_l2_only": cs2["l2_reg"] = 5e-4                              # ShapeNet L2 with Keras' default 0.01, no ParameterNet term
+    else: cs2["l1_reg"] = 3e-4; cp2["l2_reg"] = 1e-3                            # ParameterNet L2 1e-3; ShapeNet L1 with p_l1_reg = None -> 0.01
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(3)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    names = [nm for nm, _ in spec.param_shapes()]
+    ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 30.0).astype(np.float32)
+    m = nif_amd.NIFMultiScaleLastLayerParameterized(cs2, cp2)
+    model = m.build(); model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    loss, g = m._engine.loss_and_grad(x, y)
+    ws64 = [w.astype(np.float64) for w in ws]
+    lref, gref = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64))
+    preg, sreg = O.weight_regularizer_coefficients(cs2, cp2, spec.kind)
+    assert sreg != (0.0, 0.0)
+    lreg, greg = O.weight_regularizer_term(spec, ws64, preg, sreg)
+    assert lreg > 0.05 * abs(lref)          # the term is visible in the loss
+    lref += lreg
+    gref = O.flatten([a + b for a, b in zip(gref, greg)])
+    assert abs(loss - lref) < 1e-5 * abs(lref)
+    assert _rel(g, gref) < 2e-4
+    # per tensor: the ShapeNet tensors carry the term, last_layer_bias does not
+    off = 0
+    for (nm, shp), gr in zip(spec.param_shapes(), greg):
+        sz = int(np.prod(shp))
+        if nm == "last_layer_bias":
+            assert np.abs(gr).max() == 0.0
+        if nm.startswith("snet_") and nm.endswith("_w"):
+            assert _rel(g[off:off + sz], gref[off:off + sz]) < 5e-4, nm
+        off += sz
+    # the other classes refuse the call instead of ignoring it
+    (k2, cs3, cp3), _ = CONFIGS["ms_mlp_pres_so2"]
+    m2 = nif_amd.NIFMultiScale(cs3, cp3)
+    with pytest.raises(nif_amd.NifError):
+        m2._engine.set_shapenet_regularizer(0.0, 1e-3)
+
+
 def test_lbfgs_fine_tuning_reduces_loss():
     """README.md:51-69: Adam first, then TFPLBFGS(model, loss, X, Y).minimize(rounds, max_iter)."""
     import os

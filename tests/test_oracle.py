@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import nif_oracle as O
-from tests.cfgs import ALL_SMALL
+from tests.cfgs import ALL_SMALL, cfg_ll
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -326,3 +326,29 @@ def test_sobolev_plane_formulation_equals_the_materialised_one(name):
     assert l7 == l8 and 1e-6 < d8 < 2e-2
     with pytest.raises(AssertionError):
         O.sobolev_planes_loss_and_grad(spec, ws, x, y, dy, [0], 0.3)        # parameter columns: the materialised form has them
+
+
+def test_weight_regulariser_term_is_the_gradient_of_its_loss():
+    """oracle.weight_regularizer_term (model.py:109-117, :1028-1039): central differences of the loss term, last-layer class with
+    a ParameterNet L1 and a ShapeNet L2 term; last_layer_bias untouched"""
+    kind, cs, cp = cfg_ll()
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(0)
+    ws = [w.astype(np.float64) for w in O.init_weights(spec, rng, dtype=np.float32)]
+    preg, sreg = (2e-3, 0.0), (0.0, 0.01)
+    loss, grads = O.weight_regularizer_term(spec, ws, preg, sreg)
+    names = [nm for nm, _ in spec.param_shapes()]
+    assert np.abs(grads[names.index("last_layer_bias")]).max() == 0.0
+    for nm in ("pnet_first_w", "snet_first_b", "snet_bottleneck_w"):
+        i = names.index(nm)
+        w = ws[i]
+        idx = tuple(rng.integers(0, s) for s in w.shape)
+        if abs(w[idx]) < 1e-4:
+            w[idx] = 0.01
+            loss, grads = O.weight_regularizer_term(spec, ws, preg, sreg)
+        h = 1e-6
+        w0 = w[idx]
+        w[idx] = w0 + h; lp, _ = O.weight_regularizer_term(spec, ws, preg, sreg)
+        w[idx] = w0 - h; lm, _ = O.weight_regularizer_term(spec, ws, preg, sreg)
+        w[idx] = w0
+        assert abs((lp - lm) / (2 * h) - grads[i][idx]) < 1e-6 * max(1.0, abs(grads[i][idx])), nm

@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 ARGS="--steps 6 --warmup 3 --no-cpu-baseline"
 O=$R/gpurun_out/${TAG}_default
 rm -rf $O; mkdir -p $O
+python -c "import bench; print(bench.csrc_sha())" > $O/csrc_sha.txt
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py $ARGS > $O/kt_bench.json 2> $O/kt_err.txt
 echo "ktrace rc=$?"
