@@ -7,6 +7,7 @@ from .model import (NIF, NIFMultiScale, NIFMultiScaleLastLayerParameterized, Mod
                     HessianLayer, SobolevModel, set_seed)
 from . import optimizers, callbacks, distributed, data, layers, demo  # noqa: F401
 from .optimizers import Adam  # noqa: F401
+from ._lib import NifError  # noqa: F401
 
-__all__ = ["NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized", "Model", "JacobianLayer", "HessianLayer", "SobolevModel", "Adam", "set_seed",
+__all__ = ["NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized", "Model", "JacobianLayer", "HessianLayer", "SobolevModel", "Adam", "NifError", "set_seed",
            "optimizers", "callbacks", "distributed", "data", "layers", "demo"]

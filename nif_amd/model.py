@@ -2,6 +2,7 @@
 NIF / NIFMultiScale / NIFMultiScaleLastLayerParameterized with build/model/compile/fit/predict and
 the sub-model extractors.  Same constructor arguments, attribute names and error behaviour as the
 reference (file:line cited per method); every number comes from libnif_hip.so (HIP, gfx950)."""
+import contextlib
 import json
 import time
 
@@ -66,8 +67,36 @@ class Model(object):
             e.set_activity_regularizer(a1 + self._po_l1 * float(bg), 0.0)     # the engine's term is c / B * sum |out|
 
     def _pop_losses(self, e):
+        """back to the owner's configuration: models that share the engine (.model(), the sub-models, SobolevModel, the L-BFGS
+        closures) must not inherit this model's terms"""
+        e.set_jac_regularizer(0.0)
         if self._po_l1:
             e.set_activity_regularizer(*getattr(self._owner, "_act_reg", (0.0, 0.0)))
+
+    @contextlib.contextmanager
+    def _plain_loss(self, e):
+        """the bare `loss(model(x), y)` of the reference's L-BFGS closures (lbfgs.py:66-68, lbfgs_V2.py:63-66 evaluate the loss
+        FUNCTION on the model's output: `model.losses` -- kernel / bias / activity regularisers, JacRegLatentLayer's add_loss --
+        is never added there): every regularisation term of the engine is switched off for the evaluation and restored after"""
+        o = self._owner
+        reg, act, sreg = getattr(o, "_reg", (0.0, 0.0)), getattr(o, "_act_reg", (0.0, 0.0)), getattr(o, "_sreg", (0.0, 0.0))
+        n_pnet = o._n_pnet_params() if reg != (0.0, 0.0) else 0
+        e.set_jac_regularizer(0.0)
+        if reg != (0.0, 0.0):
+            e.set_regularizer(0.0, 0.0, 0, n_pnet)
+        if act != (0.0, 0.0):
+            e.set_activity_regularizer(0.0, 0.0)
+        if sreg != (0.0, 0.0):
+            e.set_shapenet_regularizer(0.0, 0.0)
+        try:
+            yield
+        finally:
+            if reg != (0.0, 0.0):
+                e.set_regularizer(reg[0], reg[1], 0, n_pnet)
+            if act != (0.0, 0.0):
+                e.set_activity_regularizer(*act)
+            if sreg != (0.0, 0.0):
+                e.set_shapenet_regularizer(*sreg)
 
     # ---- weights ---------------------------------------------------------------------------------
     @property
@@ -536,13 +565,15 @@ class NIF(object):
             self.__engine = Engine(self._spec, device_id=dist.local_device())
             self.__engine.set_weights(self._init_weights)
             if self._reg != (0.0, 0.0):
-                n_pnet = sum(int(np.prod(s)) for nm, s in self._spec.param_shapes() if nm.startswith("pnet_"))
-                self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, n_pnet)
+                self.__engine.set_regularizer(self._reg[0], self._reg[1], 0, self._n_pnet_params())
             if self._act_reg != (0.0, 0.0):
                 self.__engine.set_activity_regularizer(*self._act_reg)
             if self._sreg != (0.0, 0.0):
                 self.__engine.set_shapenet_regularizer(*self._sreg)
         return self.__engine
+
+    def _n_pnet_params(self):
+        return sum(int(np.prod(s)) for nm, s in self._spec.param_shapes() if nm.startswith("pnet_"))
 
     def call(self, inputs, training=None, mask=None):
         """model.py:130-154 / :510-539 / :1044-1068"""

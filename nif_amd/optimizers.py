@@ -243,8 +243,12 @@ class TFPLBFGS(object):
         np = self._np
         e = self.model._engine
         e.set_flat(theta.astype(np.float32))
-        e.loss_grad_dev(self._d_x.at(0), self._d_y.at(0), self._d_sw.at(0) if self._d_sw is not None else None, self._B, self._B)
-        loss, g = e.grad_read()
+        # the reference's closure is `loss(model(x), y)` -- the loss FUNCTION alone, model.losses is never added (lbfgs.py:66-68,
+        # lbfgs_V2.py:63-66): no weight / activity / latent-Jacobian regulariser in the L-BFGS objective, whatever the last
+        # fit() of a model sharing this engine left configured
+        with self.model._plain_loss(e):
+            e.loss_grad_dev(self._d_x.at(0), self._d_y.at(0), self._d_sw.at(0) if self._d_sw is not None else None, self._B, self._B)
+            loss, g = e.grad_read()
         self._losses.append(loss)
         if len(self._losses) % self.display_epoch == 0:
             print("Epoch: %d loss: %.8e" % (len(self._losses), loss))
