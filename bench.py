@@ -437,6 +437,8 @@ def main():
         fence()
         if double is None:
             dist.shutdown()
+        elif comm is not None:
+            comm.shutdown()
 
 
 if __name__ == "__main__":

@@ -505,14 +505,16 @@ bool gw_da_bf16_ok(int NBI, int NBO, int r) {
   return gw_use_lds() && NBI <= 2;                         // k_gw_lds<.., DAB>
 }
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st);
-void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
+int launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  // bf16 dL/da rows have readers of two forms only (k_gw8<R, true>, k_gw_lds<1|2, .., true>): anything else would read them as fp32
+  if (a.da_bf16 && !gw_da_bf16_ok(NBI, NBO, a.r)) return -1;
   constexpr int WV = NIF_GW_WAVES;
   dim3 block(64 * WV);
   const bool use_lds = gw_use_lds();
   // 128-wide layers: the 8-wave shared-tile kernel reads every stash tile once (k_gw8.hip); NIF_GW8=0: the r1 kernels (A/B)
   static const bool use_gw8 = [] { const char* e = getenv("NIF_GW8"); return !(e && e[0] == '0'); }();
-  if (use_gw8 && gw8_supported(a, NBI, NBO)) { launch_gw8(a, rows, st); return; }
+  if (use_gw8 && gw8_supported(a, NBI, NBO)) { launch_gw8(a, rows, st); return 0; }
   if (use_lds && NBI == NBO && (NBI <= 2 || NBI == 4)) {
 #define NIF_GWL(NBI_, OBC_, NBUF_, DAB_)                                                                                   \
   do {                                                                                                                     \
@@ -526,7 +528,7 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
     else if (NBI == 2) NIF_GWL(2, 2, 2, false);
     else NIF_GWL(4, 2, 1, false);
 #undef NIF_GWL
-    return;
+    return 0;
   }
   if (NBI == 1 && NBO == 1) {
     dim3 grid(rows, (a.r + 1 + 1) / 2, 1);
@@ -545,6 +547,7 @@ void launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st
     hipLaunchKernelGGL((k_gw_mfma<4, 2, 1, WV, true>), grid, block, 0, st, a, NBO);
 #endif
   }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

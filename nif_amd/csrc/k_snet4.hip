@@ -753,6 +753,10 @@ long snet4_bwd_elems(int n, int r) { const int NBL = snet3_nbl(n); return (long)
 
 // plain SIREN: the act'(a) ring is not needed (the cosine's sign rides in the stashed sine, any depth / width)
 bool snet4_sign_ring(const SNetArgs& a) { return !a.nif_skip; }
+// does the training launch of `a` write its hidden-layer dL/da stash rows in bf16?  The kernel's own condition (`PR && NBL != 6 &&
+// A.da_bf16` at the store), stated once next to it: the host derives the consumers' GwArgs.da_bf16 from THIS, not from a second copy
+// of the dispatch predicate
+bool snet4_writes_da_bf16(const SNetArgs& a) { return a.da_bf16 != 0 && a.prec == 1 && snet3_nbl(a.n) != 6; }
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st) {
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);

@@ -4,6 +4,8 @@
 
 long sob_ring_floats_per_wave(int n, int nh) { return (long)(nh + 1) * (2 + NIF_SOB_MAXSEED) * snet3_nbl(n) * 256; }
 
+// bf16 dL/da stash rows are written by the streams-on-waves form (k_sobw<PR>) alone; k_sob always writes fp32 rows
+bool sob_writes_da_bf16(const SNetArgs& a, int ns, bool any_par) { return a.da_bf16 != 0 && a.prec == 1 && sobw_supported(a, ns, any_par); }
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
                bool query_only, hipStream_t st, const SobPar* par) {
   bool any_par = false;

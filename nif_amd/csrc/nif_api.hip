@@ -1010,6 +1010,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
       const int nbl = snet3_nbl(c->n);
       ll_dab = sa.prec == 1 && (nbl == 2 || nbl == 4 || nbl == 8) && gw_da_bf16_ok(c->NB, c->NB, 0);
       sa.da_bf16 = ll_dab ? 1 : 0;
+      if (snet4_writes_da_bf16(sa) != ll_dab) return fail(NIF_ERR_STATE, "internal: dL/da stash format of producer and plan disagree");
     }
     nloss = launch_snet4(sa, true, true, c->st);
     const long need = (long)nloss * 4 * snet3_ring_floats_per_wave(c->n, c->nh);
@@ -1066,7 +1067,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
       else { const int i = mi / 2; w_off = (mi & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (mi & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
       g.W = dense_ref(w_off, c->n, c->n); g.Bv = vec_ref(b_off, c->n);
       g.da_bf16 = ll_dab ? 1 : 0;
-      launch_gw_mfma(g, c->NB, c->NB, rows, c->st);
+      if (launch_gw_mfma(g, c->NB, c->NB, rows, c->st) < 0) return fail(NIF_ERR_STATE, "internal: bf16 dL/da stash rows without a reader of that form");
     }
     sbase(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
     g.W = dense_ref(c->s_bott_w, c->n, c->r * c->so); g.Bv = vec_ref(c->s_bott_b, c->r * c->so);
@@ -1236,9 +1237,13 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     const int nbl = snet3_nbl(c->n);
     bool dab = sa.prec == 1 && (nbl == 2 || nbl == 4 || nbl == 8) && gw_da_bf16_ok(c->NB, c->NB, c->r);
     if (ns > 0) dab = dab && sobw_supported(sa, ns, sp && sp->any_par);
-    else dab = dab && c->use_snet4;
+    else dab = dab && c->use_snet4 && !fused_gw;
     sa.da_bf16 = dab ? 1 : 0;
   }
+  // what the producer of this step really writes (its own predicate, next to its kernels); the readers below follow THAT
+  const bool wrote_da_bf16 = ns > 0 ? sob_writes_da_bf16(sa, ns, sp && sp->any_par)
+                                    : (!fused_gw && c->use_snet4 && snet4_writes_da_bf16(sa));
+  if (wrote_da_bf16 != (sa.da_bf16 != 0)) return fail(NIF_ERR_STATE, "internal: dL/da stash format of producer and plan disagree");
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) {
@@ -1301,12 +1306,12 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   // ShapeNet hidden matrices
   for (int j = 0; j < c->nh; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
-    g.da_bf16 = sa.da_bf16;
+    g.da_bf16 = wrote_da_bf16 ? 1 : 0;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
     g.W = hyper_ref(c, wslot, c->n, c->n, c->n);
     g.Bv = hyper_ref(c, bslot, 0, 1, c->n);
-    launch_gw_mfma(g, c->NB, c->NB, rows, sb_st);
+    if (launch_gw_mfma(g, c->NB, c->NB, rows, sb_st) < 0) return fail(NIF_ERR_STATE, "internal: bf16 dL/da stash rows without a reader of that form");
   }
   // ShapeNet last layer
   {

@@ -11,8 +11,11 @@ static inline int fail(int code, const std::string& msg) { return nif_fail(code,
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess)                                                                         \
+    if (e_ != hipSuccess) {                                                                       \
+      (void)hipGetLastError(); /* HIP >= 7 keeps the last failure until it is read: drain it, or the next launch check of a   \
+                                  caller that recovered (fit()'s host-shuffle fallback after a failed hipMalloc) reports it */ \
       return fail(NIF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    }                                                                                             \
   } while (0)
 
 struct nif_ctx {

@@ -166,6 +166,8 @@ void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, float scale, hipStream_t st);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+bool snet4_writes_da_bf16(const SNetArgs& a);   // stash format the training launch of `a` produces (k_snet4.hip)
+bool sob_writes_da_bf16(const SNetArgs& a, int ns, bool any_par);   // same for launch_sob (k_sob.hip)
 // k_snet4's plain-SIREN training step with every ShapeNet weight gradient fused in (k_snet6.hip): one partial-gradient row and one
 // loss partial per workgroup; no dL/da stash, no k_gw_* launches
 bool snet6_supported(const SNetArgs& a);
@@ -200,7 +202,7 @@ void launch_mlp_jac(const PNetArgs& a, int NB, int seed, float* ZD, hipStream_t 
 void launch_ll_jac_out(const float* PHI, const float* Z, const float* PHID, const float* ZD, long B, int r, int so,
                        int nx_total, int xcol, float* dydx, hipStream_t st);
 void launch_pack16(const float* theta, const MatRef& m, int NBL, f32x4* WF, f32x4* WB, hipStream_t st);
-void launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st);
+int launch_gw_mfma(const GwArgs& a, int NBI, int NBO, int rows, hipStream_t st);   // -1: bf16 dL/da rows handed to a shape without a DAB form
 void launch_gw_first(const GwArgs& a, int NBO, int rows, hipStream_t st);
 void launch_gw_out(const GwArgs& a, int NBI, int rows, hipStream_t st);
 void launch_reduce(const float* partial, long pstride, int rows, const float* loss_partial, int nloss,

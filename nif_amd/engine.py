@@ -274,11 +274,12 @@ class Engine(object):
             raise ValueError("sample_weight: expected shape (%d,), got %s" % (n_rows, sw.shape))
         return sw
 
-    def loss_and_grad(self, inputs, y, sample_weight=None):
+    def loss_and_grad(self, inputs, y, sample_weight=None, want_grad=True):
+        """(total loss, flat gradient); want_grad=False: (total loss, None) -- only the scalar travels back (evaluation)"""
         x = self._inputs(inputs)
         y = self._targets(y, x.shape[0])
         sw = self._weights(sample_weight, x.shape[0])
-        g = np.empty((self.n_params,), dtype=np.float32)
+        g = np.empty((self.n_params,), dtype=np.float32) if want_grad else None
         loss = C.c_float()
         check(self.lib.nif_loss_and_grad(self.ctx, ptr(x), ptr(y), ptr(sw), x.shape[0], C.byref(loss), ptr(g)))
         return float(loss.value), g
@@ -315,7 +316,8 @@ class Engine(object):
             d_x.free(); d_u.free(); d_j.free()
         return u, j
 
-    def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None):
+    def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None, want_grad=True):
+        """(total loss incl. the weight regularisers, flat gradient) of the two-output model on host arrays"""
         x = self._inputs(inputs)
         B = x.shape[0]
         y, g = self._targets(y, B), _f32(dydx)
@@ -330,13 +332,15 @@ class Engine(object):
                 d_sw.upload(_f32(sample_weight))
             self.sobolev_loss_grad_dev(d_x.at(0), d_y.at(0), d_g.at(0), d_sw.at(0) if d_sw is not None else None, B, B,
                                        x_index, w_jac)
-            buf = np.empty((self.n_params + 1,), dtype=np.float32)
-            check(self.lib.nif_d2h(self.ctx, ptr(buf), self.grad_dev_ptr(), buf.nbytes))
+            if want_grad:
+                loss, grad = self.grad_read()           # adds the kernel / bias regularisers once, like nif_loss_and_grad
+            else:
+                loss, grad = self.grad_read_loss(), None
         finally:
             d_x.free(); d_y.free(); d_g.free()
             if d_sw is not None:
                 d_sw.free()
-        return float(buf[-1]), buf[:-1].copy()
+        return loss, grad
 
     def adam_step_dev(self, adam):
         check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
@@ -380,6 +384,12 @@ class Engine(object):
         loss = C.c_float()
         check(self.lib.nif_grad_read(self.ctx, C.byref(loss), ptr(g)))
         return float(loss.value), g
+
+    def grad_read_loss(self):
+        """total loss of the last loss_grad_dev (weight regulariser included); the gradient stays on the device"""
+        loss = C.c_float()
+        check(self.lib.nif_grad_read(self.ctx, C.byref(loss), None))
+        return float(loss.value)
 
     def last_loss(self):
         loss = C.c_float()

@@ -205,18 +205,24 @@ class Model(object):
     def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
         """Keras Model.evaluate: the TOTAL loss -- sample-weighted mse plus every regularisation loss of the model (kernel / bias
         L1 / L2, the ParameterNet activity regulariser, the latent Jacobian regulariser of build()), as `fit` logs it; evaluated
-        through the engine's loss kernels in chunks, each chunk's loss weighted by its rows (Keras' batch-weighted mean)."""
+        through the engine's loss kernels in chunks, each chunk's loss weighted by its rows (Keras' batch-weighted mean); only
+        the scalar of a chunk travels back.  The sub-models (model_p_to_lr() ...) are never compiled -- in Keras their evaluate()
+        raises, and so does this one."""
+        if self._role != "full":
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`. "
+                               "(only the full model can be compiled; %s is an inference-only view of its variables)" % self._role)
         e = self._engine
         x = np.asarray(x); n = x.shape[0]
         if n == 0:
             return 0.0
+        targets = self._targets(y, n)
         tot = 0.0
         try:
             for lo in range(0, n, self._EVAL_CHUNK):
                 hi = min(n, lo + self._EVAL_CHUNK)
                 sw = None if sample_weight is None else np.asarray(sample_weight)[lo:hi]
                 self._push_losses(e, hi - lo)
-                tot += (hi - lo) * e.loss_and_grad(x[lo:hi], np.asarray(y)[lo:hi], sw)[0]
+                tot += (hi - lo) * self._loss_host(e, x[lo:hi], [t[lo:hi] for t in targets], sw)
         finally:
             self._pop_losses(e)
         return float(tot / n)
@@ -233,8 +239,16 @@ class Model(object):
     def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
         e.loss_grad_dev(d_x, d_targets[0], d_sw, b, bg)
 
+    def _loss_host(self, e, x, targets, sw):
+        """total loss of one evaluation chunk (host arrays)"""
+        return e.loss_and_grad(x, targets[0], sw, want_grad=False)[0]
+
     def _n_tangents(self):
         return 0
+
+    def _scaled_weights(self, sw, n_rows):
+        """sample weights as the engine sees them (hook of the two-output model: an overall loss weight rides on them)"""
+        return sw
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
             sample_weight=None, initial_epoch=0, validation_data=None, **kwargs):
@@ -274,6 +288,8 @@ class Model(object):
             shuffle = shard.shuffle
             N = shard.n_rows
             widths = shard.widths(self)
+            if self._scaled_weights(None, 1) is not None:
+                raise NotImplementedError("loss_weights[0] != 1 with a shard dataset: fold the factor into the shards' sample weights")
             src_x, src_t, src_sw = shard.device_tables(e, self)
             has_sw = src_sw is not None
         else:
@@ -283,6 +299,7 @@ class Model(object):
                 x = np.ascontiguousarray(x[:, :ncol])
             N = x.shape[0]
             sw = None if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float32)
+            sw = self._scaled_weights(sw, N)
             widths = [t.shape[1] for t in targets]
             has_sw = sw is not None
             # the table is made resident in HBM ONCE; a shuffled epoch uploads its permutation (4 bytes per row) and
@@ -474,14 +491,12 @@ class SobolevModel(Model):
         u, j = self._engine.sobolev_forward(x, self.x_index)
         return [u, j]
 
-    def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
-        u, j = self._run(x)
-        ty, tj = self._targets(y, u.shape[0])
-        per = ((u.astype(np.float64) - ty) ** 2).mean(axis=1) * self.loss_weights[0] \
-            + ((j.reshape(tj.shape).astype(np.float64) - tj) ** 2).mean(axis=1) * self.loss_weights[1]
-        if sample_weight is not None:
-            per = per * np.asarray(sample_weight, dtype=np.float64)
-        return float(per.sum() / u.shape[0])
+    def _loss_host(self, e, x, targets, sw):
+        """Model.evaluate's chunk loss for the two-output model: w0 mse(u) + w1 mse(du/dx) + the regularisation losses -- the
+        same total `fit` logs (r3 returned the data term alone, computed on the host)"""
+        w0, w1 = self.loss_weights
+        return e.sobolev_loss_and_grad(x, targets[0], targets[1], self.x_index, w1 / w0, self._scaled_weights(sw, x.shape[0]),
+                                       want_grad=False)[0]
 
     def _targets(self, y, n_rows):
         if not (isinstance(y, (list, tuple)) and len(y) == 2):
@@ -494,12 +509,19 @@ class SobolevModel(Model):
     def _n_tangents(self):
         return len(self.x_index)
 
+    def _scaled_weights(self, sw, n_rows):
+        """Keras total loss = w0 mse(u) + w1 mse(du/dx) (+ regularisers, unscaled).  The kernels compute
+        1/B sum_a sw_a (mse_a(u) + wj mse_a(du/dx)): w0 rides on the sample weights (sw_a <- w0 sw_a, a constant column when the
+        caller gave none) and wj = w1 / w0 -- the data term and its gradient are scaled, the regularisation losses are not."""
+        w0 = self.loss_weights[0]
+        if w0 == 1.0:
+            return sw
+        if sw is None:
+            return np.full((n_rows,), w0, dtype=np.float32)
+        return np.ascontiguousarray(np.asarray(sw, dtype=np.float32) * np.float32(w0))
+
     def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
-        # Keras total loss = w0*mse(u) + w1*mse(dudx); the kernel computes mse(u) + wj*mse(dudx) and the flat
-        # gradient / loss are linear in the overall scale, so fold w0 into wj and rescale when w0 != 1
         w0, w1 = self.loss_weights
-        if w0 != 1.0:
-            raise NotImplementedError("loss_weights[0] must be 1 (scale the learning rate instead)")
         e.sobolev_loss_grad_dev(d_x, d_targets[0], d_targets[1], d_sw, b, bg, self.x_index, w1 / w0)
 
 

@@ -99,7 +99,7 @@ class OracleEngine(object):
         self.reg_applied = False
         self.calls.append(("loss_grad", int(b), int(bg)))
 
-    def loss_and_grad(self, inputs, y, sample_weight=None):
+    def loss_and_grad(self, inputs, y, sample_weight=None, want_grad=True):
         """nif_loss_and_grad: host arrays in, (loss incl. the weight-regulariser term, flat gradient) out"""
         x = np.asarray(inputs, dtype=np.float64)[:, :self.o.pi + self.o.si]
         sw = None if sample_weight is None else np.asarray(sample_weight, dtype=np.float64)
@@ -194,7 +194,10 @@ class GlooComm(object):
         self.td.barrier()
 
     def shutdown(self):
-        pass
+        # without this a rank now and then aborts at interpreter exit ("terminate called without an active exception": gloo's
+        # worker threads are still joinable) and the launcher reports the run as failed
+        if self.td.is_initialized():
+            self.td.destroy_process_group()
 
 
 def bench_double(points):

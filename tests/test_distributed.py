@@ -65,7 +65,8 @@ def _worker(rank, world, port, name, outdir):
              steps=np.array([c[1] if c[0] == "loss_grad" else 0 for c in steps]),
              gsizes=np.array([c[2] if c[0] == "loss_grad" else -1 for c in steps]), nred=comm.n_grad_reduces)
     dist.shutdown()
-    td.destroy_process_group()
+    if td.is_initialized():
+        td.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["ms_plain", "nif_swish"])
@@ -129,7 +130,8 @@ def _worker_empty(rank, world, port, outdir):
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), theta=eng.theta, loss=np.array(h.history["loss"]), nred=comm.n_grad_reduces,
              steps=np.array(steps), reserve=np.array([c[1] for c in eng.calls if c[0] == "reserve"]))
     dist.shutdown()
-    td.destroy_process_group()
+    if td.is_initialized():
+        td.destroy_process_group()
 
 
 def test_two_rank_fit_with_an_empty_shard(tmp_path):
