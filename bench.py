@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1 << 20, help="points per GPU")
+    ap.add_argument("--ramp-steps", type=int, default=40,
+                    help="untimed steps BEFORE the warm-up: the SMU needs ~30 ms of load to raise the shader clock from the idle "
+                         "state (first 25 steps after a cold start: 1.52 -> 1.35 ms, tools/exp/step_times.py); reported as clock_ramp_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the A/B and per-kernel legs after the timed region")
     ap.add_argument("--given-w-points", type=int, default=1 << 17)
@@ -303,6 +306,9 @@ def main():
         # count, stream) must sum to N (N + 1) / 2 on every rank, or the run stops here
         ranks_seen = comm.selftest(e)
         assert ranks_seen == world, "all-reduce self-check accounts for %d ranks, WORLD_SIZE is %d" % (ranks_seen, world)
+    for _ in range(max(args.ramp_steps, 0)):      # clock ramp (same count on every rank: the steps carry the collective)
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -415,6 +421,9 @@ def main():
             "value": Bg * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "clock_ramp_steps": max(args.ramp_steps, 0),
+            "clock_ramp_note": "untimed steps in front of the W warm-up steps: MI355X raises the shader clock over ~30 ms of load; a "
+                               "timed region that starts 7 ms after idle measures the ramp (1.43 ms mean) instead of the step (1.35 ms)",
             "config": {"workload": "configs[1]: 1D travelling wave, NIFMultiScale ShapeNet 4x64 SIREN (omega_0=30), "
                                    "ParameterNet 2x32 swish, latent_dim 1, P=%d, %d points/GPU" % (e.n_params, B),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "final_loss": loss,

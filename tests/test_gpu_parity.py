@@ -232,37 +232,49 @@ def test_loss_and_grad_match_oracle(name, weighted):
 
 
 def test_adam_steps_follow_oracle():
-    """three full-batch Adam steps.  lr = 2e-4: with w0 = 30 the loss surface is rough enough that at lr = 2e-3 the SECOND step's
-    gradient already differs by several per cent between an fp32 and an fp64 trajectory (r3: one entry 6 % off after three steps
-    although its first gradient agreed to four digits); the step itself is pinned to 2e-5 by smoke() and the 200-step test"""
+    """three full-batch Adam steps at lr = 2e-3 (Keras' order of magnitude), every step checked on its own: from the weights and
+    Adam slots the GPU holds BEFORE step t the oracle computes loss, gradient and the Keras-2.11 update; the GPU's weights after the
+    step must sit within 1 % of lr of that prediction wherever the gradient entry is solid, and its slots must be the oracle's.
+    (r3 compared free-running fp32 / fp64 trajectories: with w0 = 30 the SECOND gradient of two trajectories 1e-7 apart already
+    differs by per cents, so that test had to be loosened to lr = 2e-4 and a 5 % / 40 % bar; step-by-step there is nothing chaotic
+    to absorb and the bar is the one-step error.)"""
     import nif_amd
-    LR = 2e-4
+    LR = 2e-3
     m, model, spec, ws, x, y, sw = _make("ms_cfg2_64x4")
     model.compile(nif_amd.Adam(learning_rate=LR), loss="mse")
-    hist = model.fit(x, y, epochs=3, batch_size=x.shape[0], shuffle=False, verbose=0)
-    th = O.flatten(ws)
-    mm = np.zeros_like(th); vv = np.zeros_like(th)
-    losses = []
-    solid = np.ones_like(th, dtype=bool)
+    e = m._engine
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    f32 = lambda a: float(np.float32(a))
+    worst = 0.0
     for t in range(1, 4):
-        l, g = O.loss_and_grad(spec, O.unflatten(spec, th), x.astype(np.float64), y.astype(np.float64))
-        losses.append(l)
-        # entries whose gradient is not small against the tensor's own scale: there the fp32 gradient (2e-4 of the tensor's
-        # norm, test_loss_and_grad_match_oracle) has a small RELATIVE error, and only there is Adam's normalised step
-        # lr * g / |g| insensitive to it
+        th0 = O.flatten(model.get_weights()).astype(np.float64)
+        m0, v0, step0 = e.get_opt_state()
+        assert step0 == t - 1
+        hist = model.fit(x, y, epochs=1, batch_size=x.shape[0], shuffle=False, verbose=0)
+        l, g = O.loss_and_grad(spec, O.unflatten(spec, th0), x64, y64)
+        assert abs(hist.history["loss"][0] - l) <= 2e-5 * abs(l), (t, hist.history["loss"][0], l)
+        gf = O.flatten(g)
+        th1, m1, v1 = O.adam_step(th0, gf, m0.astype(np.float64), v0.astype(np.float64), t, lr=f32(LR), b1=f32(0.9), b2=f32(0.999),
+                                  eps=f32(1e-7))
+        got = O.flatten(model.get_weights())
+        gm, gv, step1 = e.get_opt_state()
+        assert step1 == t
+        # entries whose gradient is not small against the tensor's own scale: there the fp32 gradient (2e-4 of the tensor's norm,
+        # test_loss_and_grad_match_oracle) has a small RELATIVE error and Adam's normalised step lr m / sqrt(v) is insensitive to it
+        solid = np.ones_like(th0, dtype=bool)
         off = 0
         for gt in g:
             rms = np.sqrt(np.mean(gt ** 2)) + 1e-300
-            solid[off:off + gt.size] &= np.abs(gt.ravel()) > 0.02 * rms
+            solid[off:off + gt.size] = np.abs(gt.ravel()) > 0.02 * rms
             off += gt.size
-        th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=float(np.float32(LR)))
-    got = O.flatten(model.get_weights())
-    assert np.allclose(hist.history["loss"], losses, rtol=2e-4)
-    # Adam normalises the step to ~lr, so compare the displacement: 5 % of the three steps where the gradient entry is solid
-    # (the bulk), and nowhere more than a sign flip of one of the three steps would explain
-    assert solid.mean() > 0.8
-    assert np.abs(got - th)[solid].max() < 0.05 * LR * 3
-    assert np.abs(got - th).max() < 0.4 * LR * 3
+        assert solid.mean() > 0.8
+        d = np.abs(got - th1)
+        worst = max(worst, d[solid].max() / LR)
+        assert d[solid].max() < 0.01 * LR, (t, d[solid].max() / LR)
+        assert d.max() <= 2.0 * LR * 1.001                  # elsewhere: at most the sign flip of one normalised step
+        assert _rel(gm, m1) < 1e-3
+        assert _rel(gv, v1) < 1e-3
+    assert worst < 0.01
 
 
 def test_fit_batches_partial_last_batch_and_sample_weight():
@@ -968,8 +980,22 @@ def test_full_size_shard_sum_other_configs(which):
         rel = _per_tensor_rel(spec, sub[:-1], O.flatten(gref))
         # (6 x 128 under the policy, this draw: the policy itself sits 9 % from exact arithmetic -- a flipped bf16 rounding of one
         # activation then moves the gradient by 4e-3 of its norm; another draw of the same net: 3.5e-4)
-        bar = (6e-3 if spec.n > 64 else 3e-3) if bf else 3e-4
-        assert max(rel.values()) < bar, rel
+        bar = 3e-3 if bf else 3e-4
+        if bf and not xi and max(rel.values()) >= bar:
+            # r3 held the 128-wide nets to a blanket 6e-3 because "one draw sits there: a flipped bf16 rounding of one activation".
+            # The explanation is now ASSERTED: the emulating oracle itself is evaluated on weights one fp32 ulp away; where ITS
+            # gradient tensor moves by s, the kernel may sit 3 s from it -- and nowhere else above the typical 3e-3
+            rng2 = np.random.default_rng(99)
+            ws_n = [np.nextafter(w.astype(np.float32), np.float32(np.inf) * rng2.choice([-1.0, 1.0], size=w.shape).astype(np.float32))
+                    .astype(np.float64) for w in ws64]
+            gref_n = fn(spec, ws_n, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64), rnd=O.bf16_round,
+                        stash_bf16=_stash_bf16(spec))[1]
+            sens = _per_tensor_rel(spec, O.flatten(gref_n), O.flatten(gref))
+            for nm, v in rel.items():
+                assert v < max(bar, 3.0 * sens[nm]), (nm, v, sens[nm])
+            assert max(rel.values()) < 1e-2, rel
+        else:
+            assert max(rel.values()) < bar, rel
     d_x.free(); d_y.free()
     if d_g is not None:
         d_g.free()

@@ -71,3 +71,98 @@ def test_bf16_split_and_fp32_mfma_paths_agree(tmp_path):
         assert _rel(d["u"], ref) < 1e-5, _rel(d["u"], ref)
         assert abs(float(d["loss"]) - rl) <= 1e-5 * abs(rl)
         assert _rel(d["grad"], O.flatten(rg)) < 2e-4, _rel(d["grad"], O.flatten(rg))
+
+
+# ---- every runtime knob of the library, flipped, against the oracle ------------------------------------------
+# The switches are read once per process, so each case runs in a child.  The child computes (loss, flat gradient) of one config with
+# the knob set; the parent compares with the fp64 oracle at the parity bars of tests/test_gpu_parity.py.
+KNOB_CHILD = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import nif_amd
+from oracle import nif_oracle as O
+from tests.test_gpu_parity import CONFIGS
+name, mode, policy, out = sys.argv[1:5]
+(kind, cs, cp), B = CONFIGS[name]
+spec = O.Spec(kind, cs, cp)
+rng = np.random.default_rng(0)
+ws = O.init_weights(spec, rng, dtype=np.float32)
+names = [nm for nm, _ in spec.param_shapes()]
+if kind == "NIFMultiScale":
+    ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * (1.0 if policy != "float32" else 2.0)).astype(np.float32)
+if kind == "NIFMultiScaleLastLayerParameterized":
+    ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 30.0).astype(np.float32)
+m = getattr(nif_amd, kind)(cs, cp, mixed_policy=policy)
+model = m.build(); model.set_weights(ws)
+x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+xi = list(range(spec.pi, spec.pi + spec.si))
+g = np.random.default_rng(11).uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+if mode == "sobolev":
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.05, sw)
+else:
+    loss, grad = m._engine.loss_and_grad(x, y, sw)
+np.savez(out, loss=np.float64(loss), grad=grad, x=x, y=y, sw=sw, g=g, **{"w%%d" %% i: w for i, w in enumerate(ws)})
+''' % ROOT
+
+KNOBS = [
+    # (environment, config, mode, policy)
+    ({"NIF_FUSE_GW": "0"}, "ms_cfg2_64x4", "plain", "float32"),            # k_snet4 + k_gw_* instead of the fused-gradient kernel
+    ({"NIF_FUSE_GW": "1"}, "ms_cfg2_64x4", "plain", "float32"),
+    ({"NIF_SIDE_PNET": "0", "NIF_FUSE_GW": "0"}, "ms_cfg2_64x4", "plain", "float32"),
+    ({"NIF_SIDE_PNET": "1", "NIF_FUSE_GW": "0"}, "ms_cfg2_64x4", "plain", "float32"),
+    ({"NIF_PBW_TOUCH": "0", "NIF_FUSE_GW": "0"}, "ms_cfg2_64x4", "plain", "float32"),
+    ({"NIF_PNET_STASH": "1"}, "ms_cfg3_128x3", "plain", "float32"),        # ParameterNet adjoint through its HBM stash
+    ({"NIF_PNET_BF2": "0"}, "ms_cfg3_128x3", "plain", "float32"),          # 64-unit ParameterNet on the f32-input MFMAs
+    ({"NIF_GW8": "0"}, "ms_cfg3_128x3", "plain", "float32"),               # 128-wide weight gradients on k_gw_lds<4, 2, 1>
+    ({"NIF_GW8": "0", "NIF_GW_LDS": "0"}, "ms_cfg3_128x3", "plain", "float32"),   # ... on the register-load form
+    ({"NIF_GW_LDS": "0", "NIF_FUSE_GW": "0"}, "ms_64x2_r1_so5", "plain", "float32"),
+    ({"NIF_SOBW": "0"}, "ms_cfg5_64x4_si2", "sobolev", "float32"),         # k_sob instead of the streams-on-waves kernel
+    ({"NIF_SOBW": "1"}, "ms_cfg5_64x4_si2", "sobolev", "float32"),
+    ({"NIF_LL_MLP": "1"}, "ll_plain_32x2_r3", "plain", "float32"),         # last-layer class on the r1 MLP kernels
+    ({"NIF_FP32_MFMA": "1"}, "ms_res_64x2", "plain", "float32"),
+    ({"NIF_PIPE_CHUNK": "64", "NIF_FP32_MFMA": "1"}, "ms_cfg2_64x4", "plain", "float32"),   # two-stream chunk pipeline of the k_snet3 path
+    ({"NIF_DA_BF16": "0"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),     # fp32 dL/da stash rows under the policy
+    ({"NIF_DA_BF16": "1"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),
+    ({"NIF_DA_BF16": "0"}, "ms_cfg5_64x4_si2", "sobolev", "mixed_bfloat16"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(KNOBS)), ids=["+".join("%s=%s" % kv for kv in sorted(k[0].items())) + ":" + k[1] for k in KNOBS])
+def test_every_runtime_knob_against_the_oracle(case, tmp_path):
+    env_extra, name, mode, policy = KNOBS[case]
+    from tests.test_gpu_parity import CONFIGS
+    out = str(tmp_path / "knob.npz")
+    env = dict(os.environ)
+    for k in ("NIF_FUSE_GW", "NIF_SIDE_PNET", "NIF_PBW_TOUCH", "NIF_PNET_STASH", "NIF_PNET_BF2", "NIF_GW8", "NIF_GW_LDS", "NIF_SOBW", "NIF_LL_MLP",
+              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", KNOB_CHILD, name, mode, policy, out], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    d = np.load(out)
+    (kind, cs, cp), B = CONFIGS[name]
+    spec = O.Spec(kind, cs, cp)
+    ws = [d["w%d" % i].astype(np.float64) for i in range(len(spec.param_shapes()))]
+    x, y, sw, g = (d[k].astype(np.float64) for k in ("x", "y", "sw", "g"))
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    if mode == "sobolev":
+        rl, rg, _, _ = O.sobolev_loss_and_grad(spec, ws, x, y, g, xi, 0.05, sw)
+    else:
+        rl, rg = O.loss_and_grad(spec, ws, x, y, sw)
+    rg = O.flatten(rg)
+    # fp32: the parity bars of test_gpu_parity; mixed_bfloat16: the distance of the policy from exact arithmetic (the cast-for-cast
+    # pin of the default path lives in test_gpu_parity; here the knob must not change what is computed)
+    lbar, gbar = (2e-5, 3e-4) if policy == "float32" else (2e-2, 0.1)
+    assert abs(float(d["loss"]) - rl) <= lbar * abs(rl), (float(d["loss"]), rl)
+    off = 0
+    for nm, shp in spec.param_shapes():
+        k = int(np.prod(shp))
+        a, b = d["grad"][off:off + k], rg[off:off + k]
+        off += k
+        # (the metric of test_loss_and_grad_match_oracle: relative to the tensor, plus 2e-6 of the whole gradient's norm for the
+        # tensors that are small against it -- pnet_bottleneck_b of the 128-wide net is 1e-3 of the gradient)
+        err = float(np.linalg.norm(a.astype(np.float64) - b))
+        assert err <= gbar * np.linalg.norm(b) + 2e-6 * np.linalg.norm(rg), (nm, err, float(np.linalg.norm(b)))
