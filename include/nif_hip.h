@@ -201,6 +201,13 @@ int nif_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, co
 int nif_sobolev_loss_grad_dev(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
                               const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,
                               int32_t nx, float w_jac);
+/* The same step for ANY y_index / x_index of JacobianLayer (nif/layers/gradient.py:207-231): y_idx = NULL means every output,
+ * otherwise the derivative term is the mean over the ny listed outputs (distinct) x nx columns; 1 <= nx <= 16 distinct columns --
+ * more than three run as passes over groups of three tangent streams whose [grad | loss] add up.  dydx_dev rows stay [so][nx]
+ * (entries of unlisted outputs are not part of the loss). */
+int nif_sobolev_loss_grad_dev_y(nif_ctx* ctx, const float* xin_dev, const float* y_dev, const float* dydx_dev,
+                                const float* sw_dev_or_null, int64_t B_local, int64_t B_global, const int32_t* x_idx,
+                                int32_t nx, const int32_t* y_idx_or_null, int32_t ny, float w_jac);
 /* predict() of that two-output model: u [B,so] and du/dx [B,so,nx], device pointers */
 int nif_sobolev_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, const int32_t* x_idx, int32_t nx, float* u_dev,
                             float* dudx_dev);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "nif_loss_grad_dev": (C.c_int, [_CTX, _VP, _VP, _VP, C.c_int64, C.c_int64]),
     "nif_sobolev_loss_grad_dev": (C.c_int, [_CTX, _VP, _VP, _VP, _VP, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
                                             C.c_float]),
+    "nif_sobolev_loss_grad_dev_y": (C.c_int, [_CTX, _VP, _VP, _VP, _VP, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
+                                              C.POINTER(C.c_int32), C.c_int32, C.c_float]),
     "nif_sobolev_forward_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
     "nif_zero_grad": (C.c_int, [_CTX]),

@@ -29,6 +29,9 @@ struct PJacArgs {
   float* ZT;            // mode 1: [pi][tiles][r][32]
   const float* MU_in;   // mode 2: blocks of [tiles][r][32]; column d reads block mu_blk[d] (< 0: zero)
   int mu_blk[NIF_PJ_MAXPI];
+  // r4: ParameterNets with more than NIF_PJ_MAXPI inputs run in passes over groups of parameter columns -- tangent d of a pass is
+  // column c0 + d, nd <= NIF_PJ_MAXPI of them; every term is linear in the tangent seeds, so the passes' gradients simply add
+  int c0, nd;
 };
 
 __device__ __forceinline__ void pj_act(int act, float a, float* f0, float* f1, float* f2) {
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
   const long ptc = ok ? pt : A.B - 1;       // inputs of a padding thread: any valid point, its results are discarded
   const long pta = wr ? pt : ntiles * 32 - 1;
   const long tile = pta >> 5; const int pp = (int)(pta & 31);
-  const int pi = A.pi, nst = A.nst, lst = A.lst, r = A.r, res = A.res;
+  const int pia = A.pi, pi = J.nd, c0 = J.c0, nst = A.nst, lst = A.lst, r = A.r, res = A.res;      // pi: the tangents of THIS pass
   const int nm = lst * (res ? 2 : 1);
   const int FP = stash_fp(nst);           // feature rows of a stash tile as the gradient kernels read them (32, 64 or 128)
   const float s = A.siren ? A.omega : 1.0f;
@@ -73,19 +76,17 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
   auto LD = [&](const float* q) -> float { return wr ? *q : 0.f; };
   const int S_IN = 0, S_DA0 = nm + 1, S_DA = nm + 2;
   float h[NST], hd[NIF_PJ_MAXPI][NST];
-  float pin[NIF_PJ_MAXPI];
-  for (int d = 0; d < pi; ++d) pin[d] = A.xin[ptc * A.ncol + A.col0 + d];
 
   // ---------------- forward: primal + tangents; IN_m <- layer inputs, DA_m <- pre-activations (for now) ----------------
   for (int j = 0; j < nst; ++j) {
     float a = 0.f;
-    for (int d = 0; d < pi; ++d) a = fmaf(pin[d], th[A.first_w + (long)d * nst + j], a);
+    for (int d = 0; d < pia; ++d) a = fmaf(A.xin[ptc * A.ncol + A.col0 + d], th[A.first_w + (long)d * nst + j], a);
     a = s * a + th[A.first_b + j];
     float f0, f1, f2; pj_act(act, a, &f0, &f1, &f2);
     h[j] = f0;
     ST(at(S_DA0, 0, j), a);
     for (int d = 0; d < pi; ++d) {
-      const float ad = s * th[A.first_w + (long)d * nst + j];
+      const float ad = s * th[A.first_w + (long)(c0 + d) * nst + j];
       hd[d][j] = f1 * ad;
       ST(at(S_DA0, 1 + d, j), ad);
     }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(128) void k_pjac(PJacArgs J) {
     for (int d = 0; d < pi; ++d) {
       float zd = 0.f;
       for (int i = 0; i < nst; ++i) zd = fmaf(hd[d][i], th[A.bott_w + (long)i * r + c], zd);
-      if (fwd_only) { if (wr) J.ZT[(((long)d * ntiles + tile) * r + c) * 32 + pp] = ok ? zd : 0.f; continue; }
+      if (fwd_only) { if (wr) J.ZT[(((long)(c0 + d) * ntiles + tile) * r + c) * 32 + pp] = ok ? zd : 0.f; continue; }
       float m_;
       if (J.mode == 2) m_ = (ok && J.mu_blk[d] >= 0) ? J.MU_in[(((long)J.mu_blk[d] * ntiles + tile) * r + c) * 32 + pp] : 0.f;
       else { lsum = fmaf(zd, zd, lsum); m_ = ok ? 2.0f * J.coef * zd : 0.f; }
@@ -310,29 +311,37 @@ void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st)
 bool pjac_supported(const PNetArgs& a) {
   const int nm = a.lst * (a.res ? 2 : 1);
   // (first / hidden / bottleneck only: the same for every class).  r3: every ParameterNet width / depth the engine accepts --
-  // the 128-unit instantiation keeps its per-thread vectors in scratch (a scalar kernel for optional terms: slow, never refused)
-  return a.nst <= 128 && nm <= NIF_MAX_HID && a.pi <= NIF_PJ_MAXPI;
+  // the 128-unit instantiation keeps its per-thread vectors in scratch (a scalar kernel for optional terms: slow, never refused);
+  // r4: any number of parameter inputs (passes over groups of NIF_PJ_MAXPI columns)
+  return a.nst <= 128 && nm <= NIF_MAX_HID;
 }
+int pjac_group() { return NIF_PJ_MAXPI; }
 static int launch_pjac_any(const PJacArgs& J, hipStream_t st);
-int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st) {
+// the regulariser's pass over parameter columns [c0, c0 + nd): MU / stash hold (1 + nd) blocks of tiles
+int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, int c0, int nd, hipStream_t st) {
   PJacArgs J; J.p = a; J.coef = coef; J.MU = MU; J.loss_partial = loss_partial;
-  J.mode = 0; J.ZT = nullptr; J.MU_in = nullptr;
+  J.mode = 0; J.ZT = nullptr; J.MU_in = nullptr; J.c0 = c0; J.nd = nd;
   for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = -1;
   return launch_pjac_any(J, st);
 }
 // z'_d = dz/dp_d of every parameter column -> ZT [pi][tiles][r][32] (no stash traffic)
 int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st) {
-  PJacArgs J; J.p = a; J.coef = 0.f; J.MU = ZT; J.loss_partial = nullptr;
-  J.mode = 1; J.ZT = ZT; J.MU_in = nullptr;
-  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = -1;
-  return launch_pjac_any(J, st);
+  int nblk = 0;
+  for (int c0 = 0; c0 < a.pi; c0 += NIF_PJ_MAXPI) {
+    PJacArgs J; J.p = a; J.coef = 0.f; J.MU = ZT; J.loss_partial = nullptr;
+    J.mode = 1; J.ZT = ZT; J.MU_in = nullptr; J.c0 = c0; J.nd = a.pi - c0 < NIF_PJ_MAXPI ? a.pi - c0 : NIF_PJ_MAXPI;
+    for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = -1;
+    nblk = launch_pjac_any(J, st);
+  }
+  return nblk;
 }
-// adjoint of the (primal, tangent) ParameterNet for given dL/dz'_d (block mu_blk[d] of MU_in; the primal dL/dz part is the
-// ordinary ParameterNet adjoint's business): operand pairs into the stash, MU for k_gw_out, like the regulariser
-int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st) {
+// adjoint of the (primal, tangent) ParameterNet for given dL/dz'_d of the columns [c0, c0 + nd) (block mu_blk[c0 + d] of MU_in,
+// mu_blk indexed by COLUMN; the primal dL/dz part is the ordinary ParameterNet adjoint's business): operand pairs into the stash,
+// MU for k_gw_out, like the regulariser
+int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, int c0, int nd, hipStream_t st) {
   PJacArgs J; J.p = a; J.coef = 0.f; J.MU = MU; J.loss_partial = loss_partial;
-  J.mode = 2; J.ZT = nullptr; J.MU_in = MU_in;
-  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = d < a.pi ? mu_blk[d] : -1;
+  J.mode = 2; J.ZT = nullptr; J.MU_in = MU_in; J.c0 = c0; J.nd = nd;
+  for (int d = 0; d < NIF_PJ_MAXPI; ++d) J.mu_blk[d] = d < nd ? mu_blk[c0 + d] : -1;
   return launch_pjac_any(J, st);
 }
 static int launch_pjac_any(const PJacArgs& J, hipStream_t st) {

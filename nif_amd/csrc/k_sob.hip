@@ -55,6 +55,15 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     for (int d = 0; d < NIF_SOB_MAXSEED; ++d) J.par[d] = -1;
     any_par = false;
   }
+  {   // the derivative term's bookkeeping (SobArgs wu / wjn / ymask / gstride)
+    const int so_out = a.ll ? a.so_u : a.so;
+    const int nx_all = (par && par->nx_all > 0) ? par->nx_all : J.nx_tot;
+    const int ny = (par && par->ny > 0) ? par->ny : so_out;
+    J.gstride = (par && par->gstride > 0) ? par->gstride : J.nx_tot;
+    J.ymask = (par && par->ymask) ? par->ymask : 0xFFFFFFFFu;
+    J.wu = (par && par->no_primal) ? 0.0f : 1.0f;
+    J.wjn = wj / ((float)ny * (float)nx_all);
+  }
   if (wav) { launch_sobw(J, nblk, st); return nblk; }
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96

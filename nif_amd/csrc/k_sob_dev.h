@@ -48,6 +48,11 @@ struct SobArgs {
   int pcol[NIF_SOB_MAXSEED];    // column of gt / JU that head e fills
   float* DAT;                   // [npar][tiles][rl][32]
   float* ZTL; int zl_rows;      // [npar][tiles][zl_rows][32]
+  // r4 (gradient.py:207-231 takes any y_index / any number of x_index columns): the derivative term covers the outputs of ymask
+  // only (ny of them) and a launch may carry one GROUP of the x_index columns -- gt / JU rows hold gstride columns, the term's
+  // weight is wjn = w_jac / (ny * all columns) per squared error, and wu = 0 switches the primal mse off for the groups after the
+  // first (host: nif_api.hip sobolev passes)
+  float wu, wjn; unsigned ymask; int gstride;
   int one_buf;                  // 1: ONE plane buffer in LDS (shapes where two do not fit next to the small hyper-vectors): the next
                                 // plane's DMA starts after the barrier behind the current plane's products, and is waited for
 };
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       float* llap = llda + nrl * 16;                         // a'_e [3][rl][16]
       float* lldap = llap + NIF_SOB_MAXSEED * nrl * 16;      // dL/da'_e
       float* lldqp = lldap + NIF_SOB_MAXSEED * nrl * 16;     // du_e [3][so_u][16]
-      const int npar = J.npar, nxt = J.nx_tot;
+      const int npar = J.npar, nxt = J.gstride;
       if (g == 0) {
         for (int cc = 0; cc < nrl; ++cc) lla[cc * 16 + p] = A.Z[(tile32 * nrl + cc) * 32 + poff];
         for (int e = 0; e < npar; ++e)
@@ -452,20 +457,21 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
           float dq[NQ];
           const float e = uo - A.y[ptc * sou + i];
           se = fmaf(e, e, se);
-          dq[0] = 2.0f * wsamp * e * A.inv_bg / (float)sou;
+          dq[0] = J.wu * 2.0f * wsamp * e * A.inv_bg / (float)sou;
+          const float ysel = ((J.ymask >> i) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
           for (int d = 0; d < NS; ++d) {
             dq[1 + d] = 0.f;
             if (d < ns) {
-              const float ej = uq[1 + d] - J.gt[(ptc * sou + i) * nxt + J.gcol[d]];
+              const float ej = ysel * (uq[1 + d] - J.gt[(ptc * sou + i) * nxt + J.gcol[d]]);
               sej = fmaf(ej, ej, sej);
-              dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * nxt);
+              dq[1 + d] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
             }
           }
           for (int e2 = 0; e2 < npar; ++e2) {
-            const float ej = up[e2] - J.gt[(ptc * sou + i) * nxt + J.pcol[e2]];
+            const float ej = ysel * (up[e2] - J.gt[(ptc * sou + i) * nxt + J.pcol[e2]]);
             sej = fmaf(ej, ej, sej);
-            if (g == 0) lldqp[(e2 * sou + i) * 16 + p] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(sou * nxt);
+            if (g == 0) lldqp[(e2 * sou + i) * 16 + p] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
           }
           if (g == 0) {
 #pragma unroll
@@ -591,20 +597,21 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
         if (J.JU)
 #pragma unroll
           for (int d = 0; d < NS; ++d)
-            if (d < ns) J.JU[(pt * so + o) * ns + J.gcol[d]] = part[1 + d];
+            if (d < ns) J.JU[(pt * so + o) * J.gstride + J.gcol[d]] = part[1 + d];
       }
       if (TRAIN) {
         float dq[NQ];
         const float e = uo - A.y[ptc * so + o];
         se = fmaf(e, e, se);
-        dq[0] = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        dq[0] = J.wu * 2.0f * wsamp * e * A.inv_bg / (float)so;
+        const float ysel = ((J.ymask >> o) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
         for (int d = 0; d < NS; ++d) {
           dq[1 + d] = 0.f;
           if (d < ns) {
-            const float ej = part[1 + d] - J.gt[(ptc * so + o) * ns + J.gcol[d]];
+            const float ej = ysel * (part[1 + d] - J.gt[(ptc * so + o) * J.gstride + J.gcol[d]]);
             sej = fmaf(ej, ej, sej);
-            dq[1 + d] = 2.0f * J.wj * wsamp * ej * A.inv_bg / (float)(so * ns);
+            dq[1 + d] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
           }
         }
 #pragma unroll
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       }
     }
     if (TRAIN) {
-      if (g == 0) loss_lane += wsamp * A.inv_bg * (se / (float)sou + J.wj * sej / (float)(sou * (LL ? J.nx_tot : ns)));
+      if (g == 0) loss_lane += wsamp * A.inv_bg * (J.wu * se / (float)sou + J.wjn * sej);
 
       // ---- adjoint through the hidden hyper-matrices --------------------------------------------
       f32x4 skip[MODE != 0 ? NQ : 1][MODE != 0 ? NBL : 1];

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
     }
     for (int i0 = 0; i0 < CY; i0 += 4) {
       const int c = i0 + g < so ? i0 + g : so - 1;
-      const float* src = q ? J.gt + (ptn * so + c) * NS + gcol : A.y + ptn * so + c;
+      const float* src = q ? J.gt + (ptn * so + c) * J.gstride + gcol : A.y + ptn * so + c;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
     }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
     f32x4 gh[NBL];
     ZERO_T(gh)
     const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
-    const float lw = q ? J.wj / (float)(so * NS) : 1.0f / (float)so;      // weight of this stream's squared errors
+    const float lw = q ? J.wjn : J.wu / (float)so;      // weight of this stream's squared errors (r4: SobArgs wu / wjn / ymask)
     float se = 0.f;
     for (int o = 0; o < so; ++o) {
       f32x4 wg[NBL];
@@ -336,9 +336,9 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
       const float uo = q ? part : part + bias;
       if (valid && g == 0) {
         if (q == 0) { if (A.u_out) A.u_out[pt * so + o] = uo; }
-        else if (J.JU) J.JU[(pt * so + o) * NS + gcol] = uo;
+        else if (J.JU) J.JU[(pt * so + o) * J.gstride + gcol] = uo;
       }
-      const float e = uo - ys[o * 16];
+      const float e = (q && !((J.ymask >> o) & 1u)) ? 0.0f : uo - ys[o * 16];       // tangent streams: the outputs of y_index only
       se = fmaf(e, e, se);
       const float du = 2.0f * lw * wsamp * e * A.inv_bg;
       if (active && g == 0) A.DU[(((long)q * nt32 + tile32) * so + o) * 32 + poff] = du;

@@ -18,7 +18,8 @@ static inline bool act_on(const nif_ctx* c) { return c->act_l1 != 0.f || c->act_
 static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg, const int* mu_blk = nullptr);
 // Sobolev streams of one x_index: coordinate seeds first, then the parameter seeds (their pseudo-tiles trail the stashes, so
 // that the first-layer reduction simply stops in front of them); gcol = the x_index position (column of dydx) of each stream
-struct SobPlan { int ns, nsc; int seeds[3]; int par[3]; int gcol[3]; bool any_par; };
+struct SobPlan { int ns, nsc; int seeds[3]; int par[3]; int gcol[3]; bool any_par;
+                 int gstride, nx_all, ny, no_primal; unsigned ymask; };      // r4: one group of the x_index columns / a y_index subset (SobPar)
 static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const SobPlan& sp, const SNetArgs& sa);
 static int fill_snet_ll_sob(nif_ctx* c, SNetArgs& sa, const float* xin, long B, bool f32_planes = false);
 
@@ -188,7 +189,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  void* ptrs[] = {c->sob_acc, c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -734,7 +735,7 @@ static int hessian_core(nif_ctx* c, const float* xin_dev, int64_t B, const int32
   const long blk = ntl * 32 * c->r;                // floats of one latent-layout vector
   if (anyp) {
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
+      return fail(NIF_ERR_INVALID, "HessianLayer on parameter columns: ParameterNets of up to 128 units");
     const long need_zt = (long)c->pi * blk, need_dd = (long)np_ * np_ * blk;
     if (need_zt > c->zt_par_cap || need_dd > c->dzt_par_cap) HIPCHK(hipStreamSynchronize(c->st));
     if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
@@ -989,6 +990,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     if (need > c->dring_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->dring, &c->dring_cap, need); if (rc) return rc; }
     SobPar spar{};
     for (int d = 0; d < 3; ++d) { spar.par[d] = -1; spar.gcol[d] = sp->gcol[d]; }
+    spar.gstride = sp->gstride; spar.nx_all = sp->nx_all; spar.ny = sp->ny; spar.no_primal = sp->no_primal; spar.ymask = sp->ymask;
     if (nhead > 0) {     // parameter columns: heads of the epilogue (z' = dz/dp sits in c->zt_par, loss_grad_core)
       const long need_a = 3 * ntiles * 32 * c->r, need_l = 3 * ntiles * 32 * 32 * c->RB;
       if (need_a > c->dat_par_cap || need_l > c->ztl_par_cap) HIPCHK(hipStreamSynchronize(c->st));
@@ -1107,7 +1109,8 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     // the heads' share of the r x r layer: dL/dlast_w += z'^T dL/da' (a' = z' last_w has no bias), the same reduction as the
     // main one with (z', dL/da') as the operand pair; then the (primal, tangent) ParameterNet for dL/dz' (jac_reg_pass, given mu)
     if (!c->jac_tmp) HIPCHK(hipMalloc(&c->jac_tmp, sizeof(float) * (size_t)(c->P + 2)));
-    int mu_blk[3] = {-1, -1, -1};
+    int mu_blk[16];
+  for (int q = 0; q < 16; ++q) mu_blk[q] = -1;
     const long rr = (long)c->r * c->r;
     for (int e = 0; e < nhead; ++e) {
       mu_blk[sp->par[nsc + e]] = e;
@@ -1248,6 +1251,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) {
       SobPar spar{}; const SobPar* sparp = nullptr;
+      if (sp) { spar.gstride = sp->gstride; spar.nx_all = sp->nx_all; spar.ny = sp->ny; spar.no_primal = sp->no_primal; spar.ymask = sp->ymask; }
       if (sp && sp->any_par) {
         for (int d = 0; d < 3; ++d) { spar.par[d] = sp->par[d]; spar.gcol[d] = sp->gcol[d]; }
         spar.ZT = c->zt_par; spar.DZT = c->dzt_par; sparp = &spar;
@@ -1361,7 +1365,7 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
   if (sp && sp->any_par) {   // z' = dz/dp of the parameter columns, in front of the ShapeNet
     PNetArgs pa; fill_pnet(c, pa, xin, B);
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNets of up to 128 units");
     const long need_zt = (long)c->pi * ntiles * 32 * c->r, need_dzt = 3 * ntiles * 32 * c->r;
     if (need_zt > c->zt_par_cap || need_dzt > c->dzt_par_cap) HIPCHK(hipStreamSynchronize(c->st));
     if (need_zt > c->zt_par_cap) { rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
@@ -1439,7 +1443,8 @@ extern "C" int nif_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, c
 // Size every workspace of a training step over up to B_max points (n_tangents Sobolev seeds, 0 = plain step) now, so
 // that no hipMalloc / stream synchronisation happens inside a later (timed) step.
 extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
-  if (!c || B_max <= 0 || n_tangents < 0 || n_tangents > 3) return fail(NIF_ERR_INVALID, "bad argument");
+  if (!c || B_max <= 0 || n_tangents < 0 || n_tangents > 16) return fail(NIF_ERR_INVALID, "bad argument");
+  if (n_tangents > 3) n_tangents = 3;      // (more x_index columns run as passes over groups of three)
   HIPCHK(hipSetDevice(c->dev));
   int rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B_max + 31) / 32;
@@ -1463,7 +1468,7 @@ extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
 }
 
 static int sobolev_plan(nif_ctx* c, const int32_t* x_idx, int32_t nx, SobPlan* sp) {
-  if (!x_idx || nx < 1 || nx > 3) return fail(NIF_ERR_INVALID, "Sobolev training takes 1..3 input columns in x_index");
+  if (!x_idx || nx < 1 || nx > 3) return fail(NIF_ERR_INVALID, "internal: a Sobolev pass carries 1..3 columns");
   memset(sp, 0, sizeof(*sp));
   sp->ns = nx;
   for (int d = 0; d < nx; ++d) {
@@ -1480,18 +1485,82 @@ static int sobolev_plan(nif_ctx* c, const int32_t* x_idx, int32_t nx, SobPlan* s
   for (; q < 3; ++q) { sp->seeds[q] = 0; sp->par[q] = -1; sp->gcol[q] = q; }
   return NIF_OK;
 }
+// The columns of x_index in groups of <= 3 (the kernels carry up to three tangent streams): the derivative term is a sum over the
+// columns, so group k > 0 is one more pass with the primal mse (and every regularisation term) switched off, its [grad | loss]
+// added to the first pass's.  y_idx = NULL: every output; otherwise the derivative term covers the listed outputs only
+// (gradient.py:207-231).  dydx rows are [so][nx] either way (rows of unlisted outputs are not read into the loss).
+static int sobolev_check(nif_ctx* c, const int32_t* x_idx, int32_t nx, const int32_t* y_idx, int32_t ny, unsigned* ymask, int* ny_out) {
+  if (!x_idx || nx < 1 || nx > 16) return fail(NIF_ERR_INVALID, "Sobolev training takes 1..16 input columns in x_index");
+  for (int d = 0; d < nx; ++d) {
+    if (x_idx[d] < 0 || x_idx[d] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "Sobolev x_index out of range (0 <= i < pi_dim + si_dim)");
+    for (int e = 0; e < d; ++e)
+      if (x_idx[e] == x_idx[d]) return fail(NIF_ERR_INVALID, "Sobolev x_index lists a column twice");
+  }
+  *ymask = 0; *ny_out = 0;
+  if (y_idx) {
+    if (ny < 1 || ny > c->so) return fail(NIF_ERR_INVALID, "Sobolev y_index: 1..output_dim distinct outputs");
+    for (int i = 0; i < ny; ++i) {
+      if (y_idx[i] < 0 || y_idx[i] >= c->so) return fail(NIF_ERR_INVALID, "Sobolev y_index out of range");
+      if (*ymask & (1u << y_idx[i])) return fail(NIF_ERR_INVALID, "Sobolev y_index lists an output twice");
+      *ymask |= 1u << y_idx[i];
+    }
+    *ny_out = ny;
+  }
+  return NIF_OK;
+}
+extern "C" int nif_sobolev_loss_grad_dev_y(nif_ctx* c, const float* xin, const float* y, const float* dydx, const float* sw,
+                                           int64_t B, int64_t Bg, const int32_t* x_idx, int32_t nx, const int32_t* y_idx, int32_t ny,
+                                           float w_jac) {
+  if (!c || !xin || !y || !dydx || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
+  unsigned ymask; int nys;
+  int rc = sobolev_check(c, x_idx, nx, y_idx, ny, &ymask, &nys); if (rc) return rc;
+  HIPCHK(hipSetDevice(c->dev));
+  const int ngroups = (nx + 2) / 3;
+  if (ngroups > 1 && !c->sob_acc) HIPCHK(hipMalloc(&c->sob_acc, sizeof(float) * (size_t)(c->P + 1)));
+  const float jac_l1 = c->jac_l1, act_l1 = c->act_l1, act_l2 = c->act_l2;
+  for (int k = 0; k < ngroups; ++k) {
+    const int g0 = 3 * k, ng = nx - g0 < 3 ? nx - g0 : 3;
+    SobPlan sp;
+    rc = sobolev_plan(c, x_idx + g0, ng, &sp); if (rc) break;
+    for (int q = 0; q < 3; ++q) sp.gcol[q] += g0;
+    sp.gstride = nx; sp.nx_all = nx; sp.ny = nys; sp.ymask = ymask; sp.no_primal = k > 0;
+    if (k > 0) { c->jac_l1 = 0.f; c->act_l1 = 0.f; c->act_l2 = 0.f; }      // the regularisation losses belong to the first pass
+    rc = loss_grad_core(c, xin, y, sw, B, Bg, ng, sp.seeds, dydx, w_jac, &sp);
+    if (rc) break;
+    if (ngroups > 1) {
+      if (k == 0) { if (hipMemcpyAsync(c->sob_acc, c->grad, sizeof(float) * (size_t)(c->P + 1), hipMemcpyDeviceToDevice, c->st) != hipSuccess) { rc = fail(NIF_ERR_HIP, "hipMemcpyAsync"); break; } }
+      else launch_axpy_cols(c->sob_acc, c->grad, c->P, c->P, c->st);
+    }
+  }
+  c->jac_l1 = jac_l1; c->act_l1 = act_l1; c->act_l2 = act_l2;
+  if (rc) return rc;
+  if (ngroups > 1) HIPCHK(hipMemcpyAsync(c->grad, c->sob_acc, sizeof(float) * (size_t)(c->P + 1), hipMemcpyDeviceToDevice, c->st));
+  c->reg_applied = false;
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
 extern "C" int nif_sobolev_loss_grad_dev(nif_ctx* c, const float* xin, const float* y, const float* dydx, const float* sw,
                                          int64_t B, int64_t Bg, const int32_t* x_idx, int32_t nx, float w_jac) {
-  if (!c || !xin || !y || !dydx || B <= 0 || Bg < B) return fail(NIF_ERR_INVALID, "bad argument");
-  SobPlan sp;
-  int rc = sobolev_plan(c, x_idx, nx, &sp); if (rc) return rc;
-  return loss_grad_core(c, xin, y, sw, B, Bg, nx, sp.seeds, dydx, w_jac, &sp);
+  return nif_sobolev_loss_grad_dev_y(c, xin, y, dydx, sw, B, Bg, x_idx, nx, nullptr, 0, w_jac);
 }
+static int sobolev_forward_group(nif_ctx* c, const float* xin, int64_t B, const SobPlan& sp, int nx, float* u, float* dudx);
 extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, const int32_t* x_idx, int32_t nx, float* u,
                                        float* dudx) {
   if (!c || !xin || !u || !dudx || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
-  SobPlan sp;
-  int rc = sobolev_plan(c, x_idx, nx, &sp); if (rc) return rc;
+  unsigned ymask; int nys;
+  int rc = sobolev_check(c, x_idx, nx, nullptr, 0, &ymask, &nys); if (rc) return rc;
+  for (int g0 = 0; g0 < nx; g0 += 3) {      // groups of <= 3 columns, each filling its columns of the [B][so][nx] rows
+    const int ng = nx - g0 < 3 ? nx - g0 : 3;
+    SobPlan sp;
+    rc = sobolev_plan(c, x_idx + g0, ng, &sp); if (rc) return rc;
+    for (int q = 0; q < 3; ++q) sp.gcol[q] += g0;
+    sp.gstride = nx; sp.nx_all = nx;
+    rc = sobolev_forward_group(c, xin, B, sp, ng, u, dudx); if (rc) return rc;
+  }
+  return NIF_OK;
+}
+static int sobolev_forward_group(nif_ctx* c, const float* xin, int64_t B, const SobPlan& sp, int nx, float* u, float* dudx) {
+  int rc;
   HIPCHK(hipSetDevice(c->dev));
   rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
@@ -1502,10 +1571,11 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   launch_pnet(pa, c->NSTB, false, c->st);
   SobPar spar{};
   for (int d = 0; d < 3; ++d) { spar.par[d] = sp.par[d]; spar.gcol[d] = sp.gcol[d]; }
+  spar.gstride = sp.gstride; spar.nx_all = sp.nx_all;
   if (c->kind == NIF_KIND_LASTLAYER) {
     if (sp.any_par) {       // parameter columns: heads of the epilogue on z' = dz/dp
       if (!pjac_supported(pa))
-        return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
+        return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNets of up to 128 units");
       const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
       if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
       launch_pjac_fwd(pa, c->zt_par, c->st);
@@ -1522,7 +1592,7 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   }
   if (sp.any_par) {
     if (!pjac_supported(pa))
-      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: at most 3 parameter inputs (pi_dim <= 3)");
+      return fail(NIF_ERR_INVALID, "Sobolev x_index on parameter columns: ParameterNets of up to 128 units");
     const long need_zt = (long)c->pi * ((B + 31) / 32) * 32 * c->r;
     if (need_zt > c->zt_par_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->zt_par, &c->zt_par_cap, need_zt); if (rc) return rc; }
     launch_pjac_fwd(pa, c->zt_par, c->st);
@@ -1575,46 +1645,52 @@ extern "C" int nif_set_jac_regularizer(nif_ctx* c, float l1) {
 // mu_blk != null: the same pass as the adjoint of the Sobolev step's parameter streams -- dL/dz'_d is GIVEN (block mu_blk[d]
 // of c->dzt_par, written by k_sob), no loss term
 static int jac_reg_pass(nif_ctx* c, const float* xin, long B, long Bg, const int* mu_blk) {
-  const int pi = c->pi;
+  const int pi = c->pi, grp = pjac_group(), ndmax = pi < grp ? pi : grp;
   const long ntiles = (B + 31) / 32;
-  int rc = ensure_capacity(c, ntiles * 32 * (1 + pi), true); if (rc) return rc;
-  const long need_mu = (long)(1 + pi) * ntiles * 32 * c->r;
+  int rc = ensure_capacity(c, ntiles * 32 * (1 + ndmax), true); if (rc) return rc;
+  const long need_mu = (long)(1 + ndmax) * ntiles * 32 * c->r;
   if (need_mu > c->jac_mu_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->jac_mu, &c->jac_mu_cap, need_mu); if (rc) return rc; }
   if (!c->jac_tmp) HIPCHK(hipMalloc(&c->jac_tmp, sizeof(float) * (size_t)(c->P + 2)));
   const long nlp = (B + 127) / 128;
   if (nlp > c->act_loss_cap) { HIPCHK(hipStreamSynchronize(c->st)); rc = grow(&c->act_loss, &c->act_loss_cap, nlp); if (rc) return rc; }
   PNetArgs pa; fill_pnet(c, pa, xin, B);
   const float coef = c->jac_l1 / ((float)Bg * (float)c->r * (float)pi);
-  const int nloss = mu_blk ? launch_pjac_adj(pa, c->dzt_par, mu_blk, c->jac_mu, c->act_loss, c->st)
-                           : launch_pjac(pa, coef, c->jac_mu, c->act_loss, c->st);
-  const long nt_all = ntiles * (1 + pi);
-  const int rows = rows_for(c, nt_all);
-  GwArgs g;
-  auto base = [&](GwArgs& q) {
-    memset(&q, 0, sizeof(q));
-    q.ntiles = nt_all; q.zt_mod = ntiles; q.bias_ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride;
-    q.has_bias = 1; q.scale = 1.0f; q.r = 0;
-    for (int d = 0; d < 3; ++d) q.seed[d] = d < pi ? d : 0;
-  };
-  float* pST = c->stash_p;
-  const int ncol = c->pi + c->si;
-  base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = pi; g.scale = pa.omega;
-  g.W = dense_ref(c->first_w, pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
-  launch_gw_first(g, c->NSTB, rows, c->st);
-  for (int mi = 0; mi < c->nm; ++mi) {
-    base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.scale = pa.omega;
-    long w_off, b_off;
-    if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
-    else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
-    g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
-    launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
+  // r4: passes over groups of parameter columns (k_pjac carries pjac_group() tangents): loss and gradient are sums over the
+  // columns -- every pass reduces its own operand pairs (the primal pair carries the part of lambda that ITS tangents feed)
+  for (int c0 = 0; c0 < pi; c0 += grp) {
+    const int nd = pi - c0 < grp ? pi - c0 : grp;
+    if (mu_blk) { bool any = false; for (int d = 0; d < nd; ++d) any = any || mu_blk[c0 + d] >= 0; if (!any) continue; }
+    const int nloss = mu_blk ? launch_pjac_adj(pa, c->dzt_par, mu_blk, c->jac_mu, c->act_loss, c0, nd, c->st)
+                             : launch_pjac(pa, coef, c->jac_mu, c->act_loss, c0, nd, c->st);
+    const long nt_all = ntiles * (1 + nd);
+    const int rows = rows_for(c, nt_all);
+    GwArgs g;
+    auto base = [&](GwArgs& q) {
+      memset(&q, 0, sizeof(q));
+      q.ntiles = nt_all; q.zt_mod = ntiles; q.bias_ntiles = ntiles; q.B = B; q.partial = c->partial; q.pstride = c->pstride;
+      q.has_bias = 1; q.scale = 1.0f; q.r = 0;
+      for (int d = 0; d < 3; ++d) q.seed[d] = d < nd ? c0 + d : 0;
+    };
+    float* pST = c->stash_p;
+    const int ncol = c->pi + c->si;
+    base(g); g.DA = pST + (long)(c->nm + 1) * c->slot_p; g.xin = xin; g.ncol = ncol; g.col0 = 0; g.nd = pi; g.scale = pa.omega;
+    g.W = dense_ref(c->first_w, pi, c->nst); g.Bv = vec_ref(c->first_b, c->nst);
+    launch_gw_first(g, c->NSTB, rows, c->st);
+    for (int mi = 0; mi < c->nm; ++mi) {
+      base(g); g.IN = pST + (long)mi * c->slot_p; g.DA = pST + (long)(c->nm + 2 + mi) * c->slot_p; g.scale = pa.omega;
+      long w_off, b_off;
+      if (!c->cfg.p_resblock) { w_off = c->hid_w[mi]; b_off = c->hid_b[mi]; }
+      else { const int i = mi / 2; w_off = (mi & 1) ? c->hid_w2[i] : c->hid_w[i]; b_off = (mi & 1) ? c->hid_b2[i] : c->hid_b[i]; }
+      g.W = dense_ref(w_off, c->nst, c->nst); g.Bv = vec_ref(b_off, c->nst);
+      launch_gw_mfma(g, c->NSTB, c->NSTB, rows, c->st);
+    }
+    base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->jac_mu; g.nc = c->r; g.scale = 1.0f;
+    g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
+    launch_gw_out(g, c->NSTB, rows, c->st);
+    // the ParameterNet core variables are the first last_w columns of a partial row; column last_w of the result = the loss term
+    launch_reduce(c->partial, c->pstride, rows, c->act_loss, nloss, c->jac_tmp, c->last_w, c->st);
+    launch_axpy_cols(c->grad, c->jac_tmp, c->last_w, c->P, c->st);
   }
-  base(g); g.IN = pST + (long)c->nm * c->slot_p; g.SM = c->jac_mu; g.nc = c->r; g.scale = 1.0f;
-  g.W = dense_ref(c->bott_w, c->nst, c->r); g.Bv = vec_ref(c->bott_b, c->r);
-  launch_gw_out(g, c->NSTB, rows, c->st);
-  // the ParameterNet core variables are the first last_w columns of a partial row; column last_w of the result = the loss term
-  launch_reduce(c->partial, c->pstride, rows, c->act_loss, nloss, c->jac_tmp, c->last_w, c->st);
-  launch_axpy_cols(c->grad, c->jac_tmp, c->last_w, c->P, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
@@ -1633,7 +1709,8 @@ static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const Sob
   const long blk_s = ntiles * 1024 * c->NB;                 // floats of one block of tiles in a ShapeNet stash slot
   float* sIN = sa.stash; float* sDA = sa.stash + (long)(c->nh + 1) * c->slot_s;
   const long kcols = (long)c->r * c->po;                     // the hyper kernel [r][po] = columns last_w .. last_w + r*po
-  int mu_blk[3] = {-1, -1, -1};
+  int mu_blk[16];
+  for (int q = 0; q < 16; ++q) mu_blk[q] = -1;
   for (int d = sp.nsc; d < sp.ns; ++d) {
     const int col = sp.par[d];
     mu_blk[col] = d;

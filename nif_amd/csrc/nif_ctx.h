@@ -59,6 +59,7 @@ struct nif_ctx {
   float* zt_par = nullptr; long zt_par_cap = 0; float* dzt_par = nullptr; long dzt_par_cap = 0;
   float* dat_par = nullptr; long dat_par_cap = 0; float* ztl_par = nullptr; long ztl_par_cap = 0;   // last-layer class: dL/da', z' in latent-row layout   // Sobolev with parameter seeds: dz/dp, dL/d(dz/dp)
   float jac_l1 = 0.f; float* jac_mu = nullptr; long jac_mu_cap = 0; float* jac_tmp = nullptr;   // latent Jacobian regulariser (k_pjac)
+  float* sob_acc = nullptr;          // [grad | loss] summed over the column groups of a Sobolev step with more than three x_index columns
   float act_l1 = 0.f, act_l2 = 0.f; float* act_part = nullptr; long act_part_cap = 0; float* act_loss = nullptr; long act_loss_cap = 0;
   float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;
   // profiling: (group id, start, stop) event triples recorded on st

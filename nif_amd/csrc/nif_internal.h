@@ -183,6 +183,9 @@ struct SobPar {
   int par[3]; int gcol[3]; const float* ZT; float* DZT;
   // last-layer class: parameter columns as heads of the epilogue (k_sob_dev.h): column, dydx position, dL/da', padded z'
   int npar; int parc[3]; int pcol[3]; float* DAT; float* ZTL; int zl_rows;
+  // r4, all "0 = as before": the launch carries one GROUP of the x_index columns (gt / JU rows have gstride columns, the derivative
+  // term averages over nx_all columns), only the outputs of ymask (ny of them) enter the derivative term, no_primal drops mse(u)
+  int gstride, nx_all, ny, no_primal; unsigned ymask;
 };
 int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const float* gt, float wj, float* ring, float* ju,
                bool query_only, hipStream_t st, const SobPar* par = nullptr);
@@ -232,10 +235,11 @@ struct LLArgs {
 void launch_ll_out(const LLArgs& a, bool train, hipStream_t st);
 // latent Jacobian regulariser (k_pjac.hip): tangents of the ParameterNet + their adjoint; operand pairs into the stash
 bool pjac_supported(const PNetArgs& a);
-int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, hipStream_t st);
+int launch_pjac(const PNetArgs& a, float coef, float* MU, float* loss_partial, int c0, int nd, hipStream_t st);   // columns [c0, c0 + nd), nd <= pjac_group()
+int pjac_group();
 void launch_pjac2(const PNetArgs& a, int cj, int ck, float* ZDD, hipStream_t st);   // d2z/dp_cj dp_ck -> ZDD [tiles][r][32]
 int launch_pjac_fwd(const PNetArgs& a, float* ZT, hipStream_t st);      // dz/dp_d of every parameter column -> ZT [pi][tiles][r][32]
-int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, hipStream_t st);
+int launch_pjac_adj(const PNetArgs& a, const float* MU_in, const int* mu_blk, float* MU, float* loss_partial, int c0, int nd, hipStream_t st);   // mu_blk[column]
 void launch_axpy_cols(float* g, const float* tmp, long ncols, long P, hipStream_t st);
 // activity regulariser of the last-layer class (the ParameterNet output is the materialised [B, r] tensor there)
 int launch_ll_actreg(const float* Za, const float* lw, int r, long B, float coef, bool l1, float* DA, float* DZL, float* loss_partial,

@@ -203,6 +203,12 @@ class Engine(object):
         return out
 
     def jacobian(self, inputs, y_index, x_index):
+        y_index, x_index = list(y_index), list(x_index)
+        if len(set(y_index)) != len(y_index) or len(set(x_index)) != len(x_index):
+            # repeated entries (gradient.py:207-231 would simply repeat rows / columns): computed once, gathered
+            uy, ux = sorted(set(y_index)), sorted(set(x_index))
+            yv, d = self.jacobian(inputs, uy, ux)
+            return yv, np.ascontiguousarray(d[:, [uy.index(i) for i in y_index]][:, :, [ux.index(j) for j in x_index]])
         x = self._inputs(inputs)
         s = self.spec
         yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
@@ -214,6 +220,12 @@ class Engine(object):
         return y, d
 
     def hessian(self, inputs, y_index, x_index):
+        y_index, x_index = list(y_index), list(x_index)
+        if len(set(y_index)) != len(y_index) or len(set(x_index)) != len(x_index):
+            uy, ux = sorted(set(y_index)), sorted(set(x_index))       # (also lifts the C side's limit of 16 y_index entries)
+            yv, d, h = self.hessian(inputs, uy, ux)
+            iy, ix = [uy.index(i) for i in y_index], [ux.index(j) for j in x_index]
+            return yv, np.ascontiguousarray(d[:, iy][:, :, ix]), np.ascontiguousarray(h[:, iy][:, :, ix][:, :, :, ix])
         x = self._inputs(inputs)
         s = self.spec
         yi = np.ascontiguousarray(list(y_index), dtype=np.int32)
@@ -297,10 +309,12 @@ class Engine(object):
         check(self.lib.nif_loss_grad_dev(self.ctx, d_x, d_y, d_sw, int(b_local), int(b_global)))
 
     # Sobolev (two-output model u, du/dx; include/nif_hip.h nif_sobolev_*)
-    def sobolev_loss_grad_dev(self, d_x, d_y, d_g, d_sw, b_local, b_global, x_index, w_jac):
+    def sobolev_loss_grad_dev(self, d_x, d_y, d_g, d_sw, b_local, b_global, x_index, w_jac, y_index=None):
+        """y_index = None: the derivative term over every output; else over the listed outputs (d_g rows stay [so][nx])"""
         xi = (C.c_int32 * len(x_index))(*[int(i) for i in x_index])
-        check(self.lib.nif_sobolev_loss_grad_dev(self.ctx, d_x, d_y, d_g, d_sw, int(b_local), int(b_global), xi, len(x_index),
-                                                 float(w_jac)))
+        yi = None if y_index is None else (C.c_int32 * len(y_index))(*[int(i) for i in y_index])
+        check(self.lib.nif_sobolev_loss_grad_dev_y(self.ctx, d_x, d_y, d_g, d_sw, int(b_local), int(b_global), xi, len(x_index),
+                                                   yi, 0 if y_index is None else len(y_index), float(w_jac)))
 
     def sobolev_forward(self, inputs, x_index):
         x = self._inputs(inputs)
@@ -316,7 +330,7 @@ class Engine(object):
             d_x.free(); d_u.free(); d_j.free()
         return u, j
 
-    def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None, want_grad=True):
+    def sobolev_loss_and_grad(self, inputs, y, dydx, x_index, w_jac, sample_weight=None, want_grad=True, y_index=None):
         """(total loss incl. the weight regularisers, flat gradient) of the two-output model on host arrays"""
         x = self._inputs(inputs)
         B = x.shape[0]
@@ -331,7 +345,7 @@ class Engine(object):
             if d_sw is not None:
                 d_sw.upload(_f32(sample_weight))
             self.sobolev_loss_grad_dev(d_x.at(0), d_y.at(0), d_g.at(0), d_sw.at(0) if d_sw is not None else None, B, B,
-                                       x_index, w_jac)
+                                       x_index, w_jac, y_index)
             if want_grad:
                 loss, grad = self.grad_read()           # adds the kernel / bias regularisers once, like nif_loss_and_grad
             else:

@@ -459,8 +459,9 @@ class SobolevModel(Model):
     """The Keras idiom  `tf.keras.Model(inp, JacobianLayer(nif_model, y_index, x_index)(inp))`  compiled with
     loss='mse' and loss_weights=[1, w]: a two-output model (u, du/dx) whose training differentiates through
     the Jacobian (reference nif/layers/gradient.py:36-49, SURVEY 3.4 / BASELINE config 5 "Sobolev training").
-    Built for all three classes, all outputs (y_index = range(so)), 1..3 distinct input columns in x_index
-    (coordinates and / or ParameterNet inputs, as gradient.py:207-231 allows).
+    Built for all three classes, any distinct outputs in y_index and any distinct input columns in x_index (coordinates and / or
+    ParameterNet inputs, as gradient.py:207-231 allows; more than three columns run as passes over groups of three tangent streams),
+    any positive loss_weights[0].
         m = SobolevModel(JacobianLayer(model, y_index, x_index)); m.compile("adam", "mse", loss_weights=[1, .1])
         m.fit(x, [y, dydx], ...);  u, dudx = m.predict(x)"""
 
@@ -469,10 +470,16 @@ class SobolevModel(Model):
             raise TypeError("SobolevModel wraps a JacobianLayer")
         base = jac_layer.model
         Model.__init__(self, base._owner, "full")
-        so = base._owner._spec.so_dim
-        if list(jac_layer.y_index) != list(range(so)):
-            raise NotImplementedError("Sobolev training is built for y_index = all outputs")
-        self.x_index = list(jac_layer.x_index)
+        so, ncol = base._owner._spec.so_dim, base._owner._spec.pi_dim + base._owner._spec.si_dim
+        # any subset / order of outputs and input columns (gradient.py:207-231); a column or output listed twice would make the
+        # reference build duplicated Jacobian entries -- not a training set-up, refused
+        self.y_index = [int(i) for i in jac_layer.y_index]
+        self.x_index = [int(i) for i in jac_layer.x_index]
+        if len(set(self.y_index)) != len(self.y_index) or not all(0 <= i < so for i in self.y_index):
+            raise ValueError("y_index: distinct outputs in [0, %d)" % so)
+        if len(set(self.x_index)) != len(self.x_index) or not all(0 <= i < ncol for i in self.x_index):
+            raise ValueError("x_index: distinct input columns in [0, %d)" % ncol)
+        self._all_y = self.y_index == list(range(so))
         self.loss_weights = [1.0, 1.0]
 
     def compile(self, optimizer="adam", loss="mse", loss_weights=None, **kwargs):
@@ -489,22 +496,26 @@ class SobolevModel(Model):
 
     def _run(self, x):
         u, j = self._engine.sobolev_forward(x, self.x_index)
-        return [u, j]
+        return [u, j if self._all_y else np.ascontiguousarray(j[:, self.y_index, :])]
 
     def _loss_host(self, e, x, targets, sw):
         """Model.evaluate's chunk loss for the two-output model: w0 mse(u) + w1 mse(du/dx) + the regularisation losses -- the
         same total `fit` logs (r3 returned the data term alone, computed on the host)"""
         w0, w1 = self.loss_weights
         return e.sobolev_loss_and_grad(x, targets[0], targets[1], self.x_index, w1 / w0, self._scaled_weights(sw, x.shape[0]),
-                                       want_grad=False)[0]
+                                       want_grad=False, y_index=None if self._all_y else self.y_index)[0]
 
     def _targets(self, y, n_rows):
         if not (isinstance(y, (list, tuple)) and len(y) == 2):
             raise ValueError("the Sobolev model has two outputs: fit(x, [y, dydx])")
-        so, nx = self._owner._spec.so_dim, len(self.x_index)
+        so, nx, ny = self._owner._spec.so_dim, len(self.x_index), len(self.y_index)
         ty = Model._targets(self, y[0], n_rows)[0]
-        tj = np.ascontiguousarray(y[1], dtype=np.float32).reshape(n_rows, so * nx)
-        return [ty, tj]
+        tj = np.ascontiguousarray(y[1], dtype=np.float32).reshape(n_rows, ny, nx)
+        if not self._all_y:       # the engine's table rows are [so][nx]: the listed outputs' rows in place, the others unused (zeros)
+            full = np.zeros((n_rows, so, nx), dtype=np.float32)
+            full[:, self.y_index, :] = tj
+            tj = full
+        return [ty, tj.reshape(n_rows, so * nx)]
 
     def _n_tangents(self):
         return len(self.x_index)
@@ -522,7 +533,8 @@ class SobolevModel(Model):
 
     def _loss_grad_dev(self, e, d_x, d_targets, d_sw, b, bg):
         w0, w1 = self.loss_weights
-        e.sobolev_loss_grad_dev(d_x, d_targets[0], d_targets[1], d_sw, b, bg, self.x_index, w1 / w0)
+        e.sobolev_loss_grad_dev(d_x, d_targets[0], d_targets[1], d_sw, b, bg, self.x_index, w1 / w0,
+                                None if self._all_y else self.y_index)
 
 
 def _is_number(v):

@@ -719,6 +719,120 @@ def test_sobolev_parameter_columns_match_oracle(name, cols):
     assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4
 
 
+WIDE_SOB = {
+    # name: (cfg, batch, x_index, y_index)
+    # a 3-D flow with time: all four input columns (r3 refused more than three), hypernetwork and last-layer class
+    "ms_3d_time_all4": (_cfg("NIFMultiScale", 32, 2, 32, 1, 3, 3, 1, 1), 515, [0, 1, 2, 3], None),
+    "ll_3d_time_all4_so3": (_cfg("LL", 64, 2, 32, 2, 5, 3, 3, 1), 130, [3, 0, 2, 1], None),
+    "nif_4cols_pi2": (_cfg("NIF", 32, 2, 32, 2, 2, 2, 2, 2), 257, [2, 3, 0, 1], None),
+    # a 5-parameter study: every parameter column + the coordinates = 7 columns, three passes
+    "ms_pi5_all7": (_cfg("NIFMultiScale", 32, 2, 24, 2, 2, 2, 1, 5, p_act="swish"), 130, [5, 0, 6, 1, 2, 3, 4], None),
+    "ll_pi4_params_only": (_cfg("LL", 32, 1, 32, 2, 3, 2, 2, 4, p_act="tanh"), 97, [3, 2, 1, 0], None),
+    # any subset / order of outputs in y_index (r3: all outputs only)
+    "ms_so3_y_2_0": (_cfg("NIFMultiScale", 50, 2, 32, 2, 2, 2, 3, 1), 257, [1, 2], [2, 0]),
+    "ms_res_so2_y1_wave": (_cfg("NIFMultiScale", 48, 2, 40, 2, 2, 2, 2, 1, s_res=True, p_res=True), 200, [2], [1]),
+    "ll_so3_y1_4cols": (_cfg("LL", 64, 2, 32, 2, 5, 3, 3, 1), 130, [0, 1, 2, 3], [1]),
+    "nif_so2_y0": (_cfg("NIF", 30, 2, 20, 1, 2, 2, 2, 2, act="tanh"), 129, [3, 0], [0]),
+    "ms_sobw_so3_y1": (_cfg("NIFMultiScale", 64, 3, 32, 2, 1, 2, 3, 1), 515, [1, 2], [1]),       # the streams-on-waves kernel
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE_SOB))
+@pytest.mark.parametrize("policy", ["float32"])
+def test_sobolev_any_y_index_and_more_than_three_columns(name, policy):
+    """JacobianLayer as a trained output with any y_index / any number of x_index columns (gradient.py:207-231).  The oracle's
+    Sobolev step is the all-outputs one; a y_index subset is stated through it: residuals of the unlisted outputs are made zero
+    (their targets = the oracle's own derivatives, constants) and the weight carries so / ny, which is the mean over the listed
+    ny x nx entries.  fit() of the two-output model follows the oracle for two Adam steps; predict() returns [B, ny, nx]."""
+    import nif_amd
+    from nif_amd import JacobianLayer, SobolevModel
+    (kind, cs, cp), B, xi, yi = WIDE_SOB[name]
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(17)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    names = [nm for nm, _ in spec.param_shapes()]
+    ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * (30.0 if spec.kind == O.KIND_LL else 2.0)).astype(np.float32)
+    m = getattr(nif_amd, kind)(cs, cp, mixed_policy=policy)
+    model = m.build(); model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    ys = list(range(spec.so)) if yi is None else yi
+    g = rng.uniform(-1, 1, size=(B, len(ys), len(xi))).astype(np.float32)
+    wj = 0.07
+    ws64 = [w.astype(np.float64) for w in ws]
+    x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+
+    def oracle(w):
+        gf = np.zeros((B, spec.so, len(xi)))
+        if yi is not None:
+            gf[:] = O.sobolev_loss_and_grad(spec, w, x64, y64, gf, xi, 0.0, s64)[3]      # the oracle's own du/dx: zero residuals
+        gf[:, ys, :] = g
+        return O.sobolev_loss_and_grad(spec, w, x64, y64, gf, xi, wj * spec.so / len(ys), s64)
+    rl, rg, ru, rJ = oracle(ws64)
+    sm = SobolevModel(JacobianLayer(model, ys, xi))
+    u, J = sm.predict(x)
+    assert J.shape == (B, len(ys), len(xi))
+    assert _rel(u, ru) < 1e-5 and _rel(J, rJ[:, ys, :]) < 3e-5, (_rel(u, ru), _rel(J, rJ[:, ys, :]))
+    _, J2 = JacobianLayer(model, ys, xi)(x)                       # the forward-only kernels give the same entries
+    assert _rel(J, J2.astype(np.float64)) < 3e-5
+    gfull = np.zeros((B, spec.so, len(xi)), dtype=np.float32); gfull[:, ys, :] = g
+    loss, grad = m._engine.sobolev_loss_and_grad(x, y, gfull, xi, wj, sw, y_index=None if yi is None else yi)
+    assert abs(loss - rl) <= 3e-5 * abs(rl), (loss, rl)
+    rel = _per_tensor_rel(spec, grad, O.flatten(rg))
+    assert max(rel.values()) < 4e-4, rel
+    # the Keras surface: evaluate = that loss, fit = the oracle's Adam trajectory
+    sm.compile(nif_amd.Adam(1e-4), "mse", loss_weights=[1.0, wj])
+    assert abs(sm.evaluate(x, [y, g], sample_weight=sw) - rl) <= 3e-5 * abs(rl)
+    h = sm.fit(x, [y, g], batch_size=B, epochs=2, shuffle=False, verbose=0, sample_weight=sw)
+    th = O.flatten(ws64); mm = np.zeros_like(th); vv = np.zeros_like(th); ls = []
+    f32 = lambda a: float(np.float32(a))
+    for t in range(1, 3):
+        l_, g_, _, _ = oracle(O.unflatten(spec, th))
+        ls.append(l_)
+        th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-4), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+    assert np.allclose(h.history["loss"], ls, rtol=2e-3), (h.history["loss"], ls)
+    # a plain step afterwards is untouched by the passes
+    l1, g1 = m._engine.loss_and_grad(x, y, sw)
+    rl1, rg1 = O.loss_and_grad(spec, ws64, x64, y64, s64)
+    # (the model has taken two Adam steps: compare at its current weights)
+    wnow = [w.astype(np.float64) for w in model.get_weights()]
+    rl1, rg1 = O.loss_and_grad(spec, wnow, x64, y64, s64)
+    assert abs(l1 - rl1) <= 2e-5 * abs(rl1) and _rel(g1, O.flatten(rg1)) < 3e-4
+
+
+def test_sobolev_passes_keep_the_regularisers_of_the_first_pass_only():
+    """four columns = two passes; the weight / activity / latent-Jacobian regularisers of cfg_parameter_net must enter the total ONCE"""
+    import nif_amd
+    kind, cs, cp = _cfg("NIFMultiScale", 32, 2, 24, 2, 2, 2, 1, 2, p_act="swish")
+    l2w, lact, ljac = 3e-3, 2e-3, 0.04
+    cpr = dict(cp, l2_reg=l2w, act_l2_reg=lact, jac_reg=ljac)
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(23)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    mr = getattr(nif_amd, kind)(cs, cpr)
+    model = mr.build(); model.set_weights(ws)
+    B = 200
+    x = rng.uniform(-1, 1, size=(B, 4)).astype(np.float32); y = rng.uniform(-1, 1, size=(B, 1)).astype(np.float32)
+    xi = [0, 1, 2, 3]
+    g = rng.uniform(-1, 1, size=(B, 1, 4)).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]; x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    mr._engine.set_jac_regularizer(model._jac_reg)
+    loss, grad = mr._engine.sobolev_loss_and_grad(x, y, g, xi, 0.05)
+    l0, g0, _, _ = O.sobolev_loss_and_grad(spec, ws64, x64, y64, g.astype(np.float64), xi, 0.05)
+    la, ga = O.loss_and_grad(spec, ws64, x64, y64, act_reg=(0.0, lact))
+    lp, gp = O.loss_and_grad(spec, ws64, x64, y64)
+    lj, gj = O.jac_reg_loss_and_grad(spec, ws64, x64[:, :spec.pi], ljac)
+    th = O.flatten(ws64)
+    npn = sum(int(np.prod(s_)) for nm, s_ in spec.param_shapes() if nm.startswith("pnet_"))
+    ref_l = l0 + (la - lp) + lj + l2w * float((th[:npn] ** 2).sum())
+    ref_g = O.flatten(g0) + (O.flatten(ga) - O.flatten(gp)) + O.flatten(gj)
+    ref_g[:npn] += 2.0 * l2w * th[:npn]
+    assert abs(loss - ref_l) < 3e-5 * abs(ref_l), (loss, ref_l)
+    assert _rel(grad, ref_g) < 3e-4
+    mr._engine.set_jac_regularizer(0.0)
+
+
 def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
     """Train u(t,x) on values AND du/dx of the closed-form travelling wave; both errors must drop, and the
     derivative error must end lower than with value-only training on the same few points."""
@@ -1539,6 +1653,10 @@ JAC = {
     "ms_mlp_short_pnet_64": _cfg("NIFMultiScale", 32, 2, 64, 3, 2, 2, 1, 1, p_act="swish"),
     "ll_siren_pnet_r3": _cfg("LL", 32, 2, 32, 2, 3, 2, 2, 2),
     "ll_mlp_res_pnet_48": _cfg("LL", 48, 1, 24, 1, 4, 1, 1, 1, s_res=True, p_act="tanh", p_res=True),
+    # r4: more than three parameter inputs (k_pjac in passes over groups of three columns; r3 refused pi_dim > 3)
+    "ms_pi5_swish": _cfg("NIFMultiScale", 32, 2, 24, 2, 2, 2, 1, 5, p_act="swish"),
+    "ms_pi4_siren_res": _cfg("NIFMultiScale", 32, 1, 40, 1, 3, 1, 2, 4, p_res=True),
+    "ll_pi7_tanh": _cfg("LL", 32, 1, 32, 2, 3, 2, 2, 7, p_act="tanh"),
 }
 
 
