@@ -211,6 +211,16 @@ int nif_sobolev_loss_grad_dev_y(nif_ctx* ctx, const float* xin_dev, const float*
 /* predict() of that two-output model: u [B,so] and du/dx [B,so,nx], device pointers */
 int nif_sobolev_forward_dev(nif_ctx* ctx, const float* xin_dev, int64_t B, const int32_t* x_idx, int32_t nx, float* u_dev,
                             float* dudx_dev);
+/* Captured training steps (hipGraph) for the launch-bound small-batch regime (BASELINE configs[0]: batch 512 = 13 kernels of a few
+ * microseconds each per step; Keras' fit() runs such steps from one tf.function graph, README.md:23-37).  Between nif_graph_begin
+ * and nif_graph_end the device-side calls on this context are recorded instead of executed -- e.g. all batches of one epoch:
+ * nif_loss_grad_dev / nif_sobolev_loss_grad_dev[_y], nif_adam_step_dev, nif_metric_accumulate; nif_graph_launch replays them in one
+ * submission (pointers as recorded; Adam's hyper-parameters from `opt`, its iteration count continues from the context's).
+ * Workspaces must have been sized by nif_reserve; contexts with a communicator attached are refused. */
+int nif_graph_begin(nif_ctx* ctx);
+int nif_graph_end(nif_ctx* ctx, int32_t* graph_id_out);
+int nif_graph_launch(nif_ctx* ctx, int32_t graph_id, const nif_adam* opt);
+int nif_graph_destroy(nif_ctx* ctx, int32_t graph_id);
 /* optimizer.apply_gradients with Adam on the (already all-reduced) nif_grad_dev() buffer */
 int nif_adam_step_dev(nif_ctx* ctx, const nif_adam* opt);
 /* zero [grad | loss]: what a rank contributes to the step's all-reduce when its shard has no rows left (uneven shards of

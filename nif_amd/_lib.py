@@ -93,6 +93,10 @@ SIGNATURES = {
                                             C.c_float]),
     "nif_sobolev_loss_grad_dev_y": (C.c_int, [_CTX, _VP, _VP, _VP, _VP, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.c_int32,
                                               C.POINTER(C.c_int32), C.c_int32, C.c_float]),
+    "nif_graph_begin": (C.c_int, [_CTX]),
+    "nif_graph_end": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
+    "nif_graph_launch": (C.c_int, [_CTX, C.c_int32, C.POINTER(nif_adam)]),
+    "nif_graph_destroy": (C.c_int, [_CTX, C.c_int32]),
     "nif_sobolev_forward_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
     "nif_zero_grad": (C.c_int, [_CTX]),

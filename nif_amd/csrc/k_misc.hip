@@ -402,6 +402,32 @@ __global__ void k_adam(float* __restrict__ theta, const float* __restrict__ g, f
   m[i] = mi; v[i] = vi;
   theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
+// The same update with the hyper-parameters and the iteration count in DEVICE memory (AdamDev: lr, beta1, beta2, eps, step): what a
+// captured hipGraph of training steps needs -- a replayed launch cannot carry this step's lr_t as a kernel argument.  Every block
+// forms lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), t = step + 1, in fp64 like the host does; k_adam_step_inc bumps the counter behind it.
+__global__ void k_adam_dev(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long P,
+                           const AdamDev* __restrict__ ad) {
+  __shared__ float lr_s;
+  if (threadIdx.x == 0) {
+    const double t = (double)(ad->step + 1);
+    lr_s = (float)((double)ad->lr * sqrt(1.0 - pow((double)ad->beta2, t)) / (1.0 - pow((double)ad->beta1, t)));
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float b1 = ad->beta1, b2 = ad->beta2, eps = ad->eps, lr_t = lr_s;
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+  const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+  m[i] = mi; v[i] = vi;
+  theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+__global__ void k_adam_step_inc(AdamDev* ad) { ad->step += 1; }
+void launch_adam_dev(float* theta, const float* g, float* m, float* v, long P, AdamDev* ad, hipStream_t st) {
+  dim3 grid((unsigned)((P + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_adam_dev, grid, block, 0, st, theta, g, m, v, P, ad);
+  hipLaunchKernelGGL(k_adam_step_inc, dim3(1), dim3(1), 0, st, ad);
+}
 void launch_adam(float* theta, const float* g, float* m, float* v, long P, float lr_t, float b1, float b2, float eps,
                  hipStream_t st) {
   dim3 grid((unsigned)((P + 255) / 256)), block(256);

@@ -189,7 +189,9 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
-  void* ptrs[] = {c->sob_acc, c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
+  for (hipGraphExec_t ex : c->graphs) if (ex) (void)hipGraphExecDestroy(ex);
+  if (c->adam_host) (void)hipHostFree(c->adam_host);
+  void* ptrs[] = {c->adam_dev, c->sob_acc, c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
                   c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
@@ -1780,6 +1782,14 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
   HIPCHK(hipSetDevice(c->dev));
   apply_reg(c);
+  if (c->capturing) {      // inside nif_graph_begin / _end: hyper-parameters and iteration count come from device memory at replay time
+    launch_adam_dev(c->theta, c->grad, c->m, c->v, c->P, c->adam_dev, c->st);
+    HIPCHK(hipGetLastError());
+    c->step += 1; c->cap_steps += 1;
+    c->packed = false; c->packed32 = false; c->packed_p32 = false;
+    c->reg_applied = false;
+    return NIF_OK;
+  }
   c->step += 1;
   const double t = (double)c->step;
   const double lr_t = (double)opt->lr * std::sqrt(1.0 - std::pow((double)opt->beta2, t)) / (1.0 - std::pow((double)opt->beta1, t));
@@ -1790,6 +1800,66 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   // the regulariser term belongs to ONE gradient: a following step that skips nif_loss_grad_dev (nif_zero_grad on a rank
   // whose shard ran out of rows) must add it again, like the ranks that did compute a gradient
   c->reg_applied = false;
+  return NIF_OK;
+}
+
+// ---- captured training steps ----------------------------------------------------------------------------------------------------
+// Small batches are launch bound (configs[0]: 13 kernels of 3-5 us behind 4-8 us of launch overhead each): between nif_graph_begin
+// and nif_graph_end every device-side call of this context (nif_loss_grad_dev, nif_sobolev_loss_grad_dev[_y], nif_adam_step_dev,
+// nif_metric_accumulate, nif_gather_rows_dev ...) is RECORDED into a hipGraph instead of executed; nif_graph_launch replays the
+// whole sequence -- an epoch of Model.fit -- with one submission.  The batch pointers are baked in (the resident table does not
+// move between epochs); Adam's hyper-parameters and iteration count live in device memory (AdamDev) and are refreshed per launch.
+// Everything a step needs must exist before the capture (nif_reserve): a workspace that would have to grow fails the capture.
+extern "C" int nif_graph_begin(nif_ctx* c) {
+  if (!c) return fail(NIF_ERR_INVALID, "null");
+  if (c->capturing) return fail(NIF_ERR_STATE, "nif_graph_begin: already capturing");
+  if (c->comm) return fail(NIF_ERR_STATE, "nif_graph_begin: not with a communicator attached (the all-reduce is not captured)");
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ensure_packed(c); if (rc) return rc;
+  if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
+  if (!c->adam_dev) HIPCHK(hipMalloc(&c->adam_dev, sizeof(AdamDev)));
+  if (!c->adam_host) HIPCHK(hipHostMalloc(&c->adam_host, sizeof(AdamDev)));
+  HIPCHK(hipStreamSynchronize(c->st));
+  // (ensure_packed above did every first-use initialisation eagerly; the RECORDED sequence must start with the packing of whatever
+  // weights the previous replay left behind)
+  c->packed = false; c->packed32 = false; c->packed_p32 = false;
+  HIPCHK(hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed));
+  c->capturing = true; c->cap_steps = 0; c->cap_step0 = c->step;
+  return NIF_OK;
+}
+extern "C" int nif_graph_end(nif_ctx* c, int32_t* graph_id) {
+  if (!c || !graph_id) return fail(NIF_ERR_INVALID, "null");
+  if (!c->capturing) return fail(NIF_ERR_STATE, "nif_graph_end without nif_graph_begin");
+  c->capturing = false;
+  c->step = c->cap_step0;                  // nothing has run yet: the recorded steps count when the graph is launched
+  c->packed = false; c->packed32 = false; c->packed_p32 = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(c->st, &g);
+  if (e != hipSuccess || !g) { (void)hipGetLastError(); return fail(NIF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(NIF_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+  c->graphs.push_back(ex); c->graph_steps.push_back(c->cap_steps);
+  *graph_id = (int32_t)c->graphs.size() - 1;
+  return NIF_OK;
+}
+extern "C" int nif_graph_launch(nif_ctx* c, int32_t graph_id, const nif_adam* opt) {
+  if (!c || !opt || graph_id < 0 || graph_id >= (int32_t)c->graphs.size() || !c->graphs[graph_id]) return fail(NIF_ERR_INVALID, "bad argument");
+  if (c->capturing) return fail(NIF_ERR_STATE, "nif_graph_launch while capturing");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->st));      // (the pinned staging struct is reused: the previous launch's copy must be through)
+  c->adam_host->lr = opt->lr; c->adam_host->beta1 = opt->beta1; c->adam_host->beta2 = opt->beta2; c->adam_host->eps = opt->eps;
+  c->adam_host->step = c->step;
+  HIPCHK(hipMemcpyAsync(c->adam_dev, c->adam_host, sizeof(AdamDev), hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipGraphLaunch(c->graphs[graph_id], c->st));
+  c->step += c->graph_steps[graph_id];
+  c->packed = false; c->packed32 = false; c->packed_p32 = false; c->reg_applied = false;
+  return NIF_OK;
+}
+extern "C" int nif_graph_destroy(nif_ctx* c, int32_t graph_id) {
+  if (!c || graph_id < 0 || graph_id >= (int32_t)c->graphs.size()) return fail(NIF_ERR_INVALID, "bad argument");
+  if (c->graphs[graph_id]) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipGraphExecDestroy(c->graphs[graph_id]); c->graphs[graph_id] = nullptr; }
   return NIF_OK;
 }
 

@@ -59,6 +59,9 @@ struct nif_ctx {
   float* zt_par = nullptr; long zt_par_cap = 0; float* dzt_par = nullptr; long dzt_par_cap = 0;
   float* dat_par = nullptr; long dat_par_cap = 0; float* ztl_par = nullptr; long ztl_par_cap = 0;   // last-layer class: dL/da', z' in latent-row layout   // Sobolev with parameter seeds: dz/dp, dL/d(dz/dp)
   float jac_l1 = 0.f; float* jac_mu = nullptr; long jac_mu_cap = 0; float* jac_tmp = nullptr;   // latent Jacobian regulariser (k_pjac)
+  // captured training steps (nif_graph_*): hipGraph executables, the steps each one carries, the device-side Adam state
+  std::vector<hipGraphExec_t> graphs; std::vector<int> graph_steps; bool capturing = false; int cap_steps = 0; long cap_step0 = 0;
+  AdamDev* adam_dev = nullptr; AdamDev* adam_host = nullptr;
   float* sob_acc = nullptr;          // [grad | loss] summed over the column groups of a Sobolev step with more than three x_index columns
   float act_l1 = 0.f, act_l2 = 0.f; float* act_part = nullptr; long act_part_cap = 0; float* act_loss = nullptr; long act_loss_cap = 0;
   float *stash_l = nullptr, *PHI = nullptr, *DPHI = nullptr, *DA = nullptr, *DZL = nullptr; long slot_l = 0;

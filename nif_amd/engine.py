@@ -359,6 +359,21 @@ class Engine(object):
     def adam_step_dev(self, adam):
         check(self.lib.nif_adam_step_dev(self.ctx, C.byref(adam)))
 
+    # captured training steps (include/nif_hip.h nif_graph_*)
+    def graph_begin(self):
+        check(self.lib.nif_graph_begin(self.ctx))
+
+    def graph_end(self):
+        gid = C.c_int32(-1)
+        check(self.lib.nif_graph_end(self.ctx, C.byref(gid)))
+        return int(gid.value)
+
+    def graph_launch(self, gid, adam):
+        check(self.lib.nif_graph_launch(self.ctx, int(gid), C.byref(adam)))
+
+    def graph_destroy(self, gid):
+        check(self.lib.nif_graph_destroy(self.ctx, int(gid)))
+
     def zero_grad(self):
         check(self.lib.nif_zero_grad(self.ctx))
 

@@ -4,6 +4,7 @@ the sub-model extractors.  Same constructor arguments, attribute names and error
 reference (file:line cited per method); every number comes from libnif_hip.so (HIP, gfx950)."""
 import contextlib
 import json
+import os
 import time
 
 import numpy as np
@@ -201,6 +202,12 @@ class Model(object):
         self.loss = "mse"
 
     _EVAL_CHUNK = 1 << 18
+    # fit(): epochs of at least four batches no larger than _GRAPH_MAX_BATCH can be captured into a hipGraph (NIF_GRAPH=1 or
+    # model._graph_epochs = True).  OFF by default: measured on configs[0] (10 k points, batch 512, tools/exp/small_batch.py) the
+    # replayed epoch runs 83.3 us per step against 84.8 us eager -- the step is bound by the GPU-side dispatch latency between its
+    # 13-15 DEPENDENT kernels (~5.5 us each), not by the host's launch cost, and a linear graph does not shorten that
+    _GRAPH_MAX_BATCH = 16384
+    _graph_epochs = os.environ.get("NIF_GRAPH", "0") == "1"
 
     def evaluate(self, x, y, sample_weight=None, verbose=0, **kwargs):
         """Keras Model.evaluate: the TOTAL loss -- sample-weighted mse plus every regularisation loss of the model (kernel / bias
@@ -352,6 +359,9 @@ class Model(object):
             # shard is a batch shorter (or empty) join the collectives of the steps they lack with a zero gradient
             sizes, gsizes = dist.plan_steps(N, bs, comm, e)
             e.reserve(max(1, max(sizes, default=0)), self._n_tangents())
+            use_graph = (self._graph_epochs and world == 1 and shard is None and not self._po_l1 and len(sizes) >= 4
+                         and max(sizes) <= self._GRAPH_MAX_BATCH and hasattr(e, "graph_begin") and epochs - initial_epoch >= 2)
+            graph_id = None
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
                     break
@@ -377,19 +387,37 @@ class Model(object):
                         src_sw.upload(sw[perm])
                 adam = self.optimizer.as_struct()
                 e.metric_read(reset=True)
-                for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
-                    b0 = ib * bs
-                    if self._po_l1:
-                        self._push_losses(e, bg)
-                    if b > 0:
-                        self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * w) for dt, w in zip(d_t, widths)],
-                                            d_sw.at(b0) if d_sw is not None else None, b, bg)
-                    else:
-                        e.zero_grad()
-                    if world > 1:
-                        comm.all_reduce_grad(e)
-                    e.adam_step_dev(adam)
-                    e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
+
+                def run_batches():
+                    for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
+                        b0 = ib * bs
+                        if self._po_l1:
+                            self._push_losses(e, bg)
+                        if b > 0:
+                            self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * w) for dt, w in zip(d_t, widths)],
+                                                d_sw.at(b0) if d_sw is not None else None, b, bg)
+                        else:
+                            e.zero_grad()
+                        if world > 1:
+                            comm.all_reduce_grad(e)
+                        e.adam_step_dev(adam)
+                        e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
+                # launch-bound epochs (many small batches on one GPU: configs[0]'s batch 512 is 13 kernels of a few microseconds per
+                # step) are recorded ONCE into a hipGraph -- the batch pointers into the resident table do not change between
+                # epochs -- and replayed with one submission per epoch; Keras runs its steps from one traced graph as well
+                if use_graph and graph_id is None:
+                    try:
+                        e.graph_begin()
+                        try:
+                            run_batches()
+                        finally:
+                            graph_id = e.graph_end()
+                    except _lib.NifError:
+                        use_graph, graph_id = False, None       # (a workspace that had to grow, a call that cannot be captured)
+                if use_graph and graph_id is not None:
+                    e.graph_launch(graph_id, adam)
+                else:
+                    run_batches()
                 tot, cnt = e.metric_read(reset=True)   # accumulated on the device: one host sync per epoch
                 logs = {"loss": tot / max(cnt, 1.0)}
                 if validation_data is not None:
@@ -405,6 +433,8 @@ class Model(object):
                     print("Epoch %d/%d - %.2fs - loss: %.4e" % (epoch + 1, epochs, time.time() - t0, logs["loss"]))
         finally:
             self._pop_losses(e)
+            if graph_id is not None:
+                e.graph_destroy(graph_id)
             if shard is not None:
                 shard.release(e)          # the slot's device buffers may be refilled once these steps have run
             e.sync()

@@ -88,3 +88,44 @@ def test_predict_is_chunked_through_the_staging_buffers():
     sub = m.model_x_to_u_given_w()
     sub._PREDICT_CHUNK = 256
     assert np.array_equal(sub.predict([x[:600, 1:], w]), m.model_x_to_u_given_w()._run([x[:600, 1:], w]))
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_fit_10k_points_batch_512_graph_epochs_equal_eager_epochs(shuffle):
+    """BASELINE configs[0] at its own size: tutorial/1's NIF (ParameterNet 2x32, ShapeNet 2x32), 10 000 (t; x) points, batch 512 = 20
+    steps per epoch (19 full + one of 272).  fit() records such an epoch ONCE into a hipGraph and replays it (nif_graph_*: Adam's
+    bias correction from a device-side iteration counter); the trajectory must be the eager one's, epoch by epoch, and the first
+    steps the oracle's."""
+    import nif_amd
+    cs = {"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+    cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+    x, y = O.synthetic_wave_batch(10000, seed=0)
+    runs = {}
+    for graph in (True, False):
+        nif_amd.set_seed(4)
+        m = nif_amd.NIF(cs, cp); model = m.build()
+        model._graph_epochs = graph
+        model._shuffle_seed = 11
+        model.compile(nif_amd.Adam(1e-3), "mse")
+        w0 = [w.copy() for w in model.get_weights()]
+        h = model.fit(x, y, epochs=4, batch_size=512, shuffle=shuffle, verbose=0)
+        _, _, step = m._engine.get_opt_state()
+        assert step == 4 * 20
+        h2 = model.fit(x, y, epochs=2, batch_size=512, shuffle=shuffle, verbose=0)       # a second fit captures its own graph
+        runs[graph] = (h.history["loss"] + h2.history["loss"], O.flatten(model.get_weights()), w0)
+    lg, wg, _ = runs[True]
+    le, we, w0 = runs[False]
+    assert np.allclose(lg, le, rtol=2e-6), (lg, le)
+    assert np.abs(wg - we).max() < 2e-6, np.abs(wg - we).max()          # (lr_t in fp64 on the device vs the host: the same float almost always)
+    assert lg[-1] < lg[0]
+    if not shuffle:     # the first epoch against the oracle's trajectory
+        spec = O.Spec("NIF", cs, cp)
+        th = O.flatten([w.astype(np.float64) for w in w0]); mm = np.zeros_like(th); vv = np.zeros_like(th)
+        f32 = lambda a: float(np.float32(a))
+        tot = 0.0
+        for t in range(1, 21):
+            lo, hi = (t - 1) * 512, min(10000, t * 512)
+            l_, g_ = O.loss_and_grad(spec, O.unflatten(spec, th), x[lo:hi].astype(np.float64), y[lo:hi].astype(np.float64))
+            tot += l_ * (hi - lo)
+            th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+        assert abs(lg[0] - tot / 10000) < 2e-3 * (tot / 10000), (lg[0], tot / 10000)

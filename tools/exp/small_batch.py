@@ -10,9 +10,12 @@ nif_amd.set_seed(0)
 m = nif_amd.NIF(cs, cp); model = m.build()
 x, y = O.synthetic_wave_batch(10000, seed=0)
 model.compile(nif_amd.Adam(1e-3), "mse")
-for bs in (512, 2048, 10000):
+for graph in (True, False):
+  nif_amd.Model._graph_epochs = graph
+  print("epochs captured into a hipGraph:" if graph else "eager launches:")
+  for bs in (512, 2048, 10000):
     model.fit(x, y, epochs=2, batch_size=bs, shuffle=True, verbose=0)
-    t0 = time.perf_counter(); ep = 20
+    t0 = time.perf_counter(); ep = 50
     model.fit(x, y, epochs=ep, batch_size=bs, shuffle=True, verbose=0)
     dt = time.perf_counter() - t0
     nsteps = ep * ((10000 + bs - 1) // bs)
