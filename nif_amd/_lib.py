@@ -18,7 +18,7 @@ PROF_NAMES = ["pack", "pnet_fwd", "snet", "pnet_bwd", "gw", "reduce", "adam", "g
 
 ACT_IDS = {
     None: 0, "linear": 0, "sine": 1, "swish": 2, "silu": 2, "tanh": 3, "relu": 4, "sigmoid": 5,
-    "elu": 6, "softplus": 7, "gelu": 8,
+    "elu": 6, "softplus": 7, "gelu": 8, "selu": 9, "softsign": 10, "exponential": 11, "hard_sigmoid": 12,
 }
 
 

@@ -27,6 +27,10 @@ __device__ __forceinline__ void act4_dyn(int act, float (&a)[4], float (&h)[4]) 
     case ACT_ELU: act4<ACT_ELU>(a, h); break;
     case ACT_SOFTPLUS: act4<ACT_SOFTPLUS>(a, h); break;
     case ACT_GELU: act4<ACT_GELU>(a, h); break;
+    case ACT_SELU: act4<ACT_SELU>(a, h); break;
+    case ACT_SOFTSIGN: act4<ACT_SOFTSIGN>(a, h); break;
+    case ACT_EXPONENTIAL: act4<ACT_EXPONENTIAL>(a, h); break;
+    case ACT_HARD_SIGMOID: act4<ACT_HARD_SIGMOID>(a, h); break;
     default: act4<ACT_LINEAR>(a, h); break;
   }
 }

@@ -46,6 +46,12 @@ __device__ __forceinline__ void pj_act(int act, float a, float* f0, float* f1, f
     case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); *f0 = fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))); *f1 = s; *f2 = s * (1.0f - s); } break;
     case ACT_GELU: { const float cdf = 0.5f * (1.0f + nif_erff(a * 0.70710678118654752440f)), pdf = 0.3989422804014327f * expf(-0.5f * a * a);
                      *f0 = a * cdf; *f1 = cdf + a * pdf; *f2 = pdf * (2.0f - a * a); } break;
+    case ACT_SELU: { const float e = NIF_SELU_ALPHA * expf(fminf(a, 0.f)); *f0 = NIF_SELU_SCALE * (a > 0.f ? a : e - NIF_SELU_ALPHA);
+                     *f1 = NIF_SELU_SCALE * (a > 0.f ? 1.0f : e); *f2 = a > 0.f ? 0.f : NIF_SELU_SCALE * e; } break;
+    case ACT_SOFTSIGN: { const float q = 1.0f / (1.0f + fabsf(a)); *f0 = a * q; *f1 = q * q;
+                         *f2 = (a > 0.f ? -2.0f : (a < 0.f ? 2.0f : 0.f)) * q * q * q; } break;
+    case ACT_EXPONENTIAL: { const float e = expf(a); *f0 = e; *f1 = e; *f2 = e; } break;
+    case ACT_HARD_SIGMOID: { const float t = fmaf(0.2f, a, 0.5f); *f0 = fminf(fmaxf(t, 0.f), 1.f); *f1 = (t > 0.f && t < 1.f) ? 0.2f : 0.f; *f2 = 0.f; } break;
     default: *f0 = a; *f1 = 1.0f; *f2 = 0.f; break;
   }
 }

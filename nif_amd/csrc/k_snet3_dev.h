@@ -233,6 +233,10 @@ __device__ __forceinline__ void act16(int act, const f32x4 (&a)[NBL], f32x4 (&h)
     case ACT_ELU: act16_t<NBL, ACT_ELU>(a, h, d, n, g); break;
     case ACT_SOFTPLUS: act16_t<NBL, ACT_SOFTPLUS>(a, h, d, n, g); break;
     case ACT_GELU: act16_t<NBL, ACT_GELU>(a, h, d, n, g); break;
+    case ACT_SELU: act16_t<NBL, ACT_SELU>(a, h, d, n, g); break;
+    case ACT_SOFTSIGN: act16_t<NBL, ACT_SOFTSIGN>(a, h, d, n, g); break;
+    case ACT_EXPONENTIAL: act16_t<NBL, ACT_EXPONENTIAL>(a, h, d, n, g); break;
+    case ACT_HARD_SIGMOID: act16_t<NBL, ACT_HARD_SIGMOID>(a, h, d, n, g); break;
     default: act16_t<NBL, ACT_LINEAR>(a, h, d, n, g); break;
   }
 }
@@ -249,7 +253,10 @@ __device__ __forceinline__ float act_d2(int act, float a) {
     case ACT_ELU: return a > 0.f ? 0.f : expf(a);
     case ACT_SOFTPLUS: { const float s = 1.0f / (1.0f + expf(-a)); return s * (1.0f - s); }
     case ACT_GELU: return 0.3989422804014327f * expf(-0.5f * a * a) * (2.0f - a * a);
-    default: return 0.f;   // linear, relu
+    case ACT_SELU: return a > 0.f ? 0.f : NIF_SELU_SCALE * NIF_SELU_ALPHA * expf(a);
+    case ACT_SOFTSIGN: { const float q = 1.0f / (1.0f + fabsf(a)); return (a > 0.f ? -2.0f : (a < 0.f ? 2.0f : 0.f)) * q * q * q; }
+    case ACT_EXPONENTIAL: return expf(a);
+    default: return 0.f;   // linear, relu, hard_sigmoid
   }
 }
 

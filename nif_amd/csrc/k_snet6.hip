@@ -37,6 +37,9 @@
 #ifndef NIF_S6_RING_V4
 #define NIF_S6_RING_V4 0
 #endif
+#ifndef NIF_S6_VMRING
+#define NIF_S6_VMRING 0       // 1: ring stores / loads behind the chunk DMA, counted out of the chunk wait (S6_CHUNK_RING) -- measured r4: 1.327 / 1.331 vs 1.332 / 1.330 ms per step, no gain: nothing waits for the ring
+#endif
 template <int NBL>
 __device__ __forceinline__ void ring_store16(float* __restrict__ slot, const f32x4 (&h)[NBL], int g, int p) {
 #ifdef NIF_ABL_NOSTORE
@@ -107,6 +110,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr int QF = (CF + NT - 1) / NT;
   constexpr int NBUF = 2;
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
+#if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
+  constexpr int NRING = 0;
+#else
+  constexpr int NRING = NIF_S6_RING_V4 ? NBL : 4 * NBL; // vector-memory instructions of one ring_store16 / ring_load16
+#endif
   constexpr int EXT = NPL * FUSE_PLANE_BYTES;
   // per-tile weight vectors [hi 16 | lo 16] bf16 = 64 B.  Last layer (WVL): du_o (o < 3), zt, ones.  First layer (WVF), per plane k:
   // k * 4 + c = (zt | 1) x_c, k * 4 + 3 = (zt | 1)
@@ -419,6 +427,26 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     asm volatile("" ::: "memory");                                            \
     cbuf ^= 1; nbuf ^= 1;                                                     \
   }
+// the chunk step that carries the layer's ring traffic: the NRING ring instructions are issued BEHIND the next chunk's DMA, so the
+// wait at the end of the step may leave exactly them in flight (vmcnt counts in issue order: "at most NRING outstanding" = every
+// DMA instruction has landed) -- their latency gets the following chunk step as well instead of sitting in front of this barrier
+#if NIF_S6_VMRING
+#define S6_CHUNK_RING(PRE_, ...)                                              \
+  {                                                                           \
+    cs_next(nbuf);                                                            \
+    PRE_                                                                      \
+    asm volatile("" ::: "memory");                                            \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    __VA_ARGS__                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NRING & 15) | ((NRING >> 4) << 14));   /* vmcnt(NRING) lgkmcnt(0) */ \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    cbuf ^= 1; nbuf ^= 1;                                                     \
+  }
+#else
+#define S6_CHUNK_RING(PRE_, ...) { PRE_ S6_CHUNK(__VA_ARGS__) }
+#endif
 
   int iset = 0;
   for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
@@ -463,9 +491,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
     for (int j = 0; j < nh; ++j) {
-#if NIF_S6_RING
-      ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
-#else
+#if !NIF_S6_RING
       if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
 #endif
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
@@ -480,7 +506,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         const float* sb = sm + o_bh + j * NP + 4 * g;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
+#if NIF_S6_RING
+        S6_CHUNK_RING({ ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+#else
         S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+#endif
         S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], T, lane); })
         const float zt = zt_base[0];
 #pragma unroll
@@ -561,9 +591,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (int j = nh - 1; j >= 0; --j) {
       f32x4 ga[NBL];
       tag_cos<NBL>(hin, dnext);
-#if NIF_S6_RING
-      ring_load16<NBL>(ring + j * (NP * 16), hin, g, p);           // h_j: dz dot product and this layer's A planes
-#else
+#if !NIF_S6_RING
       st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
 #endif
 #pragma unroll
@@ -582,7 +610,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       split2<NBL>(ga, b0, b1);
       {
         f32x4 U[NBL];
+#if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
+        S6_CHUNK_RING({ ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+#else
         S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+#endif
         S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], U, lane); })
         float s = 0.f;
 #pragma unroll

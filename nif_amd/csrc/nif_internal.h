@@ -23,7 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 enum { ACT_LINEAR = 0, ACT_SINE = 1, ACT_SWISH = 2, ACT_TANH = 3, ACT_RELU = 4, ACT_SIGMOID = 5,
-       ACT_ELU = 6, ACT_SOFTPLUS = 7, ACT_GELU = 8 };
+       ACT_ELU = 6, ACT_SOFTPLUS = 7, ACT_GELU = 8,
+       ACT_SELU = 9, ACT_SOFTSIGN = 10, ACT_EXPONENTIAL = 11, ACT_HARD_SIGMOID = 12 };    // r4: the rest of keras.activations (Keras 2.11) that is elementwise
+#define NIF_SELU_ALPHA 1.6732632423543772f
+#define NIF_SELU_SCALE 1.0507009873554805f
 
 // Reference to a (possibly hypernetwork-generated) matrix inside the flat parameter / gradient
 // vector.  element(k, in, out) lives at (k < r ? base_k + k*kstride : base_last) + in*ld + out.
@@ -389,6 +392,17 @@ __device__ __forceinline__ void act_eval(float a, float* h, float* d) {
   } else if (ACT == ACT_GELU) {
     const float cdf = 0.5f * (1.0f + nif_erff(a * 0.70710678118654752440f));
     *h = a * cdf; *d = cdf + a * 0.3989422804014327f * expf(-0.5f * a * a);
+  } else if (ACT == ACT_SELU) {          // scale * elu(a, alpha) (keras/activations.py selu)
+    const float e = NIF_SELU_ALPHA * expf(fminf(a, 0.f));
+    *h = NIF_SELU_SCALE * (a > 0.f ? a : e - NIF_SELU_ALPHA); *d = NIF_SELU_SCALE * (a > 0.f ? 1.0f : e);
+  } else if (ACT == ACT_SOFTSIGN) {      // a / (1 + |a|)
+    const float q = 1.0f / (1.0f + fabsf(a));
+    *h = a * q; *d = q * q;
+  } else if (ACT == ACT_EXPONENTIAL) {
+    const float e = expf(a); *h = e; *d = e;
+  } else if (ACT == ACT_HARD_SIGMOID) {  // Keras 2.11: clip(0.2 a + 0.5, 0, 1)
+    const float t = fmaf(0.2f, a, 0.5f);
+    *h = fminf(fmaxf(t, 0.f), 1.f); *d = (t > 0.f && t < 1.f) ? 0.2f : 0.f;
   } else {
     *h = a; *d = 1.0f;
   }
@@ -454,6 +468,10 @@ __device__ __forceinline__ void act_tile(int act, const f32x16 (&a)[NB], f32x16 
     case ACT_ELU: act_tile_t<NB, ACT_ELU>(a, h, d, n, hf); break;
     case ACT_SOFTPLUS: act_tile_t<NB, ACT_SOFTPLUS>(a, h, d, n, hf); break;
     case ACT_GELU: act_tile_t<NB, ACT_GELU>(a, h, d, n, hf); break;
+    case ACT_SELU: act_tile_t<NB, ACT_SELU>(a, h, d, n, hf); break;
+    case ACT_SOFTSIGN: act_tile_t<NB, ACT_SOFTSIGN>(a, h, d, n, hf); break;
+    case ACT_EXPONENTIAL: act_tile_t<NB, ACT_EXPONENTIAL>(a, h, d, n, hf); break;
+    case ACT_HARD_SIGMOID: act_tile_t<NB, ACT_HARD_SIGMOID>(a, h, d, n, hf); break;
     default: act_tile_t<NB, ACT_LINEAR>(a, h, d, n, hf); break;
   }
 }

@@ -258,7 +258,7 @@ class Model(object):
         return sw
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
-            sample_weight=None, initial_epoch=0, validation_data=None, **kwargs):
+            sample_weight=None, initial_epoch=0, validation_data=None, validation_split=0.0, **kwargs):
         """Keras Model.fit semantics for in-memory arrays (or one file of a shard dataset, nif_amd.data): per epoch
         optionally shuffle, walk batches of `batch_size` (default 32, last one partial), one Adam step per batch; the
         epoch 'loss' is the sample-weighted mean of the batch losses.  The table is made resident in HBM once; a
@@ -269,6 +269,22 @@ class Model(object):
         callbacks and History; evaluated through predict on this rank's device)."""
         if validation_data is not None and not (isinstance(validation_data, (tuple, list)) and len(validation_data) in (2, 3)):
             raise ValueError("validation_data = (x_val, y_val) or (x_val, y_val, sample_weight_val)")
+        if validation_split and validation_data is None:
+            # Keras: "the validation data is selected from the last samples in the x and y data provided, before shuffling"
+            if not 0.0 < float(validation_split) < 1.0:
+                raise ValueError("`validation_split` must be between 0 and 1, received: %r" % (validation_split,))
+            if isinstance(x, ShardBatches):
+                raise ValueError("`validation_split` is only supported for arrays")
+            n_all = int(np.shape(x)[0])
+            at = int(np.floor(n_all * (1.0 - float(validation_split))))
+            if at == 0 or at == n_all:
+                raise ValueError("Training data contains %d samples, which is not sufficient to split it into a validation and "
+                                 "training set as specified by `validation_split=%r`" % (n_all, validation_split))
+            cut = lambda a, lo, hi: [np.asarray(t)[lo:hi] for t in a] if isinstance(a, (list, tuple)) else np.asarray(a)[lo:hi]
+            val = (cut(x, at, n_all), cut(y, at, n_all)) + (() if sample_weight is None else (np.asarray(sample_weight)[at:],))
+            return self.fit(cut(x, 0, at), cut(y, 0, at), batch_size=batch_size, epochs=epochs, verbose=verbose, callbacks=callbacks,
+                            shuffle=shuffle, sample_weight=None if sample_weight is None else np.asarray(sample_weight)[:at],
+                            initial_epoch=initial_epoch, validation_data=val, **kwargs)
         if self.optimizer is None:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
         if kwargs:

@@ -71,6 +71,16 @@ def act_fn(name):
         def df(a):
             return 0.5 * (1.0 + _erf(a / math.sqrt(2.0))) + a * np.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
         return f, df
+    if name == "selu":      # keras/activations.py selu: scale * elu(x, alpha)
+        al, sc = 1.6732632423543772, 1.0507009873554805
+        return (lambda a: sc * np.where(a > 0, a, al * np.expm1(np.minimum(a, 0.0)))), (
+            lambda a: sc * np.where(a > 0, 1.0, al * np.exp(np.minimum(a, 0.0))))
+    if name == "softsign":
+        return (lambda a: a / (1.0 + np.abs(a))), (lambda a: 1.0 / (1.0 + np.abs(a)) ** 2)
+    if name == "exponential":
+        return np.exp, np.exp
+    if name == "hard_sigmoid":      # Keras 2.11 backend.hard_sigmoid: clip(0.2 x + 0.5, 0, 1)
+        return (lambda a: np.clip(0.2 * a + 0.5, 0.0, 1.0)), (lambda a: np.where((0.2 * a + 0.5 > 0) & (0.2 * a + 0.5 < 1), 0.2, 0.0))
     if name == "sine":
         return np.sin, np.cos
     raise ValueError("unknown activation %r" % (name,))
@@ -1437,8 +1447,14 @@ def jac_reg_loss_and_grad(spec, ws, p, l1, batch_global=None):
 
 def act_d2(name):
     """f'' for a Keras activation name / 'sine'"""
-    if name in (None, "linear", "relu"):
+    if name in (None, "linear", "relu", "hard_sigmoid"):
         return lambda a: np.zeros_like(a)
+    if name == "selu":
+        return lambda a: np.where(a > 0, 0.0, 1.0507009873554805 * 1.6732632423543772 * np.exp(np.minimum(a, 0.0)))
+    if name == "softsign":
+        return lambda a: -2.0 * np.sign(a) / (1.0 + np.abs(a)) ** 3
+    if name == "exponential":
+        return np.exp
     if name in ("swish", "silu"):
         return lambda a: _sigmoid(a) * (1.0 - _sigmoid(a)) * (2.0 + a * (1.0 - 2.0 * _sigmoid(a)))
     if name == "tanh":

@@ -833,6 +833,56 @@ def test_sobolev_passes_keep_the_regularisers_of_the_first_pass_only():
     mr._engine.set_jac_regularizer(0.0)
 
 
+@pytest.mark.parametrize("act", ["selu", "softsign", "exponential", "hard_sigmoid"])
+def test_remaining_keras_activations(act):
+    """the rest of keras.activations (Keras 2.11) on every kernel family that evaluates an activation: class NIF (ShapeNet and
+    ParameterNet, skip connections) and an MLP_ResNet ParameterNet of NIFMultiScale -- forward, loss / gradient, JacobianLayer on
+    every column, HessianLayer, the Sobolev step, the latent-Jacobian regulariser"""
+    import nif_amd
+    from nif_amd import JacobianLayer, HessianLayer
+    for kind, cs, cp, B in ((*_cfg("NIF", 40, 2, 24, 2, 2, 2, 2, 2, act=act), 130),
+                            (*_cfg("NIFMultiScale", 32, 1, 40, 1, 2, 1, 1, 2, p_act=act, p_res=True), 97)):
+        spec = O.Spec(kind, cs, cp)
+        rng = np.random.default_rng(31)
+        ws = O.init_weights(spec, rng, dtype=np.float32)
+        if kind == "NIFMultiScale":
+            names = [nm for nm, _ in spec.param_shapes()]
+            ws[names.index("pnet_last_w")] = (ws[names.index("pnet_last_w")] * 2.0).astype(np.float32)
+        if act == "exponential":          # exp(exp(.)) with skip connections overflows at the default initial scale: a tamer draw
+            ws = [(w * 0.3).astype(np.float32) for w in ws]
+        m = getattr(nif_amd, kind)(cs, cp); model = m.build(); model.set_weights(ws)
+        x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+        y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+        sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+        ws64 = [w.astype(np.float64) for w in ws]; x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+        assert _rel(model.predict(x), O.forward(spec, ws64, x64)) < 1e-5
+        loss, g = m._engine.loss_and_grad(x, y, sw)
+        rl, rg = O.loss_and_grad(spec, ws64, x64, y64, s64)
+        assert abs(loss - rl) < 2e-5 * abs(rl)
+        assert max(_per_tensor_rel(spec, g, O.flatten(rg)).values()) < 3e-4
+        yi, xi = list(range(spec.so)), list(range(spec.pi + spec.si))
+        _, J = JacobianLayer(model, yi, xi)(x)
+        _, Jr = O.jacobian(spec, ws64, x64, yi, xi)
+        assert _rel(J, Jr) < 2e-4
+        _, Jh, H = HessianLayer(model, yi, xi)(x[:64])
+        _, Jr2, Hr = O.hessian_analytic(spec, ws64, x64[:64], yi, xi)
+        assert _rel(Jh, Jr2) < 3e-5 and _rel(H, Hr) < 3e-4, (_rel(Jh, Jr2), _rel(H, Hr))
+        xs = [spec.pi + spec.si - 1, 0]
+        gt = rng.uniform(-1, 1, size=(B, spec.so, 2)).astype(np.float32)
+        sl, sg = m._engine.sobolev_loss_and_grad(x, y, gt, xs, 0.05, sw)
+        rsl, rsg, _, _ = O.sobolev_loss_and_grad(spec, ws64, x64, y64, gt.astype(np.float64), xs, 0.05, s64)
+        assert abs(sl - rsl) < 3e-5 * abs(rsl)
+        assert max(_per_tensor_rel(spec, sg, O.flatten(rsg)).values()) < 4e-4
+        m._engine.set_jac_regularizer(0.04)
+        lj, gj = m._engine.loss_and_grad(x, y, sw)
+        m._engine.set_jac_regularizer(0.0)
+        rj, rgj = O.jac_reg_loss_and_grad(spec, ws64, x64[:, :spec.pi], 0.04)
+        assert abs((lj - loss) - rj) < 3e-4 * rj + 1e-6 * abs(loss)
+    with pytest.raises(ValueError):
+        nif_amd.NIF(dict(cs, activation="softmax") if kind == "NIF" else {"input_dim": 1, "output_dim": 1, "units": 8, "nlayers": 1, "activation": "softmax"},
+                    {"input_dim": 1, "latent_dim": 1, "units": 8, "nlayers": 1, "activation": "softmax"})
+
+
 def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
     """Train u(t,x) on values AND du/dx of the closed-form travelling wave; both errors must drop, and the
     derivative error must end lower than with value-only training on the same few points."""

@@ -352,3 +352,32 @@ def test_weight_regulariser_term_is_the_gradient_of_its_loss():
         w[idx] = w0 - h; lm, _ = O.weight_regularizer_term(spec, ws, preg, sreg)
         w[idx] = w0
         assert abs((lp - lm) / (2 * h) - grads[i][idx]) < 1e-6 * max(1.0, abs(grads[i][idx])), nm
+
+
+NEW_ACTS = ["selu", "softsign", "exponential", "hard_sigmoid"]
+
+
+@pytest.mark.parametrize("act", NEW_ACTS)
+def test_remaining_keras_activations_match_torch_and_their_own_derivatives(act):
+    """keras.activations of Keras 2.11 beyond the nine r3 had (model.py:303 takes any name keras.activations.get knows): selu,
+    softsign, exponential, hard_sigmoid (= clip(0.2 x + 0.5, 0, 1) in 2.11) -- forward / gradient of class NIF and of an MLP
+    ParameterNet against torch autograd, f' and f'' against central differences of f and f'."""
+    torch = pytest.importorskip("torch")
+    from tests import torch_ref as T
+    from tests.cfgs import cfg_nif, cfg_ms
+    f, df = O.act_fn(act)
+    d2 = O.act_d2(act)
+    a = np.linspace(-3.0, 3.0, 601) + 1e-3          # (off the kinks of hard_sigmoid at +-2.5 and of softsign / selu at 0)
+    hstep = 1e-6
+    assert np.allclose(df(a), (f(a + hstep) - f(a - hstep)) / (2 * hstep), atol=2e-6)
+    assert np.allclose(d2(a), (df(a + hstep) - df(a - hstep)) / (2 * hstep), atol=2e-5)
+    for kind, cs, cp in (cfg_nif(r=2, so=2, si=2, act=act), cfg_ms(p_act=act, p_res=True, so=2)):
+        spec = O.Spec(kind, cs, cp)
+        rng = np.random.default_rng(1)
+        ws = O.init_weights(spec, rng)
+        x = rng.uniform(-1, 1, size=(9, spec.pi + spec.si)); y = rng.uniform(-1, 1, size=(9, spec.so))
+        loss, grads = O.loss_and_grad(spec, ws, x, y)
+        tl, tg, tu = T.loss_and_grad(kind, cs, cp, ws, x, y, None)
+        assert np.allclose(O.forward(spec, ws, x), tu, rtol=1e-12, atol=1e-12) and abs(loss - tl) <= 1e-12 * max(1.0, abs(tl))
+        for g, t in zip(grads, tg):
+            assert np.abs(g - t).max() / max(np.abs(t).max(), 1e-30) < 1e-9

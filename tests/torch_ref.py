@@ -18,6 +18,10 @@ def _act(name):
         "elu": torch.nn.functional.elu,
         "softplus": torch.nn.functional.softplus,
         "gelu": torch.nn.functional.gelu,
+        "selu": torch.selu,
+        "softsign": torch.nn.functional.softsign,
+        "exponential": torch.exp,
+        "hard_sigmoid": lambda a: torch.clamp(0.2 * a + 0.5, 0.0, 1.0),      # Keras 2.11 (torch's hardsigmoid is x / 6 + 0.5)
         "sine": torch.sin,
         "linear": lambda a: a,
         None: lambda a: a,
