@@ -307,3 +307,30 @@ def test_bench_self_launch_fails_fast_when_a_rank_dies_early():
     assert time.time() - t0 < 60
     assert "[rank 1] double: rank 1 fails on purpose" in r.stderr and "stopping the other ranks" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.strip()]
+
+
+def test_bench_under_torchrun_two_ranks_on_the_double():
+    """the DRIVER's command for its N > 1 legs -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks on the engine double: bench.py takes RANK / WORLD_SIZE /
+    MASTER_* from the launcher's environment, does not launch ranks of its own, and rank 0 alone prints the one JSON line"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NIF_BENCH_ENGINE="tests.doubles:bench_double", PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "40",
+           "--no-cpu-baseline", "--no-extras", "--ramp-steps", "2"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["global_batch"] == 80
+    assert d["dist"]["rccl_ranks_seen"] == 2 and d["dist"]["world"] == 2
+    assert abs(d["value"] - 80 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
