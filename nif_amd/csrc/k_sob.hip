@@ -17,8 +17,8 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par && !a.ll;     // the 1- / 2-seed instantiations: two workgroups per CU
   // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
   const bool two = slim && (NBL <= 2 || ns == 1 || (NIF_SOB_TWO_BF2 && ns == 2 && a.prec == 1));
-  const bool wav = train && sobw_supported(a, ns, any_par);      // k_sobw.hip: one 12-wave workgroup per CU
-  if (wav) ngroups = (nt16 + sobw_tiles_per_group(ns) - 1) / sobw_tiles_per_group(ns);
+  const bool wav = sobw_supported(a, ns, any_par);      // k_sobw.hip: one 12-wave (65..128 units: 8-wave) workgroup per CU; r4: predict() too
+  if (wav) ngroups = (nt16 + sobw_tiles_per_group(a.n, ns) - 1) / sobw_tiles_per_group(a.n, ns);
   const long cap = wav ? sobw_grid_cap() : (two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256));
   const int nblk = (int)(ngroups < cap ? ngroups : cap);
   int one_buf = 0;
@@ -64,7 +64,7 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     J.wu = (par && par->no_primal) ? 0.0f : 1.0f;
     J.wjn = wj / ((float)ny * (float)nx_all);
   }
-  if (wav) { launch_sobw(J, nblk, st); return nblk; }
+  if (wav) { launch_sobw(J, nblk, st, train); return nblk; }
   dim3 grid(nblk), block(256);
   const bool bf = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;      // whole bf16 planes in LDS: up to n = 96
   const bool sgn = !a.res && !a.nif_skip && (long)(a.nh + 1) * 4 * NBL <= 128;  // sign bits fit the 128-bit shift register (SIREN only)

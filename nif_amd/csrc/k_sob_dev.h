@@ -61,8 +61,8 @@ struct SobArgs {
 void launch_sob_par(const SobArgs& J, bool train, bool bf, int nblk, size_t shm, hipStream_t st);
 // two coordinate seeds of a plain SIREN net, the streams on separate waves (k_sobw.hip)
 bool sobw_supported(const SNetArgs& a, int ns, bool any_par);
-void launch_sobw(const SobArgs& J, int nblk, hipStream_t st);
-int sobw_tiles_per_group(int ns);
+void launch_sobw(const SobArgs& J, int nblk, hipStream_t st, bool train = true);
+int sobw_tiles_per_group(int n, int ns);
 int sobw_grid_cap();
 // last-layer class (k_sob_ll.hip)
 void launch_sob_ll(const SobArgs& J, bool train, bool bf, int nblk, size_t shm, hipStream_t st);

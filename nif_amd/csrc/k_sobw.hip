@@ -53,15 +53,18 @@ __device__ __forceinline__ void sine16_tagc(const f32x4 (&a)[NBL], f32x4 (&h)[NB
 #define NIF_SOBW_OCC 3      // waves per SIMD the register budget allows (hipcc: the second __launch_bounds__ argument is waves per EU)
 #endif
 // tiles per workgroup: 12 waves / (1 + seeds) streams = one 12-wave workgroup per CU (two 6-wave workgroups of 2 tiles with two
-// seeds: 4.6 instead of 3.4 ms)
-#define NIF_SOBW_TPG(NS_) (12 / (1 + (NS_)))
+// seeds: 4.6 instead of 3.4 ms).  r4: nets of 65..128 units (six / eight 16-feature blocks) need k_snet4<8>'s 256 registers per
+// wave: two waves per SIMD, 8 / (1 + seeds) tiles (two seeds: 2 tiles = 6 waves)
+#define NIF_SOBW_WMAX(NBL_) ((NBL_) <= 4 ? 12 : 8)
+#define NIF_SOBW_TPG(NBL_, NS_) (NIF_SOBW_WMAX(NBL_) / (1 + (NS_)))
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
-template <int NBL, bool PR, int NS>
-__global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
+// TRAIN = false (r4): the two-output model's predict() -- primal and tangent streams forward only (no stash, no ring, no targets)
+template <int NBL, bool PR, int NS, bool TRAIN = true>
+__global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC : 2)) void k_sobw(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
-  constexpr int NQ = 1 + NS, TPG = NIF_SOBW_TPG(NS), WAVES = TPG * NQ, NT = 64 * WAVES;
+  constexpr int NQ = 1 + NS, TPG = NIF_SOBW_TPG(NBL, NS), WAVES = TPG * NQ, NT = 64 * WAVES;
   constexpr int NCH = NBL / 2;
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;
   constexpr int QF = (CF + NT - 1) / NT;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
   auto cs_phase_step = [&]() {
     ++cs_phase;
-    if (cs_phase < 1 + nh) {
+    if (TRAIN && cs_phase < 1 + nh) {
       cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - cs_phase) * NPC * CB; cs_units = CB; cs_left = NPC;
     } else {
       if (cs_groups <= 0) { cs_left = -1; return; }
@@ -139,15 +142,17 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (tile32n * r + c) * 32 + poffn),
                                        (__attribute__((address_space(3))) void*)(dst + (CX + i0) * 16), 4, 0, 0);
     }
-    for (int i0 = 0; i0 < CY; i0 += 4) {
-      const int c = i0 + g < so ? i0 + g : so - 1;
-      const float* src = q ? J.gt + (ptn * so + c) * J.gstride + gcol : A.y + ptn * so + c;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
+    if (TRAIN) {
+      for (int i0 = 0; i0 < CY; i0 += 4) {
+        const int c = i0 + g < so ? i0 + g : so - 1;
+        const float* src = q ? J.gt + (ptn * so + c) * J.gstride + gcol : A.y + ptn * so + c;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
+      }
+      const float* swp = A.sw ? A.sw + ptn : A.y + ptn * so;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
     }
-    const float* swp = A.sw ? A.sw + ptn : A.y + ptn * so;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
-                                     (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
   };
   {
     const long s_wl = (long)si * n + (long)nh * n * n;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices ------------------------------------------------------------------------------------------
     for (int j = 0; j < nh; ++j) {
-      if (active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); }
+      if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
       if (q == 0) {
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
         sine16_tagc<NBL>(acc, h, c);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) xc[b * 64] = c[b];
-      } else {
+      } else if (TRAIN) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) ring[((long)j * NBL + b) * 64] = acc[b];
       }
@@ -307,6 +312,31 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
       }
     }
     // ---- last layer (n -> so, linear), the stream's loss term, start of the adjoint ---------------------------------------
+    if (!TRAIN) {      // predict: u (primal wave) / du/dx_d (tangent waves), nothing else
+      for (int o = 0; o < so; ++o) {
+        float part = 0.f, bias = 0.f;
+        for (int k = 0; k <= r; ++k) {
+          const float zt = k < r ? zt_base[k * 16] : 1.0f;
+          const float* s0 = sm + k * nsm;
+          float sk = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+            sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          }
+          part = fmaf(zt, sk, part);
+          bias = fmaf(zt, s0[o_bl + o], bias);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float uo = q ? part : part + bias;
+        if (valid && g == 0) {
+          if (q == 0) { if (A.u_out) A.u_out[pt * so + o] = uo; }
+          else if (J.JU) J.JU[(pt * so + o) * J.gstride + gcol] = uo;
+        }
+      }
+      continue;
+    }
     if (active) { st_store16<NBL>(IN0 + (long)nh * sstride, row0, h, g); }
     f32x4 gh[NBL];
     ZERO_T(gh)
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
       }
       st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);     // the stream's input of this layer (dz) -- primal: also sin(a) of layer j-1
       if (active) {
-        if (PR && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
+        if (PR && NBL != 6 && A.da_bf16) st_store16_bf<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
         else st_store16<NBL>(DA0 + (long)(j + 1) * sstride, row0, ga, g);
       }
       if (q == 0)
@@ -486,6 +516,7 @@ __global__ __launch_bounds__(768, NIF_SOBW_OCC) void k_sobw(SobArgs J) {
   }
 #undef SW_CHUNK
 #undef SW_MEET
+  if (!TRAIN) return;
   for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
   if (lane == 0) lsum[wid] = loss_lane;
   __syncthreads();
@@ -501,7 +532,7 @@ static size_t sobw_shmem(const SNetArgs& a, int NBL, int ns) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  const size_t W = 12;      // waves = tiles per group x streams, whatever the seed count
+  const size_t W = NIF_SOBW_WMAX(NBL);      // waves = tiles per group x streams (an upper bound over the seed counts)
   return (size_t)2 * NBL * 3 * 64 * 16 + (sm_tot + W * pw + W * NBL * 256 + W * a.r * 16 + 16) * sizeof(float);
 }
 // coordinate seeds of a plain SIREN NIFMultiScale net on the packed bf16 planes, n <= 64, training
@@ -509,24 +540,29 @@ bool sobw_supported(const SNetArgs& a, int ns, bool any_par) {
   static const int on = [] { const char* e = getenv("NIF_SOBW"); return e ? atoi(e) : 1; }();
   const int NBL = snet3_nbl(a.n);
   if (!on || ns < 1 || ns > 3 || any_par || a.ll || a.res || a.nif_skip || !a.WF4 || !a.WB4) return false;
-  if ((NBL != 2 && NBL != 4) || a.nh < 1 || a.r < 1) return false;
+  if ((NBL & 1) || NBL > 8 || a.nh < 1 || a.r < 1) return false;
+  if (NBL > 4 && a.prec != 0) return false;      // (the wide forms: fp32 results only -- under the policy k_sob<.., BF> keeps them)
   return sobw_shmem(a, NBL, ns) <= 160u * 1024u;
 }
-int sobw_tiles_per_group(int ns) { return NIF_SOBW_TPG(ns); }
+int sobw_tiles_per_group(int n, int ns) { return NIF_SOBW_TPG(snet3_nbl(n), ns); }
 int sobw_grid_cap() { return 256; }       // one workgroup per CU
-void launch_sobw(const SobArgs& J, int nblk, hipStream_t st) {
+void launch_sobw(const SobArgs& J, int nblk, hipStream_t st, bool train) {
   const SNetArgs& a = J.s;
   const int NBL = snet3_nbl(a.n);
   const size_t shm = sobw_shmem(a, NBL, J.ns);
-  dim3 grid(nblk), block(768);
-#define SWL(NBL_, PR_, NS_)                                                                                               \
+  dim3 grid(nblk), block(64 * sobw_tiles_per_group(a.n, J.ns) * (1 + J.ns));
+#define SWT(NBL_, PR_, NS_, TR_)                                                                                               \
   {                                                                                                                      \
-    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_sobw<NBL_, PR_, NS_>), grid, block, shm, st, J);                                                \
+    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_, NS_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_sobw<NBL_, PR_, NS_, TR_>), grid, block, shm, st, J);                                                \
   }
+#define SWL(NBL_, PR_, NS_) { if (train) SWT(NBL_, PR_, NS_, true) else SWT(NBL_, PR_, NS_, false) }
 #define SWN(NBL_, PR_) { if (J.ns == 1) SWL(NBL_, PR_, 1) else if (J.ns == 2) SWL(NBL_, PR_, 2) else SWL(NBL_, PR_, 3) }
-  if (NBL == 4) { if (a.prec == 1) SWN(4, true) else SWN(4, false) }
+  if (NBL == 8) SWN(8, false)
+  else if (NBL == 6) SWN(6, false)
+  else if (NBL == 4) { if (a.prec == 1) SWN(4, true) else SWN(4, false) }
   else { if (a.prec == 1) SWN(2, true) else SWN(2, false) }
 #undef SWN
 #undef SWL
+#undef SWT
 }

@@ -733,7 +733,7 @@ static int hessian_core(nif_ctx* c, const float* xin_dev, int64_t B, const int32
   std::vector<int> xc, xp;                         // positions (in x_idx) of the coordinate / parameter columns
   for (int j = 0; j < nx; ++j) (x_idx[j] >= c->pi ? xc : xp).push_back(j);
   const int np_ = (int)xp.size();
-  if (xc.size() > 16 || np_ > 4) return fail(NIF_ERR_INVALID, "HessianLayer: at most 16 coordinate and 4 parameter columns in x_index");
+  if (xc.size() > 16 || np_ > 16) return fail(NIF_ERR_INVALID, "HessianLayer: at most 16 coordinate and 16 parameter columns in x_index");
   const long blk = ntl * 32 * c->r;                // floats of one latent-layout vector
   if (anyp) {
     if (!pjac_supported(pa))

@@ -264,7 +264,7 @@ struct HessLLArgs {
   const float *f0, *fj, *fh;      // phi [B][so*rl], phi' [B][so*rl][nxc], phi'' [B][so*rl][nxc][nxc]
   const float *Za, *AP, *bias;    // a [tiles][rl][32]; AP: [np + np*np][npts][rl] blocks in latent layout: a'_j, then a''_{jk} at np + j*np + k (j <= k)
   long B, npts; int so, rl, nxc, np, nx;
-  HessIdx I; int xc[16], xp[4];   // positions (in x_index) of the coordinate / parameter columns
+  HessIdx I; int xc[16], xp[16];   // positions (in x_index) of the coordinate / parameter columns (r4: up to 16 parameter columns)
   float *y, *dydx, *d2;
 };
 void launch_hess_gather(const float* fj, const float* fh, long B, int so, int nx, const HessIdx& I, float* dydx, float* d2, hipStream_t st);

@@ -22,7 +22,7 @@ def _case(i):
     import fuzz_parity as F
     rng = np.random.default_rng(SWEEP_SEED)
     for _ in range(i + 1):
-        cfg, B, desc = F.draw(rng)
+        cfg, B, desc = F.draw(rng, wide=False)
     return cfg, B, desc, SWEEP_SEED * 1000 + i
 
 
