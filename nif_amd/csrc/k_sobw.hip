@@ -60,7 +60,11 @@ __device__ __forceinline__ void sine16_tagc(const f32x4 (&a)[NBL], f32x4 (&h)[NB
 #define ZERO_T(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
 // TRAIN = false (r4): the two-output model's predict() -- primal and tangent streams forward only (no stash, no ring, no targets)
-template <int NBL, bool PR, int NS, bool TRAIN = true>
+// MODE = 1 (r4): SIREN_ResNet blocks (siren.py:381-410) -- h_out = 0.5 (u + sin(a2)), a2 = w0 t W2 + b2, t = sin(a1), a1 = w0 u W1 + b1:
+// every stream carries the skip on its own (tangent: h'_out = 0.5 (u' + cos(a2) a2')); the block input u comes back from the stream's
+// stash row of matrix j - 1 (training) or waits in registers (predict); the block output carries the tag of cos(a2) and the adjoint
+// rebuilds sin(a2) = 2 h - u (k_snet4's resblock form)
+template <int NBL, bool PR, int NS, bool TRAIN = true, int MODE = 0>
 __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC : 2)) void k_sobw(SobArgs J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SNetArgs& A = J.s;
@@ -272,8 +276,13 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
     }
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices ------------------------------------------------------------------------------------------
+    f32x4 ublk[(MODE == 1 && !TRAIN) ? NBL : 1];
     for (int j = 0; j < nh; ++j) {
       if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); }
+      if (MODE == 1 && !TRAIN && !(j & 1)) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) ublk[b] = h[b];
+      }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       split3<NBL>(h, b0, b1, b2);
       if (q == 0) {
@@ -296,9 +305,11 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
       }
 #pragma unroll
       for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+      const bool blk_end = MODE == 1 && (j & 1);      // second matrix of a resblock: the layer's result meets the block input
       if (q == 0) {
         f32x4 c[NBL];
-        sine16_tagc<NBL>(acc, h, c);
+        if (blk_end) sine16_tagc<NBL>(acc, acc, c);
+        else sine16_tagc<NBL>(acc, h, c);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) xc[b * 64] = c[b];
       } else if (TRAIN) {
@@ -306,7 +317,27 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
         for (int b = 0; b < NBL; ++b) ring[((long)j * NBL + b) * 64] = acc[b];
       }
       SW_MEET()
-      if (q) {
+      if (blk_end) {
+        if (q) {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) acc[b] = xc[b * 64] * acc[b];
+        }
+        // acc: sin(a2) (primal, tagged) / cos(a2) a2' (tangent)
+        f32x4 u[NBL];
+        if (TRAIN) st_load16<NBL>(IN0 + (long)(j - 1) * sstride, row0, u, g);
+        else {
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) u[b] = ublk[b];
+        }
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) h[b] = 0.5f * (u[b] + acc[b]);
+        if (TRAIN && q == 0) {      // the block output carries the tag of cos(a2)
+#pragma unroll
+          for (int b = 0; b < NBL; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[b][v] = __uint_as_float((__float_as_uint(h[b][v]) & ~1u) | (__float_as_uint(acc[b][v]) & 1u));
+        }
+      } else if (q) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) h[b] = xc[b * 64] * acc[b];
       }
@@ -390,8 +421,24 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
 #pragma unroll
       for (int b = 0; b < NBL; ++b) ex[b] = ring[((long)(nh - 1) * NBL + b) * 64];
     }
+    f32x4 skip[MODE == 1 ? NBL : 1];
     for (int j = nh - 1; j >= 0; --j) {
       f32x4 ga[NBL];
+      if (MODE == 1 && (j & 1)) {      // second matrix of a block: half of the incoming adjoint passes the block by
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) { skip[b] = 0.5f * gh[b]; gh[b] = skip[b]; }
+        if (q == 0) {                  // hin = the block output with the tag of cos(a2): sin(a2) = 2 h - u, u = the block input
+          f32x4 ub[NBL];
+          st_load16<NBL>(IN0 + (long)(j - 1) * sstride, row0, ub, g);
+#pragma unroll
+          for (int b = 0; b < NBL; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float t = fmaf(2.0f, hin[b][v], -ub[b][v]);
+              hin[b][v] = __uint_as_float((__float_as_uint(t) & ~1u) | (__float_as_uint(hin[b][v]) & 1u));
+            }
+        }
+      }
       if (q == 0) {
         tag_cos<NBL>(hin, ex);
 #pragma unroll
@@ -459,6 +506,10 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
       }
 #pragma unroll
       for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
+      if (MODE == 1 && !(j & 1)) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) gh[b] += skip[b];
+      }
     }
     // ---- first layer ------------------------------------------------------------------------------------------------------
     {
@@ -539,7 +590,8 @@ static size_t sobw_shmem(const SNetArgs& a, int NBL, int ns) {
 bool sobw_supported(const SNetArgs& a, int ns, bool any_par) {
   static const int on = [] { const char* e = getenv("NIF_SOBW"); return e ? atoi(e) : 1; }();
   const int NBL = snet3_nbl(a.n);
-  if (!on || ns < 1 || ns > 3 || any_par || a.ll || a.res || a.nif_skip || !a.WF4 || !a.WB4) return false;
+  if (!on || ns < 1 || ns > 3 || any_par || a.ll || a.nif_skip || !a.WF4 || !a.WB4) return false;
+  if (a.res && (a.nh & 1)) return false;
   if ((NBL & 1) || NBL > 8 || a.nh < 1 || a.r < 1) return false;
   if (NBL > 4 && a.prec != 0) return false;      // (the wide forms: fp32 results only -- under the policy k_sob<.., BF> keeps them)
   return sobw_shmem(a, NBL, ns) <= 160u * 1024u;
@@ -551,11 +603,12 @@ void launch_sobw(const SobArgs& J, int nblk, hipStream_t st, bool train) {
   const int NBL = snet3_nbl(a.n);
   const size_t shm = sobw_shmem(a, NBL, J.ns);
   dim3 grid(nblk), block(64 * sobw_tiles_per_group(a.n, J.ns) * (1 + J.ns));
-#define SWT(NBL_, PR_, NS_, TR_)                                                                                               \
+#define SWM(NBL_, PR_, NS_, TR_, MODE_)                                                                                               \
   {                                                                                                                      \
-    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_, NS_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((k_sobw<NBL_, PR_, NS_, TR_>), grid, block, shm, st, J);                                                \
+    (void)hipFuncSetAttribute((const void*)k_sobw<NBL_, PR_, NS_, TR_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_sobw<NBL_, PR_, NS_, TR_, MODE_>), grid, block, shm, st, J);                                                \
   }
+#define SWT(NBL_, PR_, NS_, TR_) { if (a.res) SWM(NBL_, PR_, NS_, TR_, 1) else SWM(NBL_, PR_, NS_, TR_, 0) }
 #define SWL(NBL_, PR_, NS_) { if (train) SWT(NBL_, PR_, NS_, true) else SWT(NBL_, PR_, NS_, false) }
 #define SWN(NBL_, PR_) { if (J.ns == 1) SWL(NBL_, PR_, 1) else if (J.ns == 2) SWL(NBL_, PR_, 2) else SWL(NBL_, PR_, 3) }
   if (NBL == 8) SWN(8, false)
@@ -565,4 +618,5 @@ void launch_sobw(const SobArgs& J, int nblk, hipStream_t st, bool train) {
 #undef SWN
 #undef SWL
 #undef SWT
+#undef SWM
 }

@@ -1301,8 +1301,8 @@ def _stash_bf16(spec, xi=None):
         return False
     if xi is None:
         return True
-    return (spec.kind == O.KIND_MS and not spec.s_res and nbl in (2, 4) and 1 <= len(xi) <= 3 and all(j >= spec.pi for j in xi)
-            and spec.r >= 1)
+    # (r4: k_sobw takes resblock nets too)
+    return (spec.kind == O.KIND_MS and nbl in (2, 4) and 1 <= len(xi) <= 3 and all(j >= spec.pi for j in xi) and spec.r >= 1)
 
 
 def _make_policy(name, policy, boost=1.0):

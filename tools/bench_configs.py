@@ -31,6 +31,8 @@ WORK = {
     "cfg4_linear_nif_3d": ("NIFMultiScaleLastLayerParameterized", ms(128, 2, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
     "cfg5_sobolev_2d_4x64": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1, 2]),
     "sobolev_6x128_2d": ("NIFMultiScale", ms(128, 6, 64, 2, 1, 2, 1, 1), 1 << 18, [1, 2]),      # (not a BASELINE config: the wide Sobolev kernels)
+    "sobolev_res_3x128_2d": ("NIFMultiScale", ms(128, 3, 64, 2, 1, 2, 1, 1, res=True), 1 << 18, [1, 2]),
+    "sobolev_res_2x64_2d": ("NIFMultiScale", ms(64, 2, 32, 2, 1, 2, 1, 1, res=True), 1 << 20, [1, 2]),
     "sobolev_3x96_2d": ("NIFMultiScale", ms(96, 3, 32, 2, 2, 2, 1, 1), 1 << 18, [1, 2]),
     "cfg5_sobolev_2d_dx_only": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1]),
     # configs[4] names bf16: the mixed_bfloat16 policy of the build (single bf16 product per n x n operand pair)
