@@ -593,7 +593,6 @@ bool sobw_supported(const SNetArgs& a, int ns, bool any_par) {
   if (!on || ns < 1 || ns > 3 || any_par || a.ll || a.nif_skip || !a.WF4 || !a.WB4) return false;
   if (a.res && (a.nh & 1)) return false;
   if ((NBL & 1) || NBL > 8 || a.nh < 1 || a.r < 1) return false;
-  if (NBL > 4 && a.prec != 0) return false;      // (the wide forms: fp32 results only -- under the policy k_sob<.., BF> keeps them)
   return sobw_shmem(a, NBL, ns) <= 160u * 1024u;
 }
 int sobw_tiles_per_group(int n, int ns) { return NIF_SOBW_TPG(snet3_nbl(n), ns); }
@@ -611,8 +610,8 @@ void launch_sobw(const SobArgs& J, int nblk, hipStream_t st, bool train) {
 #define SWT(NBL_, PR_, NS_, TR_) { if (a.res) SWM(NBL_, PR_, NS_, TR_, 1) else SWM(NBL_, PR_, NS_, TR_, 0) }
 #define SWL(NBL_, PR_, NS_) { if (train) SWT(NBL_, PR_, NS_, true) else SWT(NBL_, PR_, NS_, false) }
 #define SWN(NBL_, PR_) { if (J.ns == 1) SWL(NBL_, PR_, 1) else if (J.ns == 2) SWL(NBL_, PR_, 2) else SWL(NBL_, PR_, 3) }
-  if (NBL == 8) SWN(8, false)
-  else if (NBL == 6) SWN(6, false)
+  if (NBL == 8) { if (a.prec == 1) SWN(8, true) else SWN(8, false) }
+  else if (NBL == 6) { if (a.prec == 1) SWN(6, true) else SWN(6, false) }
   else if (NBL == 4) { if (a.prec == 1) SWN(4, true) else SWN(4, false) }
   else { if (a.prec == 1) SWN(2, true) else SWN(2, false) }
 #undef SWN

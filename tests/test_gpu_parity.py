@@ -1301,8 +1301,9 @@ def _stash_bf16(spec, xi=None):
         return False
     if xi is None:
         return True
-    # (r4: k_sobw takes resblock nets too)
-    return (spec.kind == O.KIND_MS and nbl in (2, 4) and 1 <= len(xi) <= 3 and all(j >= spec.pi for j in xi) and spec.r >= 1)
+    # (r4: k_sobw takes resblock nets and the 65..128-unit nets too)
+    return (spec.kind == O.KIND_MS and (nbl in (2, 4) or (nbl == 8 and spec.r <= 1)) and 1 <= len(xi) <= 3
+            and all(j >= spec.pi for j in xi) and spec.r >= 1)
 
 
 def _make_policy(name, policy, boost=1.0):
@@ -1424,7 +1425,8 @@ def test_mixed_bfloat16_training_and_sobolev_step():
         nif_amd.NIFMultiScale(*CONFIGS["ms_cfg2_64x4"][0][1:], mixed_policy="mixed_float16")
 
 
-@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_res_64x2", "ms_64x2_r1_so4", "ll_plain_32x2_r3", "ms_cfg5_64x4_si2"])
+@pytest.mark.parametrize("name", ["nif_cfg1_32x2", "ms_res_64x2", "ms_64x2_r1_so4", "ll_plain_32x2_r3", "ms_cfg5_64x4_si2",
+                                  "ms_cfg3_128x3", "ms_96x2_r2", "ms_res_128x1_nst128"])      # r4: the wide k_sobw<6 | 8, PR> forms
 def test_sobolev_step_under_the_policy_cast_for_cast(name):
     """configs[4] beyond its own shape: class NIF (skip connections, swish), a resblock net, several outputs -- the Sobolev
     step under mixed_bfloat16 against the oracle that rounds where k_sob<..., BF = 2> and k_sobw<PR> round (5e-4 loss / predictions, 3e-3 per
@@ -1446,7 +1448,22 @@ def test_sobolev_step_under_the_policy_cast_for_cast(name):
         bar_l, bar_g = 5e-4, 3e-3
     assert abs(loss - rl) <= bar_l * abs(rl), (loss, rl)
     rel = _per_tensor_rel(spec, grad, O.flatten(rg))
-    assert max(rel.values()) < bar_g, rel
+    if max(rel.values()) >= bar_g and spec.kind != O.KIND_LL:
+        # a tensor above the typical bar is accepted only where the EMULATING ORACLE itself moves that much when its weights move by
+        # one fp32 ulp (a different set of bf16 roundings flips): the kernel may sit 3 s from it, and nowhere above 1e-2
+        ws_n = _one_ulp_weights(ws)
+        rg_n = O.sobolev_planes_loss_and_grad(spec, ws_n, x64, y64, g64, xi, 0.1, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec, xi))[1]
+        sens = _per_tensor_rel(spec, O.flatten(rg_n), O.flatten(rg))
+        for nm, v in rel.items():
+            assert v < max(bar_g, 3.0 * sens[nm]) and v < 1e-2, (nm, v, sens[nm])
+    else:
+        assert max(rel.values()) < bar_g, rel
+
+
+def _one_ulp_weights(ws64, seed=99):
+    rng2 = np.random.default_rng(seed)
+    return [np.nextafter(w.astype(np.float32), np.float32(np.inf) * rng2.choice([-1.0, 1.0], size=w.shape).astype(np.float32)).astype(np.float64)
+            for w in ws64]
 
 
 @pytest.mark.parametrize("name", ["ms_cfg5_64x4_si2", "ll_cfg4_128x2_r10_so3"])
