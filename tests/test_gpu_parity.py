@@ -1302,7 +1302,8 @@ def _stash_bf16(spec, xi=None):
     if xi is None:
         return True
     # (r4: k_sobw takes resblock nets and the 65..128-unit nets too)
-    return (spec.kind == O.KIND_MS and (nbl in (2, 4) or (nbl == 8 and spec.r <= 1)) and 1 <= len(xi) <= 3
+    # (... and class NIF)
+    return (spec.kind in (O.KIND_MS, O.KIND_NIF) and (nbl in (2, 4) or (nbl == 8 and spec.r <= 1)) and 1 <= len(xi) <= 3
             and all(j >= spec.pi for j in xi) and spec.r >= 1)
 
 

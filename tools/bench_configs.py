@@ -33,6 +33,8 @@ WORK = {
     "sobolev_6x128_2d": ("NIFMultiScale", ms(128, 6, 64, 2, 1, 2, 1, 1), 1 << 18, [1, 2]),      # (not a BASELINE config: the wide Sobolev kernels)
     "sobolev_res_3x128_2d": ("NIFMultiScale", ms(128, 3, 64, 2, 1, 2, 1, 1, res=True), 1 << 18, [1, 2]),
     "sobolev_res_2x64_2d": ("NIFMultiScale", ms(64, 2, 32, 2, 1, 2, 1, 1, res=True), 1 << 20, [1, 2]),
+    "sobolev_nif_2x64_swish": ("NIF", ({"input_dim": 2, "output_dim": 1, "units": 64, "nlayers": 2, "activation": "swish"},
+                                      {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}), 1 << 20, [1, 2]),
     "sobolev_3x96_2d": ("NIFMultiScale", ms(96, 3, 32, 2, 2, 2, 1, 1), 1 << 18, [1, 2]),
     "cfg5_sobolev_2d_dx_only": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 2, 1, 1), 1 << 20, [1]),
     # configs[4] names bf16: the mixed_bfloat16 policy of the build (single bf16 product per n x n operand pair)
