@@ -120,6 +120,11 @@ KNOBS = [
     ({"NIF_GW_LDS": "0", "NIF_FUSE_GW": "0"}, "ms_64x2_r1_so5", "plain", "float32"),
     ({"NIF_SOBW": "0"}, "ms_cfg5_64x4_si2", "sobolev", "float32"),         # k_sob instead of the streams-on-waves kernel
     ({"NIF_SOBW": "1"}, "ms_cfg5_64x4_si2", "sobolev", "float32"),
+    # r4: k_sobw took over resblock nets, class NIF and the 65..128-unit nets -- k_sob's forms for them stay the fallback (LDS) and A/B path
+    ({"NIF_SOBW": "0"}, "ms_res_64x2", "sobolev", "float32"),
+    ({"NIF_SOBW": "0"}, "nif_cfg1_32x2", "sobolev", "float32"),
+    ({"NIF_SOBW": "0"}, "ms_cfg3_128x3", "sobolev", "float32"),
+    ({"NIF_SOBW": "0"}, "ms_res_64x2", "sobolev", "mixed_bfloat16"),
     ({"NIF_LL_MLP": "1"}, "ll_plain_32x2_r3", "plain", "float32"),         # last-layer class on the r1 MLP kernels
     ({"NIF_FP32_MFMA": "1"}, "ms_res_64x2", "plain", "float32"),
     ({"NIF_PIPE_CHUNK": "64", "NIF_FP32_MFMA": "1"}, "ms_cfg2_64x4", "plain", "float32"),   # two-stream chunk pipeline of the k_snet3 path
