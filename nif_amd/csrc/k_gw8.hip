@@ -17,6 +17,11 @@
 // blocks as (input block, output-block pair)).  Tangent pseudo-tiles of the Sobolev step (zt_mod / bias_ntiles) as in k_gw_lds.
 #include "nif_internal.h"
 
+#ifndef NIF_G8_ABL
+#define NIF_G8_ABL 0      // measurement builds: bit 0 = no MFMAs, bit 1 = operand splits without the lo planes (results wrong).
+                          // r4, cfg-3 (six 128 x 128 x 2-plane gradients, 512 k points): all gradient kernels 1.09 ms; without MFMAs 0.98, without
+                          // lo-plane stores 1.04, neither 1.00 -- neither the matrix pipe nor the LDS writes bound k_gw8<1>, its load stream does
+#endif
 typedef __bf16 g8_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 g8_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float g8_f32x16 __attribute__((ext_vector_type(16)));
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
     for (int e = 0; e < 4; ++e) { const __bf16 h = (__bf16)v[e]; hi[e] = h; lo[e] = (__bf16)(v[e] - (float)h); }
     const int o = g8_off(f, p0);
     *reinterpret_cast<g8_bf16x4*>(plane_hi + o) = hi;
-    if (!DAB) *reinterpret_cast<g8_bf16x4*>(plane_lo + o) = lo;
+    if (!DAB && !(NIF_G8_ABL & 2)) *reinterpret_cast<g8_bf16x4*>(plane_lo + o) = lo;
   };
   // one tile: split register set RS into operand buffer `set`, barrier, refill RS with tile t + 2 grid, products
 #define G8_TILE(RS)                                                                                                    \
@@ -128,11 +133,14 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
         const int cb = ((((2 * hh + kg) ^ (fb >> 2)) & 3) << 4);                                                       \
         const g8_bf16x8 bh = *reinterpret_cast<const g8_bf16x8*>(Bhi + fb * 64 + cb);                                  \
         const g8_bf16x8 bl = *reinterpret_cast<const g8_bf16x8*>(Blo + fb * 64 + cb);                                  \
+        if (NIF_G8_ABL & 1) { acc[o][0] += (float)ah[0] * (float)bl[1] + (float)al[2] * (float)bh[3]; }                \
+        else {                                                                                                         \
         if (!DAB) {                                                                                                    \
           acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[o], 0, 0, 0);                                   \
           acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[o], 0, 0, 0);                                   \
         }                                                                                                              \
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[o], 0, 0, 0);                                     \
+        }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
     t += gridDim.x; set ^= 1;                                                                                          \
