@@ -5,7 +5,7 @@ set -u
 TAG=$1
 R=$PWD
 export TMPDIR=/tmp
-CMD="python $R/tools/bench_configs.py --only cfg5_sobolev_2d_4x64 --steps 6 --warmup 3"
+CMD="python $R/tools/bench_configs.py --only ${SOB_ONLY:-cfg5_sobolev_2d_4x64} --steps 6 --warmup 3"
 O=$R/gpurun_out/${TAG}_sobolev
 rm -rf $O; mkdir -p $O
 cd /tmp
