@@ -221,6 +221,10 @@ int nif_graph_begin(nif_ctx* ctx);
 int nif_graph_end(nif_ctx* ctx, int32_t* graph_id_out);
 int nif_graph_launch(nif_ctx* ctx, int32_t graph_id, const nif_adam* opt);
 int nif_graph_destroy(nif_ctx* ctx, int32_t graph_id);
+/* model.compile(loss=...) (README.md:33 passes 'mse'; keras.losses.get resolves any name): the per-element loss of every training /
+ * evaluation entry point of the context.  Reduction as Keras': mean over the outputs, sample-weighted sum over the batch / B_global. */
+typedef enum { NIF_LOSS_MSE_ = 0, NIF_LOSS_MAE_ = 1, NIF_LOSS_HUBER_ = 2, NIF_LOSS_LOG_COSH_ = 3 } nif_loss;
+int nif_set_loss(nif_ctx* ctx, int32_t kind /* nif_loss */);
 /* optimizer.apply_gradients with Adam on the (already all-reduced) nif_grad_dev() buffer */
 int nif_adam_step_dev(nif_ctx* ctx, const nif_adam* opt);
 /* zero [grad | loss]: what a rank contributes to the step's all-reduce when its shard has no rows left (uneven shards of

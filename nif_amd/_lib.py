@@ -22,6 +22,15 @@ ACT_IDS = {
 }
 
 
+# keras.losses.get names -> nif_loss
+LOSS_IDS = {
+    "mse": 0, "MSE": 0, "mean_squared_error": 0, "MeanSquaredError": 0,
+    "mae": 1, "MAE": 1, "mean_absolute_error": 1, "MeanAbsoluteError": 1,
+    "huber": 2, "huber_loss": 2, "Huber": 2,
+    "log_cosh": 3, "logcosh": 3, "LogCosh": 3,
+}
+
+
 class NifError(RuntimeError):
     pass
 
@@ -97,6 +106,7 @@ SIGNATURES = {
     "nif_graph_end": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
     "nif_graph_launch": (C.c_int, [_CTX, C.c_int32, C.POINTER(nif_adam)]),
     "nif_graph_destroy": (C.c_int, [_CTX, C.c_int32]),
+    "nif_set_loss": (C.c_int, [_CTX, C.c_int32]),
     "nif_sobolev_forward_dev": (C.c_int, [_CTX, _VP, C.c_int64, C.POINTER(C.c_int32), C.c_int32, _VP, _VP]),
     "nif_adam_step_dev": (C.c_int, [_CTX, C.POINTER(nif_adam)]),
     "nif_zero_grad": (C.c_int, [_CTX]),

@@ -496,8 +496,8 @@ __global__ __launch_bounds__(256) void k_ll_out(LLArgs A) {
       if (valid && A.u_out) A.u_out[pt * so + s] = u;
       if (TRAIN) {
         const float e = u - A.y[ptc * so + s];
-        se = fmaf(e, e, se);
-        const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+        const float du = dfac * wsamp * A.inv_bg / (float)so;
         A.DU[(tile * so + s) * 32 + p] = du;
         for (int j = 0; j < r; ++j) A.DPHI[(tile * (long)(so * r) + s * r + j) * 32 + p] = du * z[j * 32];
       }

@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256, (NB <= 2 ? 2 : 1)) void k_snet(SNetArgs A) {
       if (valid && hf == 0 && A.u_out) A.u_out[pt * A.so + o] = uo;
       if (TRAIN) {
         const float e = uo - A.y[ptc * A.so + o];
-        se = fmaf(e, e, se);
-        const float du = 2.0f * wsamp * e * A.inv_bg / (float)A.so;
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+        const float du = dfac * wsamp * A.inv_bg / (float)A.so;
         if (hf == 0) A.DU[(tile * A.so + o) * 32 + p] = du;
 #pragma unroll
         for (int b = 0; b < NB; ++b) gh[b] += du * wg[b];

@@ -325,8 +325,8 @@ __global__ __launch_bounds__(WAVES * 64, (NBL <= 2 ? 4 : (NBL == 3 ? 3 : (NBL ==
       if (valid && g == 0 && A.u_out) A.u_out[pt * so + o] = uo;
       if (TRAIN) {
         const float e = uo - A.y[ptc * so + o];
-        se = fmaf(e, e, se);
-        const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+        const float du = dfac * wsamp * A.inv_bg / (float)so;
         if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];

@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
         if (valid && g == 0 && A.u_out) A.u_out[pt * sou + s_] = uo;
         if (TRAIN) {
           const float e = uo - ys[s_ * 16];
-          se = fmaf(e, e, se);
-          const float du = 2.0f * wsamp * e * A.inv_bg / (float)sou;
+          NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+          const float du = dfac * wsamp * A.inv_bg / (float)sou;
           if (g == 0) {
             dul[s_ * 16 + p] = du;
             if (active) A.DU[(tile32 * sou + s_) * 32 + poff] = du;
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       if (valid && g == 0 && A.u_out) A.u_out[pt * so + o] = uo;
       if (TRAIN) {
         const float e = uo - ys[o * 16];
-        se = fmaf(e, e, se);
-        const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+        const float du = dfac * wsamp * A.inv_bg / (float)so;
         if (active && g == 0) A.DU[(tile32 * so + o) * 32 + poff] = du;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];

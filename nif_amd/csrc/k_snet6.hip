@@ -551,8 +551,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       part += __shfl_xor(part, 32);
       const float uo = part + bias;
       const float e = uo - ys[o * 16];
-      se = fmaf(e, e, se);
-      const float du = 2.0f * wsamp * e * A.inv_bg / (float)so;
+      NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+      const float du = dfac * wsamp * A.inv_bg / (float)so;
 #pragma unroll
       for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
       {

@@ -456,22 +456,26 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
         if (TRAIN) {
           float dq[NQ];
           const float e = uo - A.y[ptc * sou + i];
-          se = fmaf(e, e, se);
-          dq[0] = J.wu * 2.0f * wsamp * e * A.inv_bg / (float)sou;
+          NIF_LOSS_ACC(A.loss_kind, e, se, dfac0)
+          dq[0] = J.wu * dfac0 * wsamp * A.inv_bg / (float)sou;
           const float ysel = ((J.ymask >> i) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
           for (int d = 0; d < NS; ++d) {
             dq[1 + d] = 0.f;
             if (d < ns) {
-              const float ej = ysel * (uq[1 + d] - J.gt[(ptc * sou + i) * nxt + J.gcol[d]]);
-              sej = fmaf(ej, ej, sej);
-              dq[1 + d] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
+              const float ej = uq[1 + d] - J.gt[(ptc * sou + i) * nxt + J.gcol[d]];
+              float vj = 0.f;
+              NIF_LOSS_ACC(A.loss_kind, ej, vj, dfj)
+              sej = fmaf(ysel, vj, sej);
+              dq[1 + d] = ysel * dfj * J.wjn * wsamp * A.inv_bg;
             }
           }
           for (int e2 = 0; e2 < npar; ++e2) {
-            const float ej = ysel * (up[e2] - J.gt[(ptc * sou + i) * nxt + J.pcol[e2]]);
-            sej = fmaf(ej, ej, sej);
-            if (g == 0) lldqp[(e2 * sou + i) * 16 + p] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
+            const float ej = up[e2] - J.gt[(ptc * sou + i) * nxt + J.pcol[e2]];
+            float vj = 0.f;
+            NIF_LOSS_ACC(A.loss_kind, ej, vj, dfj)
+            sej = fmaf(ysel, vj, sej);
+            if (g == 0) lldqp[(e2 * sou + i) * 16 + p] = ysel * dfj * J.wjn * wsamp * A.inv_bg;
           }
           if (g == 0) {
 #pragma unroll
@@ -602,16 +606,18 @@ __global__ __launch_bounds__(256, ((NBL <= 2 && NSD <= 2) || (NBL <= 4 && NSD ==
       if (TRAIN) {
         float dq[NQ];
         const float e = uo - A.y[ptc * so + o];
-        se = fmaf(e, e, se);
-        dq[0] = J.wu * 2.0f * wsamp * e * A.inv_bg / (float)so;
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac0)
+        dq[0] = J.wu * dfac0 * wsamp * A.inv_bg / (float)so;
         const float ysel = ((J.ymask >> o) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
         for (int d = 0; d < NS; ++d) {
           dq[1 + d] = 0.f;
           if (d < ns) {
-            const float ej = ysel * (part[1 + d] - J.gt[(ptc * so + o) * J.gstride + J.gcol[d]]);
-            sej = fmaf(ej, ej, sej);
-            dq[1 + d] = 2.0f * J.wjn * wsamp * ej * A.inv_bg;
+            const float ej = part[1 + d] - J.gt[(ptc * so + o) * J.gstride + J.gcol[d]];
+            float vj = 0.f;
+            NIF_LOSS_ACC(A.loss_kind, ej, vj, dfj)
+            sej = fmaf(ysel, vj, sej);
+            dq[1 + d] = ysel * dfj * J.wjn * wsamp * A.inv_bg;
           }
         }
 #pragma unroll

@@ -427,8 +427,8 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
         else if (J.JU) J.JU[(pt * so + o) * J.gstride + gcol] = uo;
       }
       const float e = (q && !((J.ymask >> o) & 1u)) ? 0.0f : uo - ys[o * 16];       // tangent streams: the outputs of y_index only
-      se = fmaf(e, e, se);
-      const float du = 2.0f * lw * wsamp * e * A.inv_bg;
+      NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+      const float du = dfac * lw * wsamp * A.inv_bg;
       if (active && g == 0) A.DU[(((long)q * nt32 + tile32) * so + o) * 32 + poff] = du;
 #pragma unroll
       for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];

@@ -445,7 +445,7 @@ static void fill_snet_mlp(const nif_ctx* c, PNetArgs& a, const float* xin, int n
 }
 static void fill_ll(const nif_ctx* c, LLArgs& a, long B) {
   memset(&a, 0, sizeof(a));
-  a.theta = c->theta; a.bias_off = c->ll_bias; a.last_w = c->last_w;
+  a.theta = c->theta; a.bias_off = c->ll_bias; a.last_w = c->last_w; a.loss_kind = c->loss_kind;
   a.PHI = c->PHI; a.Z = c->Z; a.B = B; a.r = c->r; a.so = c->so;
   a.DU = c->DU; a.DPHI = c->DPHI; a.DA = c->DA; a.DZL = c->DZL; a.loss_partial = c->loss_partial;
 }
@@ -453,7 +453,7 @@ static void fill_ll(const nif_ctx* c, LLArgs& a, long B) {
 static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
   const int sop = c->so * c->r;
-  a.theta = c->ll_slots; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
+  a.theta = c->ll_slots; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B; a.loss_kind = c->loss_kind;
   a.si = c->si; a.so = sop; a.n = c->n; a.nh = c->nh; a.r = 0; a.po = 0;
   a.act = NIF_ACT_SINE; a.res = c->cfg.s_resblock; a.nif_skip = 0; a.omega = c->cfg.s_omega0;
   a.off_Wh = 0; a.off_bh = 0;
@@ -467,7 +467,7 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
 }
 static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
-  a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
+  a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B; a.loss_kind = c->loss_kind;
   a.si = c->si; a.so = c->so; a.n = c->n; a.nh = c->nh; a.r = c->r; a.po = c->po;
   a.act = c->kind == NIF_KIND_NIF ? c->cfg.s_act : NIF_ACT_SINE;
   a.res = c->cfg.s_resblock; a.nif_skip = (c->kind == NIF_KIND_NIF);
@@ -1750,6 +1750,13 @@ static int sob_par_pass(nif_ctx* c, const float* xin, long B, long Bg, const Sob
   return jac_reg_pass(c, xin, B, Bg, mu_blk);
 }
 
+// compile(loss=...) of the Keras surface (README.md:33 'mse'): the per-element loss of every training / evaluation entry point of this
+// context -- 0 'mse', 1 'mae', 2 'huber' (delta 1), 3 'log_cosh' (include/nif_hip.h nif_loss); the Sobolev step applies it to both outputs
+extern "C" int nif_set_loss(nif_ctx* c, int32_t kind) {
+  if (!c || kind < 0 || kind > 3) return fail(NIF_ERR_INVALID, "nif_set_loss: 0 mse, 1 mae, 2 huber, 3 log_cosh");
+  c->loss_kind = kind;
+  return NIF_OK;
+}
 // Keras activity_regularizer of the last ParameterNet layer (nif/model.py:118-125, :226, :659, :731)
 extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
   if (!c || l1 < 0.f || l2 < 0.f) return fail(NIF_ERR_INVALID, "bad argument");

@@ -67,7 +67,30 @@ struct PNetArgs {
 // ------------------------------------------------------------------------------------------
 // hypernetwork ShapeNet kernels (NIF / NIFMultiScale)
 // ------------------------------------------------------------------------------------------
+// Keras loss of compile(loss=...) (README.md:33 uses 'mse'; r4: the other regression losses keras.losses.get knows for this surface).
+// Per element e = prediction - target: value v(e) and derivative v'(e); the reduction is Keras' for all of them (mean over the last
+// axis, sample-weighted sum over the batch / batch size).  kind 0 keeps the mse arithmetic of r1-r3 bit for bit.
+enum { NIF_LOSS_MSE = 0, NIF_LOSS_MAE = 1, NIF_LOSS_HUBER = 2, NIF_LOSS_LOGCOSH = 3 };
+__device__ __forceinline__ void nif_loss_vd(int kind, float e, float* v, float* d) {
+  if (kind == NIF_LOSS_MAE) { *v = fabsf(e); *d = e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); }
+  else if (kind == NIF_LOSS_HUBER) {            // keras.losses.huber, delta = 1
+    const float a = fabsf(e);
+    *v = a <= 1.0f ? 0.5f * e * e : a - 0.5f;
+    *d = a <= 1.0f ? e : (e > 0.f ? 1.0f : -1.0f);
+  } else {                                      // log_cosh: e + softplus(-2 e) - log 2 (keras.losses.log_cosh), derivative tanh(e)
+    const float t = -2.0f * e;
+    *v = e + (fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)))) - 0.69314718055994531f;
+    *d = tanhf(e);
+  }
+}
+// se += v(e), dfac = v'(e): the squared error inline (fmaf, factor 2 e as before), everything else through nif_loss_vd
+#define NIF_LOSS_ACC(KIND_, E_, SE_, DFAC_)                                   \
+  float DFAC_;                                                                \
+  if ((KIND_) == NIF_LOSS_MSE) { SE_ = fmaf(E_, E_, SE_); DFAC_ = 2.0f * (E_); } \
+  else { float v_; nif_loss_vd(KIND_, E_, &v_, &DFAC_); SE_ += v_; }
+
 struct SNetArgs {
+  int loss_kind;                          // NIF_LOSS_*
   const float* theta;
   const float* xin; int ncol; int col0;   // coordinates are columns col0..col0+si
   long B;
@@ -225,6 +248,7 @@ void launch_given_w(const float* x, const float* w, float* u, long B, int si, in
                     int act, int res, int nif_skip, float omega, hipStream_t st);
 // last-layer-parameterised class: u = Dot(phi(x), a) + bias and its adjoint (nif/model.py:1240-1269)
 struct LLArgs {
+  int loss_kind;
   const float* theta; long bias_off; long last_w;   // last_layer_bias [so]; pnet last layer W[r][r]
   const float* PHI;     // [tiles][so*r][32]  (row s*r + j)
   const float* Z;       // [tiles][r][32]     pnet output a

@@ -390,6 +390,10 @@ class Engine(object):
         """last-layer class: cfg_shape_net l1_reg / l2_reg over the shared ShapeNet's kernels and biases (model.py:1028-1039)"""
         check(self.lib.nif_set_shapenet_regularizer(self.ctx, float(l1), float(l2)))
 
+    def set_loss(self, name):
+        """compile(loss=name): 'mse' | 'mae' | 'huber' | 'log_cosh' (and Keras' aliases)"""
+        check(self.lib.nif_set_loss(self.ctx, int(_lib.LOSS_IDS[name])))
+
     def set_jac_regularizer(self, l1):
         check(self.lib.nif_set_jac_regularizer(self.ctx, float(l1)))
 

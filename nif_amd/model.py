@@ -61,6 +61,8 @@ class Model(object):
     def _push_losses(self, e, bg):
         """the loss terms THIS model adds on top of its owner's configuration, for a step / evaluation over bg rows"""
         e.set_jac_regularizer(self._jac_reg)
+        if hasattr(e, "set_loss"):
+            e.set_loss(self.loss or "mse")          # compile(loss=...): per model, the engine is shared
         if self._po_l1:
             a1, a2 = getattr(self._owner, "_act_reg", (0.0, 0.0))
             if a2:
@@ -71,11 +73,13 @@ class Model(object):
         """back to the owner's configuration: models that share the engine (.model(), the sub-models, SobolevModel, the L-BFGS
         closures) must not inherit this model's terms"""
         e.set_jac_regularizer(0.0)
+        if hasattr(e, "set_loss"):
+            e.set_loss("mse")
         if self._po_l1:
             e.set_activity_regularizer(*getattr(self._owner, "_act_reg", (0.0, 0.0)))
 
     @contextlib.contextmanager
-    def _plain_loss(self, e):
+    def _plain_loss(self, e, loss="mse"):
         """the bare `loss(model(x), y)` of the reference's L-BFGS closures (lbfgs.py:66-68, lbfgs_V2.py:63-66 evaluate the loss
         FUNCTION on the model's output: `model.losses` -- kernel / bias / activity regularisers, JacRegLatentLayer's add_loss --
         is never added there): every regularisation term of the engine is switched off for the evaluation and restored after"""
@@ -83,6 +87,8 @@ class Model(object):
         reg, act, sreg = getattr(o, "_reg", (0.0, 0.0)), getattr(o, "_act_reg", (0.0, 0.0)), getattr(o, "_sreg", (0.0, 0.0))
         n_pnet = o._n_pnet_params() if reg != (0.0, 0.0) else 0
         e.set_jac_regularizer(0.0)
+        if hasattr(e, "set_loss"):
+            e.set_loss(loss)
         if reg != (0.0, 0.0):
             e.set_regularizer(0.0, 0.0, 0, n_pnet)
         if act != (0.0, 0.0):
@@ -92,6 +98,8 @@ class Model(object):
         try:
             yield
         finally:
+            if hasattr(e, "set_loss"):
+                e.set_loss("mse")
             if reg != (0.0, 0.0):
                 e.set_regularizer(reg[0], reg[1], 0, n_pnet)
             if act != (0.0, 0.0):
@@ -190,16 +198,16 @@ class Model(object):
     def compile(self, optimizer="adam", loss="mse", **kwargs):
         if self._role != "full":
             raise ValueError("only the full model can be compiled for training")
-        name = loss if isinstance(loss, str) else getattr(loss, "name", None)
-        if name not in ("mse", "mean_squared_error", "MSE"):
-            raise NotImplementedError("only loss='mse' is built (README.md:33)")
+        name = loss if isinstance(loss, str) else (getattr(loss, "name", None) or getattr(loss, "__name__", None))
+        if name not in _lib.LOSS_IDS:
+            raise NotImplementedError("loss=%r: built are 'mse' (README.md:33), 'mae', 'huber' (delta 1), 'log_cosh'" % (loss,))
         if kwargs:
             raise NotImplementedError("compile(%s): not on the built hot path" % ", ".join(sorted(kwargs)))
         new = get_optimizer(optimizer)
         if new is not self.optimizer:
             self._fresh_slots = True     # Keras: a newly compiled optimizer starts with zero slots and iteration 0
         self.optimizer = new
-        self.loss = "mse"
+        self.loss = ("mse", "mae", "huber", "log_cosh")[_lib.LOSS_IDS[name]]
 
     _EVAL_CHUNK = 1 << 18
     # fit(): epochs of at least four batches no larger than _GRAPH_MAX_BATCH can be captured into a hipGraph (NIF_GRAPH=1 or
@@ -531,7 +539,7 @@ class SobolevModel(Model):
     def compile(self, optimizer="adam", loss="mse", loss_weights=None, **kwargs):
         if isinstance(loss, (list, tuple)):
             if len(set(loss)) != 1:
-                raise NotImplementedError("both outputs use loss='mse'")
+                raise NotImplementedError("both outputs of the two-output model take the same loss")
             loss = loss[0]
         Model.compile(self, optimizer=optimizer, loss=loss, **kwargs)
         if loss_weights is not None:

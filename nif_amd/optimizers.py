@@ -216,8 +216,10 @@ class TFPLBFGS(object):
         import numpy as np
         self._np = np
         name = loss_fun if isinstance(loss_fun, str) else getattr(loss_fun, "name", None) or getattr(loss_fun, "__name__", None)
-        if name not in (None, "mse", "MSE", "mean_squared_error", "MeanSquaredError"):
-            raise NotImplementedError("TFPLBFGS: only the mean-squared-error loss is on the built hot path, got %r" % (loss_fun,))
+        from . import _lib
+        if name is not None and name not in _lib.LOSS_IDS:
+            raise NotImplementedError("TFPLBFGS: built losses are 'mse', 'mae', 'huber', 'log_cosh', got %r" % (loss_fun,))
+        self._loss = "mse" if name is None else ("mse", "mae", "huber", "log_cosh")[_lib.LOSS_IDS[name]]
         self.model = model
         e = model._engine
         x = e._inputs(inps)
@@ -246,7 +248,7 @@ class TFPLBFGS(object):
         # the reference's closure is `loss(model(x), y)` -- the loss FUNCTION alone, model.losses is never added (lbfgs.py:66-68,
         # lbfgs_V2.py:63-66): no weight / activity / latent-Jacobian regulariser in the L-BFGS objective, whatever the last
         # fit() of a model sharing this engine left configured
-        with self.model._plain_loss(e):
+        with self.model._plain_loss(e, **({} if getattr(self, "_loss", "mse") == "mse" else {"loss": self._loss})):
             e.loss_grad_dev(self._d_x.at(0), self._d_y.at(0), self._d_sw.at(0) if self._d_sw is not None else None, self._B, self._B)
             loss, g = e.grad_read()
         self._losses.append(loss)

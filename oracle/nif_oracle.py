@@ -86,6 +86,21 @@ def act_fn(name):
     raise ValueError("unknown activation %r" % (name,))
 
 
+def loss_vd(name):
+    """(v, v') of the per-element Keras regression losses keras.losses.get resolves for compile(loss=...): e = prediction - target.
+    'mse' e^2; 'mae' |e|; 'huber' (delta = 1): e^2 / 2 for |e| <= 1, |e| - 1/2 beyond; 'log_cosh': log cosh e.  The reduction is the
+    same for all of them: mean over the last axis, sample-weighted sum over the batch / batch size (README.md:33 uses 'mse')."""
+    if name in ("mse", "mean_squared_error"):
+        return (lambda e: e ** 2), (lambda e: 2.0 * e)
+    if name in ("mae", "mean_absolute_error"):
+        return np.abs, np.sign
+    if name in ("huber", "huber_loss"):
+        return (lambda e: np.where(np.abs(e) <= 1.0, 0.5 * e ** 2, np.abs(e) - 0.5)), (lambda e: np.clip(e, -1.0, 1.0))
+    if name in ("log_cosh", "logcosh"):
+        return (lambda e: np.logaddexp(e, -e) - math.log(2.0)), np.tanh
+    raise ValueError("unknown loss %r" % (name,))
+
+
 # ----------------------------------------------------------------------------------------------
 # model description (what nif/model.py's three constructors derive from the cfg dicts)
 # ----------------------------------------------------------------------------------------------
@@ -842,7 +857,7 @@ def weight_regularizer_term(spec, ws, preg, sreg=(0.0, 0.0)):
     return loss, grads
 
 
-def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, act_reg=None):
+def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, act_reg=None, loss="mse"):
     """MSE loss and gradient w.r.t. every variable (Keras order), hand-derived adjoint
     (SURVEY a-10).  `batch_global` lets a shard compute its share of a larger batch's
     mean (loss and grads are scaled by 1/batch_global instead of 1/B).
@@ -859,10 +874,11 @@ def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, ac
     else:
         u, tape = shapenet_given_w(spec, x, pout, keep=True)
     e = u - y
-    per = (e ** 2).mean(axis=1)
+    lv, ld = loss_vd(loss)
+    per = lv(e).mean(axis=1)
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
     loss = (per * w_a).sum() / Bg
-    g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
+    g_u = ld(e) * w_a[:, None] / (Bg * spec.so)
     if spec.kind == KIND_LL:
         g_pout = np.einsum("bsj,bs->bj", phi, g_u)
         if act_reg is not None and (act_reg[0] or act_reg[1]):     # the ParameterNet output of this class is a [B, r]
@@ -890,7 +906,7 @@ def loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, ac
     return loss, pnet_backward(spec, ws, ptape, g_pout)
 
 
-def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
+def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, loss="mse"):
     """Sobolev training step (BASELINE config 5): the two-output Keras model
         y, dys_dxs = JacobianLayer(model, y_index=all, x_index)(inputs)      (nif/layers/gradient.py:36-49)
     compiled with loss='mse', loss_weights=[1, w_jac]:   loss = mse(y) + w_jac * mse(dys_dxs)   (Keras 'mse' =
@@ -906,7 +922,7 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     hyper layer and the (primal, tangent) ParameterNet (pnet_tangents_backward).
     Returns (loss, grads in Keras order, u, dudx)."""
     if spec.kind == KIND_LL:
-        return _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight, batch_global)
+        return _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight, batch_global, loss=loss)
     assert spec.kind in (KIND_MS, KIND_NIF)
     nif = spec.kind == KIND_NIF
     B = inputs.shape[0]
@@ -971,9 +987,10 @@ def sobolev_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weig
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
     e = u - y
     ej = J - np.asarray(dydx).reshape(B, so, nx)
-    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
-    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
-    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    lv, ld = loss_vd(loss)
+    loss = (lv(e).mean(axis=1) * w_a).sum() / Bg + w_jac * (lv(ej).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = ld(e) * w_a[:, None] / (Bg * so)
+    g_ud = [w_jac * ld(ej[:, :, k]) * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
     # ---- adjoint ---------------------------------------------------------------------------------
     gw = np.zeros((B, spec.po), dtype=u.dtype)
     gwd = [np.zeros((B, spec.po), dtype=u.dtype) if tw[q] is not None else None for q in range(nx)]   # dL/dpnet_out'
@@ -1108,9 +1125,10 @@ def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, samp
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
     e = u - y
     ej = J - np.asarray(dydx).reshape(B, so, nx)
-    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
-    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
-    g_ud = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    lv, ld = loss_vd("mse")
+    loss = (lv(e).mean(axis=1) * w_a).sum() / Bg + w_jac * (lv(ej).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = ld(e) * w_a[:, None] / (Bg * so)
+    g_ud = [w_jac * ld(ej[:, :, k]) * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
     # ---- adjoint -----------------------------------------------------------------------------------------------------
     gM = np.zeros_like(M)
     gzt = np.zeros_like(zt)
@@ -1165,7 +1183,7 @@ def sobolev_planes_loss_and_grad(spec, ws, inputs, y, dydx, x_index, w_jac, samp
     return loss, grads, u, J
 
 
-def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None):
+def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, batch_global=None, loss="mse"):
     """Sobolev step of the last-layer-parameterised class (model.py:1044-1068, :1219-1269 under JacobianLayer): the shared
     SIREN ShapeNet x -> phi [B,so,r] carries the coordinate tangents phi'_d (_mlp_tangents), u = Dot(phi, a) + bias and
     du/dx_d = Dot(phi'_d, a) with a = the ParameterNet output.  A parameter column c leaves phi alone and moves a:
@@ -1201,9 +1219,10 @@ def _sobolev_ll(spec, ws, inputs, y, dydx, x_index, w_jac, sample_weight=None, b
     w_a = np.ones((B,), dtype=u.dtype) if sample_weight is None else sample_weight
     e = u - y
     ej = J - np.asarray(dydx).reshape(B, so, nx)
-    loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg + w_jac * ((ej ** 2).mean(axis=(1, 2)) * w_a).sum() / Bg
-    g_u = 2.0 * e * w_a[:, None] / (Bg * so)
-    g_J = [2.0 * w_jac * ej[:, :, k] * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
+    lv, ld = loss_vd(loss)
+    loss = (lv(e).mean(axis=1) * w_a).sum() / Bg + w_jac * (lv(ej).mean(axis=(1, 2)) * w_a).sum() / Bg
+    g_u = ld(e) * w_a[:, None] / (Bg * so)
+    g_J = [w_jac * ld(ej[:, :, k]) * w_a[:, None] / (Bg * so * nx) for k in range(nx)]
     g_a = np.einsum("bsj,bs->bj", phi, g_u)
     g_phi = g_u[:, :, None] * a[:, None, :]
     g_phid = [np.zeros((B, so * r), dtype=u.dtype) for _ in seeds]

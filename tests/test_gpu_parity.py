@@ -883,6 +883,50 @@ def test_remaining_keras_activations(act):
                     {"input_dim": 1, "latent_dim": 1, "units": 8, "nlayers": 1, "activation": "softmax"})
 
 
+@pytest.mark.parametrize("loss", ["mae", "huber", "log_cosh"])
+@pytest.mark.parametrize("name", ["ms_cfg2_64x4", "ms_cfg3_128x3", "ms_res_48x2_pres", "nif_cfg1_32x2", "ll_plain_32x2_r3", "ms_32x2_r7_si3"])
+def test_compile_with_the_other_keras_losses(name, loss):
+    """compile(loss='mae' | 'huber' | 'log_cosh') (keras.losses.get; README.md:33 passes 'mse'): loss and every gradient tensor of
+    the plain step (the fused-gradient kernel, the 128-wide / resblock / class-NIF / last-layer forms, the f32-input MFMA path of an
+    odd block count) and of the Sobolev step against the oracle; evaluate(); one model's loss does not leak into another model of
+    the same engine"""
+    import nif_amd
+    from nif_amd import JacobianLayer, SobolevModel
+    m, model, spec, ws, x, y, sw = _make(name)
+    y = (3.0 * y).astype(np.float32)                       # |e| on both sides of Huber's delta
+    model.compile(nif_amd.Adam(1e-3), loss)
+    x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+    rl, rg = O.loss_and_grad(spec, ws, x64, y64, s64, loss=loss)
+    assert abs(model.evaluate(x, y, sample_weight=sw) - rl) < 2e-5 * abs(rl)
+    m._engine.set_loss(loss)
+    l_, g_ = m._engine.loss_and_grad(x, y, sw)
+    assert abs(l_ - rl) < 2e-5 * abs(rl), (l_, rl)
+    def close(g, ref, bar):      # the metric of test_loss_and_grad_match_oracle: per tensor, relative + 2e-6 of the whole gradient's norm
+        off, gn = 0, np.linalg.norm(ref)
+        for nm, shp in spec.param_shapes():
+            k = int(np.prod(shp))
+            err = np.linalg.norm(g[off:off + k].astype(np.float64) - ref[off:off + k])
+            assert err <= bar * np.linalg.norm(ref[off:off + k]) + 2e-6 * gn, (nm, err, np.linalg.norm(ref[off:off + k]), gn)
+            off += k
+    close(g_, O.flatten(rg), 3e-4 if loss != "mae" else 6e-4)        # (mae: sign(e) flips where |e| ~ 1e-7)
+    xi = list(range(spec.pi, spec.pi + spec.si))[:2]
+    gt = np.random.default_rng(5).uniform(-2, 2, size=(x.shape[0], spec.so, len(xi))).astype(np.float32)
+    sl, sg = m._engine.sobolev_loss_and_grad(x, y, gt, xi, 0.1, sw)
+    rsl, rsg, _, _ = O.sobolev_loss_and_grad(spec, ws, x64, y64, gt.astype(np.float64), xi, 0.1, s64, loss=loss)
+    assert abs(sl - rsl) < 3e-5 * abs(rsl), (sl, rsl)
+    close(sg, O.flatten(rsg), 4e-4 if loss != "mae" else 8e-4)
+    m._engine.set_loss("mse")
+    # the two-output model compiled with the same loss: fit()'s first logged loss is the oracle's
+    sm = SobolevModel(JacobianLayer(model, list(range(spec.so)), xi))
+    sm.compile(nif_amd.Adam(1e-4), loss, loss_weights=[1.0, 0.1])
+    h = sm.fit(x, [y, gt], batch_size=x.shape[0], epochs=1, shuffle=False, verbose=0, sample_weight=sw)
+    assert abs(h.history["loss"][0] - rsl) < 3e-5 * abs(rsl)
+    # another model of the same engine still evaluates ITS loss (mse)
+    other = m.model(); other.compile("adam", "mse")
+    wnow = [w.astype(np.float64) for w in other.get_weights()]
+    assert abs(other.evaluate(x, y) - O.loss_and_grad(spec, wnow, x64, y64)[0]) < 2e-5 * abs(rl)
+
+
 def test_sobolev_fit_learns_value_and_slope_of_travelling_wave():
     """Train u(t,x) on values AND du/dx of the closed-form travelling wave; both errors must drop, and the
     derivative error must end lower than with value-only training on the same few points."""

@@ -381,3 +381,31 @@ def test_remaining_keras_activations_match_torch_and_their_own_derivatives(act):
         assert np.allclose(O.forward(spec, ws, x), tu, rtol=1e-12, atol=1e-12) and abs(loss - tl) <= 1e-12 * max(1.0, abs(tl))
         for g, t in zip(grads, tg):
             assert np.abs(g - t).max() / max(np.abs(t).max(), 1e-30) < 1e-9
+
+
+@pytest.mark.parametrize("loss", ["mae", "huber", "log_cosh"])
+@pytest.mark.parametrize("name", ["nif_swish", "ms_plain_r3_si2", "ll_plain"])
+def test_other_keras_losses_match_torch_autograd(name, loss):
+    """compile(loss=...) beyond 'mse' (keras.losses.get: 'mae', 'huber' with delta 1, 'log_cosh'): the oracle's loss / gradient against
+    torch autograd; targets scaled so that |e| straddles Huber's delta"""
+    pytest.importorskip("torch")
+    from tests import torch_ref as T
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name, B=17)
+    y = 3.0 * y
+    l_, g_ = O.loss_and_grad(spec, ws, inputs, y, sw, loss=loss)
+    tl, tg, _ = T.loss_and_grad(kind, cs, cp, ws, inputs, y, sw, loss=loss)
+    assert abs(l_ - tl) <= 1e-12 * max(1.0, abs(tl))
+    for g, t in zip(g_, tg):
+        assert np.abs(g - t).max() / max(np.abs(t).max(), 1e-30) < 1e-9
+    # the Sobolev step takes the same loss on both outputs: against central differences of the loss in two random directions
+    xi = list(range(spec.pi, spec.pi + spec.si))
+    rng = np.random.default_rng(3)
+    gt = rng.uniform(-2, 2, size=(17, spec.so, len(xi)))
+    l0, g0, _, _ = O.sobolev_loss_and_grad(spec, ws, inputs, y, gt, xi, 0.3, sw, loss=loss)
+    for _ in range(2):
+        d = [rng.standard_normal(w.shape) for w in ws]
+        h = 1e-6
+        lp = O.sobolev_loss_and_grad(spec, [w + h * q for w, q in zip(ws, d)], inputs, y, gt, xi, 0.3, sw, loss=loss)[0]
+        lm = O.sobolev_loss_and_grad(spec, [w - h * q for w, q in zip(ws, d)], inputs, y, gt, xi, 0.3, sw, loss=loss)[0]
+        dd = sum((a * b).sum() for a, b in zip(g0, d))
+        assert abs((lp - lm) / (2 * h) - dd) <= 2e-5 * max(1.0, abs(dd)), ((lp - lm) / (2 * h), dd)

@@ -113,12 +113,24 @@ def forward(kind, cs, cp, ws, inputs):
     return ein(u, Wl) + bl
 
 
-def loss_and_grad(kind, cs, cp, ws_np, inputs_np, y_np, sw_np=None):
+def _loss_elem(name, e):
+    if name == "mse":
+        return e ** 2
+    if name == "mae":
+        return e.abs()
+    if name == "huber":          # keras.losses.huber, delta = 1
+        return torch.where(e.abs() <= 1.0, 0.5 * e ** 2, e.abs() - 0.5)
+    if name == "log_cosh":
+        return torch.log(torch.cosh(e))
+    raise ValueError(name)
+
+
+def loss_and_grad(kind, cs, cp, ws_np, inputs_np, y_np, sw_np=None, loss="mse"):
     ws = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws_np]
     inputs = torch.tensor(inputs_np, dtype=torch.float64)
     y = torch.tensor(y_np, dtype=torch.float64)
     u = forward(kind, cs, cp, ws, inputs)
-    per = ((u - y) ** 2).mean(dim=1)
+    per = _loss_elem(loss, u - y).mean(dim=1)
     if sw_np is not None:
         per = per * torch.tensor(sw_np, dtype=torch.float64)
     loss = per.sum() / u.shape[0]
