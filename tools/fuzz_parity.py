@@ -25,6 +25,7 @@ def draw(rng, wide=True):
     p_res = bool(rng.integers(0, 2)) and kind != "NIF"
     p_act = str(rng.choice(["sine", "swish", "tanh"]))
     act = str(rng.choice(["swish", "tanh", "gelu", "selu", "softsign", "hard_sigmoid"] if wide else ["swish", "tanh", "gelu"]))     # (r4: + the rest of keras.activations)
+    loss = str(rng.choice(["mse", "mse", "mse", "huber", "log_cosh", "mae"])) if wide else "mse"      # (r4: compile(loss=...))
     if kind == "LL" and so * r > 32:
         r = max(1, 32 // so)
     B = int(rng.choice([1, 31, 33, 64, 97, 130, 257, 515, 1031, 4099]))
@@ -35,10 +36,10 @@ def draw(rng, wide=True):
         cfg = _cfg("NIF", n, L, nst, lst, r, si, so, pi, act=act)
     else:
         cfg = _cfg(kind, n, L, nst, lst, r, si, so, pi, s_res=s_res, p_act=p_act, p_res=p_res)
-    return cfg, B, dict(kind=kind, n=n, L=L, nst=nst, lst=lst, r=r, si=si, so=so, pi=pi, s_res=s_res, p_res=p_res, p_act=p_act, act=act, B=B)
+    return cfg, B, dict(kind=kind, n=n, L=L, nst=nst, lst=lst, r=r, si=si, so=so, pi=pi, s_res=s_res, p_res=p_res, p_act=p_act, act=act, B=B, loss=loss)
 
 
-def run_case(cfg, B, seed):
+def run_case(cfg, B, seed, loss="mse"):
     kind, cs, cp = cfg
     spec = O.Spec(kind, cs, cp)
     rng = np.random.default_rng(seed)
@@ -72,6 +73,17 @@ def run_case(cfg, B, seed):
         if e < 3.0 * s_ + 1e-5:
             return [("cond", e, s_)]           # everything downstream inherits the conditioning: nothing more to learn from the case
         bad.append(("forward", e, "one-ulp sensitivity of the oracle", s_))
+    if loss != "mse":      # the plain and the Sobolev step under another Keras loss (targets scaled: |e| on both sides of Huber's delta)
+        ys = (3.0 * y).astype(np.float32)
+        m._engine.set_loss(loss)
+        try:
+            l2, g2 = m._engine.loss_and_grad(x, ys, sw)
+            rl2, rg2 = O.loss_and_grad(spec, ws64, x64, ys.astype(np.float64), sw64, loss=loss)
+            gn = np.linalg.norm(O.flatten(rg2))
+            if abs(l2 - rl2) > 2e-5 * abs(rl2) or np.linalg.norm(g2 - O.flatten(rg2)) > (6e-4 if loss == "mae" else 3e-4) * gn:
+                bad.append(("loss " + loss, l2, rl2, float(np.linalg.norm(g2 - O.flatten(rg2)) / gn)))
+        finally:
+            m._engine.set_loss("mse")
     loss, grad = m._engine.loss_and_grad(x, y, sw)
     rl, rg = O.loss_and_grad(spec, ws64, x64, y64, sw64)
     if abs(loss - rl) > 2e-5 * abs(rl):
@@ -207,7 +219,7 @@ def main():
         if only is not None and i not in only:
             continue
         try:
-            bad = run_case(cfg, B, seed * 1000 + i)
+            bad = run_case(cfg, B, seed * 1000 + i, desc.get("loss", "mse"))
         except Exception as ex:      # noqa: BLE001
             bad = [("EXCEPTION", repr(ex)[:200])]
             traceback.print_exc()
