@@ -96,6 +96,10 @@ struct S6Args {
   float* partial; long pstride;     // partial-gradient rows [gridDim.x][pstride] (the ShapeNet = hypernetwork columns of them)
 };
 
+#ifndef NIF_S6_RECOMP0
+#define NIF_S6_RECOMP0 1     // the first layer's output (input of hidden matrix 0) is recomputed in the adjoint from the tile's inputs
+                             // (si FMAs + a sine per element) instead of going through the ring: a quarter of the ring traffic less
+#endif
 #ifndef NIF_S6_CONS_PRIO
 #define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
 #endif
@@ -468,26 +472,30 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 
     f32x4 h[NBL], acc[NBL];
     // ---- first layer ----------------------------------------------------------------------------------------------------
-    {
-      const float* s0 = sm + r * nsm + 4 * g;
+    auto first_layer = [&](f32x4 (&out)[NBL]) __attribute__((always_inline)) {
+      f32x4 a_[NBL];
+      {
+        const float* s0 = sm + r * nsm + 4 * g;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-        acc[b] = s;
+        for (int b = 0; b < NBL; ++b) {
+          f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          a_[b] = s;
+        }
       }
-    }
-    {
-      const float zt = zt_base[0];
-      const float* s0 = sm + 4 * g;
+      {
+        const float zt = zt_base[0];
+        const float* s0 = sm + 4 * g;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-        acc[b] += zt * s;
+        for (int b = 0; b < NBL; ++b) {
+          f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          a_[b] += zt * s;
+        }
       }
-    }
-    sine16_tag<NBL>(acc, h);
+      sine16_tag<NBL>(a_, out);
+    };
+    first_layer(h);
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
     for (int j = 0; j < nh; ++j) {
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
-        S6_CHUNK_RING({ ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
 #else
         S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
 #endif
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
 #else
         S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
 #endif
