@@ -58,10 +58,11 @@ def roofline_block(dims, B, snet_ms, fused, traffic_json, sha):
     sn_s = snet_ms * 1e-3
     alg_bytes = 4.0 * (pi + si + so)                            # what a training step must read per point
     nblk = (n + 31) // 32
-    if fused:     # k_snet6: forward + data adjoint + weight gradients; h_j through the private ring (write + read), latent in, dL/dz out
+    if fused:     # k_snet6: forward + data adjoint + weight gradients; h_1 .. h_{nh-1} through the private ring (write + read; h_0 is
+                  # recomputed in the adjoint), latent in, dL/dz out
         alg_flop = 6.0 * (r + 1) * n_w
         exec_bf16 = (6.0 + 3.0 + 3.0) * 2.0 * (r + 1) * nh * n * n
-        design_bytes = 4.0 * 32 * nblk * 2 * nh + 4.0 * (si + so + 1) + 8.0 * r
+        design_bytes = 4.0 * 32 * nblk * 2 * (nh - 1) + 4.0 * (si + so + 1) + 8.0 * r
         kernel = ("k_snet6<4> (ShapeNet forward + MSE + data adjoint + every ShapeNet weight gradient; fp32 products as bf16 splits on "
                   "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, 8 producer + 8 consumer waves per workgroup)")
     else:         # k_snet4: forward + data adjoint; h and dL/da stash rows written, h re-read
