@@ -266,7 +266,7 @@ class Model(object):
         return sw
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
-            sample_weight=None, initial_epoch=0, validation_data=None, validation_split=0.0, **kwargs):
+            sample_weight=None, initial_epoch=0, validation_data=None, validation_split=0.0, steps_per_epoch=None, **kwargs):
         """Keras Model.fit semantics for in-memory arrays (or one file of a shard dataset, nif_amd.data): per epoch
         optionally shuffle, walk batches of `batch_size` (default 32, last one partial), one Adam step per batch; the
         epoch 'loss' is the sample-weighted mean of the batch losses.  The table is made resident in HBM once; a
@@ -292,7 +292,7 @@ class Model(object):
             val = (cut(x, at, n_all), cut(y, at, n_all)) + (() if sample_weight is None else (np.asarray(sample_weight)[at:],))
             return self.fit(cut(x, 0, at), cut(y, 0, at), batch_size=batch_size, epochs=epochs, verbose=verbose, callbacks=callbacks,
                             shuffle=shuffle, sample_weight=None if sample_weight is None else np.asarray(sample_weight)[:at],
-                            initial_epoch=initial_epoch, validation_data=val, **kwargs)
+                            initial_epoch=initial_epoch, validation_data=val, steps_per_epoch=steps_per_epoch, **kwargs)
         if self.optimizer is None:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
         if kwargs:
@@ -386,6 +386,12 @@ class Model(object):
             use_graph = (self._graph_epochs and world == 1 and shard is None and not self._po_l1 and len(sizes) >= 4
                          and max(sizes) <= self._GRAPH_MAX_BATCH and hasattr(e, "graph_begin") and epochs - initial_epoch >= 2)
             graph_id = None
+            stream = [-1, 0]          # steps_per_epoch: (pass, next batch of the pass) of the one iterator over `epochs` passes
+            if steps_per_epoch is not None:
+                if int(steps_per_epoch) < 1:
+                    raise ValueError("steps_per_epoch must be a positive integer")
+                if world > 1 or shard is not None:
+                    raise NotImplementedError("steps_per_epoch: in-memory arrays on one GPU (ranks with uneven shards would disagree on the stream)")
             for epoch in range(initial_epoch, epochs):
                 if self.stop_training:
                     break
@@ -393,27 +399,30 @@ class Model(object):
                     if hasattr(cb, "on_epoch_begin"):
                         cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
-                if dev_shuffle:
-                    perm = rng.permutation(N).astype(np.int32)
-                    d_perm.upload(perm.view(np.float32))
-                    e.gather_rows(src_x, d_perm, N, ncol, d_x)
-                    for st_, dt, w in zip(src_t, d_t, widths):
-                        e.gather_rows(st_, d_perm, N, w, dt)
-                    if has_sw:
-                        e.gather_rows(src_sw, d_perm, N, 1, d_sw)
-                elif host_shuffle:
-                    perm = rng.permutation(N)
-                    e.sync()                      # the previous epoch's steps have read the table
-                    src_x.upload(x[perm])
-                    for dt, t in zip(src_t, targets):
-                        dt.upload(t[perm])
-                    if has_sw:
-                        src_sw.upload(sw[perm])
+
+                def new_pass():      # one pass over the table = one permutation (Keras: the adapter's dataset of `epochs` passes)
+                    if dev_shuffle:
+                        perm = rng.permutation(N).astype(np.int32)
+                        d_perm.upload(perm.view(np.float32))
+                        e.gather_rows(src_x, d_perm, N, ncol, d_x)
+                        for st_, dt, w in zip(src_t, d_t, widths):
+                            e.gather_rows(st_, d_perm, N, w, dt)
+                        if has_sw:
+                            e.gather_rows(src_sw, d_perm, N, 1, d_sw)
+                    elif host_shuffle:
+                        perm = rng.permutation(N)
+                        e.sync()                      # the previous pass's steps have read the table
+                        src_x.upload(x[perm])
+                        for dt, t in zip(src_t, targets):
+                            dt.upload(t[perm])
+                        if has_sw:
+                            src_sw.upload(sw[perm])
                 adam = self.optimizer.as_struct()
                 e.metric_read(reset=True)
 
-                def run_batches():
-                    for ib, (b, bg) in enumerate(zip(sizes, gsizes)):
+                def run_batches(lo=0, hi=None):
+                    for ib in range(lo, len(sizes) if hi is None else hi):
+                        b, bg = sizes[ib], gsizes[ib]
                         b0 = ib * bs
                         if self._po_l1:
                             self._push_losses(e, bg)
@@ -426,10 +435,32 @@ class Model(object):
                             comm.all_reduce_grad(e)
                         e.adam_step_dev(adam)
                         e.metric_accumulate(bg)     # Keras' loss metric: sample-weighted mean over the batches,
+                if steps_per_epoch is not None:
+                    # Keras with array inputs and steps_per_epoch (TensorLikeDataAdapter: ONE iterator over `epochs` successive passes,
+                    # never recreated): an epoch takes its steps from where the last one stopped, a new permutation whenever a pass is
+                    # used up; when the passes run out Keras warns ("Your input ran out of data") and interrupts training
+                    left = int(steps_per_epoch)
+                    while left > 0 and not self.stop_training:
+                        if stream[1] >= len(sizes) or stream[0] < 0:
+                            stream[0] += 1; stream[1] = 0
+                            if stream[0] >= epochs - initial_epoch:
+                                import warnings
+                                warnings.warn("Your input ran out of data; interrupting training. Make sure that your dataset can "
+                                              "generate at least `steps_per_epoch * epochs` batches.")
+                                self.stop_training = True
+                                break
+                            new_pass()
+                        take = min(left, len(sizes) - stream[1])
+                        run_batches(stream[1], stream[1] + take)
+                        stream[1] += take; left -= take
+                else:
+                    new_pass()
                 # launch-bound epochs (many small batches on one GPU: configs[0]'s batch 512 is 13 kernels of a few microseconds per
                 # step) are recorded ONCE into a hipGraph -- the batch pointers into the resident table do not change between
                 # epochs -- and replayed with one submission per epoch; Keras runs its steps from one traced graph as well
-                if use_graph and graph_id is None:
+                if steps_per_epoch is not None:
+                    pass
+                elif use_graph and graph_id is None:
                     try:
                         e.graph_begin()
                         try:
@@ -438,7 +469,9 @@ class Model(object):
                             graph_id = e.graph_end()
                     except _lib.NifError:
                         use_graph, graph_id = False, None       # (a workspace that had to grow, a call that cannot be captured)
-                if use_graph and graph_id is not None:
+                if steps_per_epoch is not None:
+                    pass
+                elif use_graph and graph_id is not None:
                     e.graph_launch(graph_id, adam)
                 else:
                     run_batches()
