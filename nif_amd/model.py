@@ -212,8 +212,8 @@ class Model(object):
     _EVAL_CHUNK = 1 << 18
     # fit(): epochs of at least four batches no larger than _GRAPH_MAX_BATCH can be captured into a hipGraph (NIF_GRAPH=1 or
     # model._graph_epochs = True).  OFF by default: measured on configs[0] (10 k points, batch 512, tools/exp/small_batch.py) the
-    # replayed epoch runs 83.3 us per step against 84.8 us eager -- the step is bound by the GPU-side dispatch latency between its
-    # 13-15 DEPENDENT kernels (~5.5 us each), not by the host's launch cost, and a linear graph does not shorten that
+    # replayed epoch runs 83.3 us per step against 84.8 us eager -- the step is the sum of its 11 kernels' EXECUTION times (fixed
+    # prologue / epilogue costs of persistent kernels built for 1e6 points: DESIGN 8.6), not host launch cost or dispatch gaps
     _GRAPH_MAX_BATCH = 16384
     _graph_epochs = os.environ.get("NIF_GRAPH", "0") == "1"
 
