@@ -14,9 +14,10 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
   const long nt16 = 2 * ((a.B + 31) / 32);
   long ngroups = (nt16 + 3) / 4;
   const bool bf_ = a.WF4 && a.WB4 && !(NBL & 1) && NBL <= 6;
-  const bool slim = bf_ && NBL <= 4 && ns <= 2 && !a.nif_skip && !any_par && !a.ll;     // the 1- / 2-seed instantiations: two workgroups per CU
-  // measured on cfg-5 (n = 64): one seed 5.21 -> 3.98 ms at two workgroups per CU; two seeds spill 83 registers there (6.97 -> 7.87 ms)
-  const bool two = slim && (NBL <= 2 || ns == 1 || (NIF_SOB_TWO_BF2 && ns == 2 && a.prec == 1));
+  // r4: the 1- / 2-seed "slim" instantiations (two workgroups per CU; r2's configs[4] kernels) are gone -- k_sobw takes those shapes,
+  // and what still falls back to k_sob (NIF_SOBW=0, exchange tiles beyond the LDS) runs the general 3-stream form
+  const bool slim = false, two = false;
+  (void)bf_;
   const bool wav = sobw_supported(a, ns, any_par);      // k_sobw.hip: one 12-wave (65..128 units: 8-wave) workgroup per CU; r4: predict() too
   if (wav) ngroups = (nt16 + sobw_tiles_per_group(a.n, ns) - 1) / sobw_tiles_per_group(a.n, ns);
   const long cap = wav ? sobw_grid_cap() : (two ? 512 : (NBL <= 4 ? 256 * NIF_SOB_OCC : 256));
@@ -89,34 +90,11 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
                                 (int)shm);                                                                      \
     hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_>), grid, block, shm, st, J);                                \
   }
-#define SBN(NBL_, MODE_, TR_, BF_, SGN_, NSD_)                                                                      \
-  {                                                                                                             \
-    if (shm > 48 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)k_sob<NBL_, MODE_, TR_, BF_, SGN_, NSD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)shm);                                                                      \
-    hipLaunchKernelGGL((k_sob<NBL_, MODE_, TR_, BF_, SGN_, NSD_>), grid, block, shm, st, J);                          \
-  }
-  // SIREN nets on the bf16 planes with 1 or 2 seeds (BASELINE configs[4]: d/dx, d/dy)
-#define SBS(NBL_, BF_, NSD_)                                                         \
-  if (a.res) { if (train) SBN(NBL_, 1, true, BF_, false, NSD_) else SBN(NBL_, 1, false, BF_, false, NSD_) }   \
-  else if (train) { if (sgn) SBN(NBL_, 0, true, BF_, true, NSD_) else SBN(NBL_, 0, true, BF_, false, NSD_) } \
-  else SBN(NBL_, 0, false, BF_, false, NSD_)
 #define SBK(NBL_, BF_)                                                               \
   if (a.nif_skip) { if (train) SBL(NBL_, 2, true, BF_, false) else SBL(NBL_, 2, false, BF_, false) }   \
   else if (a.res) { if (train) SBL(NBL_, 1, true, BF_, false) else SBL(NBL_, 1, false, BF_, false) }   \
   else if (train) { if (sgn) SBL(NBL_, 0, true, BF_, true) else SBL(NBL_, 0, true, BF_, false) } \
   else SBL(NBL_, 0, false, BF_, false)
-  if (slim) {
-    const int bfv = a.prec == 1 ? 2 : 1;
-    if (NBL == 4) {
-      if (bfv == 1) { if (ns == 1) { SBS(4, 1, 1) } else { SBS(4, 1, 2) } }
-      else { if (ns == 1) { SBS(4, 2, 1) } else { SBS(4, 2, 2) } }
-    } else {
-      if (bfv == 1) { if (ns == 1) { SBS(2, 1, 1) } else { SBS(2, 1, 2) } }
-      else { if (ns == 1) { SBS(2, 2, 1) } else { SBS(2, 2, 2) } }
-    }
-    return nblk;
-  }
   switch (NBL) {
     case 1: SBK(1, 0) break;
     case 2: if (bf && a.prec == 1) { SBK(2, 2) } else if (bf) { SBK(2, 1) } else { SBK(2, 0) } break;
@@ -126,8 +104,6 @@ int launch_sob(const SNetArgs& a, bool train, int ns, const int* seeds, const fl
     default: SBK(8, 0) break;
   }
 #undef SBK
-#undef SBS
-#undef SBN
 #undef SBL
   return nblk;
 }
