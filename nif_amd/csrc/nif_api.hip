@@ -432,6 +432,22 @@ static void fill_pnet(const nif_ctx* c, PNetArgs& a, const float* xin, long B) {
   a.Z = c->Z; a.DZ = a.ll_kind ? c->DZL : c->DZ; a.ZL = c->ZL;
 }
 // last-layer class: the shared-weight SIREN ShapeNet x -> phi is the same MLP machinery (model.py:1219-1238)
+// f32-input MFMA planes of the last-layer class's shared ShapeNet for the 32-point MLP kernels (k_pnet as the dense SIREN: the NIF_LL_MLP
+// path, nets k_snet4<LL> does not take, model_x_to_phi / x_to_u_given_w).  r4: on demand -- the default training step (k_snet4<LL>) never
+// reads them, and packing them after every Adam step cost L launches per step
+static void ensure_ll_mlp_planes(nif_ctx* c) {
+  if (c->ll_mlp_packed) return;
+  const long plane_l = (long)c->NB * c->NB * 256;
+  for (int i = 0; i < c->L; ++i) {
+    if (!c->cfg.s_resblock) {
+      launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + i * plane_l, c->lWB + i * plane_l, c->st);
+    } else {
+      launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i) * plane_l, c->lWB + (2 * i) * plane_l, c->st);
+      launch_pack(c->theta, dense_ref(c->s_hid_w2[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i + 1) * plane_l, c->lWB + (2 * i + 1) * plane_l, c->st);
+    }
+  }
+  c->ll_mlp_packed = true;
+}
 static void fill_snet_mlp(const nif_ctx* c, PNetArgs& a, const float* xin, int ncol, int col0, long B) {
   memset(&a, 0, sizeof(a));
   a.theta = c->theta; a.xin = xin; a.ncol = ncol; a.col0 = col0; a.B = B;
@@ -527,15 +543,7 @@ static int ensure_packed(nif_ctx* c) {
   ProfScope ps_(c, NIF_PROF_PACK);
   if (c->kind == NIF_KIND_LASTLAYER) {
     c->ll_packed32 = false;
-    const long plane_l = (long)c->NB * c->NB * 256;
-    for (int i = 0; i < c->L; ++i) {
-      if (!c->cfg.s_resblock) {
-        launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + i * plane_l, c->lWB + i * plane_l, c->st);
-      } else {
-        launch_pack(c->theta, dense_ref(c->s_hid_w[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i) * plane_l, c->lWB + (2 * i) * plane_l, c->st);
-        launch_pack(c->theta, dense_ref(c->s_hid_w2[i], c->n, c->n), c->NB, c->NB, c->lWF + (2 * i + 1) * plane_l, c->lWB + (2 * i + 1) * plane_l, c->st);
-      }
-    }
+    c->ll_mlp_packed = false;       // the f32 planes of the 32-point MLP kernels: packed when one of them runs (ensure_ll_mlp_planes)
     {
       SNetArgs probe; fill_snet_ll(c, probe, nullptr, 0, 0, 32);
       static const bool ll_old = [] { const char* e = getenv("NIF_LL_MLP"); return e && e[0] == '1'; }();
@@ -603,7 +611,7 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
       HIPCHK(hipGetLastError());
       return NIF_OK;
     }
-    PNetArgs ma; fill_snet_mlp(c, ma, xin, c->pi + c->si, c->pi, B);
+    ensure_ll_mlp_planes(c); PNetArgs ma; fill_snet_mlp(c, ma, xin, c->pi + c->si, c->pi, B);
     launch_pnet(ma, c->NB, false, c->st);
     LLArgs la; fill_ll(c, la, B); la.u_out = u;
     launch_ll_out(la, false, c->st);
@@ -668,7 +676,7 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   if (ll) {
     // u = Dot(phi(x), a(p)) + bias: coordinate columns move phi, parameter columns move a
     rc = nif_forward_dev(c, c->d_a, B, c->d_d); if (rc) return rc;     // leaves Z (= a) on the device
-    PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, ncol, c->pi, B);
+    ensure_ll_mlp_planes(c); PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, ncol, c->pi, B);
     if (c->use_ll4) launch_pnet(ma, c->NB, false, c->st);               // the fused forward keeps phi on chip: compute it here
     for (int j = 0; j < nx; ++j) {
       if (x_idx[j] >= c->pi) {
@@ -877,7 +885,7 @@ extern "C" int nif_x_to_phi(nif_ctx* c, const float* x, int64_t B, float* phi) {
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   rc = stage(c, &c->d_a, &c->cap_a, x, B * c->si); if (rc) return rc;
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so * c->r); if (rc) return rc;
-  PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, c->si, 0, B);
+  ensure_ll_mlp_planes(c); PNetArgs ma; fill_snet_mlp(c, ma, c->d_a, c->si, 0, B);
   launch_pnet(ma, c->NB, false, c->st);
   launch_tiles_to_rows(c->PHI, B, c->so * c->r, c->d_d, c->st);
   HIPCHK(hipGetLastError());
@@ -914,7 +922,7 @@ extern "C" int nif_shapenet_given_w_dev(nif_ctx* c, const float* x, const float*
   if (c->kind == NIF_KIND_LASTLAYER) {   // u = Dot(phi(x), w) + bias with caller-supplied w [B, r]
     int rc = ensure_packed(c); if (rc) return rc;
     rc = ensure_capacity(c, B, false); if (rc) return rc;
-    PNetArgs ma; fill_snet_mlp(c, ma, x, c->si, 0, B);
+    ensure_ll_mlp_planes(c); PNetArgs ma; fill_snet_mlp(c, ma, x, c->si, 0, B);
     launch_pnet(ma, c->NB, false, c->st);
     launch_rows_to_tiles(w, B, c->r, c->Z, c->st);
     LLArgs la; fill_ll(c, la, B); la.u_out = u;
@@ -974,7 +982,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   const int ncol = c->pi + c->si;
   const int nsc = ns > 0 ? sp->nsc : 0, nhead = ns > 0 ? sp->ns - sp->nsc : 0;   // coordinate streams / parameter-column heads
   PNetArgs pa; fill_pnet(c, pa, xin, B);
-  PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
+  ensure_ll_mlp_planes(c); PNetArgs ma; fill_snet_mlp(c, ma, xin, ncol, c->pi, B);
   LLArgs la; fill_ll(c, la, B);
   la.y = y; la.sw = sw; la.inv_bg = 1.0f / (float)Bg;
   static const bool force_stash_ll = [] { const char* e = getenv("NIF_PNET_STASH"); return e && e[0] == '1'; }();

@@ -62,6 +62,7 @@ struct nif_ctx {
   // captured training steps (nif_graph_*): hipGraph executables, the steps each one carries, the device-side Adam state
   std::vector<hipGraphExec_t> graphs; std::vector<int> graph_steps; bool capturing = false; int cap_steps = 0; long cap_step0 = 0;
   AdamDev* adam_dev = nullptr; AdamDev* adam_host = nullptr;
+  bool ll_mlp_packed = false;        // last-layer class: the f32 planes of the 32-point MLP kernels are current
   int loss_kind = 0;                 // NIF_LOSS_* (nif_set_loss)
   float* sob_acc = nullptr;          // [grad | loss] summed over the column groups of a Sobolev step with more than three x_index columns
   float act_l1 = 0.f, act_l2 = 0.f; float* act_part = nullptr; long act_part_cap = 0; float* act_loss = nullptr; long act_loss_cap = 0;
