@@ -1112,7 +1112,7 @@ def test_fit_follows_oracle_adam_and_checkpoint_round_trip(name, tmp_path):
 
 
 @pytest.mark.parametrize("which", ["cfg3_ms_128", "cfg4_last_layer", "cfg5_sobolev", "cfg5_sobolev_bf16", "cfg3_ms_128_bf16",
-                                   "cfg4_last_layer_bf16"])
+                                   "cfg4_last_layer_bf16", "wide_sobolev_6x128", "wide_sobolev_res_3x128"])
 def test_full_size_shard_sum_other_configs(which):
     """The same size-independent properties at the TRUE per-GPU shard sizes and shapes of BASELINE configs[2..4]: the sum over 8
     contiguous shards of [grad | loss] equals the full-batch result, a repeated launch is bit-identical, and the
@@ -1125,6 +1125,10 @@ def test_full_size_shard_sum_other_configs(which):
     if which.startswith("cfg3_ms_128"):          # configs[2]: NIFMultiScale 6x128, 4M points / 8 GPUs
         kind, cs, cp = _cfg("NIFMultiScale", 128, 6, 32, 2, 1, 2, 1, 1, p_act="swish")
         B = 1 << 19
+    elif which.startswith("wide_sobolev"):       # r4: the Sobolev step of 128-wide nets on k_sobw<8, .., MODE> at a 2^18-point shard
+        kind, cs, cp = _cfg("NIFMultiScale", 128, 3 if "res" in which else 6, 32, 2, 1, 2, 1, 1, p_act="swish", s_res="res" in which)
+        B = 1 << 18
+        xi = [1, 2]
     elif which.startswith("cfg4_last_layer"):    # configs[3]: last-layer class 128x6, 16M points / 8 GPUs
         kind, cs, cp = _cfg("LL", 128, 6, 32, 2, 10, 3, 3, 1, p_act="swish")
         B = 1 << 21
