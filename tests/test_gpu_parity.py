@@ -59,6 +59,9 @@ CONFIGS = {
     "ll_128x4_r4": (_cfg("LL", 128, 4, 32, 2, 4, 2, 1, 1), 70),
     "ll_res_64x1_r4_so2": (_cfg("LL", 64, 1, 40, 2, 4, 3, 2, 2, s_res=True, p_res=True, p_act="swish"), 130),
     "ll_96x2_r5": (_cfg("LL", 96, 2, 32, 1, 5, 2, 3, 1), 77),
+    # r4: k_llg (PT tiles per wave and stream pass) takes the plain 64- and 128-wide nets of the class; 331 points = 21 tiles:
+    # two full tile groups of a workgroup under the policy (16 tiles each), a partly active wave in the second
+    "ll_64x3_r5_so2": (_cfg("LL", 64, 3, 32, 2, 5, 3, 2, 1, p_act="swish"), 331),
     # 65..96 units = six 16-blocks in the fused kernels but 128-row stash tiles for the gradient kernels (stash_fp): r1 / early r2
     # builds disagreed on the tile stride there and produced wrong ShapeNet weight gradients without any error
     "ms_96x2_r2": (_cfg("NIFMultiScale", 96, 2, 32, 1, 2, 2, 1, 1), 77),
@@ -1404,7 +1407,8 @@ def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
     assert _rel(model32.predict(x), O.forward(spec, ws, x64)) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5"])
+@pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5", "ll_64x3_r5_so2",
+                                  "ll_cfg4_128x6_r10_so3"])
 def test_mixed_bfloat16_policy_on_the_last_layer_class(name):
     """the policy on NIFMultiScaleLastLayerParameterized: operands of the SHARED hidden n x n products rounded to bf16 (one product,
     fp32 accumulation), the phi layer / Dot / loss / weight-gradient sums fp32 -- against the oracle with the same casts
