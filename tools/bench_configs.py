@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--exact", action="store_true", help="--only names ONE config (default: every config whose name contains it)")
     a = ap.parse_args()
     import nif_amd
     from nif_amd.engine import DeviceArray
@@ -87,7 +88,7 @@ def main():
     for name, work in WORK.items():
         cls, (cs, cp), B, xi = work[:4]
         policy = work[4] if len(work) > 4 else "float32"
-        if a.only and a.only not in name:
+        if a.only and (a.only != name if a.exact else a.only not in name):
             continue
         nif_amd.set_seed(0)
         m = getattr(nif_amd, cls)(cs, cp, mixed_policy=policy)
@@ -155,7 +156,7 @@ def main():
         if d_g is not None:
             d_g.free()
         e.close()
-    if not a.only or "cfg0" in a.only:
+    if not a.only or ("cfg0" in a.only and not a.exact):
         # configs[0]: tutorial 1 -- NIF 2x32 + 2x32, the 10k-point lattice of SURVEY 8d, Model.fit with batch 512, 20 steps per epoch
         import time
         nif_amd.set_seed(0)
