@@ -57,8 +57,15 @@ typedef enum {
  * ParameterNet and the weight-gradient sums stay fp32 (strictly more accurate than Keras' policy, which also stores
  * every layer output in bf16).  Nets of 17..32 / 49..64 units (and 113..128 with at most two planes per layer) also keep the hidden layers' dL/da stash rows in bf16 and form
  * the weight-gradient sums of those layers as one bf16 product.  Kernels without a bf16 path (odd 16-feature block
- * counts, 128-wide Sobolev) keep fp32. */
-typedef enum { NIF_POLICY_FLOAT32 = 0, NIF_POLICY_MIXED_BF16 = 1 } nif_policy;
+ * counts, 128-wide Sobolev) keep fp32.
+ * NIF_POLICY_MIXED_F16 (r4, Keras' 'mixed_float16'): the same rounding points with IEEE half-precision operands on
+ * v_mfma_f32_16x16x32_f16 (RNE, saturated at 65504), in the plain training step and the forward pass of every shape k_snet4
+ * takes (even 16-feature block counts up to 128 units, all three classes); dL/da enters the adjoint products as
+ * half(s dL/da) and the chain is scaled back, with s the power of two that brings the POINT's largest |dL/da| into
+ * [2^14, 2^15) -- in place of the single dynamic loss scale Keras' compile() puts around the optimizer under this policy
+ * (LossScaleOptimizer): no overflow, no skipped step.  The dL/da stash rows and
+ * every weight-gradient sum stay fp32; Sobolev / Jacobian / Hessian kernels and shapes outside k_snet4 run the exact products. */
+typedef enum { NIF_POLICY_FLOAT32 = 0, NIF_POLICY_MIXED_BF16 = 1, NIF_POLICY_MIXED_F16 = 2 } nif_policy;
 
 /* What NIF.__init__ (model.py:73-128) / NIFMultiScale._initialize_pnet (model.py:541-736)
  * derive from cfg_shape_net / cfg_parameter_net. */

@@ -11,7 +11,7 @@ NIF_ABI_VERSION = 2
 KIND_NIF, KIND_MULTISCALE, KIND_LASTLAYER = 0, 1, 2
 COMM_ID_BYTES = 128
 DT_F32, DT_F64, DT_I64 = 0, 1, 2
-POLICY_IDS = {"float32": 0, "mixed_bfloat16": 1}
+POLICY_IDS = {"float32": 0, "mixed_bfloat16": 1, "mixed_float16": 2}
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 PROF_NAMES = ["pack", "pnet_fwd", "snet", "pnet_bwd", "gw", "reduce", "adam", "given_w", "latent_to_w", "snet_fwd"]

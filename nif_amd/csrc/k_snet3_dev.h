@@ -288,19 +288,54 @@ __device__ __forceinline__ void split2(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL /
       s0[ks][t] = x0; s1[ks][t] = (__bf16)(x - (float)x0);
     }
 }
+// mixed_float16 (PR == 2, r4): ONE half-precision operand per value (RNE, saturated at the largest finite half: no infinity can
+// enter a product), carried in the bf16x8 register type of the split planes; `scale` = the loss scale of the data adjoint (a
+// power of two: exact), 1 in the forward sweep
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NBL>
+__device__ __forceinline__ void cast_f16(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], float scale) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks) {
+    f16x8 q;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) q[t] = (_Float16)__builtin_amdgcn_fmed3f(scale * h[2 * ks + (t >> 2)][t & 3], -65504.0f, 65504.0f);
+    s0[ks] = __builtin_bit_cast(bf16x8, q);
+  }
+}
+// PR-aware operand forms of a layer's activation / dL/da tile (the exact splits unless a policy asks for one rounded operand)
+template <int NBL, int PR>
+__device__ __forceinline__ void split3p(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2], bf16x8 (&s2)[NBL / 2]) {
+  if (PR == 2) cast_f16<NBL>(h, s0, 1.0f);
+  else split3<NBL>(h, s0, s1, s2);
+}
+template <int NBL, int PR>
+__device__ __forceinline__ void split2p(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2], float scale) {
+  if (PR == 2) cast_f16<NBL>(h, s0, scale);
+  else split2<NBL>(h, s0, s1);
+}
+__device__ __forceinline__ f32x4 mfma_f16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // one K-step chunk of a forward plane: T[ob] (+)= sum over the 32 features of the chunk, 6-product fp32-exact form.
 // Two output blocks at a time: their 6-MFMA chains interleave (a dependent v_mfma_f32_16x16x32_bf16 cannot issue
 // back to back) and one LDS round trip feeds 12 MFMAs
-// PR (the mixed_bfloat16 policy of the build): operands rounded to bf16, ONE product a0*b0 instead of the exact split
+// PR = 1 (the mixed_bfloat16 policy of the build): operands rounded to bf16, ONE product a0*b0 instead of the exact split
+// PR = 2 (mixed_float16, r4): the same with half-precision operands (slot 0 of the chunk holds the f16 plane: k_pack16b)
 // ZI: the chains start from zero (the first MFMA of every chain takes the inline constant 0 as C: no v_mov zeroing)
 // NT / OB0: the chunk holds NBL of the NT output blocks of T, starting at block OB0 (128-wide nets stream half chunks)
-template <int NBL, bool PR = false, bool ZI = false, int NT = NBL, int OB0 = 0>
+template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4* T = T_ + OB0;
 #pragma unroll
   for (int ob = 0; ob < NBL; ob += 2) {
+    if (PR == 2) {
+      const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
+      T[ob] = mfma_f16(a0, b0, ZI ? z4 : T[ob]);
+      T[ob + 1] = mfma_f16(c0, b0, ZI ? z4 : T[ob + 1]);
+      continue;
+    }
     if (PR) {
       const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
       T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ob], 0, 0, 0);
@@ -325,13 +360,19 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
-template <int NBL, bool PR = false, bool ZI = false, int NT = NBL, int OB0 = 0>
+template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4* T = T_ + OB0;
 #pragma unroll
   for (int ib = 0; ib < NBL; ib += 2) {
+    if (PR == 2) {
+      const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
+      T[ib] = mfma_f16(a0, b0, ZI ? z4 : T[ib]);
+      T[ib + 1] = mfma_f16(c0, b0, ZI ? z4 : T[ib + 1]);
+      continue;
+    }
     if (PR) {
       const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
       T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ib], 0, 0, 0);

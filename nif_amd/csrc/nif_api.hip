@@ -98,7 +98,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     return fail(NIF_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", libnif_hip is built for gfx950 only");
   if (cfg->kind != NIF_KIND_NIF && cfg->kind != NIF_KIND_MULTISCALE && cfg->kind != NIF_KIND_LASTLAYER)
     return fail(NIF_ERR_INVALID, "unknown model kind");
-  if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->mixed_policy != NIF_POLICY_MIXED_BF16)
+  if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->mixed_policy != NIF_POLICY_MIXED_BF16 && cfg->mixed_policy != NIF_POLICY_MIXED_F16)
     return fail(NIF_ERR_INVALID, "unknown mixed_policy");
   for (int i = 0; i < 7; ++i) if (cfg->reserved[i] != 0) return fail(NIF_ERR_INVALID, "reserved fields must be zero");
   if (cfg->kind == NIF_KIND_LASTLAYER && cfg->latent_dim * cfg->so_dim > 64)
@@ -159,6 +159,10 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
     if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    if (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16) {     // the half-precision plane set of k_snet4<.., PR = 2>, next to the exact splits
+      if (e == hipSuccess) e = hipMalloc(&c->sWF4h, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
+      if (e == hipSuccess) e = hipMalloc(&c->sWB4h, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    }
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpf, (size_t)snet4_phi_fwd_elems(c->n) * 2);
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpb, (size_t)snet4_phi_bwd_elems(c->n) * 2);
   }
@@ -192,7 +196,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   for (hipGraphExec_t ex : c->graphs) if (ex) (void)hipGraphExecDestroy(ex);
   if (c->adam_host) (void)hipHostFree(c->adam_host);
   void* ptrs[] = {c->adam_dev, c->sob_acc, c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->sWF4h, c->sWB4h, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -477,7 +481,8 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
   a.DU = c->DU; a.DZ = nullptr; a.dring = c->dring;
   a.ll = 1; a.rl = c->r; a.so_u = c->so; a.DPHI = c->DPHI; a.DA_ll = c->DA; a.DZL = c->DZL;
   a.WPF = c->ll_wpf; a.WPB = c->ll_wpb;
-  a.prec = (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 && !c->opt_fp32_mfma) ? 1 : 0;     // (k_snet4<LL> only; k_sob / k_jac stay exact)
+  a.prec = c->opt_fp32_mfma ? 0 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 ? 1 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 0));     // (k_snet4<LL> only; k_sob / k_jac stay exact)
+  a.WF4h = c->sWF4h; a.WB4h = c->sWB4h;
   a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
   a.tl = c->tl;
 }
@@ -493,7 +498,9 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
   a.WF4 = c->use_snet4 ? c->sWF4 : nullptr; a.WB4 = c->use_snet4 ? c->sWB4 : nullptr;   // packed only then
-  a.prec = (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 && !c->opt_fp32_mfma) ? 1 : 0;
+  a.prec = c->opt_fp32_mfma ? 0 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 ? 1 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 0));
+  if (!c->use_snet4) a.prec = a.prec == 2 ? 0 : a.prec;      // (no k_snet4 for this shape: the policy runs on the exact kernels)
+  a.WF4h = c->use_snet4 ? c->sWF4h : nullptr; a.WB4h = c->use_snet4 ? c->sWB4h : nullptr;
   a.dring = c->dring;
   a.tl = c->tl;
 }
@@ -566,6 +573,10 @@ static int ensure_packed(nif_ctx* c) {
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
                          (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2,
                          c->cfg.s_omega0, c->st);
+        if (c->use_ll4 && c->sWF4h)
+          launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
+                         (char*)c->sWF4h + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4h + (size_t)j * snet4_bwd_elems(n, 0) * 2,
+                         c->cfg.s_omega0, c->st, 1);
       }
       seg(c->s_bott_b, s_bl, sop);
       seg(c->ll_bias, s_bl + sop, c->so);
@@ -589,6 +600,9 @@ static int ensure_packed(nif_ctx* c) {
   if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
                          c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st);
+  if (c->use_snet4 && c->nh > 0 && c->sWF4h)
+    launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
+                         c->sWF4h, c->sWB4h, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st, 1);
   HIPCHK(hipGetLastError());
   c->packed = true;
   if (!c->use_snet4) return ensure_packed32(c);

@@ -672,7 +672,7 @@ class NIF(object):
         self._sreg = (0.0, 0.0)
         self.mixed_policy_name = mixed_policy
         self.variable_Dtype = "float32"
-        self.compute_Dtype = "bfloat16" if mixed_policy == "mixed_bfloat16" else "float32"
+        self.compute_Dtype = {"mixed_bfloat16": "bfloat16", "mixed_float16": "float16"}.get(mixed_policy, "float32")
         self.po_dim = s.po_dim
         self.pnet_list = [nm for nm, _ in s.param_shapes() if nm.startswith("pnet_") and nm.endswith("_w")]
         self.__engine = None

@@ -19,8 +19,8 @@ class Spec(object):
         if not isinstance(cfg_shape_net, dict):
             raise TypeError("cfg_shape_net must be a dictionary")
         if mixed_policy not in _lib.POLICY_IDS:
-            raise NotImplementedError("mixed_policy %r: 'float32' and 'mixed_bfloat16' are built (float16 needs loss scaling, "
-                                      "which the reference does not set up either)" % (mixed_policy,))
+            raise NotImplementedError("mixed_policy %r: 'float32', 'mixed_bfloat16' and 'mixed_float16' are built (fp32 variables; Keras' "
+                                      "pure 'float16' / 'bfloat16' / 'float64' policies also change the variable dtype)" % (mixed_policy,))
         self.kind = kind
         self.cfg_shape_net = cfg_shape_net
         self.cfg_parameter_net = cfg_parameter_net

@@ -558,6 +558,34 @@ def bf16_round(a):
     return r.view(np.float32).astype(np.float64).reshape(a32.shape)
 
 
+def f16_round(a):
+    """round-to-nearest-even to IEEE half precision of the float32 value of `a`, saturated at the largest finite half (65504):
+    what v_med3_f32 + v_cvt_pk_f16_f32 do in k_snet4<.., PR = 2> / k_pack16b(f16) -- the build's mixed_float16 policy
+    (model.py:101-105 hands 'mixed_float16' to tf.keras.mixed_precision.Policy).  As float64."""
+    a32 = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
+    return a32.astype(np.float16).astype(np.float64)
+
+
+def _f16_round_grad(g):
+    """dL/da [B, n] under mixed_float16: every point's row is rounded as half(s dL/da) / s with s the power of two that brings the
+    row's largest |entry| (as float32) into [2^14, 2^15), at most 2^100 -- k_snet4<.., PR = 2>'s per-point loss scale (Keras holds
+    one dynamic scale per step, 2^15 at first, and skips overflowing steps: keras/mixed_precision/loss_scale_optimizer.py).
+    Exact powers of two: only the rounding -- half's subnormals below 6.1e-5, saturation above 65504 -- sees the scale"""
+    g = np.asarray(g, dtype=np.float64)
+    mx = np.ascontiguousarray(np.abs(g).max(axis=-1, keepdims=True), dtype=np.float32)
+    ef = ((mx.view(np.uint32) >> 23) & 0xFF).astype(np.int64)
+    sf = np.minimum(268 - ef, 227)
+    s = np.ldexp(1.0, sf - 127)
+    return f16_round(s * g) / s
+
+
+f16_round.grad = _f16_round_grad     # the rounding of the data adjoint's dL/da operand where it differs from the forward operands'
+
+
+def _grad_round(rnd):
+    return (lambda a_: a_) if rnd is None else getattr(rnd, "grad", rnd)
+
+
 def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False):
     """loss, grads (Keras order) and predictions of NIF / NIFMultiScale in the plane formulation.
     rnd=None: exact; rnd=bf16_round: the build's mixed_bfloat16 policy.  stash_bf16 (with rnd): the hidden layers' weight-gradient
@@ -565,6 +593,7 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
     (k_gw_lds<.., DAB>: nets of 17..32 / 49..64 units on the bf16 kernels); biases sum the same bf16 dL/da."""
     assert spec.kind in (KIND_NIF, KIND_MS)
     R = (lambda a: a) if rnd is None else rnd
+    Rg = _grad_round(rnd)
     B = inputs.shape[0]
     Bg = B if batch_global is None else batch_global
     p = inputs[:, :spec.pi]
@@ -642,7 +671,7 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
 
     def back(ab, shape, ga, hin, scale, rounded):     # dL/dh_in and the latent part through the matrix
         if rounded:                                   # hidden matrices: the adjoint planes hold scale * M_k as well
-            U = [R(ga) @ R(scale * mat(k, ab, shape)).T for k in range(K)]
+            U = [Rg(ga) @ R(scale * mat(k, ab, shape)).T for k in range(K)]
             scale = 1.0
         else:
             U = [ga @ mat(k, ab, shape).T for k in range(K)]
@@ -731,6 +760,7 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
     first, hidden, bott, _ = _snet_split(spec, rest)
     R = (lambda a_: a_) if rnd is None else rnd      # policy: dL/da and the weights rounded in the data adjoint; weight gradients fp32
     S = R if stash_bf16 else (lambda a_: a_)         # ... unless the dL/da stash rows are bf16: hidden sums bf16(h_in)^T bf16(dL/da)
+    Rg = _grad_round(rnd)                            # (mixed_float16: dL/da is rounded under the loss scale)
     tape, hL = tape_h
     om = spec.omega_s
     g = g_phi.reshape(g_phi.shape[0], -1)
@@ -742,16 +772,16 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
             _, hin, a1, t, a2 = rec
             ga2 = 0.5 * gh * np.cos(a2)
             gw2 = om * (S(t).T @ S(ga2)); gb2 = S(ga2).sum(0)
-            gt = R(ga2) @ R(om * lay[2]).T
+            gt = Rg(ga2) @ R(om * lay[2]).T
             ga1 = gt * np.cos(a1)
             gw1 = om * (S(hin).T @ S(ga1)); gb1 = S(ga1).sum(0)
-            gh = 0.5 * gh + R(ga1) @ R(om * lay[0]).T
+            gh = 0.5 * gh + Rg(ga1) @ R(om * lay[0]).T
             g_hidden.append([gw1, gb1, gw2, gb2])
         else:
             _, hin, a1 = rec
             ga1 = gh * np.cos(a1)
             g_hidden.append([om * (S(hin).T @ S(ga1)), S(ga1).sum(0)])
-            gh = R(ga1) @ R(om * lay[0]).T
+            gh = Rg(ga1) @ R(om * lay[0]).T
     _, x, a = tape[0]
     ga = gh * np.cos(a)
     grads = [om * (x.T @ ga), ga.sum(0)]

@@ -214,6 +214,40 @@ def test_plane_formulation_equals_the_materialised_reference_formulation(name):
     assert np.array_equal(r, np.array([1.0, 1.0, 1.0078125, 1.015625, -3.140625, 0.0]))      # ties to even, 8-bit significand
 
 
+@pytest.mark.parametrize("name", ["nif_swish", "ms_plain", "ms_res", "ll_plain", "ll_res"])
+def test_mixed_float16_emulation_of_the_oracle(name):
+    """f16_round is IEEE half with RNE and saturation (what v_med3_f32 + v_cvt_pk_f16_f32 do); its .grad form rounds under the 2^15
+    loss scale, so adjoints below half's normal range survive; the emulated step is a rounding of the exact one -- finer than the
+    bf16 emulation (11 significand bits against 8) -- and torch's own float16 cast agrees bit for bit"""
+    r = O.f16_round(np.array([1.0, 1.00048828125, 1.000732421875, 1.00146484375, 65519.0, 65520.0, 1e9, -1e9, 5.96e-8, 2.9e-8]))
+    assert np.array_equal(r, np.array([1.0, 1.0, 1.0009765625, 1.001953125, 65504.0, 65504.0, 65504.0, -65504.0, 2.0 ** -24, 0.0]))
+    torch = pytest.importorskip("torch")
+    v = np.random.default_rng(0).standard_normal(4096).astype(np.float32) * np.float32(10.0) ** np.random.default_rng(1).integers(-9, 5, 4096)
+    assert np.array_equal(O.f16_round(v), torch.from_numpy(np.clip(v, -65504, 65504)).to(torch.float16).to(torch.float64).numpy())
+    g = np.array([[1e-7, 3e-9, 1e-20, 0.0], [3.0, 1.0, 1e-3, 1e-13], [0.0, 0.0, 0.0, 0.0]])
+    assert np.all(O.f16_round(g[0, :2]) != g[0, :2]) and O.f16_round(3e-9) == 0.0    # unscaled: subnormal or flushed
+    rg = O.f16_round.grad(g)        # per-point power of two: the row's largest entry lands in [2^14, 2^15)
+    assert np.allclose(rg[0, :2], g[0, :2], rtol=1e-3) and np.allclose(rg[1, :3], g[1, :3], rtol=1e-3) and np.all(rg[2] == 0.0)
+    assert rg[0, 2] == 0.0 and rg[1, 3] == 0.0            # more than 38 binades below the row's maximum: below half's subnormals
+    assert np.all(np.isfinite(O.f16_round.grad(np.array([[1e30, -3e38, 1.0]]))))
+    kind, cs, cp, spec, ws, inputs, y, sw = _setup(name)
+    if spec.kind == O.KIND_LL:
+        fn = O.ll_policy_loss_and_grad
+        le, ge = O.loss_and_grad(spec, ws, inputs, y, sw)
+    else:
+        fn = O.planes_loss_and_grad
+        le, ge = O.loss_and_grad(spec, ws, inputs, y, sw)
+    lh, gh, uh = fn(spec, ws, inputs, y, sw, rnd=O.f16_round)
+    lb, gb, ub = fn(spec, ws, inputs, y, sw, rnd=O.bf16_round)
+    fl = O.flatten
+    dh = np.linalg.norm(fl(gh) - fl(ge)) / np.linalg.norm(fl(ge))
+    db = np.linalg.norm(fl(gb) - fl(ge)) / np.linalg.norm(fl(ge))
+    assert lh != le and 0 < dh < 5e-2 and dh < 0.5 * db, (dh, db)      # (ms_res: large weights, bf16 sits 0.26 away, half 0.03)
+    # without rounding the .grad hook changes nothing: rnd=None is the exact formulation
+    l0, g0, _ = fn(spec, ws, inputs, y, sw, rnd=None)
+    assert abs(l0 - le) <= 1e-12 * max(1.0, abs(le))
+
+
 @pytest.mark.parametrize("name", ["nif_tanh_r2_so2", "nif_swish", "ms_plain_r3_si2", "ms_res", "ms_mlp_pres", "ll_plain", "ll_res"])
 def test_hessian_analytic_vs_fd_of_the_jacobian_and_torch(name):
     """HessianLayer oracle: second-order forward mode against central differences of the analytic Jacobian and against
