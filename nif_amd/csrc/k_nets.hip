@@ -77,6 +77,13 @@ __device__ __forceinline__ void pnet_first(const PNetArgs& A, long ptc, int hf, 
   act_tile<NB>(A.act, h, h, d, A.nst, hf);
 }
 
+// floats of the bf16 plane region of k_pnet's LDS (the launcher decides A.pbf2 before the launch)
+__host__ __device__ inline int pnet_plane_floats(const PNetArgs& A, int NB) {
+  const int nm = A.lst * (A.res ? 2 : 1);
+  return NB == 1 ? nm * PBF_FWD_U4 * 4 : ((NB == 2 && A.pbf2) ? nm * 4 * PBF_FWD_U4 * 4 : 0);
+}
+__host__ __device__ inline int pnet_tail_floats(const PNetArgs& A) { return A.r + (A.ll_kind ? A.r + A.r * A.r : 0); }
+
 template <int NB, bool TRAIN, int ACT>
 __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -86,6 +93,14 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   const long plane = (long)NB * NB * 256;  // f32x4 per packed matrix
   extern __shared__ __attribute__((aligned(16))) float pn_lds[];   // [LL kind: 4 waves x r x 32][small vectors]
   float* zl_lds = pn_lds;
+  // r4: the bottleneck bias and the last-layer class's r x r map + bias live in LDS (tail of the small-vector region) -- the
+  // r-trip loops at the end of a tile used to take them from global memory, one dependent scalar load per latent row (cfg-4, r = 10)
+  float* tailv = pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0) + ((psmall_floats(A, NB) + 3) & ~3) + pnet_plane_floats(A, NB);
+  for (int e = threadIdx.x; e < A.r; e += 256) tailv[e] = A.theta[A.bott_b + e];
+  if (A.ll_kind) {
+    for (int e = threadIdx.x; e < A.r; e += 256) tailv[A.r + e] = A.theta[A.last_b + e];
+    for (int e = threadIdx.x; e < A.r * A.r; e += 256) tailv[2 * A.r + e] = A.theta[A.last_w + e];
+  }
   const PSmall S = psmall_stage<NB>(A, pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0), threadIdx.x, 256);
   // one 32-feature block: the hidden products run as exact bf16 splits (k_pnet_bf16.h), forward planes built here
   pbf16x8* bpl = reinterpret_cast<pbf16x8*>(pn_lds + (A.ll_kind ? 4 * A.r * 32 : 0) + ((psmall_floats(A, NB) + 3) & ~3));
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
       for (int v = 0; v < 16; ++v) s = fmaf(h[b][v], w[v], s);
     }
     s += __shfl_xor(s, 32);
-    s += A.theta[A.bott_b + c];
+    s += tailv[c];
     if (A.ll_kind) {
       if (hf == 0) { zl[c * 32 + p] = s; A.ZL[(tile * A.zl_rows + c) * 32 + p] = s; }
     } else if (hf == 0) {
@@ -186,9 +201,11 @@ __global__ __launch_bounds__(256) void k_pnet(PNetArgs A) {
   }
   if (A.ll_kind) {
     // last-layer class: pnet_out = latent @ W[r,r] + b   (HyperLinearForSIREN with po = r, model.py:583-585)
+    const float* lw = tailv + 2 * A.r;
     for (int c = hf; c < A.r; c += 2) {
-      float s = A.theta[A.last_b + c];
-      for (int kk = 0; kk < A.r; ++kk) s = fmaf(zl[kk * 32 + p], A.theta[A.last_w + (long)kk * A.r + c], s);
+      float s = tailv[A.r + c];
+#pragma unroll 4
+      for (int kk = 0; kk < A.r; ++kk) s = fmaf(zl[kk * 32 + p], lw[kk * A.r + c], s);
       A.Z[(tile * A.r + c) * 32 + p] = s;
     }
   }
@@ -262,6 +279,7 @@ __global__ __launch_bounds__(256) void k_pnet_bwd(PNetArgs A) {
 }
 
 void launch_pnet(const PNetArgs& a_, int NSTB, bool train, hipStream_t st) {
+  // (LDS layout of k_pnet: [LL: 4 x r x 32 latent rows][small vectors][bf16 planes][tail vectors: r + (LL: r + r^2)])
   PNetArgs a = a_;
   const long ntiles = (a.B + 31) / 32;
   long nblk = (ntiles + 3) / 4;
@@ -269,10 +287,11 @@ void launch_pnet(const PNetArgs& a_, int NSTB, bool train, hipStream_t st) {
   const int nmat = a.lst * (a.res ? 2 : 1);
   const size_t shm0 = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)((psmall_floats(a, NSTB) + 3) & ~3)) * sizeof(float);
   static const bool bf2_on = [] { const char* e = getenv("NIF_PNET_BF2"); return !(e && e[0] == '0'); }();
-  a.pbf2 = (NSTB == 2 && bf2_on && shm0 + (size_t)nmat * 4 * PBF_FWD_U4 * 16 <= 64u * 1024u) ? 1 : 0;   // two workgroups per CU keep their planes
+  const size_t tailb = (size_t)pnet_tail_floats(a) * sizeof(float);
+  a.pbf2 = (NSTB == 2 && bf2_on && shm0 + tailb + (size_t)nmat * 4 * PBF_FWD_U4 * 16 <= 64u * 1024u) ? 1 : 0;   // two workgroups per CU keep their planes
   if (a.pbf2 && nblk > 512) nblk = 512;  // the planes are built once per workgroup: fewer, longer-lived workgroups
   dim3 grid((unsigned)nblk), block(256);
-  const size_t shm = shm0 + (NSTB == 1 ? (size_t)nmat * PBF_FWD_U4 * 16 : (a.pbf2 ? (size_t)nmat * 4 * PBF_FWD_U4 * 16 : 0));
+  const size_t shm = shm0 + (size_t)pnet_plane_floats(a, NSTB) * sizeof(float) + tailb;
 #define PNL(NB_, TR_, ACT_)                                                                                             \
   {                                                                                                                     \
     if (shm > 48 * 1024)                                                                                                \

@@ -36,10 +36,15 @@ typedef __bf16 pbw_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef NIF_PBW_BF16
 #define NIF_PBW_BF16 1
 #endif
-__device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x16& C, int i, int hf) {
+// in_rows < 32: IN holds only that many feature rows (the X^T tile of the first layer): the others count as zero
+__device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x16& C, int i, int hf, int in_rows = 32) {
   f32x4 a[4], b[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { a[q] = lds4(IN + i * 32 + 16 * hf + 4 * q); b[q] = lds4(DA + i * 32 + 16 * hf + 4 * q); }
+  for (int q = 0; q < 4; ++q) {
+    a[q] = lds4(IN + (i < in_rows ? i : 0) * 32 + 16 * hf + 4 * q);
+    if (i >= in_rows) { a[q][0] = 0.f; a[q][1] = 0.f; a[q][2] = 0.f; a[q][3] = 0.f; }
+    b[q] = lds4(DA + i * 32 + 16 * hf + 4 * q);
+  }
 #if NIF_PBW_BF16
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
@@ -70,6 +75,10 @@ __device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
   return s;
 }
 
+#ifndef NIF_PBW_DZR
+#define NIF_PBW_DZR 8     // registers of the dL/dz prefetch: 64 x 8 floats = latent rows 0..15 of the [r <= 32][32] tile (rows 16.. are
+                          // fetched where they are parked: 16 registers across the forward pass cost the generic-activation forms 40 spills)
+#endif
 #ifndef NIF_PBW_WAVES
 #define NIF_PBW_WAVES 8   // 2 waves per SIMD (256 registers each, some spills) beat 1 wave with 478 registers: 0.27 -> 0.24 ms
 #endif
@@ -131,6 +140,17 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     const long pt = tile * 32 + p;
     const long ptc = pt < A.B ? pt : A.B - 1;
     const float* prow = A.xin + ptc * A.ncol + A.col0;
+    // !SMALL (r > 1 or pi > 1: the last-layer class, multi-parameter nets): the tile's dL/dz rows ([r][32], contiguous) are
+    // fetched HERE, all loads in flight together behind the forward recomputation, and parked in the dL/da tile of the LDS (free
+    // until the adjoint) -- r4: the r-trip loop below used to issue one dependent global load per latent row (cfg-4, r = 10:
+    // 10 serial memory latencies per tile)
+    float dzr[NIF_PBW_DZR];
+    if (!SMALL) {
+      const float* dzg = A.DZ + tile * A.r * 32;
+      const int nd = A.r * 32;
+#pragma unroll
+      for (int q = 0; q < NIF_PBW_DZR; ++q) { const int e = lane + 64 * q; dzr[q] = e < nd ? dzg[e] : 0.f; }
+    }
     // ---- forward (recomputed), layer inputs into the private LDS stash ---------------------------
     f32x16 h[1], T[1], d[NM + 1][1];
     {
@@ -181,30 +201,27 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     f32x16 gh[1], ga[1], U[1];
 #pragma unroll
     for (int v = 0; v < 16; ++v) gh[0][v] = 0.f;
-    for (int c = 0; c < A.r; ++c) {
-      const float dz = A.DZ[(tile * A.r + c) * 32 + p];
-      gh[0] += dz * psmall_get(S.bw + c * 32, 0, hf);
+    if (!SMALL) {
+#pragma unroll
+      for (int q = 0; q < NIF_PBW_DZR; ++q) gaT[lane + 64 * q] = dzr[q];       // rows >= r are zero
+#pragma unroll
+      for (int q = NIF_PBW_DZR; q < 16; ++q) {
+        const int e = lane + 64 * q;
+        gaT[e] = e < A.r * 32 ? A.DZ[tile * A.r * 32 + e] : 0.f;
+      }
+      for (int c = 0; c < A.r; ++c) gh[0] += gaT[c * 32 + p] * psmall_get(S.bw + c * 32, 0, hf);
+    } else {
+      gh[0] += A.DZ[tile * 32 + p] * psmall_get(S.bw, 0, hf);
     }
     if (SMALL) {
       const float dz = A.DZ[tile * 32 + p];
       Cb += dz * h[0];
       gbb += hf == 0 ? dz : 0.f;
     } else {
-      // the dz tile in the B-operand layout: lane (j = c, hf) holds dz_c of 16 consecutive points
-      f32x4 a[4], b[4];
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = lds4(hs + NM * 1024 + i * 32 + 16 * hf + 4 * q);
-        if (i < A.r) b[q] = *reinterpret_cast<const f32x4*>(A.DZ + (tile * A.r + i) * 32 + 16 * hf + 4 * q);
-        else { b[q][0] = 0.f; b[q][1] = 0.f; b[q][2] = 0.f; b[q][3] = 0.f; }
-        s += (b[q][0] + b[q][1]) + (b[q][2] + b[q][3]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Cb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], Cb, 0, 0, 0);
-      gbb += s;
+      // dL/dW_b = h^T dz over the tile's points: the parked dL/dz tile is the DA operand as it lies (zero rows beyond r).  r4: the
+      // bf16 hi / lo form of the hidden matrices (6 x 32 matrix-pipe cycles) instead of 16 f32-input MFMAs (16 x 64)
+      grad_mfma(hs + NM * 1024, gaT, Cb, i, hf);
+      gbb += col_sum(gaT, i, hf);
     }
     // touch loads (see PbwArgs): issued once this tile's own global loads are consumed, waited for at the end of
     // the tile.  This needs a spill-free kernel: scratch reloads count in vmcnt and the queue completes in order, so
@@ -254,18 +271,8 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       C1 += prow[0] * ga[0];
       CB1 += ga[0];
     } else {
-    stash_store<1>(gaT, 0, ga, p, hf);
-      f32x4 a[4], b[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (i < 8) a[q] = lds4(xT + i * 32 + 16 * hf + 4 * q);
-        else { a[q][0] = 0.f; a[q][1] = 0.f; a[q][2] = 0.f; a[q][3] = 0.f; }
-        b[q] = lds4(gaT + i * 32 + 16 * hf + 4 * q);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][c], b[q][c], C1, 0, 0, 0);
+      stash_store<1>(gaT, 0, ga, p, hf);
+      grad_mfma(xT, gaT, C1, i, hf, 8);     // rows of X^T: the pi <= 6 inputs, then ones (the bias row)
     }
     asm volatile("" ::"v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]));
   }

@@ -44,6 +44,14 @@ WORK = {
     "cfg4_linear_nif_3d_128x6": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None),
     "cfg4_linear_nif_3d_128x6_bf16": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None,
                                       "mixed_bfloat16"),
+    # Keras' mixed_float16 (r4: k_snet4<.., PR = 2>; the dL/da stash rows and the weight-gradient sums stay fp32)
+    "cfg2_wave_4x64_f16": ("NIFMultiScale", ms(64, 4, 32, 2, 1, 1, 1, 1), 1 << 20, None, "mixed_float16"),
+    "cfg3_ms_6x128_2d_f16": ("NIFMultiScale", ms(128, 6, 64, 2, 1, 2, 1, 1), 1 << 19, None, "mixed_float16"),
+    "cfg4_linear_nif_3d_128x6_f16": ("NIFMultiScaleLastLayerParameterized", ms(128, 6, 32, 2, 10, 3, 3, 1, conn="last_layer"), 1 << 21, None,
+                                     "mixed_float16"),
+    # (not BASELINE configs: the !SMALL forms of k_pnet_bwg -- latent_dim 3, two parameter inputs -- with a fixed and a generic activation)
+    "aux_pnet_r3_swish_4x64": ("NIFMultiScale", ms(64, 4, 32, 2, 3, 1, 1, 2), 1 << 20, None),
+    "aux_pnet_r3_tanh_4x64": ("NIFMultiScale", ms(64, 4, 32, 2, 3, 1, 1, 2, p_act="tanh"), 1 << 20, None),
     "cfg1_nif_swish_2x32": ("NIF", ({"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"},
                                     {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}), 1 << 20, None),
 }
@@ -62,7 +70,7 @@ def roofline(s, B, ns, policy, snet_ms):
     so_eff = s.so_dim * (s.pi_hidden if s.connectivity == "last_layer" else 1)
     n_w = s.si_dim * n + nh * n * n + n * so_eff
     flop32 = 4.0 * planes * n_w * (1 + ns) * B                     # forward + data adjoint, fp32-equivalent
-    prod = 2.0 if policy == "mixed_bfloat16" else 9.0              # bf16 products per fp32 product: 6 forward + 3 adjoint (1 + 1)
+    prod = 2.0 if policy in ("mixed_bfloat16", "mixed_float16") else 9.0   # 16-bit products per fp32 product: 6 forward + 3 adjoint (1 + 1)
     nbl_even = (((n + 15) // 16) % 2) == 0 and n > 16
     exec16 = prod * 2.0 * planes * nh * n * n * (1 + ns) * B if nbl_even else 0.0
     t = snet_ms * 1e-3

@@ -207,6 +207,17 @@ def run_case(cfg, B, seed, loss="mse"):
                 bad.append(("bf16 policy", lb, rlb, _rel(gb, O.flatten(rgb))))
         except (nif_amd._lib.NifError, NotImplementedError) as ex:
             bad.append(("bf16 refused", str(ex)[:80]))
+        # ... and mixed_float16 (k_snet4<.., PR = 2>: half-precision operands, per-point loss scale, fp32 stash rows)
+        try:
+            mh = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_float16")
+            modelh = mh.build(); modelh.set_weights(ws)
+            fn = O.ll_policy_loss_and_grad if ll else O.planes_loss_and_grad
+            rlh, rgh, ruh = fn(spec, ws64, x64, y64, sw64, rnd=O.f16_round)
+            lh, gh = mh._engine.loss_and_grad(x, y, sw)
+            if abs(lh - rlh) > 1e-3 * abs(rlh) or _rel(gh, O.flatten(rgh)) > 5e-3:
+                bad.append(("f16 policy", lh, rlh, _rel(gh, O.flatten(rgh))))
+        except (nif_amd._lib.NifError, NotImplementedError) as ex:
+            bad.append(("f16 refused", str(ex)[:80]))
     return bad
 
 
