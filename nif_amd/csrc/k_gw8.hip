@@ -64,8 +64,12 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   const long nt = A.ntiles;
   // two register sets: while tile t is split and multiplied, tiles t+1 and t+2 (64 KB per CU) are in flight -- one tile
   // (32 KB) does not cover the HBM latency at 5 TB/s (measured 3.8 TB/s)
-  f32x4 rin[2][2], rda[DAB ? 1 : 2][2], rz[2];
-  g8_bf16x4 rdb[DAB ? 2 : 1][2];
+  // r4: the one-plane fp32 form takes three sets (cfg-4 128 x 6: 0.49 -> 0.47 ms per matrix); the two-plane forms lose with a
+  // third set (registers: 1.12 -> 2.1 ms on cfg-3), the bf16-row forms do not move.  Also measured and not kept: the split of
+  // tile t + 1 sharing the barrier interval with the products of tile t, the two waves of a SIMD in opposite order (+10 %)
+  constexpr int NS = (R == 0 && !DAB) ? 3 : 2;
+  f32x4 rin[NS][2], rda[DAB ? 1 : NS][2], rz[NS];
+  g8_bf16x4 rdb[DAB ? NS : 1][2];
 #define G8_LOAD(SET_, T_)                                                                          \
   {                                                                                                \
     const float* in_ = A.IN + (T_) * (128 * 32);                                                   \
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
       else split_store(S + 2 * NPL * PLANE, S + (2 * NPL + 1) * PLANE, f, dav);                                        \
     }                                                                                                                  \
     __syncthreads();   /* planes of `set` complete; the other buffer's readers finished before the previous barrier */ \
-    const long tn = t + 2 * (long)gridDim.x;                                                                           \
+    const long tn = t + NS * (long)gridDim.x;                                                                          \
     if (tn < nt) G8_LOAD(RS, tn)                                                                                       \
     const char* Ahi = S + (2 * uk) * PLANE, *Alo = Ahi + PLANE;                                                        \
     const char* Bhi = S + 2 * NPL * PLANE, *Blo = Bhi + PLANE;                                                         \
@@ -148,11 +152,16 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   long t = blockIdx.x;
   if (t < nt) G8_LOAD(0, t)
   if (t + gridDim.x < nt) G8_LOAD(1, t + gridDim.x)
+  if constexpr (NS > 2) { if (t + 2 * (long)gridDim.x < nt) G8_LOAD(2, t + 2 * (long)gridDim.x) }
   int set = 0;
   while (t < nt) {
     G8_TILE(0)
     if (t >= nt) break;
     G8_TILE(1)
+    if constexpr (NS > 2) {
+      if (t >= nt) break;
+      G8_TILE(2)
+    }
   }
 #undef G8_TILE
 #undef G8_LOAD
