@@ -1532,6 +1532,29 @@ static int sobolev_check(nif_ctx* c, const int32_t* x_idx, int32_t nx, const int
   }
   return NIF_OK;
 }
+// Columns per pass of a Sobolev step / forward: three tangent streams where the kernel's working set allows it.  A parameter-column
+// stream of the hypernetwork classes keeps 4 x (r x 80) floats of per-wave LDS next to the planes (k_sob.hip launch_sob): at 128
+// units and latent_dim 8 three of them exceed the 160 KB by a few KB (fuzz sweep r04, seed 7, case 5) -- the passes then take two
+// columns, or one, instead of refusing the shape.  Probed with the query the step itself makes (snet_plan), no launch.
+static int sob_cols_per_pass(nif_ctx* c, const int32_t* x_idx, int nx) {
+  if (c->kind == NIF_KIND_LASTLAYER) return 3;        // (parameter columns are heads of the epilogue there, not streams)
+  if (ensure_packed(c) != NIF_OK) return 3;           // (surfaces again, with its message, in the step)
+  for (int gs = 3; gs > 1; --gs) {
+    bool ok = true;
+    for (int g0 = 0; g0 < nx && ok; g0 += gs) {
+      const int ng = nx - g0 < gs ? nx - g0 : gs;
+      SobPlan sp;
+      if (sobolev_plan(c, x_idx + g0, ng, &sp) != NIF_OK) return 3;
+      SNetArgs sa; fill_snet(c, sa, nullptr, c->pi + c->si, c->pi, 64);
+      SobPar spq{};
+      for (int d = 0; d < 3; ++d) spq.par[d] = sp.par[d];
+      ok = launch_sob(sa, true, ng, sp.seeds, nullptr, 0.f, nullptr, nullptr, true, c->st, &spq) >= 0;
+    }
+    if (ok) return gs;
+  }
+  return 1;
+}
+
 extern "C" int nif_sobolev_loss_grad_dev_y(nif_ctx* c, const float* xin, const float* y, const float* dydx, const float* sw,
                                            int64_t B, int64_t Bg, const int32_t* x_idx, int32_t nx, const int32_t* y_idx, int32_t ny,
                                            float w_jac) {
@@ -1539,11 +1562,12 @@ extern "C" int nif_sobolev_loss_grad_dev_y(nif_ctx* c, const float* xin, const f
   unsigned ymask; int nys;
   int rc = sobolev_check(c, x_idx, nx, y_idx, ny, &ymask, &nys); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
-  const int ngroups = (nx + 2) / 3;
+  const int gs = sob_cols_per_pass(c, x_idx, nx);
+  const int ngroups = (nx + gs - 1) / gs;
   if (ngroups > 1 && !c->sob_acc) HIPCHK(hipMalloc(&c->sob_acc, sizeof(float) * (size_t)(c->P + 1)));
   const float jac_l1 = c->jac_l1, act_l1 = c->act_l1, act_l2 = c->act_l2;
   for (int k = 0; k < ngroups; ++k) {
-    const int g0 = 3 * k, ng = nx - g0 < 3 ? nx - g0 : 3;
+    const int g0 = gs * k, ng = nx - g0 < gs ? nx - g0 : gs;
     SobPlan sp;
     rc = sobolev_plan(c, x_idx + g0, ng, &sp); if (rc) break;
     for (int q = 0; q < 3; ++q) sp.gcol[q] += g0;
@@ -1573,8 +1597,10 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   if (!c || !xin || !u || !dudx || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   unsigned ymask; int nys;
   int rc = sobolev_check(c, x_idx, nx, nullptr, 0, &ymask, &nys); if (rc) return rc;
-  for (int g0 = 0; g0 < nx; g0 += 3) {      // groups of <= 3 columns, each filling its columns of the [B][so][nx] rows
-    const int ng = nx - g0 < 3 ? nx - g0 : 3;
+  HIPCHK(hipSetDevice(c->dev));
+  const int gs = sob_cols_per_pass(c, x_idx, nx);
+  for (int g0 = 0; g0 < nx; g0 += gs) {      // groups of <= 3 columns, each filling its columns of the [B][so][nx] rows
+    const int ng = nx - g0 < gs ? nx - g0 : gs;
     SobPlan sp;
     rc = sobolev_plan(c, x_idx + g0, ng, &sp); if (rc) return rc;
     for (int q = 0; q < 3; ++q) sp.gcol[q] += g0;

@@ -152,3 +152,33 @@ def test_one_point_batches_are_judged_on_the_prediction():
         solid = np.concatenate([(np.abs(gt.ravel()) > 0.02 * (np.sqrt(np.mean(gt ** 2)) + 1e-300)) for gt in g_])
         d = np.abs(O.flatten(model.get_weights()) - th1)
         assert d[solid].max() < 0.02 * LR, (t, d[solid].max() / LR)
+
+
+def test_sobolev_step_takes_fewer_columns_per_pass_when_three_do_not_fit():
+    """sweep r04 seed 7 case 5 (NIFMultiScale 128 x 6, latent 8, 3 coordinates + 4 parameters) was the round's only refusal: the Sobolev
+    step over all seven input columns needs three parameter-column streams' per-wave LDS next to a 128-wide plane (165 KB).  The passes
+    now take two columns (or one) where three do not fit (nif_api.hip sob_cols_per_pass): the step and the two-output predictions of
+    that shape agree with the oracle like any other"""
+    import nif_amd
+    from tests.test_gpu_parity import _cfg, _per_tensor_rel
+    kind, cs, cp = _cfg("NIFMultiScale", 128, 6, 16, 3, 8, 3, 3, 4, s_res=False, p_act="swish", p_res=True)
+    spec = O.Spec(kind, cs, cp)
+    rng = np.random.default_rng(7005)
+    ws = O.init_weights(spec, rng, dtype=np.float32)
+    B = 130
+    m = getattr(nif_amd, kind)(cs, cp)
+    model = m.build(); model.set_weights(ws)
+    x = rng.uniform(-1, 1, size=(B, spec.pi + spec.si)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, spec.so)).astype(np.float32)
+    sw = rng.uniform(0.5, 1.5, size=(B,)).astype(np.float32)
+    xi = [int(v) for v in rng.permutation(spec.pi + spec.si)]
+    g = rng.uniform(-1, 1, size=(B, spec.so, len(xi))).astype(np.float32)
+    ws64 = [w.astype(np.float64) for w in ws]
+    sl, sg = m._engine.sobolev_loss_and_grad(x, y, g, xi, 0.05, sw)
+    rl, rg, ru, rJ = O.sobolev_loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64), g.astype(np.float64), xi, 0.05,
+                                             sw.astype(np.float64))
+    assert abs(sl - rl) <= 2e-5 * abs(rl), (sl, rl)
+    rel = _per_tensor_rel(spec, sg, O.flatten(rg))
+    assert max(rel.values()) < 4e-4, rel
+    u, J = m._engine.sobolev_forward(x, xi)
+    assert _rel(u, ru) < 1e-5 and _rel(J.reshape(rJ.shape), rJ) < 3e-5
