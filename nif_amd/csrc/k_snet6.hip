@@ -104,7 +104,12 @@ struct S6Args {
 #define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
 #endif
 
-template <int NBL>
+// PR (late r4): the producers' hidden n x n products under a Keras policy -- 1 = mixed_bfloat16 (ONE bf16 product per operand pair),
+// 2 = mixed_float16 (half operands, per-point loss scale on dL/da; k_snet4_dev.h) -- as in k_snet4<.., PR>.  The CONSUMER side is
+// untouched: the deposits stay bf16 (hi, lo) pairs of the fp32 rows and the weight-gradient sums three products, i.e. the policy's
+// weight gradients here are those of fp32 stash rows (oracle: stash_bf16 = False).  (r4's first policy form also cut the consumers
+// to one MFMA per tile and hipcc answered with 327 spilled registers; with the consumer code unchanged the allocation holds.)
+template <int NBL, int PR = 0>
 __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   extern __shared__ __attribute__((aligned(256))) char smem6[];
   const SNetArgs& A = F.s;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
 #endif
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
-      split3<NBL>(h, b0, b1, b2);
+      split3p<NBL, PR>(h, b0, b1, b2);
       {
         const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
 #pragma unroll
@@ -515,17 +520,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
-        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], T, lane); })
 #else
-        S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], T, lane); })
 #endif
-        S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], T, lane); })
+        S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[1], b1[1], b2[1], T, lane); })
         const float zt = zt_base[0];
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      S6_CHUNK({ mfma_x6<NBL>(cur, b0[0], b1[0], b2[0], acc, lane); })
-      S6_CHUNK({ mfma_x6<NBL>(cur, b0[1], b1[1], b2[1], acc, lane); })
+      S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], acc, lane); })
+      S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[1], b1[1], b2[1], acc, lane); })
       sine16_tag<NBL>(acc, acc);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) h[b] = acc[b];
@@ -615,15 +620,31 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         dzs[lane] += sbv;
       }
       bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);
+      split2<NBL>(ga, b0, b1);                // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
+      bf16x8 q0[NCH];                         // the products' operand: b0, or under mixed_float16 half(s dL/da), s per point
+      float ils = 1.0f;
+      if (PR == 2) {
+        float mx = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ga[b][0]), fabsf(ga[b][1]))), fmaxf(fabsf(ga[b][2]), fabsf(ga[b][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const unsigned ef = (__float_as_uint(mx) >> 23) & 0xFFu;
+        const unsigned sf = 268u - ef < 227u ? 268u - ef : 227u;
+        ils = __uint_as_float((254u - sf) << 23);
+        cast_f16<NBL>(ga, q0, __uint_as_float(sf << 23));
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < NCH; ++ks) q0[ks] = b0[ks];
+      }
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PR, true>(cur, q0[0], b1[0], U, lane); })
 #else
-        S6_CHUNK({ mfma_x3<NBL, false, true>(cur, b0[0], b1[0], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PR, true>(cur, q0[0], b1[0], U, lane); })
 #endif
-        S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[1], b1[1], U, lane); })
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
@@ -631,10 +652,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
           for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] = zt0 * U[b];
-        dzs[lane] += s;
+        dzs[lane] += PR == 2 ? ils * s : s;
       }
-      S6_CHUNK({ mfma_x3<NBL>(cur, b0[0], b1[0], gh, lane); })
-      S6_CHUNK({ mfma_x3<NBL>(cur, b0[1], b1[1], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[0], b1[0], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[1], b1[1], gh, lane); })
+      if (PR == 2) {
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) gh[b] *= ils;
+      }
       {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
         fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
         fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
@@ -714,7 +739,11 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {
-  if (a.ll || a.res || a.nif_skip || a.prec != 0) return false;
+  if (a.ll || a.res || a.nif_skip) return false;
+  if (a.prec != 0) {     // the policy forms: NIF_S6_POLICY=0 keeps the r3 policy step (k_snet4<PR> + bf16 dL/da stash + k_gw_lds<DAB>) for A/B
+    static const bool pol = [] { const char* e = getenv("NIF_S6_POLICY"); return !(e && e[0] == '0'); }();
+    if (!pol) return false;
+  }
   if (snet3_nbl(a.n) != 4 || a.r != 1 || a.nh < 1 || a.nh > 4 || a.si > 3 || a.so > 3) return false;
   return snet6_shmem(a, 4) <= 160u * 1024u;
 }
@@ -728,7 +757,14 @@ int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st
   const int nblk = snet6_rows(a);
   S6Args f; f.s = a; f.partial = partial; f.pstride = pstride;
   const size_t shm = snet6_shmem(a, 4);
-  (void)hipFuncSetAttribute((const void*)k_snet6<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL((k_snet6<4>), dim3(nblk), dim3(1024), shm, st, f);
+#define S6L(PR_)                                                                                                  \
+  {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)k_snet6<4, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_snet6<4, PR_>), dim3(nblk), dim3(1024), shm, st, f);                                    \
+  }
+  if (a.prec == 2) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(2) }      // the half-precision plane set (k_pack16b f16)
+  else if (a.prec == 1) S6L(1)
+  else S6L(0)
+#undef S6L
   return nblk;
 }

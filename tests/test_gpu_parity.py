@@ -1341,11 +1341,20 @@ def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
 BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_so2_b33", "nif_cfg1_32x2", "ms_64x8"]
 
 
+def _snet6_shape(spec):
+    """the plain training step of this shape runs on k_snet6 (csrc/k_snet6.hip snet6_supported): plain-SIREN NIFMultiScale, 49..64
+    units, latent_dim 1, at most four hidden matrices, si / so <= 3"""
+    return (spec.kind == O.KIND_MS and not spec.s_res and (spec.n + 15) // 16 == 4 and spec.r == 1 and 1 <= spec.n_hidden_mats <= 4
+            and spec.si <= 3 and spec.so <= 3)
+
+
 def _stash_bf16(spec, xi=None):
     """does the step of this shape keep its hidden-layer dL/da stash rows in bf16 under mixed_bfloat16?  The bf16 kernels' widths:
     two or four 16-feature blocks (k_gw_lds<DAB>), eight with at most two planes per layer (k_gw8<R, DAB>: the last-layer class,
     latent_dim 1); plain step: k_snet4<PR>; Sobolev step: only k_sobw<PR> (plain SIREN, coordinate seeds, <= 64 units)"""
     nbl = (spec.n + 15) // 16
+    if xi is None and _snet6_shape(spec):
+        return False        # late r4: the fused-gradient kernel's policy forms -- no stash at all, weight-gradient sums from exact (hi, lo) rows
     if spec.kind == O.KIND_LL:
         return xi is None and nbl in (2, 4, 8)
     if not (nbl in (2, 4) or (nbl == 8 and spec.r <= 1)):

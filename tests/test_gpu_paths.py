@@ -128,8 +128,11 @@ KNOBS = [
     ({"NIF_LL_MLP": "1"}, "ll_plain_32x2_r3", "plain", "float32"),         # last-layer class on the r1 MLP kernels
     ({"NIF_FP32_MFMA": "1"}, "ms_res_64x2", "plain", "float32"),
     ({"NIF_PIPE_CHUNK": "64", "NIF_FP32_MFMA": "1"}, "ms_cfg2_64x4", "plain", "float32"),   # two-stream chunk pipeline of the k_snet3 path
-    ({"NIF_DA_BF16": "0"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),     # fp32 dL/da stash rows under the policy
-    ({"NIF_DA_BF16": "1"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),
+    ({"NIF_DA_BF16": "0", "NIF_S6_POLICY": "0"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),     # fp32 dL/da stash rows under the policy
+    ({"NIF_DA_BF16": "1", "NIF_S6_POLICY": "0"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),
+    ({"NIF_S6_POLICY": "1"}, "ms_cfg2_64x4", "plain", "mixed_bfloat16"),   # late r4: the fused-gradient kernel's policy forms (default)
+    ({"NIF_S6_POLICY": "1"}, "ms_cfg2_64x4", "plain", "mixed_float16"),
+    ({"NIF_S6_POLICY": "0"}, "ms_cfg2_64x4", "plain", "mixed_float16"),    # k_snet4<.., PR = 2> + the fp32-row reductions
     ({"NIF_DA_BF16": "0"}, "ms_cfg5_64x4_si2", "sobolev", "mixed_bfloat16"),
 ]
 
@@ -141,7 +144,7 @@ def test_every_runtime_knob_against_the_oracle(case, tmp_path):
     out = str(tmp_path / "knob.npz")
     env = dict(os.environ)
     for k in ("NIF_FUSE_GW", "NIF_SIDE_PNET", "NIF_PBW_TOUCH", "NIF_PNET_STASH", "NIF_PNET_BF2", "NIF_GW8", "NIF_GW_LDS", "NIF_SOBW", "NIF_LL_MLP",
-              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16"):
+              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", KNOB_CHILD, name, mode, policy, out], env=env, cwd=ROOT, stdout=subprocess.PIPE,
