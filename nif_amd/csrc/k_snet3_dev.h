@@ -323,7 +323,8 @@ __device__ __forceinline__ f32x4 mfma_f16(const bf16x8 a, const bf16x8 b, const 
 // PR = 2 (mixed_float16, r4): the same with half-precision operands (slot 0 of the chunk holds the f16 plane: k_pack16b)
 // ZI: the chains start from zero (the first MFMA of every chain takes the inline constant 0 as C: no v_mov zeroing)
 // NT / OB0: the chunk holds NBL of the NT output blocks of T, starting at block OB0 (128-wide nets stream half chunks)
-template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0>
+// CP (late r4): the chunk holds ONE 16-bit plane per block (the policies' compact plane set: unit ob * 64 + lane) instead of the split groups
+template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0, bool CP = false>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -331,13 +332,13 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
 #pragma unroll
   for (int ob = 0; ob < NBL; ob += 2) {
     if (PR == 2) {
-      const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
+      const bf16x8 a0 = cur[(CP ? ob : ob * 3) * 64 + lane], c0 = cur[(CP ? ob + 1 : ob * 3 + 3) * 64 + lane];
       T[ob] = mfma_f16(a0, b0, ZI ? z4 : T[ob]);
       T[ob + 1] = mfma_f16(c0, b0, ZI ? z4 : T[ob + 1]);
       continue;
     }
     if (PR) {
-      const bf16x8 a0 = cur[(ob * 3 + 0) * 64 + lane], c0 = cur[(ob * 3 + 3) * 64 + lane];
+      const bf16x8 a0 = cur[(CP ? ob : ob * 3) * 64 + lane], c0 = cur[(CP ? ob + 1 : ob * 3 + 3) * 64 + lane];
       T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ob], 0, 0, 0);
       T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, ZI ? z4 : T[ob + 1], 0, 0, 0);
       continue;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   __builtin_amdgcn_s_setprio(0);
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
-template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0>
+template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0, bool CP = false>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T_)[NT], int lane) {
   __builtin_amdgcn_s_setprio(1);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -368,13 +369,13 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
 #pragma unroll
   for (int ib = 0; ib < NBL; ib += 2) {
     if (PR == 2) {
-      const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
+      const bf16x8 a0 = cur[(CP ? ib : ib * 2) * 64 + lane], c0 = cur[(CP ? ib + 1 : ib * 2 + 2) * 64 + lane];
       T[ib] = mfma_f16(a0, b0, ZI ? z4 : T[ib]);
       T[ib + 1] = mfma_f16(c0, b0, ZI ? z4 : T[ib + 1]);
       continue;
     }
     if (PR) {
-      const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], c0 = cur[(ib * 2 + 2) * 64 + lane];
+      const bf16x8 a0 = cur[(CP ? ib : ib * 2) * 64 + lane], c0 = cur[(CP ? ib + 1 : ib * 2 + 2) * 64 + lane];
       T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ib], 0, 0, 0);
       T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, ZI ? z4 : T[ib + 1], 0, 0, 0);
       continue;

@@ -27,19 +27,21 @@
 //   bwd chunk (plane, ks): unit ((ib*2 + s)*64 + lane), 8 bf16: split s of M[in = 16ib + (lane&15)][out = slot(ks,g,t)]
 // blockIdx.y = matrix j of a batch of equally shaped matrices `mstride` slots apart (the hidden hyper-matrices)
 // scale: omega_0 of the SIREN layer, folded into the planes (r3) so that no consumer multiplies by it per element
-// f16 (mixed_float16): slot 0 of every split group holds half(x) (RNE, saturated) instead of bf16(x), the other slots zero --
-// the same chunk geometry, so k_snet4<.., PR = 2> streams it with the same DMA program
+// mode 0: the split groups above.  mode 1 / 2 (the policies' COMPACT plane set, late r4): one 16-bit value per element -- bf16(x)
+// (mixed_bfloat16) or half(x) (mixed_float16; RNE, saturated) -- unit (ob * 64 + lane) of a chunk, a third / half of the split
+// planes' bytes: k_snet4<.., PR> / k_snet6<.., PR> stream these (CP in mfma_x6 / mfma_x3), every other kernel the split groups
 __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstride, int NBL, __bf16* __restrict__ WF,
-                          __bf16* __restrict__ WB, long fstride, long bstride, float scale, int f16) {
+                          __bf16* __restrict__ WB, long fstride, long bstride, float scale, int mode) {
   m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
   WF += (long)blockIdx.y * fstride; WB += (long)blockIdx.y * bstride;
   const int NCH = NBL / 2;
-  const long fwd_plane = (long)NCH * NBL * 3 * 64 * 8, bwd_plane = (long)NCH * NBL * 2 * 64 * 8;
+  const int nsf = mode ? 1 : 3, nsb = mode ? 1 : 2;
+  const long fwd_plane = (long)NCH * NBL * nsf * 64 * 8, bwd_plane = (long)NCH * NBL * nsb * 64 * 8;
   const long total_f = fwd_plane * (m.r + 1), total_b = bwd_plane * (m.r + 1);
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
     const bool fwd = idx < total_f;
     const long e = fwd ? idx : idx - total_f;
-    const int ns = fwd ? 3 : 2;
+    const int ns = fwd ? nsf : nsb;
     const long per_plane = fwd ? fwd_plane : bwd_plane;
     const int k = (int)(e / per_plane);
     long rem = e - (long)k * per_plane;
@@ -52,28 +54,27 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstrid
     const int row = 16 * blk + (lane & 15);
     const int in = fwd ? slot : row, out = fwd ? row : slot;
     const float x = (in < m.nin && out < m.nout) ? scale * theta[matref_index(m, k, in, out)] : 0.f;
+    if (mode == 2) {
+      reinterpret_cast<_Float16*>(fwd ? WF : WB)[e] = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+      continue;
+    }
     const __bf16 x0 = (__bf16)x;
     const float r1 = x - (float)x0;
     const __bf16 x1 = (__bf16)r1;
     const __bf16 x2 = (__bf16)(r1 - (float)x1);
-    if (f16) {
-      const _Float16 xh = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
-      reinterpret_cast<_Float16*>(fwd ? WF : WB)[e] = s == 0 ? xh : (_Float16)0.0f;
-      continue;
-    }
     (fwd ? WF : WB)[e] = s == 0 ? x0 : (s == 1 ? x1 : x2);
   }
 }
-void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int f16) {
-  launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, scale, st, f16);
+void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode) {
+  launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, scale, st, mode);
 }
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
-                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int f16) {
+                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode) {
   const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m0.r + 1);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pack16b, dim3(grid, nmat), dim3(256), 0, st, theta, m0, mstride, NBL, (__bf16*)WF, (__bf16*)WB,
-                     fstride_elems, bstride_elems, scale, f16);
+                     fstride_elems, bstride_elems, scale, mode);
 }
 
 // phi layer of the last-layer class: dense W[n][sop], sop <= 32 (two 16-output blocks)
@@ -152,9 +153,9 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   if (query_only) return nblk;
   dim3 grid(nblk), block(256);
   const size_t shm = snet4_shmem(a, NBL);
-  if (a.prec == 2) {      // mixed_float16: the PR = 2 instantiations (k_snet4_f16.hip) on the half-precision planes
-    SNetArgs h = a;
-    h.WF4 = a.WF4h; h.WB4 = a.WB4h;
+  SNetArgs h = a;
+  if (a.prec != 0) { h.WF4 = a.WF4h; h.WB4 = a.WB4h; }      // the policies' compact plane set (k_pack16b mode 1 / 2)
+  if (a.prec == 2) {      // mixed_float16: the PR = 2 instantiations (k_snet4_f16.hip)
     launch_snet4_f16(h, train, nblk, shm, st);
     return nblk;
   }
@@ -163,7 +164,7 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
     if (shm > 48 * 1024)                                                                                            \
       (void)hipFuncSetAttribute((const void*)k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
-    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_>), grid, block, shm, st, a);                      \
+    hipLaunchKernelGGL((k_snet4<NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_>), grid, block, shm, st, h);                      \
   }
 // PR_: the mixed_bfloat16 policy (ONE bf16 product per n x n operand pair); plain SIREN training always takes the tagged-sine form
 #define S4M(NBL_, LL_, PR_)                                                                                         \

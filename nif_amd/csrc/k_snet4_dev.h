@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   constexpr int NCH = NBL / 2;                      // K-step chunks per plane
   constexpr int SPL = (NBL == 8 && LL) ? NIF_S4_SPLIT8 : (NBL == 4 ? NIF_S4_SPLIT4 : 1), NBS = NBL / SPL;   // chunk pieces per K-step, output (input) blocks per piece
   constexpr int CF = NBS * 3 * 64, CB = NBS * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  // the policies' compact plane set (late r4): ONE 16-bit plane per block -- a third / half of the chunk DMA (LDS buffers keep the
+  // stride CF: the phi layer's chunks of the last-layer class stay split groups)
+  constexpr bool CP = PR != 0;
+  constexpr int CFH = CP ? NBS * 64 : CF, CBH = CP ? NBS * 64 : CB;   // units per HIDDEN-matrix chunk
   constexpr int QF = (CF + NT - 1) / NT;
   // LDS ring of the chunk stream: NBUF buffers, the DMA runs DIST = NBUF - 1 chunk steps ahead of the MFMAs.  r2 had two buffers
   // and drained vmcnt(0) in front of every barrier: the L2 -> LDS latency of a chunk (~1.5-2 k cycles) had to hide behind ONE
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   constexpr int PHF = 2 * 3 * 64;                       // units of a phi-layer forward chunk (LL)
   const int NPC = (r + 1) * NCH * SPL;                  // chunks of one hidden matrix
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
+  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;      // tile groups of this workgroup behind the current one
   auto cs_phase_step = [&]() {          // the current phase has been issued completely: find the next one that has chunks
     for (;;) {
@@ -105,11 +109,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       if (cs_phase == 1) { if (LL) { cs_src = reinterpret_cast<const bf16x8*>(A.WPF); cs_units = PHF; cs_left = NCH; return; } }
       else if (cs_phase == 2) { if (LL && TRAIN) { cs_src = reinterpret_cast<const bf16x8*>(A.WPB); cs_units = CB; cs_left = SPL; return; } }
       else if (TRAIN && cs_phase < 3 + nh) {
-        cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 3)) * NPC * CB; cs_units = CB; cs_left = NPC; return;
+        cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 3)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
       } else {
         if (cs_groups <= 0) { cs_left = -1; return; }
         --cs_groups; cs_phase = 0;
-        cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CF; cs_left = nh * NPC; return;
+        cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC; return;
       }
     }
   };
@@ -244,17 +248,17 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
 // the SPL pieces of K-step ks_: forward (6-product) into T_, adjoint (3-product) into U_; ZI_: the chains start from zero
 #define NIF_FWD_STEP(KS_, T_)                                                                                          \
   _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
-    if (sp_ == 0) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, 0>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); })            \
-    else if (sp_ == 1) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 1 ? NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
-    else if (sp_ == 2) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 2 ? 2 * NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
-    else NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 3 ? 3 * NBS : 0)>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    if (sp_ == 0) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); })            \
+    else if (sp_ == 1) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 1 ? NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    else if (sp_ == 2) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 2 ? 2 * NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    else NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 3 ? 3 * NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
   }
 #define NIF_BWD_STEP(B0_, B1_, U_, ZI_, PR_, ...)                                                                      \
   _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
-    if (sp_ == 0) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, 0>(cur, B0_, B1_, U_, lane); __VA_ARGS__ })                  \
-    else if (sp_ == 1) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 1 ? NBS : 0)>(cur, B0_, B1_, U_, lane); })       \
-    else if (sp_ == 2) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 2 ? 2 * NBS : 0)>(cur, B0_, B1_, U_, lane); })   \
-    else NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 3 ? 3 * NBS : 0)>(cur, B0_, B1_, U_, lane); })                 \
+    if (sp_ == 0) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, 0, (PR_ != 0)>(cur, B0_, B1_, U_, lane); __VA_ARGS__ })                  \
+    else if (sp_ == 1) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 1 ? NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })       \
+    else if (sp_ == 2) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 2 ? 2 * NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })   \
+    else NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 3 ? 3 * NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })                 \
   }
 
   int iset = 0;

@@ -116,6 +116,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr int NT = 512, WAVES = 8, r = 1;             // producer threads / waves (= tiles per round); 8 consumer waves behind them
   constexpr int NCH = NBL / 2;
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
+  constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
   constexpr int NBUF = 2;
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
@@ -362,16 +364,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
   const int NPC = (r + 1) * NCH;
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
+  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
   auto cs_phase_step = [&]() {
     ++cs_phase;
     if (cs_phase < 1 + nh) {
-      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CB; cs_units = CB; cs_left = NPC; return;
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
     }
     if (cs_groups <= 0) { cs_left = -1; return; }
     --cs_groups; cs_phase = 0;
-    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CF; cs_left = nh * NPC;
+    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
   };
   auto cs_next = [&](int buf) {
     if (cs_left < 0) return;
@@ -520,17 +522,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
-        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], T, lane); })
 #else
-        S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], T, lane); })
 #endif
-        S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[1], b1[1], b2[1], T, lane); })
+        S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[1], b1[1], b2[1], T, lane); })
         const float zt = zt_base[0];
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[0], b1[0], b2[0], acc, lane); })
-      S6_CHUNK({ mfma_x6<NBL, PR>(cur, b0[1], b1[1], b2[1], acc, lane); })
+      S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], acc, lane); })
+      S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[1], b1[1], b2[1], acc, lane); })
       sine16_tag<NBL>(acc, acc);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) h[b] = acc[b];
@@ -640,11 +642,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PR, true>(cur, q0[0], b1[0], U, lane); })
+        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PR, true, NBL, 0, CP>(cur, q0[0], b1[0], U, lane); })
 #else
-        S6_CHUNK({ mfma_x3<NBL, PR, true>(cur, q0[0], b1[0], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PR, true, NBL, 0, CP>(cur, q0[0], b1[0], U, lane); })
 #endif
-        S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[1], b1[1], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[1], b1[1], U, lane); })
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
@@ -654,8 +656,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         for (int b = 0; b < NBL; ++b) gh[b] = zt0 * U[b];
         dzs[lane] += PR == 2 ? ils * s : s;
       }
-      S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[0], b1[0], gh, lane); })
-      S6_CHUNK({ mfma_x3<NBL, PR>(cur, q0[1], b1[1], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[0], b1[0], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[1], b1[1], gh, lane); })
       if (PR == 2) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] *= ils;
@@ -762,8 +764,8 @@ int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st
     (void)hipFuncSetAttribute((const void*)k_snet6<4, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
     hipLaunchKernelGGL((k_snet6<4, PR_>), dim3(nblk), dim3(1024), shm, st, f);                                    \
   }
-  if (a.prec == 2) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(2) }      // the half-precision plane set (k_pack16b f16)
-  else if (a.prec == 1) S6L(1)
+  if (a.prec == 2) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(2) }      // the policy's compact plane set (k_pack16b mode 2 / 1)
+  else if (a.prec == 1) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(1) }
   else S6L(0)
 #undef S6L
   return nblk;

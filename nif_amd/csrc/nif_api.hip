@@ -159,9 +159,9 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
     if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
-    if (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16) {     // the half-precision plane set of k_snet4<.., PR = 2>, next to the exact splits
-      if (e == hipSuccess) e = hipMalloc(&c->sWF4h, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
-      if (e == hipSuccess) e = hipMalloc(&c->sWB4h, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    if (c->cfg.mixed_policy != NIF_POLICY_FLOAT32) {     // the policy's compact plane set (k_snet4 / k_snet6<.., PR>), next to the exact splits
+      if (e == hipSuccess) e = hipMalloc(&c->sWF4h, (size_t)nh * (snet4_fwd_elems(c->n, rr) / 3) * 2);
+      if (e == hipSuccess) e = hipMalloc(&c->sWB4h, (size_t)nh * (snet4_bwd_elems(c->n, rr) / 2) * 2);
     }
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpf, (size_t)snet4_phi_fwd_elems(c->n) * 2);
     if (c->kind == NIF_KIND_LASTLAYER && e == hipSuccess) e = hipMalloc(&c->ll_wpb, (size_t)snet4_phi_bwd_elems(c->n) * 2);
@@ -575,8 +575,8 @@ static int ensure_packed(nif_ctx* c) {
                          c->cfg.s_omega0, c->st);
         if (c->use_ll4 && c->sWF4h)
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
-                         (char*)c->sWF4h + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4h + (size_t)j * snet4_bwd_elems(n, 0) * 2,
-                         c->cfg.s_omega0, c->st, 1);
+                         (char*)c->sWF4h + (size_t)j * (snet4_fwd_elems(n, 0) / 3) * 2, (char*)c->sWB4h + (size_t)j * (snet4_bwd_elems(n, 0) / 2) * 2,
+                         c->cfg.s_omega0, c->st, c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 1);
       }
       seg(c->s_bott_b, s_bl, sop);
       seg(c->ll_bias, s_bl + sop, c->so);
@@ -602,7 +602,8 @@ static int ensure_packed(nif_ctx* c) {
                          c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st);
   if (c->use_snet4 && c->nh > 0 && c->sWF4h)
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
-                         c->sWF4h, c->sWB4h, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st, 1);
+                         c->sWF4h, c->sWB4h, snet4_fwd_elems(c->n, c->r) / 3, snet4_bwd_elems(c->n, c->r) / 2, probe.omega, c->st,
+                         c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 1);
   HIPCHK(hipGetLastError());
   c->packed = true;
   if (!c->use_snet4) return ensure_packed32(c);
