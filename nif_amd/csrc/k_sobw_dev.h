@@ -75,6 +75,8 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
   constexpr int NQ = 1 + NS, TPG = NIF_SOBW_TPG(NBL, NS), WAVES = TPG * NQ, NT = 64 * WAVES;
   constexpr int NCH = NBL / 2;
   constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;
+  constexpr bool CP = PR;                                // the policy's compact plane set (k_snet4_dev.h): one bf16 plane per block
+  constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
   constexpr int NBUF = 2;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,16 +109,16 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
   // the chunk stream (k_snet4): forward planes, then the adjoint planes of hidden matrix nh-1 .. 0, then the next tile group
   const int NPC = (r + 1) * NCH;
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CF, cs_left = nh * NPC, cs_phase = 0;
+  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
   auto cs_phase_step = [&]() {
     ++cs_phase;
     if (TRAIN && cs_phase < 1 + nh) {
-      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - cs_phase) * NPC * CB; cs_units = CB; cs_left = NPC;
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - cs_phase) * NPC * CBH; cs_units = CBH; cs_left = NPC;
     } else {
       if (cs_groups <= 0) { cs_left = -1; return; }
       --cs_groups; cs_phase = 0;
-      cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CF; cs_left = nh * NPC;
+      cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
     }
   };
   auto cs_next = [&](int buf) {
@@ -313,13 +315,13 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
           for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
         } else ZERO_T(T)
 #pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
+        for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[ks], b1[ks], b2[ks], T, lane); })
         const float zt = zt_base[k * 16];
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
 #pragma unroll
-      for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x6<NBL, PR>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
+      for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[ks], b1[ks], b2[ks], acc, lane); })
       const bool blk_end = (MODE == 1 && (j & 1)) || MODE == 2;      // the layer's result meets the block / layer input
       if (q == 0) {
         f32x4 c[NBL];
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
         f32x4 U[NBL];
 #pragma unroll
         for (int ks = 0; ks < NCH; ++ks) {
-          if (ks == 0) SW_CHUNK({ mfma_x3<NBL, PR, true>(cur, b0[0], b1[0], U, lane); })
-          else SW_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], U, lane); })
+          if (ks == 0) SW_CHUNK({ mfma_x3<NBL, PR, true, NBL, 0, CP>(cur, b0[0], b1[0], U, lane); })
+          else SW_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, b0[ks], b1[ks], U, lane); })
         }
         const float zt = zt_base[k * 16];
         float s = 0.f;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
         for (int b = 0; b < NBL; ++b) ex[b] = ring[((long)(j - 1) * NBL + b) * 64];
       }
 #pragma unroll
-      for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x3<NBL, PR>(cur, b0[ks], b1[ks], gh, lane); })
+      for (int ks = 0; ks < NCH; ++ks) SW_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, b0[ks], b1[ks], gh, lane); })
       if (MODE == 2 || (MODE == 1 && !(j & 1))) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] += skip[b];
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(64 * NIF_SOBW_WMAX(NBL), (NBL <= 4 ? NIF_SOBW_OCC :
 // 48 kernels apiece compile side by side) -------------------------------------------------------------------------------------------
 size_t sobw_shmem(const SNetArgs& a, int NBL, int ns);
 template <int MODE>
-static void launch_sobw_mode(const SobArgs& J, int nblk, hipStream_t st, bool train) {
+static void launch_sobw_mode(const SobArgs& J_, int nblk, hipStream_t st, bool train) {
+  SobArgs J = J_;
+  if (J.s.prec == 1) { J.s.WF4 = J.s.WF4h; J.s.WB4 = J.s.WB4h; }      // k_sobw<.., PR> streams the policy's compact plane set
   const SNetArgs& a = J.s;
   const int NBL = snet3_nbl(a.n);
   const size_t shm = sobw_shmem(a, NBL, J.ns);
