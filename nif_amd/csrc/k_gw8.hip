@@ -122,9 +122,9 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
       if (DAB) *reinterpret_cast<g8_bf16x4*>(S + 2 * NPL * PLANE + g8_off(f, p0)) = rdb[DAB ? RS : 0][j];              \
       else split_store(S + 2 * NPL * PLANE, S + (2 * NPL + 1) * PLANE, f, dav);                                        \
     }                                                                                                                  \
-    __syncthreads();   /* planes of `set` complete; the other buffer's readers finished before the previous barrier */ \
-    const long tn = t + NS * (long)gridDim.x;                                                                          \
+    const long tn = t + NS * (long)gridDim.x;   /* the set's registers are dead once split: refill them BEFORE the barrier */ \
     if (tn < nt) G8_LOAD(RS, tn)                                                                                       \
+    __syncthreads();   /* planes of `set` complete; the other buffer's readers finished before the previous barrier */ \
     const char* Ahi = S + (2 * uk) * PLANE, *Alo = Ahi + PLANE;                                                        \
     const char* Bhi = S + 2 * NPL * PLANE, *Blo = Bhi + PLANE;                                                         \
     const int fa = 32 * ubi + i32;                                                                                     \
