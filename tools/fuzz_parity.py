@@ -89,10 +89,13 @@ def run_case(cfg, B, seed, loss="mse"):
     if abs(loss - rl) > 2e-5 * abs(rl):
         bad.append(("loss", loss, rl))
     off = 0
+    gn_all = float(np.linalg.norm(O.flatten(rg)))
     for (nm, shp), r_ in zip(spec.param_shapes(), rg):
         k = int(np.prod(shp)); got = grad[off:off + k].reshape(shp); off += k
         err = _rel(got, r_) if np.linalg.norm(r_) > 1e-12 else float(np.abs(got).max())
-        if err > 3e-4:
+        # (the metric of tests/test_gpu_parity: relative to the tensor, plus 2e-6 of the whole gradient's norm for tensors that are small
+        # against it -- sweep r04 seed 7 case 39: a ONE-element bias gradient, a sum of 515 terms cancelling to 8e-4 of their magnitude)
+        if err > 3e-4 and float(np.linalg.norm(got.astype(np.float64) - r_)) > 2e-6 * gn_all:
             bad.append(("grad " + nm, err))
     yi = list(range(spec.so)); xi_all = list(range(spec.pi + spec.si))
     try:
