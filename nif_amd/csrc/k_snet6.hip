@@ -107,7 +107,7 @@ struct S6Args {
 // PR (late r4): the producers' hidden n x n products under a Keras policy -- 1 = mixed_bfloat16 (ONE bf16 product per operand pair),
 // 2 = mixed_float16 (half operands, per-point loss scale on dL/da; k_snet4_dev.h) -- as in k_snet4<.., PR>.  The CONSUMER side is
 // untouched: the deposits stay bf16 (hi, lo) pairs of the fp32 rows and the weight-gradient sums three products, i.e. the policy's
-// weight gradients here are those of fp32 stash rows (oracle: stash_bf16 = False).  (r4's first policy form also cut the consumers
+// weight gradients here are those of fp32 stash rows (the tests emulate it with stash_bf16 = False).  (r4's first policy form also cut the consumers
 // to one MFMA per tile and hipcc answered with 327 spilled registers; with the consumer code unchanged the allocation holds.)
 template <int NBL, int PR = 0>
 __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
