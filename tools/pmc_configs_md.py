@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmcc/<cfg>.md (tools/pmc_configs.sh) -> profiles/<tag>_configs_traffic.md: HBM bytes per launch of the kernels that
+carry each config's step (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of profiles/traffic.json), next to the stash bytes the
+design moves for them (tools/bench_configs.py roofline(): rows written + re-read) and the kernel's time in the same step.
+    python tools/pmc_configs_md.py r04 > profiles/r04_configs_traffic.md"""
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(fn):
+    out, cur = {}, None
+    for line in open(fn):
+        m = re.match(r"### `(.*)`  \(dispatches: (\d+)\)", line)
+        if m:
+            cur = m.group(1); out[cur] = {"n": int(m.group(2))}
+        m = re.match(r"- (\w+): mean ([0-9.e+-]+)", line)
+        if m and cur:
+            out[cur][m.group(1)] = float(m.group(2))
+    return out
+
+
+def main(tag):
+    print("# HBM traffic per launch of the other BASELINE configs' kernels, round %s (tools/pmc_configs.sh: rocprofv3 --pmc, FETCH_SIZE and "
+          "WRITE_SIZE in separate passes)\n" % tag)
+    print("bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE counts half of a 16-B/lane read stream: profiles/traffic.json). "
+          "The ms / step in a heading is the step UNDER the counter pass (dispatches serialised: 1.5-2x the untraced step of profiles/%s_configs.json).\n" % tag)
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmcc", "*.md"))):
+        cfg = os.path.basename(f)[:-3]
+        k = parse(f)
+        rec = None
+        try:
+            line = open(f[:-3] + ".out").read().strip()
+            rec = json.loads(line.partition(" ")[2])
+        except (OSError, ValueError):
+            pass
+        print("## %s%s\n" % (cfg, " — %d points, %.3f ms / step under the counter pass" % (rec["points"], rec["ms_per_step"]) if rec else ""))
+        print("| kernel | launches | FETCH_SIZE KB | WRITE_SIZE KB | HBM GB per launch |")
+        print("|---|---|---|---|---|")
+        rows = []
+        for name, v in k.items():
+            gb = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / 1e9
+            rows.append((gb * v["n"], name, v, gb))
+        tot = 0.0
+        for _, name, v, gb in sorted(rows, reverse=True):
+            if gb < 0.005:
+                continue
+            print("| `%s` | %d | %.4g | %.4g | %.3f |" % (name[:90], v["n"], v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0), gb))
+        if rec and rec.get("roofline"):
+            r = rec["roofline"]
+            print("\nfused ShapeNet kernel: %.3f ms per launch under the counter pass, design stash traffic %.0f GB/s (`stash_GBs`), executed 16-bit matrix work %.0f TFLOP/s."
+                  % (r["avg_ms"], r["stash_GBs"], r["executed_bf16_TFLOPs"]))
+        print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r04")
