@@ -195,7 +195,34 @@ class Model(object):
         return self._run(x)
 
     # ---- training --------------------------------------------------------------------------------
-    def compile(self, optimizer="adam", loss="mse", **kwargs):
+    # Keras' compile(metrics=[...]): names / metric objects -> (history key, kind).  Unweighted (Keras applies sample_weight to
+    # `weighted_metrics` only); the value of an epoch is the running mean over every sample the epoch saw, evaluated with the weights
+    # each batch's loss was evaluated with (before its update).  Computed on the host from a forward pass per batch: metrics are off
+    # the hot path and cost nothing unless asked for
+    _METRIC_KINDS = {"mse": "mse", "mean_squared_error": "mse", "MSE": "mse", "mae": "mae", "mean_absolute_error": "mae", "MAE": "mae",
+                     "root_mean_squared_error": "rmse", "rmse": "rmse"}
+
+    def _parse_metrics(self, metrics):
+        out = []
+        for mtr in ([metrics] if isinstance(metrics, str) else list(metrics or [])):
+            key = mtr if isinstance(mtr, str) else (getattr(mtr, "name", None) or getattr(mtr, "__name__", None))
+            if key not in self._METRIC_KINDS:
+                raise NotImplementedError("compile(metrics=[%r]): built are 'mse' / 'mean_squared_error', 'mae' / 'mean_absolute_error' and "
+                                          "RootMeanSquaredError (by name or Keras object)" % (mtr,))
+            out.append((key, self._METRIC_KINDS[key]))
+        return out
+
+    @staticmethod
+    def _metric_sums(kinds, u, y):
+        """per-batch sums whose ratio to the sample count is the metric (rmse: the root is taken at the end)"""
+        d = np.asarray(u, dtype=np.float64) - np.asarray(y, dtype=np.float64)
+        return [float(np.abs(d).mean(axis=1).sum()) if k == "mae" else float((d * d).mean(axis=1).sum()) for _, k in kinds]
+
+    @staticmethod
+    def _metric_values(kinds, sums, count):
+        return {key: (np.sqrt(s_ / max(count, 1)) if k == "rmse" else s_ / max(count, 1)) for (key, k), s_ in zip(kinds, sums)}
+
+    def compile(self, optimizer="adam", loss="mse", metrics=None, **kwargs):
         if self._role != "full":
             raise ValueError("only the full model can be compiled for training")
         name = loss if isinstance(loss, str) else (getattr(loss, "name", None) or getattr(loss, "__name__", None))
@@ -203,6 +230,9 @@ class Model(object):
             raise NotImplementedError("loss=%r: built are 'mse' (README.md:33), 'mae', 'huber' (delta 1), 'log_cosh'" % (loss,))
         if kwargs:
             raise NotImplementedError("compile(%s): not on the built hot path" % ", ".join(sorted(kwargs)))
+        self._metrics = self._parse_metrics(metrics)
+        if self._metrics and self._n_tangents() != 0:
+            raise NotImplementedError("compile(metrics=...) on the two-output model")
         new = get_optimizer(optimizer)
         if new is not self.optimizer:
             self._fresh_slots = True     # Keras: a newly compiled optimizer starts with zero slots and iteration 0
@@ -240,6 +270,11 @@ class Model(object):
                 tot += (hi - lo) * self._loss_host(e, x[lo:hi], [t[lo:hi] for t in targets], sw)
         finally:
             self._pop_losses(e)
+        kinds = getattr(self, "_metrics", [])
+        if kinds:      # Keras: [loss, metric, ...] when metrics were compiled
+            sums = self._metric_sums(kinds, self.predict(x), targets[0])
+            vals = self._metric_values(kinds, sums, n)
+            return [float(tot / n)] + [float(vals[k]) for k, _ in kinds]
         return float(tot / n)
 
     # hooks the two-output Sobolev model overrides
@@ -300,6 +335,9 @@ class Model(object):
                                       % ", ".join(sorted(kwargs)))
         s = self._owner._spec
         e = self._engine
+        kinds = getattr(self, "_metrics", [])
+        if kinds and (isinstance(x, ShardBatches) or dist.get() is not None):
+            raise NotImplementedError("compile(metrics=...): in-memory arrays on one GPU")
         self._push_losses(e, 1)                   # (raises here, not at first engine access, when the shape has no kernel for it)
         self.stop_training = False
         if getattr(self, "_fresh_slots", False):
@@ -383,7 +421,7 @@ class Model(object):
             # shard is a batch shorter (or empty) join the collectives of the steps they lack with a zero gradient
             sizes, gsizes = dist.plan_steps(N, bs, comm, e)
             e.reserve(max(1, max(sizes, default=0)), self._n_tangents())
-            use_graph = (self._graph_epochs and world == 1 and shard is None and not self._po_l1 and len(sizes) >= 4
+            use_graph = (self._graph_epochs and world == 1 and shard is None and not self._po_l1 and not kinds and len(sizes) >= 4
                          and max(sizes) <= self._GRAPH_MAX_BATCH and hasattr(e, "graph_begin") and epochs - initial_epoch >= 2)
             graph_id = None
             stream = [-1, 0]          # steps_per_epoch: (pass, next batch of the pass) of the one iterator over `epochs` passes
@@ -400,9 +438,13 @@ class Model(object):
                         cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
 
+                msum, mcnt, cur_perm = [0.0] * len(kinds), [0], [None]
+
                 def new_pass():      # one pass over the table = one permutation (Keras: the adapter's dataset of `epochs` passes)
+                    cur_perm[0] = None
                     if dev_shuffle:
                         perm = rng.permutation(N).astype(np.int32)
+                        cur_perm[0] = perm
                         d_perm.upload(perm.view(np.float32))
                         e.gather_rows(src_x, d_perm, N, ncol, d_x)
                         for st_, dt, w in zip(src_t, d_t, widths):
@@ -411,6 +453,7 @@ class Model(object):
                             e.gather_rows(src_sw, d_perm, N, 1, d_sw)
                     elif host_shuffle:
                         perm = rng.permutation(N)
+                        cur_perm[0] = perm
                         e.sync()                      # the previous pass's steps have read the table
                         src_x.upload(x[perm])
                         for dt, t in zip(src_t, targets):
@@ -426,6 +469,11 @@ class Model(object):
                         b0 = ib * bs
                         if self._po_l1:
                             self._push_losses(e, bg)
+                        if kinds and b > 0:      # compile(metrics=...): the batch's predictions with the weights its loss sees
+                            rows = slice(b0, b0 + b) if cur_perm[0] is None else cur_perm[0][b0:b0 + b]
+                            for i_, v_ in enumerate(self._metric_sums(kinds, e.forward(x[rows]), targets[0][rows])):
+                                msum[i_] += v_
+                            mcnt[0] += b
                         if b > 0:
                             self._loss_grad_dev(e, d_x.at(b0 * ncol), [dt.at(b0 * w) for dt, w in zip(d_t, widths)],
                                                 d_sw.at(b0) if d_sw is not None else None, b, bg)
@@ -477,9 +525,15 @@ class Model(object):
                     run_batches()
                 tot, cnt = e.metric_read(reset=True)   # accumulated on the device: one host sync per epoch
                 logs = {"loss": tot / max(cnt, 1.0)}
+                logs.update({k: float(v) for k, v in self._metric_values(kinds, msum, mcnt[0]).items()})
                 if validation_data is not None:
-                    logs["val_loss"] = self.evaluate(validation_data[0], validation_data[1],
-                                                     sample_weight=validation_data[2] if len(validation_data) == 3 else None)
+                    ev = self.evaluate(validation_data[0], validation_data[1],
+                                       sample_weight=validation_data[2] if len(validation_data) == 3 else None)
+                    if isinstance(ev, list):
+                        logs["val_loss"] = ev[0]
+                        logs.update({"val_" + k: v for (k, _), v in zip(kinds, ev[1:])})
+                    else:
+                        logs["val_loss"] = ev
                 for cb in callbacks:
                     if hasattr(cb, "on_epoch_end"):
                         cb.on_epoch_end(epoch, logs)

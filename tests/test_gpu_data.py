@@ -129,3 +129,39 @@ def test_fit_10k_points_batch_512_graph_epochs_equal_eager_epochs(shuffle):
             tot += l_ * (hi - lo)
             th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
         assert abs(lg[0] - tot / 10000) < 2e-3 * (tot / 10000), (lg[0], tot / 10000)
+
+
+def test_fit_with_compiled_metrics_on_the_device_path():
+    """compile(metrics=[...]) through the real engine: device shuffle, a partial last batch, sample weights (which the unweighted
+    metrics ignore) -- the epoch's 'mse' metric is the oracle's unweighted mean over the same permutations with the pre-update
+    weights, training itself is untouched (same losses as without metrics), evaluate() returns [loss, mse, mae]"""
+    nif_amd, m, model, spec = _model()
+    x, y = nif_amd.data.synthetic_wave_batch(700, seed=4)
+    sw = np.random.default_rng(1).uniform(0.5, 1.5, 700).astype(np.float32)
+    ws0 = model.get_weights()
+    model._shuffle_seed = 13
+    h_plain = model.fit(x, y, sample_weight=sw, epochs=2, batch_size=256, shuffle=True, verbose=0)
+    model.set_weights(ws0)
+    model.compile(nif_amd.Adam(1e-3), "mse", metrics=["mse", "mae"])
+    model._shuffle_seed = 13
+    h = model.fit(x, y, sample_weight=sw, epochs=2, batch_size=256, shuffle=True, verbose=0)
+    assert np.allclose(h.history["loss"], h_plain.history["loss"], rtol=1e-6)
+    rng = np.random.default_rng(13)
+    th = O.flatten([w.astype(np.float64) for w in ws0]); mm = np.zeros_like(th); vv = np.zeros_like(th); t = 0
+    f32 = lambda a: float(np.float32(a))
+    mse, mae = [], []
+    for _ in range(2):
+        perm = rng.permutation(700)
+        xs, ys, ss = x[perm].astype(np.float64), y[perm].astype(np.float64), sw[perm].astype(np.float64)
+        s2 = s1 = 0.0
+        for b0 in range(0, 700, 256):
+            u = O.forward(spec, O.unflatten(spec, th), xs[b0:b0 + 256])
+            s2 += ((u - ys[b0:b0 + 256]) ** 2).sum(); s1 += np.abs(u - ys[b0:b0 + 256]).sum()
+            l, g = O.loss_and_grad(spec, O.unflatten(spec, th), xs[b0:b0 + 256], ys[b0:b0 + 256], ss[b0:b0 + 256])
+            t += 1
+            th, mm, vv = O.adam_step(th, O.flatten(g), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+        mse.append(s2 / 700); mae.append(s1 / 700)
+    assert np.allclose(h.history["mse"], mse, rtol=2e-4) and np.allclose(h.history["mae"], mae, rtol=2e-4), (h.history, mse, mae)
+    ev = model.evaluate(x, y)
+    u = model.predict(x)
+    assert np.allclose(ev[1:], [np.mean((u - y) ** 2), np.mean(np.abs(u - y))], rtol=1e-5) and abs(ev[0] - ev[1]) < 1e-5 * ev[0]
