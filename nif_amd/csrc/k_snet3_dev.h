@@ -205,6 +205,44 @@ __device__ __forceinline__ void sine16_tag(const f32x4 (&a)[NBL], f32x4 (&h)[NBL
       }
     }
 }
+// the same for a = inv x with inv a power of two (k_snet6's half products carry the plane's scale): the scale rides in the
+// constants, so that not one instruction is added and the result is bit for bit that of sine16_tag(inv x)
+template <int NBL>
+__device__ __forceinline__ void sine16_tag_sc(const f32x4 (&x_)[NBL], f32x4 (&h)[NBL], float inv) {
+  {
+    float mx = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(x_[b][v]));
+    if (__builtin_expect(__any(!(mx * inv < NIF_SINCOS_FAST_LIMIT)), 0)) {
+      f32x4 a[NBL];
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) a[b] = x_[b] * inv;
+      sine16_tag<NBL>(a, h);
+      return;
+    }
+  }
+  const float c0 = 0.15915493667125702f * inv, c1 = 6.420638326565253e-09f * inv, c2 = 0.318309886183790672f * inv;
+  const f32x2 C = {c0, c0}, CL = {c1, c1}, M = {12582912.0f, 12582912.0f}, IP = {c2, c2};
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; v += 2) {
+      const f32x2 x = {x_[b][v], x_[b][v + 1]};
+      const f32x2 k = __builtin_elementwise_fma(x, C, M) - M;
+      f32x2 f = __builtin_elementwise_fma(x, C, -k);
+      f = __builtin_elementwise_fma(x, CL, f);
+      const f32x2 t = __builtin_elementwise_fma(x, IP, M);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sv = __builtin_amdgcn_sinf(f[e]);
+        unsigned o;
+        asm("s_nop 0\n\tv_bfi_b32 %0, 1, %1, %2" : "=v"(o) : "v"(__float_as_uint(t[e])), "v"(__float_as_uint(sv)));
+        h[b][v + e] = __uint_as_float(o);
+      }
+    }
+}
 // cos(a) from the tagged sine: sqrt(1 - s^2) with the sign from the tag bit
 template <int NBL>
 __device__ __forceinline__ void tag_cos(const f32x4 (&sn)[NBL], f32x4 (&d)[NBL]) {
@@ -302,6 +340,23 @@ __device__ __forceinline__ void cast_f16(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL
     s0[ks] = __builtin_bit_cast(bf16x8, q);
   }
 }
+// the exact-product HALF form (r5, k_snet6): x = hi + lo, hi = half(scale x), lo = half(scale x - hi); `scale` a power of two that
+// brings the tile into half's range (4096 for sines, the per-point loss scale for dL/da) -- 11 + 11 significand bits, so that
+// hi.hi + hi.lo + lo.hi of two such pairs is an fp32 product (tools/exp/f16_split_mfma.hip)
+template <int NBL>
+__device__ __forceinline__ void split2h(const f32x4 (&h)[NBL], float scale, bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2]) {
+#pragma unroll
+  for (int ks = 0; ks < NBL / 2; ++ks) {
+    f16x8 q0, q1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = scale * h[2 * ks + (t >> 2)][t & 3];
+      const _Float16 x0 = (_Float16)x;
+      q0[t] = x0; q1[t] = (_Float16)(x - (float)x0);
+    }
+    s0[ks] = __builtin_bit_cast(bf16x8, q0); s1[ks] = __builtin_bit_cast(bf16x8, q1);
+  }
+}
 // PR-aware operand forms of a layer's activation / dL/da tile (the exact splits unless a policy asks for one rounded operand)
 template <int NBL, int PR>
 __device__ __forceinline__ void split3p(const f32x4 (&h)[NBL], bf16x8 (&s0)[NBL / 2], bf16x8 (&s1)[NBL / 2], bf16x8 (&s2)[NBL / 2]) {
@@ -374,7 +429,7 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
       T[ib + 1] = mfma_f16(c0, b0, ZI ? z4 : T[ib + 1]);
       continue;
     }
-    if (PR) {
+    if (PR == 1) {
       const bf16x8 a0 = cur[(CP ? ib : ib * 2) * 64 + lane], c0 = cur[(CP ? ib + 1 : ib * 2 + 2) * 64 + lane];
       T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ZI ? z4 : T[ib], 0, 0, 0);
       T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, ZI ? z4 : T[ib + 1], 0, 0, 0);
@@ -382,6 +437,15 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
     }
     const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
     const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
+    if (PR == 3) {      // exact-product half planes (hi, lo) x half operand pair (b0 = hi, b1 = lo): three products, small terms first
+      T[ib] = mfma_f16(a0, b1, ZI ? z4 : T[ib]);
+      T[ib + 1] = mfma_f16(c0, b1, ZI ? z4 : T[ib + 1]);
+      T[ib] = mfma_f16(a1, b0, T[ib]);
+      T[ib + 1] = mfma_f16(c1, b0, T[ib + 1]);
+      T[ib] = mfma_f16(a0, b0, T[ib]);
+      T[ib + 1] = mfma_f16(c0, b0, T[ib + 1]);
+      continue;
+    }
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ZI ? z4 : T[ib], 0, 0, 0);
     T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b1, ZI ? z4 : T[ib + 1], 0, 0, 0);
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, T[ib], 0, 0, 0);

@@ -30,12 +30,18 @@
 // mode 0: the split groups above.  mode 1 / 2 (the policies' COMPACT plane set, late r4): one 16-bit value per element -- bf16(x)
 // (mixed_bfloat16) or half(x) (mixed_float16; RNE, saturated) -- unit (ob * 64 + lane) of a chunk, a third / half of the split
 // planes' bytes: k_snet4<.., PR> / k_snet6<.., PR> stream these (CP in mfma_x6 / mfma_x3), every other kernel the split groups
+// mode 3 (r5): the EXACT-PRODUCT HALF planes of k_snet6 -- x = hi + lo with hi = half(x), lo = half(x - hi) (11 + 11 significand bits:
+// |x - hi - lo| <= 2^-24 |x|), x = s w0 M with s the plane's power of two (k_plane_scales: max |s w0 M| in [2^13, 2^14), so that lo
+// keeps its bits inside half's exponent range; the kernels scale the products back, exactly).  Three half products hi.hi + hi.lo + lo.hi
+// then carry an fp32 product: measured on MI355X 2.8e-8 rms / 2.1e-7 max of sum|a_k b_k| at K = 64 -- the bf16 6-product form's
+// 2.7e-8 / 2.9e-7, the f32-input MFMA's 3.9e-8 / 4.0e-7 (tools/exp/f16_split_mfma.hip, profiles/r05_f16_probe.txt) -- at HALF the
+// matrix work and two thirds of the plane bytes.  Both directions use the adjoint geometry: unit ((blk*2 + s)*64 + lane)
 __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstride, int NBL, __bf16* __restrict__ WF,
-                          __bf16* __restrict__ WB, long fstride, long bstride, float scale, int mode) {
+                          __bf16* __restrict__ WB, long fstride, long bstride, float scale, int mode, const float* __restrict__ pscale) {
   m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
   WF += (long)blockIdx.y * fstride; WB += (long)blockIdx.y * bstride;
   const int NCH = NBL / 2;
-  const int nsf = mode ? 1 : 3, nsb = mode ? 1 : 2;
+  const int nsf = mode == 3 ? 2 : (mode ? 1 : 3), nsb = (mode == 1 || mode == 2) ? 1 : 2;
   const long fwd_plane = (long)NCH * NBL * nsf * 64 * 8, bwd_plane = (long)NCH * NBL * nsb * 64 * 8;
   const long total_f = fwd_plane * (m.r + 1), total_b = bwd_plane * (m.r + 1);
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
@@ -53,7 +59,14 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstrid
     const int slot = 16 * (2 * ks + (t >> 2)) + 4 * (lane >> 4) + (t & 3);
     const int row = 16 * blk + (lane & 15);
     const int in = fwd ? slot : row, out = fwd ? row : slot;
-    const float x = (in < m.nin && out < m.nout) ? scale * theta[matref_index(m, k, in, out)] : 0.f;
+    float x = (in < m.nin && out < m.nout) ? scale * theta[matref_index(m, k, in, out)] : 0.f;
+    if (mode == 3) {
+      x *= pscale[(blockIdx.y * (m.r + 1) + k) * 2];
+      const _Float16 h0 = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+      const _Float16 h1 = (_Float16)(x - (float)h0);
+      reinterpret_cast<_Float16*>(fwd ? WF : WB)[e] = s == 0 ? h0 : h1;
+      continue;
+    }
     if (mode == 2) {
       reinterpret_cast<_Float16*>(fwd ? WF : WB)[e] = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
       continue;
@@ -65,16 +78,43 @@ __global__ void k_pack16b(const float* __restrict__ theta, MatRef m, long mstrid
     (fwd ? WF : WB)[e] = s == 0 ? x0 : (s == 1 ? x1 : x2);
   }
 }
+// power-of-two scale of plane (matrix blockIdx.y, k = blockIdx.x) for the half planes (mode 3): max |scale M| 2^e in [2^13, 2^14)
+__global__ void k_plane_scales(const float* __restrict__ theta, MatRef m, long mstride, float scale, float* __restrict__ pscale) {
+  m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
+  const int k = blockIdx.x;
+  float mx = 0.f;
+  for (int idx = threadIdx.x; idx < m.nin * m.nout; idx += blockDim.x) {
+    const int in = idx / m.nout, out = idx - in * m.nout;
+    mx = fmaxf(mx, fabsf(scale * theta[matref_index(m, k, in, out)]));
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    mx = red[0];
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex); else ex = 14;     // mx = f 2^ex, f in [0.5, 1)
+    int sh = 14 - ex;
+    sh = sh > 60 ? 60 : (sh < -60 ? -60 : sh);       // (the scaled constants of sine16_tag_sc stay normal numbers)
+    pscale[(blockIdx.y * (m.r + 1) + k) * 2] = ldexpf(1.0f, sh);          // [s | 1 / s]
+    pscale[(blockIdx.y * (m.r + 1) + k) * 2 + 1] = ldexpf(1.0f, -sh);
+  }
+}
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode) {
   launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, scale, st, mode);
 }
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
-                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode) {
+                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode, float* pscale) {
   const long total = (long)(NBL / 2) * NBL * 5 * 64 * 8 * (m0.r + 1);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
+  if (mode == 3) hipLaunchKernelGGL(k_plane_scales, dim3(m0.r + 1, nmat), dim3(256), 0, st, theta, m0, mstride, scale, pscale);
   hipLaunchKernelGGL(k_pack16b, dim3(grid, nmat), dim3(256), 0, st, theta, m0, mstride, NBL, (__bf16*)WF, (__bf16*)WB,
-                     fstride_elems, bstride_elems, scale, mode);
+                     fstride_elems, bstride_elems, scale, mode, pscale);
 }
 
 // phi layer of the last-layer class: dense W[n][sop], sop <= 32 (two 16-output blocks)

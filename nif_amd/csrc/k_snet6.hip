@@ -115,7 +115,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   const SNetArgs& A = F.s;
   constexpr int NT = 512, WAVES = 8, r = 1;             // producer threads / waves (= tiles per round); 8 consumer waves behind them
   constexpr int NCH = NBL / 2;
-  constexpr int CF = NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  // PR = 0 (r5): fp32-exact products on HALF pairs -- planes (hi, lo) x operand (hi, lo), three v_mfma_f32_16x16x32_f16 per pair in both
+  // directions (k_pack16b mode 3, split2h; forward: half of r4's six bf16 products and two thirds of its chunk bytes; adjoint: 22
+  // significand bits where r4's bf16 pairs carried 16).  The planes carry a power of two s_jk, the sines 2^12, dL/da a power of two per
+  // point: all of it is scaled back exactly (biases pre-scaled in the LDS image, the combine factor zt s1 / s0, the sine's constants)
+  constexpr bool X16 = PR == 0;
+  constexpr int CF = X16 ? NBL * 2 * 64 : NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
   constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   const int NI = (CX + CZ + CY + 4) * 16;
   const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
+  float* scl = lsum + 16;                               // X16: [matrix][plane][s | 1 / s] of the half planes
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
@@ -159,10 +165,15 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
       else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
-      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl) {
+        const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP;
+        if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f);
+        if (X16) v *= 4096.0f * A.wscale[(j * (r + 1) + k) * 2];      // the hidden biases start the scaled MFMA chains
+      }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
       sm[idx] = v;
     }
+    if (X16 && tid < nh * (r + 1) * 2) scl[tid] = A.wscale[tid];
     for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += 1024) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
@@ -510,7 +521,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
 #endif
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
-      split3p<NBL, PR>(h, b0, b1, b2);
+      if (X16) split2h<NBL>(h, 4096.0f, b0, b1);
+      else split3p<NBL, PR>(h, b0, b1, b2);
+      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
       {
         const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
 #pragma unroll
@@ -522,18 +535,21 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
-        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, { mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], T, lane); })
+#define S6_FWD(KS_, T_) { if (X16) mfma_x3<NBL, 3, false, NBL, 0, false>(cur, b0[KS_], b1[KS_], T_, lane); else mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }
+        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, S6_FWD(0, T))
 #else
-        S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], T, lane); })
+        S6_CHUNK(S6_FWD(0, T))
 #endif
-        S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[1], b1[1], b2[1], T, lane); })
-        const float zt = zt_base[0];
+        S6_CHUNK(S6_FWD(1, T))
+        const float zt = X16 ? zt_base[0] * (s1_ * is0_) : zt_base[0];      // (plane 0's chain carries s0, the sum s1)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[0], b1[0], b2[0], acc, lane); })
-      S6_CHUNK({ mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[1], b1[1], b2[1], acc, lane); })
-      sine16_tag<NBL>(acc, acc);
+      S6_CHUNK(S6_FWD(0, acc))
+      S6_CHUNK(S6_FWD(1, acc))
+#undef S6_FWD
+      if (X16) sine16_tag_sc<NBL>(acc, acc, is1_ * (1.0f / 4096.0f));
+      else sine16_tag<NBL>(acc, acc);
 #pragma unroll
       for (int b = 0; b < NBL; ++b) h[b] = acc[b];
     }
@@ -619,13 +635,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
           sbv += (ga[b][0] * bb[0] + ga[b][1] * bb[1]) + (ga[b][2] * bb[2] + ga[b][3] * bb[3]);
         }
-        dzs[lane] += sbv;
+        dzs[lane] += X16 ? sbv * (scl[j * 4 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s0 b^(0))
       }
       bf16x8 b0[NCH], b1[NCH];
       split2<NBL>(ga, b0, b1);                // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
-      bf16x8 q0[NCH];                         // the products' operand: b0, or under mixed_float16 half(s dL/da), s per point
+      bf16x8 q0[NCH], q1[NCH];                // the products' operand: b0, or half(s dL/da), s per point (mixed_float16: hi alone; X16: (hi, lo))
+      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
       float ils = 1.0f;
-      if (PR == 2) {
+      if (PR == 2 || X16) {
         float mx = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ga[b][0]), fabsf(ga[b][1]))), fmaxf(fabsf(ga[b][2]), fabsf(ga[b][3])));
@@ -634,33 +651,41 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         const unsigned ef = (__float_as_uint(mx) >> 23) & 0xFFu;
         const unsigned sf = 268u - ef < 227u ? 268u - ef : 227u;
         ils = __uint_as_float((254u - sf) << 23);
-        cast_f16<NBL>(ga, q0, __uint_as_float(sf << 23));
+        if (X16) split2h<NBL>(ga, __uint_as_float(sf << 23), q0, q1);
+        else cast_f16<NBL>(ga, q0, __uint_as_float(sf << 23));
       } else {
 #pragma unroll
         for (int ks = 0; ks < NCH; ++ks) q0[ks] = b0[ks];
       }
+      if (!X16) {
+#pragma unroll
+        for (int ks = 0; ks < NCH; ++ks) q1[ks] = b1[ks];
+      }
+      constexpr int PB = X16 ? 3 : PR;
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PR, true, NBL, 0, CP>(cur, q0[0], b1[0], U, lane); })
+        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #else
-        S6_CHUNK({ mfma_x3<NBL, PR, true, NBL, 0, CP>(cur, q0[0], b1[0], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #endif
-        S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[1], b1[1], U, lane); })
+        S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], U, lane); })
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
 #pragma unroll
           for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
+        const float ztc = X16 ? zt0 * (s1_ * is0_) : zt0;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) gh[b] = zt0 * U[b];
-        dzs[lane] += PR == 2 ? ils * s : s;
+        for (int b = 0; b < NBL; ++b) gh[b] = ztc * U[b];
+        dzs[lane] += X16 ? (ils * is0_) * s : (PR == 2 ? ils * s : s);
       }
-      S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[0], b1[0], gh, lane); })
-      S6_CHUNK({ mfma_x3<NBL, PR, false, NBL, 0, CP>(cur, q0[1], b1[1], gh, lane); })
-      if (PR == 2) {
+      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
+      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
+      if (PR == 2 || X16) {
+        const float f_ = X16 ? ils * is1_ : ils;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) gh[b] *= ils;
+        for (int b = 0; b < NBL; ++b) gh[b] *= f_;
       }
       {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
         fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
@@ -737,7 +762,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * 3 * 64 * 16 + (sm_tot + 8 * pw + 16) * sizeof(float);
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {
@@ -747,6 +772,7 @@ bool snet6_supported(const SNetArgs& a) {
     if (!pol) return false;
   }
   if (snet3_nbl(a.n) != 4 || a.r != 1 || a.nh < 1 || a.nh > 4 || a.si > 3 || a.so > 3) return false;
+  if (a.prec == 0 && (!a.WF4x || !a.WB4x || !a.wscale)) return false;
   return snet6_shmem(a, 4) <= 160u * 1024u;
 }
 // workgroups = partial-gradient rows = loss partials of the launch
@@ -766,7 +792,7 @@ int launch_snet6(const SNetArgs& a, float* partial, long pstride, hipStream_t st
   }
   if (a.prec == 2) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(2) }      // the policy's compact plane set (k_pack16b mode 2 / 1)
   else if (a.prec == 1) { f.s.WF4 = a.WF4h; f.s.WB4 = a.WB4h; S6L(1) }
-  else S6L(0)
+  else { f.s.WF4 = a.WF4x; f.s.WB4 = a.WB4x; S6L(0) }      // the exact-product half planes (k_pack16b mode 3)
 #undef S6L
   return nblk;
 }

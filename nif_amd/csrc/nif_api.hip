@@ -159,6 +159,11 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
     if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+    if (c->kind != NIF_KIND_LASTLAYER && snet3_nbl(c->n) == 4 && c->r == 1) {   // k_snet6's shapes: the exact-product half planes
+      if (e == hipSuccess) e = hipMalloc(&c->sWF4x, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+      if (e == hipSuccess) e = hipMalloc(&c->sWB4x, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
+      if (e == hipSuccess) e = hipMalloc(&c->sWscale, sizeof(float) * (size_t)nh * (rr + 1) * 2);
+    }
     if (c->cfg.mixed_policy != NIF_POLICY_FLOAT32) {     // the policy's compact plane set (k_snet4 / k_snet6<.., PR>), next to the exact splits
       if (e == hipSuccess) e = hipMalloc(&c->sWF4h, (size_t)nh * (snet4_fwd_elems(c->n, rr) / 3) * 2);
       if (e == hipSuccess) e = hipMalloc(&c->sWB4h, (size_t)nh * (snet4_bwd_elems(c->n, rr) / 2) * 2);
@@ -196,7 +201,7 @@ extern "C" int nif_destroy(nif_ctx* c) {
   for (hipGraphExec_t ex : c->graphs) if (ex) (void)hipGraphExecDestroy(ex);
   if (c->adam_host) (void)hipHostFree(c->adam_host);
   void* ptrs[] = {c->adam_dev, c->sob_acc, c->comm_scratch, c->chunk_grad, c->act_part, c->act_loss, c->jac_mu, c->jac_tmp, c->zt_par, c->dzt_par, c->dat_par, c->ztl_par, c->theta, c->grad, c->m, c->v, c->pWF, c->pWB, c->sWF, c->sWB, c->stash_s, c->stash_p, c->Z, c->DZ,
-                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->sWF4h, c->sWB4h, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
+                  c->DU, c->ZL, c->partial, c->loss_partial, c->dring, c->metric, c->tl, c->lWF, c->lWB, c->sWF4, c->sWB4, c->sWF4x, c->sWB4x, c->sWscale, c->sWF4h, c->sWB4h, c->ll_slots, c->ll_wpf, c->ll_wpb, c->stash_l, c->PHI, c->DPHI, c->DA, c->DZL, c->d_a, c->d_b, c->d_c, c->d_d};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -498,6 +503,7 @@ static void fill_snet(const nif_ctx* c, SNetArgs& a, const float* xin, int ncol,
   a.DU = c->DU; a.DZ = c->DZ;
   a.nsm = snet3_nsm(c->si, c->so, c->nh, c->n);
   a.WF4 = c->use_snet4 ? c->sWF4 : nullptr; a.WB4 = c->use_snet4 ? c->sWB4 : nullptr;   // packed only then
+  a.WF4x = c->use_snet4 ? c->sWF4x : nullptr; a.WB4x = c->use_snet4 ? c->sWB4x : nullptr; a.wscale = c->sWscale;
   a.prec = c->opt_fp32_mfma ? 0 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 ? 1 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 0));
   if (!c->use_snet4) a.prec = a.prec == 2 ? 0 : a.prec;      // (no k_snet4 for this shape: the policy runs on the exact kernels)
   a.WF4h = c->use_snet4 ? c->sWF4h : nullptr; a.WB4h = c->use_snet4 ? c->sWB4h : nullptr;
@@ -600,6 +606,9 @@ static int ensure_packed(nif_ctx* c) {
   if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
                          c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st);
+  if (c->use_snet4 && c->nh > 0 && c->sWF4x)
+    launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
+                         c->sWF4x, c->sWB4x, snet4_bwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st, 3, c->sWscale);
   if (c->use_snet4 && c->nh > 0 && c->sWF4h)
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
                          c->sWF4h, c->sWB4h, snet4_fwd_elems(c->n, c->r) / 3, snet4_bwd_elems(c->n, c->r) / 2, probe.omega, c->st,

@@ -39,6 +39,8 @@ struct nif_ctx {
   bool have_params = false, packed = false, packed32 = false, packed_p32 = false, use_snet3 = false, use_snet4 = false;
   bool jac_ok = false;        // JacobianLayer / HessianLayer kernels take this shape (jac_supported)
   void *sWF4 = nullptr, *sWB4 = nullptr;   // bf16-split planes of the hidden hyper-matrices (k_snet4)
+  void *sWF4x = nullptr, *sWB4x = nullptr; // k_snet6 (r5): exact-product HALF (hi, lo) planes of the hidden hyper-matrices (k_pack16b mode 3)
+  float* sWscale = nullptr;                //   and their powers of two [matrix][plane]
   void *sWF4h = nullptr, *sWB4h = nullptr; // the policies' compact plane set (one bf16 / half plane per block: k_snet4 / k_snet6<.., PR>)
   bool use_ll4 = false;                    // last-layer class: dense ShapeNet on k_snet4
   float* ll_slots = nullptr;               // its parameters in k_snet4's slot order (launch_ll_slots)

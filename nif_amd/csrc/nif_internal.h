@@ -111,6 +111,8 @@ struct SNetArgs {
   long long* tl;                          // -DNIF_TIMELINE builds: s_memtime stamps of wave 0 of block 0
   const void* WF4; const void* WB4;       // k_snet4: bf16-split planes (k_pack16b), per plane NCH chunks
   const void* WF4h; const void* WB4h;     // the policies' compact plane set (prec != 0): one bf16 / half plane per block (k_pack16b mode 1 / 2)
+  const void* WF4x; const void* WB4x;     // k_snet6 (r5): the exact-product HALF planes (hi, lo), k_pack16b mode 3, both in the adjoint geometry
+  const float* wscale;                    //   their powers of two [matrix][plane][s | 1 / s] (k_plane_scales)
   // last-layer-parameterised class on k_snet4 (r = 0: shared dense SIREN; theta = the slot-ordered copy built by
   // launch_ll_slots; so = so_u * rl outputs phi): u = Dot(phi, a) + bias, a = Z [tiles][rl][32]
   int ll, rl, so_u;
@@ -193,7 +195,7 @@ long snet4_bwd_elems(int n, int r);
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode = 0);
 void launch_snet4_f16(const SNetArgs& a, bool train, int nblk, size_t shm, hipStream_t st);     // k_snet4_f16.hip
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
-                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode = 0);
+                          long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode = 0, float* pscale = nullptr);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
 bool snet4_writes_da_bf16(const SNetArgs& a);   // stash format the training launch of `a` produces (k_snet4.hip)
 bool sob_writes_da_bf16(const SNetArgs& a, int ns, bool any_par);   // same for launch_sob (k_sob.hip)
