@@ -171,17 +171,26 @@ __device__ __forceinline__ void sine16_sign(const f32x4 (&a)[NBL], f32x4 (&h)[NB
 // v_sub + 3 pack instructions + a 128-bit shift register (r2).  The activation moves by at most one ulp (6e-8): the tagged
 // value is what the next layer, the stash and the weight-gradient kernels see; near cos(a) = 0, where the parity can
 // disagree with the true sign, the cosine rebuilt from it is ~0 anyway.
+// |a| >= 2^20 somewhere in the tile (never on a working SIREN): the argument reduction in fp64 -- t = x / 2 pi, f = t - rint(t) -- and
+// the same v_sin_f32; cos(2 pi f) < 0 <=> |f| > 1/4 gives the tag.  r5: this replaces the fp64 reduction + cephes kernels of
+// sine16_slow in the TAGGED forms (8 instructions per element instead of ~40: the training kernels carry 3 .. 6 copies of it, and
+// the ping-pong form of k_snet6 has to fit the instruction cache); same accuracy as the fast path (2.6e-7 abs)
+template <int NBL>
+__device__ __forceinline__ void sine16_tag_big(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], float inv) {
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double t = (double)(a[b][v] * inv) * 0.15915494309189535;
+      t -= __builtin_rint(t);
+      const float f = (float)t;
+      const float sv = __builtin_amdgcn_sinf(f);
+      h[b][v] = __uint_as_float((__float_as_uint(sv) & ~1u) | (fabsf(f) > 0.25f ? 1u : 0u));
+    }
+}
 template <int NBL>
 __device__ __forceinline__ void sine16_tag(const f32x4 (&a)[NBL], f32x4 (&h)[NBL]) {
-  if (sine16_big<NBL>(a)) {
-    f32x4 s[NBL], c[NBL];
-    sine16_slow<NBL>(a, s, c);
-#pragma unroll
-    for (int b = 0; b < NBL; ++b)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) h[b][v] = __uint_as_float((__float_as_uint(s[b][v]) & ~1u) | (__float_as_uint(c[b][v]) >> 31));
-    return;
-  }
+  if (sine16_big<NBL>(a)) { sine16_tag_big<NBL>(a, h, 1.0f); return; }
   // two elements per instruction (v_pk_fma_f32 / v_pk_add_f32); rint(x / 2pi) by the 1.5 * 2^23 trick (|x / 2pi| < 2^22 here)
   const f32x2 C = {0.15915493667125702f, 0.15915493667125702f}, CL = {6.420638326565253e-09f, 6.420638326565253e-09f};
   const f32x2 M = {12582912.0f, 12582912.0f}, IP = {0.318309886183790672f, 0.318309886183790672f};
@@ -215,13 +224,7 @@ __device__ __forceinline__ void sine16_tag_sc(const f32x4 (&x_)[NBL], f32x4 (&h)
     for (int b = 0; b < NBL; ++b)
 #pragma unroll
       for (int v = 0; v < 4; ++v) mx = fmaxf(mx, fabsf(x_[b][v]));
-    if (__builtin_expect(__any(!(mx * inv < NIF_SINCOS_FAST_LIMIT)), 0)) {
-      f32x4 a[NBL];
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) a[b] = x_[b] * inv;
-      sine16_tag<NBL>(a, h);
-      return;
-    }
+    if (__builtin_expect(__any(!(mx * inv < NIF_SINCOS_FAST_LIMIT)), 0)) { sine16_tag_big<NBL>(x_, h, inv); return; }
   }
   const float c0 = 0.15915493667125702f * inv, c1 = 6.420638326565253e-09f * inv, c2 = 0.318309886183790672f * inv;
   const f32x2 C = {c0, c0}, CL = {c1, c1}, M = {12582912.0f, 12582912.0f}, IP = {c2, c2};
@@ -299,6 +302,11 @@ __device__ __forceinline__ float act_d2(int act, float a) {
 }
 
 
+// s_setprio around the MFMA clusters of mfma_x6 / mfma_x3 (a translation unit that manages the priority itself defines the two away)
+#ifndef NIF_MFMA_PRIO_ON
+#define NIF_MFMA_PRIO_ON __builtin_amdgcn_s_setprio(1);
+#define NIF_MFMA_PRIO_OFF __builtin_amdgcn_s_setprio(0);
+#endif
 // ---- fp32 products as exact bf16 splits (k_snet4.hip has the derivation and the measured accuracy) ---------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -381,7 +389,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const bf16x8 a, const bf16x8 b, const 
 // CP (late r4): the chunk holds ONE 16-bit plane per block (the policies' compact plane set: unit ob * 64 + lane) instead of the split groups
 template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0, bool CP = false>
 __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, const bf16x8 b2, f32x4 (&T_)[NT], int lane) {
-  __builtin_amdgcn_s_setprio(1);
+  NIF_MFMA_PRIO_ON
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4* T = T_ + OB0;
 #pragma unroll
@@ -413,12 +421,12 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
     T[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ob], 0, 0, 0);
     T[ob + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ob + 1], 0, 0, 0);
   }
-  __builtin_amdgcn_s_setprio(0);
+  NIF_MFMA_PRIO_OFF
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
 template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0, bool CP = false>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T_)[NT], int lane) {
-  __builtin_amdgcn_s_setprio(1);
+  NIF_MFMA_PRIO_ON
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4* T = T_ + OB0;
 #pragma unroll
@@ -453,7 +461,7 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
     T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
   }
-  __builtin_amdgcn_s_setprio(0);
+  NIF_MFMA_PRIO_OFF
 }
 
 // ---- sign-of-cosine shift register (plain SIREN: cos(a) = +-sqrt(1 - sin^2(a)), sin(a) is the next layer's stashed

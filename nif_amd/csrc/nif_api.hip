@@ -2049,16 +2049,16 @@ extern "C" int nif_profile_read(nif_ctx* c, float* ms, int64_t* cnt, int n, int 
   return NIF_OK;
 }
 extern "C" int nif_debug_timeline(nif_ctx* c, int64_t* out, int32_t n_pairs) {
-  if (!c || n_pairs < 0 || n_pairs > 256) return fail(NIF_ERR_INVALID, "bad argument");
+  if (!c || n_pairs < 0 || n_pairs > 2048) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->st));
   if (!c->tl) {
-    HIPCHK(hipMalloc(&c->tl, 512 * sizeof(long long)));
-    HIPCHK(hipMemset(c->tl, 0, 512 * sizeof(long long)));
+    HIPCHK(hipMalloc(&c->tl, 4096 * sizeof(long long)));
+    HIPCHK(hipMemset(c->tl, 0, 4096 * sizeof(long long)));
     return NIF_OK;   // first call arms the buffer
   }
   if (out && n_pairs > 0) HIPCHK(hipMemcpy(out, c->tl, sizeof(long long) * 2 * n_pairs, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(c->tl, 0, 512 * sizeof(long long)));
+  HIPCHK(hipMemset(c->tl, 0, 4096 * sizeof(long long)));
   return NIF_OK;
 }
 extern "C" int nif_timer_start(nif_ctx* c) {

@@ -22,13 +22,6 @@
 //   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
 // Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
 // Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
-#ifndef NIF_S6_GPRIO
-#define NIF_S6_GPRIO 0      // 1: the chunk step's operand reads + products of producer waves 0-3 at a higher priority than those of waves 4-7 (their
-#endif                      // SIMD partners): one wave's reads are served first and its products overlap the partner's reads -- measured: see DESIGN 5.5
-#if NIF_S6_GPRIO
-#define NIF_MFMA_PRIO_ON
-#define NIF_MFMA_PRIO_OFF
-#endif
 #include "k_fuse_dev.h"
 
 #define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
@@ -136,9 +129,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
   constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
-  // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
-  // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
-  constexpr int NBUF = 2;
+  // r5: THREE chunk buffers, the DMA two chunk steps ahead.  The s_memtime timeline of r4's two-buffer form (tools/exp/timeline_s6.py,
+  // profiles/r05_timeline_*.txt) showed every chunk step waiting ~330 ticks for the chunk it had issued ~1 200 ticks earlier: a chunk's
+  // L2 -> LDS round trip is longer than the step that was supposed to cover it.  The DMA of chunk c + 2 is issued at the END of step c
+  // (behind the step's products and ring traffic: vmcnt(1) then leaves exactly it in flight and every older access has landed)
+  constexpr int NBUF = 3;
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
 #if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
   constexpr int NRING = 0;
@@ -445,8 +440,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   prefetch_inputs(blockIdx.x, 0);
   if (cs_left <= 0) cs_left = -1;
   cs_next(0);
+  cs_next(1);
   __syncthreads();
-  int cbuf = 0, nbuf = 1;
+  int cbuf = 0, nbuf = 2;
   int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
   float loss_lane = 0.f;
   const long sstride = A.slot_stride, tstride = (long)stash_fp(n) * 32;
@@ -459,20 +455,19 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CHUNK(...)                                                         \
   {                                                                           \
     S6_TL(100);                                                               \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    __VA_ARGS__                                                               \
+    S6_TL(300);                                                               \
+    asm volatile("" ::: "memory");                                            \
     cs_next(nbuf);                                                            \
     S6_TL(200);                                                               \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
-    if (NIF_S6_GPRIO) { if (wid < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); } \
-    __VA_ARGS__                                                               \
-    if (NIF_S6_GPRIO) __builtin_amdgcn_s_setprio(0);                          \
-    S6_TL(300);                                                               \
-    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
+    __builtin_amdgcn_s_waitcnt(0x0070 | 1);    /* vmcnt(1) lgkmcnt(0) -- a chunk is ONE DMA instruction of a wave in every form (512 or 256 units) --: chunk c + 1 has landed (c + 2 may be in flight), the deposits are visible */ \
     S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
     S6_TL(500);                                                               \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    cbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1; nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;   \
   }
 // the chunk step that carries the layer's ring traffic: the NRING ring instructions are issued BEHIND the next chunk's DMA, so the
 // wait at the end of the step may leave exactly them in flight (vmcnt counts in issue order: "at most NRING outstanding" = every
@@ -788,7 +783,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 3 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {

@@ -3,72 +3,47 @@
 //
 // Why: k_snet4 writes 2.5 KB/point of h / dL/da rows that exist only so that the K = batch reductions
 //     dL/dM_j^(k)[in][out] = w0 sum_p zt_k(p) h_j[in][p] dL/da_{j+1}[out][p]
-// can run as separate HBM-bound kernels (0.54 ms of the 1.76 ms step, next to a 1.02 ms kernel whose arithmetic side is 0.71 ms).
-// Here they are accumulated where both operands are live:
-//   * ONE workgroup of 8 waves per CU (2 per SIMD, 256 registers), wave = one 16-point tile as in k_snet4;
-//   * the accumulators of all hidden matrices and planes (nh (r+1) n^2 = 128 KB at 4 x 64, r = 1) live in the 8 waves' registers:
-//     wave (k, I, J) = (wid >> 2, (wid >> 1) & 1, wid & 1) owns the 32 x 32 block (plane k, input block I, output block J) of EVERY
-//     hidden matrix: 16 accumulator registers per matrix;
-//   * at the end of adjoint layer j every wave DEPOSITS its tile's operands in LDS as bf16 (hi, lo) planes in the form it holds
-//     MFMA B operands anyway (dL/da: the split of the data adjoint's own product; h_j and zt h_j: split when the row comes back from
-//     the stash -- nothing is held across the layer for it): 24 ds_write_b64 per layer and tile, no packing arithmetic beyond the
-//     splits; during the chunk steps of layer j-1 every wave runs
-//     ITS block over the 8 deposited tiles: ds_read_b64_tr_b16 hands the operands over with features on lanes (k_fuse_dev.h) --
-//     8 transpose reads + 3 v_mfma_f32_32x32x16_bf16 (hi.lo + lo.hi + hi.hi, K = the tile's 16 points) per tile, no VALU work;
-//     the chunk barriers that exist anyway order deposit and consumption (two extra barriers per tile round around the first layer);
+// can run as separate HBM-bound kernels.  Here they are accumulated where both operands are live:
+//   * ONE workgroup of 16 waves per CU at 128 registers: 8 PRODUCER waves run k_snet4's tile program (one 16-point tile per wave and
+//     round) and DEPOSIT, at the end of adjoint layer j, their tile's operands in LDS as bf16 (hi, lo) planes in the layout they
+//     hold MFMA B operands in anyway -- h_j, zt h_j, dL/da_{j+1}: 6 planes x 2 KB per tile, 24 ds_write_b64; 8 CONSUMER waves own the
+//     accumulators (nh (r+1) n^2 = 128 KB at 4 x 64, r = 1): wave (k, I, J) holds the 32 x 32 block (plane k, input block I, output
+//     block J) of EVERY hidden matrix, reads the deposited tiles with ds_read_b64_tr_b16 (features on lanes, k_fuse_dev.h) and runs
+//     3 v_mfma_f32_32x32x16_bf16 per tile (hi.lo + lo.hi + hi.hi, K = the tile's 16 points);
 //   * biases, the first layer (K = si) and the last layer (N = so) are v_dot2_f32_bf16 sums of the same transposed operands against
-//     per-tile weight vectors (zt, 1, x_c, zt x_c, du_o as bf16 hi | lo rows of 16 points): the lane already holds 8 points of its
-//     feature -- 12 VALU instructions per tile, vector and wave role;
-//   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
+//     per-tile weight vectors (zt, 1, x_c, zt x_c, du_o as bf16 hi | lo rows of 16 points);
+//   * what is left of the stash: the layer inputs h_1 .. h_{nh-1} of the wave's own tile between its forward and adjoint sweep, in a
+//     private ring [matrix][feature][16 points]; h_0 is recomputed from the tile's inputs.
+//
+// r5: PING-PONG.  r4 ran all 8 producers in lock step -- one barrier per K-step chunk, every wave reading its
+// A operands, multiplying and then doing its activation / split arithmetic at the same time as all the others, so that LDS, matrix
+// pipe and VALU took turns (27 % / 36 % / 43 % busy, adding up to the whole kernel).  Now the producers are two GROUPS of four (one
+// wave of each group per SIMD) that run the same program ONE BARRIER INTERVAL APART, and the program alternates strictly between
+//     M items: the two K-step chunks of one plane (24 MFMAs per wave, nothing else), and
+//     V items: everything between two planes' products (the latent combine; or sine + operand splits + ring traffic + the next
+//              layer's bias loads; or the adjoint's cosine, dL/da, loss scale, splits, deposits),
+// so that in every interval one wave of a SIMD multiplies while its partner does vector work.  The chunk stream runs in PAIRS (a
+// plane = two chunks) through two pair buffers: pair q is multiplied by group 0 in interval 2q and by group 1 in interval 2q + 1,
+// pair q + 1 is DMA'd during those two intervals (every producer wave issues its slice in interval 2q and waits for it in front of
+// the barrier that ends interval 2q + 1).  The consumers walk the same barrier sequence, two deposited tiles per interval.
+// Products: fp32-exact on HALF pairs (below).
 // Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
 // Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
-#ifndef NIF_S6_GPRIO
-#define NIF_S6_GPRIO 0      // 1: the chunk step's operand reads + products of producer waves 0-3 at a higher priority than those of waves 4-7 (their
-#endif                      // SIMD partners): one wave's reads are served first and its products overlap the partner's reads -- measured: see DESIGN 5.5
-#if NIF_S6_GPRIO
-#define NIF_MFMA_PRIO_ON
-#define NIF_MFMA_PRIO_OFF
-#endif
 #include "k_fuse_dev.h"
 
 #define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
 
-#ifndef NIF_S6_RING
-#define NIF_S6_RING 1       // 1: the h_j rows of a wave's tile in a private ring [matrix j][feature][16 points] that stays cache resident; 0: the [tile32][feature][32] stash
-#endif
-// private ring of a wave, point-major: the 4 features of (block b, lane group g) of point p are ONE 16-byte piece at
-// p * NP + 16 b + 4 g -- 4 store / load instructions per layer instead of 16 (NIF_S6_RING_V4 = 0: feature-major rows f * 16 + p)
-#ifndef NIF_S6_RING_NT
-#define NIF_S6_RING_NT 0      // bit 0: non-temporal ring stores, bit 1: non-temporal ring loads (measured: see DESIGN)
-#endif
-#ifndef NIF_S6_RING_V4
-#define NIF_S6_RING_V4 0
-#endif
-#ifndef NIF_S6_VMRING
-#define NIF_S6_VMRING 0       // 1: ring stores / loads behind the chunk DMA, counted out of the chunk wait (S6_CHUNK_RING) -- measured r4: 1.327 / 1.331 vs 1.332 / 1.330 ms per step, no gain: nothing waits for the ring
-#endif
+// private ring of a wave: [matrix j][feature][16 points]
 template <int NBL>
 __device__ __forceinline__ void ring_store16(float* __restrict__ slot, const f32x4 (&h)[NBL], int g, int p) {
 #ifdef NIF_ABL_NOSTORE
   if (h[0][0] != 12345.678f) return;
 #endif
-#if NIF_S6_RING_V4
-  f32x4* q = reinterpret_cast<f32x4*>(slot + p * (16 * NBL) + 4 * g);
-#pragma unroll
-  for (int b = 0; b < NBL; ++b) q[4 * b] = h[b];
-#else
   float* q = slot + 4 * g * 16 + p;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-#if NIF_S6_RING_NT & 1
-      __builtin_nontemporal_store(h[b][v], q + (16 * b + v) * 16);
-#else
-      q[(16 * b + v) * 16] = h[b][v];
-#endif
-    }
-#endif
+    for (int v = 0; v < 4; ++v) q[(16 * b + v) * 16] = h[b][v];
 }
 template <int NBL>
 __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x4 (&h)[NBL], int g, int p) {
@@ -79,30 +54,13 @@ __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x
     return;
   }
 #endif
-#if NIF_S6_RING_V4
-  const f32x4* q = reinterpret_cast<const f32x4*>(slot + p * (16 * NBL) + 4 * g);
-#pragma unroll
-  for (int b = 0; b < NBL; ++b) h[b] = q[4 * b];
-#else
   const float* q = slot + 4 * g * 16 + p;
 #pragma unroll
   for (int b = 0; b < NBL; ++b)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-#if NIF_S6_RING_NT & 2
-      h[b][v] = __builtin_nontemporal_load(q + (16 * b + v) * 16);
-#else
-      h[b][v] = q[(16 * b + v) * 16];
-#endif
-    }
-#endif
+    for (int v = 0; v < 4; ++v) h[b][v] = q[(16 * b + v) * 16];
 }
 
-#ifdef NIF_TIMELINE      // measurement builds: s_memtime stamps of producer wave 0 (entries 0 ..) and consumer wave 8 (entries 1024 ..) of block 0, third round
-#define S6_TL(id) do { if (A.tl && blockIdx.x == 0 && (tid == 0 || tid == 512) && tlr == 2 && tlc < 1000) { long long* q_ = A.tl + (tid ? 2048 : 0) + 2 * tlc; q_[0] = (id); q_[1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
-#else
-#define S6_TL(id) do { } while (0)
-#endif
 struct S6Args {
   SNetArgs s;
   float* partial; long pstride;     // partial-gradient rows [gridDim.x][pstride] (the ShapeNet = hypernetwork columns of them)
@@ -116,35 +74,26 @@ struct S6Args {
 #define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
 #endif
 
-// PR (late r4): the producers' hidden n x n products under a Keras policy -- 1 = mixed_bfloat16 (ONE bf16 product per operand pair),
-// 2 = mixed_float16 (half operands, per-point loss scale on dL/da; k_snet4_dev.h) -- as in k_snet4<.., PR>.  The CONSUMER side is
-// untouched: the deposits stay bf16 (hi, lo) pairs of the fp32 rows and the weight-gradient sums three products, i.e. the policy's
-// weight gradients here are those of fp32 stash rows (the tests emulate it with stash_bf16 = False).  (r4's first policy form also cut the consumers
-// to one MFMA per tile and hipcc answered with 327 spilled registers; with the consumer code unchanged the allocation holds.)
+// PR = 0 (r5): fp32-exact products on HALF pairs -- planes (hi, lo) x operand (hi, lo), three v_mfma_f32_16x16x32_f16 per pair in both
+// directions (k_pack16b mode 3, split2h; forward: half of r4's six bf16 products and two thirds of its chunk bytes; adjoint: 22
+// significand bits where r4's bf16 pairs carried 16).  The planes carry a power of two s_jk, the sines 2^12, dL/da a power of two per
+// point: all of it is scaled back exactly (biases pre-scaled in the LDS image, the combine factor zt s1 / s0, the sine's constants).
+// PR = 1 / 2: the producers' hidden n x n products under a Keras policy -- mixed_bfloat16 (ONE bf16 product per operand pair) /
+// mixed_float16 (half operands, per-point loss scale on dL/da; k_snet4_dev.h) -- from the policy's compact plane set.  The CONSUMER side
+// is the same for all three: bf16 (hi, lo) deposits of the fp32 rows, three-product weight-gradient sums.
 template <int NBL, int PR = 0>
 __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   extern __shared__ __attribute__((aligned(256))) char smem6[];
   const SNetArgs& A = F.s;
   constexpr int NT = 512, WAVES = 8, r = 1;             // producer threads / waves (= tiles per round); 8 consumer waves behind them
   constexpr int NCH = NBL / 2;
-  // PR = 0 (r5): fp32-exact products on HALF pairs -- planes (hi, lo) x operand (hi, lo), three v_mfma_f32_16x16x32_f16 per pair in both
-  // directions (k_pack16b mode 3, split2h; forward: half of r4's six bf16 products and two thirds of its chunk bytes; adjoint: 22
-  // significand bits where r4's bf16 pairs carried 16).  The planes carry a power of two s_jk, the sines 2^12, dL/da a power of two per
-  // point: all of it is scaled back exactly (biases pre-scaled in the LDS image, the combine factor zt s1 / s0, the sine's constants)
   constexpr bool X16 = PR == 0;
-  constexpr int CF = X16 ? NBL * 2 * 64 : NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
-  constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
-  constexpr int QF = (CF + NT - 1) / NT;
-  // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
-  // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
-  constexpr int NBUF = 2;
+  constexpr int CU = X16 ? NBL * 2 * 64 : NBL * 64;      // 16-byte units per chunk (forward and adjoint alike), = the LDS stride of a chunk
+  constexpr int PB = X16 ? 3 : PR;                       // product form of mfma_x3
+  constexpr int QP = (2 * CU) / NT;                      // DMA instructions per thread and chunk PAIR (exactly: 2 CU is a multiple of NT)
+  static_assert((2 * CU) % NT == 0, "a chunk pair is a whole number of DMA instructions per producer thread");
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
-#if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
-  constexpr int NRING = 0;
-#else
-  constexpr int NRING = NIF_S6_RING_V4 ? NBL : 4 * NBL; // vector-memory instructions of one ring_store16 / ring_load16
-#endif
   constexpr int EXT = NPL * FUSE_PLANE_BYTES;
   // per-tile weight vectors [hi 16 | lo 16] bf16 = 64 B.  Last layer (WVL): du_o (o < 3), zt, ones.  First layer (WVF), per plane k:
   // k * 4 + c = (zt | 1) x_c, k * 4 + 3 = (zt | 1)
@@ -154,23 +103,25 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
   const long nt16 = 2 * ((A.B + 31) / 32);
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
+  const long nrounds = ngroups > (long)blockIdx.x ? (ngroups - 1 - (long)blockIdx.x) / gridDim.x + 1 : 0;   // tile rounds of this workgroup
 
   char* EX = smem6;                                     // [tile 8][plane 6][2 KB]
   char* WVL = EX + WAVES * EXT;
   char* WVF = WVL + WAVES * WVLT;
-  bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);
-  float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
+  bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);      // two pair buffers of two chunks
+  float* sm = reinterpret_cast<float*>(chunks + 4 * CU);
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
-  const int NI = (CX + CZ + CY + 4) * 16;
+  // per-tile input rows [column][16 points], two sets: coordinates (padded to 4 columns), (latent, sample weight, -, -) and the targets
+  const int CX = (si + 3) & ~3, CY = (so + 3) & ~3;
+  const int NI = (CX + 4 + CY) * 16;
   const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   float* scl = lsum + 16;                               // X16: [matrix][plane][s | 1 / s] of the half planes
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
-  {   // prologue, all 12 waves: LDS image of the small hyper-vectors; the exchange images start as zeros (the first tile round
-      // consumes a first-layer deposit that nobody made)
+  {   // prologue, all 16 waves: LDS image of the small hyper-vectors; the exchange images start as zeros (the first tile round
+      // consumes deposits that nobody made)
     const long s_wl = (long)si * n + (long)nh * n * n;
     const long s_b1 = s_wl + (long)n * so, s_bh = s_b1 + n, s_bl = s_bh + (long)nh * n;
     for (int idx = tid; idx < (r + 1) * nsm; idx += 1024) {
@@ -191,6 +142,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += 1024) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // The barrier intervals of a round (8 nh of them), numbered by group 0's items: forward layer j = items 4j .. 4j + 3 (M plane 0, V,
+  // M plane 1, V), adjoint layer j = items 4 nh + 4 (nh - 1 - j) .. + 3; group 1 runs item x in interval x + 1.  Deposits (group 0 /
+  // group 1 write during the interval): last layer 4 nh - 1 / 4 nh; hidden matrix j >= 1 at D_j = 4 nh + 4 (nh - 1 - j) + 3 / + 1;
+  // matrix 0 at 8 nh - 1 / the next round's 0; the first layer's dL/da planes at the next round's 1 / 2.  The consumers read tiles
+  // 0 .. 3 (group 0) before 4 .. 7 (group 1), never a tile in the interval its producer writes it.
   if (wid >= WAVES) {
     // =====================================================================================================================
     // consumer wave (plane kk, input block bI, output block bJ): the 32 x 32 block (kk, bI, bJ) of every hidden matrix; the
@@ -198,7 +154,6 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     // the first layer, the bJ = 0 waves rows 32 bI .. of the last layer, wave (kk, 1, 1) the last layer's bias
     // =====================================================================================================================
     const int cw = wid - WAVES, kk = cw >> 2, bI = (cw >> 1) & 1, bJ = cw & 1;
-    int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
     __syncthreads();
     if (tid - NT < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
       const int t = (tid - NT) >> 4, q = (tid - NT) & 15;
@@ -222,11 +177,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CBAR()                                                             \
   {                                                                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): the transpose reads are back */ \
-    S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    S6_TL(500);                                                               \
   }
     // hidden matrix J_: this wave's block over the deposited tiles [T0_, T1_).  One tile's operands ahead of the MFMAs (the
     // transpose reads of tile t + 1 are in flight while tile t multiplies), never more: 64 accumulator + 2 x 16 operand registers
@@ -253,18 +206,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       ah_ = ah2_; al_ = al2_; bh_ = bh2_; bl_ = bl2_;                                                       \
     }                                                                                                       \
   }
-    // the four chunk steps of an adjoint layer with the consumption of hidden deposit DJ_ (a compile-time index: the accumulators
-    // are never selected at run time -- a switch over them made hipcc copy and spill whole accumulators around every call)
-#define S6_HID_LAYER(DJ_)                                                                                   \
-  if (DJ_ < nh) {                                                                                           \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 0, 3))                                                                          \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 3, 6))                                                                          \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                          \
-    S6_CBAR()                                                                                               \
-  }
+    // the deposit of hidden matrix DJ_ (DJ_ >= 1; a compile-time index: the accumulators are never selected at run time -- a switch
+    // over them made hipcc copy and spill whole accumulators around every call) in the four intervals behind D_j, two tiles each
+#define S6_HID_STEP(DJ_, M_)                                                                                \
+  if (DJ_ < nh && iv == 4 * nh + 4 * (nh - 1 - DJ_) + 4 + (M_)) { S6_DO(S6_HID_TILES(DJ_, 2 * (M_), 2 * (M_) + 2)) }
+#define S6_HID_LAYER(DJ_) S6_HID_STEP(DJ_, 0) S6_HID_STEP(DJ_, 1) S6_HID_STEP(DJ_, 2) S6_HID_STEP(DJ_, 3)
     // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors).  The skinny sums run as ROLLED loops over the tiles:
     // unrolled, hipcc fetched the weight vectors of all tiles first and spilled the accumulators to make room
     auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
@@ -311,33 +257,28 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_DO(...) __VA_ARGS__
 #endif
     // the barrier sequence of the producers' tile program, with this wave's share of the products between the barriers
-    for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
-      for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
-        S6_CBAR()
-        if (j == 0) { S6_DO(consume_first(0, 4);) }
-        S6_CBAR()
-        if (j == 0) { S6_DO(consume_first(4, 8);) }
-        S6_CBAR()
+    for (long rd = 0; rd < nrounds; ++rd) {
+      for (int iv = 0; iv < 8 * nh; ++iv) {
+        // the previous round's deposit of matrix 0: group 0's tiles, then group 1's
+        if (iv == 0) { S6_DO(S6_HID_TILES(0, 0, 4)) }
+        if (iv == 1) { S6_DO(S6_HID_TILES(0, 4, 8)) }
+        // the previous round's first-layer deposit (written in intervals 1 / 2)
+        if (iv >= 2 && iv < 6) { S6_DO(consume_first(2 * (iv - 2), 2 * (iv - 2) + 2);) }
+        // the last layer's deposit (4 nh - 1 / 4 nh)
+        if (iv >= 4 * nh && iv < 4 * nh + 4) { S6_DO(consume_last(2 * (iv - 4 * nh), 2 * (iv - 4 * nh) + 2);) }
+        S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
         S6_CBAR()
       }
-      // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
-      S6_CBAR()
-      S6_DO(consume_last(0, 3);)
-      S6_CBAR()
-      S6_DO(consume_last(3, 6);)
-      S6_CBAR()
-      S6_DO(consume_last(6, 8);)
-      S6_CBAR()
-      S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
-      S6_CBAR()                              // deposit 0 next to the first layer's adjoint
-      S6_DO(S6_HID_TILES(0, 0, 8))
-      S6_CBAR()
     }
+    if (nrounds > 0) S6_CBAR()    // (group 1 is one interval behind: its last item)
+    __syncthreads();          // every deposit of the last round is visible
+    S6_DO(S6_HID_TILES(0, 0, 8))
+    __syncthreads();          // ... consumed: the producers write the last round's first-layer deposit
     __syncthreads();
     S6_DO(consume_first(0, 8);)
-    __syncthreads();
 #undef S6_DO
 #undef S6_HID_LAYER
+#undef S6_HID_STEP
 #undef S6_HID_TILES
 #undef S6_HID_LOAD
 #undef S6_CBAR
@@ -384,35 +325,36 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   }
 
   // =======================================================================================================================
-  // producer wave = one 16-point tile per round: k_snet4's tile program + the deposits
+  // producer wave = one 16-point tile per round: k_snet4's tile program as alternating M / V items + the deposits
   // =======================================================================================================================
+  const int grp = wid >> 2;                             // waves w and w + 4 share a SIMD: one of each group
   float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
   float* inp = sks + r * 64;
-  // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
-  const int NPC = (r + 1) * NCH;
+  // ---- the chunk stream (k_snet4), in pairs: forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 --
+  const int NPP = r + 1;                                // pairs of one hidden matrix (a plane = its two K-step chunks)
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
-  long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
+  int cs_left = nh * NPP, cs_phase = 0, cs_pb = 0;
+  long cs_groups = nrounds - 1;
   auto cs_phase_step = [&]() {
     ++cs_phase;
     if (cs_phase < 1 + nh) {
-      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPP * 2 * CU; cs_left = NPP; return;
     }
     if (cs_groups <= 0) { cs_left = -1; return; }
     --cs_groups; cs_phase = 0;
-    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
+    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_left = nh * NPP;
   };
-  auto cs_next = [&](int buf) {
+  auto cs_next_pair = [&]() {      // this wave's slice of the next pair into the pair buffer that the pair before last has left
     if (cs_left < 0) return;
-    bf16x8* dst = chunks + buf * CF;
+    bf16x8* dst = chunks + cs_pb * 2 * CU;
 #pragma unroll
-    for (int q = 0; q < QF; ++q)
-      if (wid * 64 + NT * q < cs_units)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + tid + NT * q),
-                                         (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
+    for (int q = 0; q < QP; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + tid + NT * q),
+                                       (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
     asm volatile("" ::: "memory");
-    cs_src += cs_units;
+    cs_src += 2 * CU;
+    cs_pb ^= 1;
     if (--cs_left == 0) cs_phase_step();
   };
   auto prefetch_inputs = [&](long tgn, int set) {
@@ -428,231 +370,148 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.xin + ptn * A.ncol + A.col0 + c),
                                        (__attribute__((address_space(3))) void*)(dst + i0 * 16), 4, 0, 0);
     }
-    for (int i0 = 0; i0 < CZ; i0 += 4) {
-      const int c = i0 + g < r ? i0 + g : r - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (tile32n * r + c) * 32 + poffn),
-                                       (__attribute__((address_space(3))) void*)(dst + (CX + i0) * 16), 4, 0, 0);
+    {   // column 0: the latent, column 1: the sample weight (or a target, unused), columns 2, 3: the latent again
+      const float* src = (g == 1) ? (A.sw ? A.sw + ptn : A.y + ptn * so) : A.Z + (tile32n * r) * 32 + poffn;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + CX * 16), 4, 0, 0);
     }
     for (int i0 = 0; i0 < CY; i0 += 4) {
       const int c = i0 + g < so ? i0 + g : so - 1;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.y + ptn * so + c),
-                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + (CX + 4 + i0) * 16), 4, 0, 0);
     }
-    const float* swp = A.sw ? A.sw + ptn : A.y + ptn * so;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
-                                     (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
   };
   prefetch_inputs(blockIdx.x, 0);
-  if (cs_left <= 0) cs_left = -1;
-  cs_next(0);
+  if (cs_left <= 0 || nrounds <= 0) cs_left = -1;
+  cs_next_pair();                                        // pair 0
   __syncthreads();
-  int cbuf = 0, nbuf = 1;
-  int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
+  int mq = 0;                                            // M items done = the pair this wave multiplies next
   float loss_lane = 0.f;
-  const long sstride = A.slot_stride, tstride = (long)stash_fp(n) * 32;
-  float* IN0 = A.stash;
-  float* ring = A.stash + ((long)blockIdx.x * WAVES + wid) * (long)nh * (NP * 16);    // NIF_S6_RING: [matrix][NP features][16 points]
-  (void)ring; (void)IN0; (void)sstride; (void)tstride;
+  float* ring = A.stash + ((long)blockIdx.x * WAVES + wid) * (long)nh * (NP * 16);    // [matrix][NP features][16 points]
   const FuseDep dep = fuse_dep_addr(p, g);
   char* exw = EX + wid * EXT;                            // this wave's tile images
 
-#define S6_CHUNK(...)                                                         \
+  // s_waitcnt vmcnt(N) lgkmcnt(0); vmcnt counts in issue order, so "at most QP outstanding" behind a DMA slice that was issued LAST
+  // means: everything older has landed, the slice may stay in flight for one more interval
+#define S6_WAIT(N_) __builtin_amdgcn_s_waitcnt(0x0070 | ((N_) & 15) | (((N_) >> 4) << 14))
+#define S6_SYNC()                                                             \
   {                                                                           \
-    S6_TL(100);                                                               \
-    cs_next(nbuf);                                                            \
-    S6_TL(200);                                                               \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
-    if (NIF_S6_GPRIO) { if (wid < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); } \
-    __VA_ARGS__                                                               \
-    if (NIF_S6_GPRIO) __builtin_amdgcn_s_setprio(0);                          \
-    S6_TL(300);                                                               \
-    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
-    S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    S6_TL(500);                                                               \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
   }
-// the chunk step that carries the layer's ring traffic: the NRING ring instructions are issued BEHIND the next chunk's DMA, so the
-// wait at the end of the step may leave exactly them in flight (vmcnt counts in issue order: "at most NRING outstanding" = every
-// DMA instruction has landed) -- their latency gets the following chunk step as well instead of sitting in front of this barrier
-#if NIF_S6_VMRING
-#define S6_CHUNK_RING(PRE_, ...)                                              \
+  // The next pair's DMA goes out in the interval in which group 0 multiplies the current one: group 0 issues its slice at the start
+  // of its M item (no other vector-memory traffic in an M item: vmcnt(QP) at its end leaves exactly the slice in flight, vmcnt(0)
+  // at the end of the V item behind it waits for it); group 1 at the END of the V item in front of its M item (behind that item's
+  // ring / input traffic: vmcnt(QP) again), vmcnt(0) at the end of the M item.
+  // end of a V item
+#define S6_V_END()                                                            \
   {                                                                           \
-    cs_next(nbuf);                                                            \
-    PRE_                                                                      \
-    asm volatile("" ::: "memory");                                            \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
-    __VA_ARGS__                                                               \
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NRING & 15) | ((NRING >> 4) << 14));   /* vmcnt(NRING) lgkmcnt(0) */ \
-    asm volatile("" ::: "memory");                                            \
-    __builtin_amdgcn_s_barrier();                                             \
-    asm volatile("" ::: "memory");                                            \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    if (grp == 1) { cs_next_pair(); S6_WAIT(QP); } else { S6_WAIT(0); }       \
+    S6_SYNC()                                                                 \
   }
-#else
-#define S6_CHUNK_RING(PRE_, ...) { PRE_ S6_CHUNK(__VA_ARGS__) }
-#endif
-
-  int iset = 0;
-  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset, ++tlr) {
-    S6_TL(1);
-    const long t16_raw = tg * WAVES + wid;
-    const bool active = t16_raw < nt16;
-    const long t16 = active ? t16_raw : nt16 - 1;
-    const long tile32 = t16 >> 1;
-    const int poff = 16 * (int)(t16 & 1) + p;
-    const long pt = t16 * 16 + p;
-    const bool valid = active && pt < A.B;
-    const float* xs = inp + (iset & 1) * NI + p;
-    const float* zs = inp + (iset & 1) * NI + CX * 16;
-    const float* ys = zs + CZ * 16 + p;
-    const float* wsp = zs + (CZ + CY) * 16 + p;
-    const float* zt_base = zs + p;
-    const long row0 = tile32 * tstride + poff;
-    (void)row0;
-    dzs[lane] = 0.f;
-
-    f32x4 h[NBL], acc[NBL];
-    // ---- first layer ----------------------------------------------------------------------------------------------------
-    auto first_layer = [&](f32x4 (&out)[NBL]) __attribute__((always_inline)) {
-      f32x4 a_[NBL];
-      {
-        const float* s0 = sm + r * nsm + 4 * g;
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) {
-          f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-          a_[b] = s;
-        }
-      }
-      {
-        const float zt = zt_base[0];
-        const float* s0 = sm + 4 * g;
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) {
-          f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-          a_[b] += zt * s;
-        }
-      }
-      sine16_tag<NBL>(a_, out);
-    };
-    first_layer(h);
-    prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
-    // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
-    for (int j = 0; j < nh; ++j) {
-#if !NIF_S6_RING
-      if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
-#endif
-      bf16x8 b0[NCH], b1[NCH], b2[NCH];
-      if (X16) split2h<NBL>(h, 4096.0f, b0, b1);
-      else split3p<NBL, PR>(h, b0, b1, b2);
-      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
-      {
-        const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) acc[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
-      }
-      {
-        f32x4 T[NBL];
-        const float* sb = sm + o_bh + j * NP + 4 * g;
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
-#if NIF_S6_RING
+  // an M item: the two K-step chunks of pair mq
+#define S6_M_ITEM(KS0_, KS1_)                                                 \
+  {                                                                           \
+    if (grp == 0) cs_next_pair();                                             \
+    { const bf16x8* cur = chunks + ((mq & 1) * 2) * CU; KS0_ }               \
+    asm volatile("" ::: "memory");    /* (the second chunk's operand reads stay behind the first chunk's products: registers) */ \
+    { const bf16x8* cur = chunks + ((mq & 1) * 2 + 1) * CU; KS1_ }           \
+    ++mq;                                                                     \
+    if (grp == 0) { S6_WAIT(QP); } else { S6_WAIT(0); }                       \
+    S6_SYNC()                                                                 \
+  }
+#define S6_BWD(KS_, T_, ZI_) { mfma_x3<NBL, PB, ZI_, NBL, 0, CP>(cur, q0[KS_], q1[KS_], T_, lane); }
 #define S6_FWD(KS_, T_) { if (X16) mfma_x3<NBL, 3, false, NBL, 0, false>(cur, b0[KS_], b1[KS_], T_, lane); else mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }
-        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, S6_FWD(0, T))
-#else
-        S6_CHUNK(S6_FWD(0, T))
-#endif
-        S6_CHUNK(S6_FWD(1, T))
-        const float zt = X16 ? zt_base[0] * (s1_ * is0_) : zt_base[0];      // (plane 0's chain carries s0, the sum s1)
+
+  // ---- state of the current round's tile --------------------------------------------------------------------------------
+  bool active = false, valid = false;
+  long tile32 = 0; int poff = 0;
+  const float *xs = inp, *ys = inp, *wsp = inp, *zt_base = inp;
+  auto setup_round = [&](long tg, int iset) {
+    const long t16_raw = tg * WAVES + wid;
+    active = t16_raw < nt16;
+    const long t16 = active ? t16_raw : nt16 - 1;
+    tile32 = t16 >> 1;
+    poff = 16 * (int)(t16 & 1) + p;
+    const long pt = t16 * 16 + p;
+    valid = active && pt < A.B;
+    const float* zs = inp + (iset & 1) * NI + CX * 16;
+    xs = inp + (iset & 1) * NI + p;
+    zt_base = zs + p;
+    wsp = zs + 16 + p;
+    ys = zs + 4 * 16 + p;
+  };
+  f32x4 h[NBL], acc[NBL], T[NBL], gh[NBL];
+  bf16x8 b0[NCH], b1[NCH], b2[NCH];                     // forward operand splits of h
+  bf16x8 e0[NCH], e1[NCH];                              // the first layer's dL/da (hi, lo) of the previous round, until its deposit
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
-      }
-      S6_CHUNK(S6_FWD(0, acc))
-      S6_CHUNK(S6_FWD(1, acc))
-#undef S6_FWD
-      if (X16) sine16_tag_sc<NBL>(acc, acc, is1_ * (1.0f / 4096.0f));
-      else sine16_tag<NBL>(acc, acc);
+  for (int ks = 0; ks < NCH; ++ks)
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) h[b] = acc[b];
-    }
-    // ---- last layer (n -> so, linear), MSE, start of the adjoint ---------------------------------------------------------------
-    f32x4 gh[NBL];
-    ZERO_T6(gh)
-    const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
-    const float zt0 = zt_base[0];
-    float se = 0.f;
-    for (int o = 0; o < so; ++o) {
-      f32x4 wg[NBL];
-      ZERO_T6(wg)
-      float part = 0.f, bias = 0.f;
+    for (int t = 0; t < 8; ++t) { e0[ks][t] = (__bf16)0.f; e1[ks][t] = (__bf16)0.f; b2[ks][t] = (__bf16)0.f; }
+  auto first_layer = [&](f32x4 (&out)[NBL]) __attribute__((always_inline)) {
+    f32x4 a_[NBL];
+    {
+      const float* s0 = sm + r * nsm + 4 * g;
 #pragma unroll
-      for (int k = 0; k <= r; ++k) {
-        const float zt = k < r ? zt0 : 1.0f;
-        const float* s0 = sm + k * nsm;
-        float sk = 0.f;
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
-          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
-          wg[b] += zt * w;
-        }
-        part = fmaf(zt, sk, part);
-        bias = fmaf(zt, s0[o_bl + o], bias);
-        if (k < r) sks[k * 64 + lane] = sk;
-      }
-      part += __shfl_xor(part, 16);
-      part += __shfl_xor(part, 32);
-      const float uo = part + bias;
-      const float e = uo - ys[o * 16];
-      NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
-      const float du = dfac * wsamp * A.inv_bg / (float)so;
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
-      {
-        float t = du * sks[lane];
-        if (g == 0) t = fmaf(du, sm[o_bl + o], t);
-        dzs[lane] += t;
-      }
-      if (g == 0 && o < 3) {     // du_o of the tile's 16 points as a bf16 (hi | lo) row: the last layer's weight-gradient vector
-        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
-        const __bf16 d0 = (__bf16)du;
-        wv[o * 32 + p] = d0; wv[o * 32 + 16 + p] = (__bf16)(du - (float)d0);
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        a_[b] = s;
       }
     }
-    if (g == 1) {     // zt of the tile (the hidden layers' plane-0 bias sums use it too)
-      __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
-      const __bf16 z0 = (__bf16)zt0;
-      wv[3 * 32 + p] = z0; wv[3 * 32 + 16 + p] = (__bf16)(zt0 - (float)z0);
-    }
-    {   // deposit "nh": the last layer's input h_nh (and zt h_nh) as the A planes
-      bf16x8 a0[NCH], a1[NCH];
-      split2<NBL>(h, a0, a1);
-      fuse_deposit4(exw, dep, a0);
-      fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
-      f32x4 zh[NBL];
+    {
+      const float zt = zt_base[0];
+      const float* s0 = sm + 4 * g;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) zh[b] = zt0 * h[b];
-      split2<NBL>(zh, a0, a1);
-      fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
-      fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
+      for (int b = 0; b < NBL; ++b) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
+        for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+        a_[b] += zt * s;
+      }
     }
-    if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
-    // ---- adjoint through the hidden hyper-matrices ---------------------------------------------------------------------------
-    f32x4 dnext[NBL], hin[NBL];
+    sine16_tag<NBL>(a_, out);
+  };
+  // what the V item in front of forward layer j's first product leaves behind: the operand splits of h, the accumulators started
+  // with the (scaled) biases, h_j on its way to the ring
+  auto prep_fwd = [&](int j) __attribute__((always_inline)) {
+    if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
+    if (X16) split2h<NBL>(h, 4096.0f, b0, b1);
+    else split3p<NBL, PR>(h, b0, b1, b2);
+    const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
+    const float* sc = sm + o_bh + j * NP + 4 * g;
 #pragma unroll
-    for (int b = 0; b < NBL; ++b) hin[b] = h[b];
-    for (int j = nh - 1; j >= 0; --j) {
+    for (int b = 0; b < NBL; ++b) { acc[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b); T[b] = *reinterpret_cast<const f32x4*>(sc + 16 * b); }
+  };
+
+  // ---- item -1 (V): the first round's first layer.  Group 1 spends interval 0 on it (group 0 multiplies pair 0 meanwhile) ------
+  int iset = 0;
+  setup_round(blockIdx.x, 0);
+  if (nrounds > 0) {
+    dzs[lane] = 0.f;
+    first_layer(h);
+    prefetch_inputs((long)blockIdx.x + gridDim.x, 1);
+    prep_fwd(0);
+    if (grp == 1) S6_V_END()
+  }
+  for (long rd = 0; rd < nrounds; ++rd, ++iset) {
+    const long tg = (long)blockIdx.x + rd * gridDim.x;
+    float zt0 = 0.f;
+    bf16x8 d0[NCH], d1[NCH];                // the deposit's (hi, lo) pair of dL/da
+    bf16x8 q0[NCH], q1[NCH];                // the adjoint products' operand
+    float ils = 1.0f;
+    // what the V item in front of adjoint layer j's first product does: dL/da_{j+1} = cos(a_{j+1}) dL/dh_{j+1} (h holds the tagged
+    // sine h_{j+1}), its share of dL/dz, its operand forms; then h_j comes back (ring, or recomputed)
+    auto prep_bwd = [&](int j) __attribute__((always_inline)) {
       f32x4 ga[NBL];
-      tag_cos<NBL>(hin, dnext);
-#if !NIF_S6_RING
-      st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
-#endif
+      {
+        f32x4 dnext[NBL];
+        tag_cos<NBL>(h, dnext);
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+        for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+      }
+      if (NIF_S6_RECOMP0 && j == 0) first_layer(h);
+      else ring_load16<NBL>(ring + j * (NP * 16), h, g, p);
       {
         const float* sb = sm + o_bh + j * NP + 4 * g;
         float sbv = 0.f;
@@ -663,12 +522,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         }
         dzs[lane] += X16 ? sbv * (scl[j * 4 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s0 b^(0))
       }
-      bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);                // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
-      bf16x8 q0[NCH], q1[NCH];                // the products' operand: b0, or half(s dL/da), s per point (mixed_float16: hi alone; X16: (hi, lo))
-      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
-      float ils = 1.0f;
-      if (PR == 2 || X16) {
+      split2<NBL>(ga, d0, d1);
+      ils = 1.0f;
+      if (PR == 2 || X16) {      // half operands: s dL/da with s a power of two per point (the point's largest |dL/da| into [2^14, 2^15))
         float mx = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ga[b][0]), fabsf(ga[b][1]))), fmaxf(fabsf(ga[b][2]), fabsf(ga[b][3])));
@@ -681,63 +537,165 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         else cast_f16<NBL>(ga, q0, __uint_as_float(sf << 23));
       } else {
 #pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) q0[ks] = b0[ks];
+        for (int ks = 0; ks < NCH; ++ks) q0[ks] = d0[ks];
       }
       if (!X16) {
 #pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) q1[ks] = b1[ks];
+        for (int ks = 0; ks < NCH; ++ks) q1[ks] = d1[ks];
       }
-      constexpr int PB = X16 ? 3 : PR;
+    };
+
+    // the first three items of forward layer j: M (plane 0), V (the latent combine: plane 0's chain carries s0, the sum s1; in layer 0
+    // also the previous round's first-layer deposit), M (plane 1)
+    auto fwd_head = [&](int j, auto dep_e) __attribute__((always_inline)) {
+      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f;
+      S6_M_ITEM(S6_FWD(0, T), S6_FWD(1, T))
       {
-        f32x4 U[NBL];
-#if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
-#else
-        S6_CHUNK({ mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
-#endif
-        S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], U, lane); })
+        const float zt = X16 ? zt_base[0] * (s1_ * is0_) : zt_base[0];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
+        if (decltype(dep_e)::value) {      // (layer 0 only -- a compile-time flag: e0 / e1 are dead behind it)
+          fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, e0);
+          fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, e1);
+        }
+        S6_V_END()
+      }
+      S6_M_ITEM(S6_FWD(0, acc), S6_FWD(1, acc))
+      if (X16) sine16_tag_sc<NBL>(acc, h, scl[j * 4 + 3] * (1.0f / 4096.0f));
+      else sine16_tag<NBL>(acc, h);
+    };
+    // the first three items of adjoint layer j: M (plane 0), V (<h_j, M^(0) dL/da> for dL/dz; the second plane's chain starts from zt
+    // times the first one's result), M (plane 1); then dL/dh_j is scaled back and deposit j written: (h_j ; zt h_j ; dL/da_{j+1})
+    auto bwd_head = [&](int j) __attribute__((always_inline)) {
+      const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
+      S6_M_ITEM(S6_BWD(0, T, true), S6_BWD(1, T, false))
+      {
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
+          for (int v = 0; v < 4; ++v) s = fmaf(h[b][v], T[b][v], s);
         const float ztc = X16 ? zt0 * (s1_ * is0_) : zt0;
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) gh[b] = ztc * U[b];
+        for (int b = 0; b < NBL; ++b) gh[b] = ztc * T[b];
         dzs[lane] += X16 ? (ils * is0_) * s : (PR == 2 ? ils * s : s);
+        S6_V_END()
       }
-      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
-      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
+      S6_M_ITEM(S6_BWD(0, gh, false), S6_BWD(1, gh, false))
       if (PR == 2 || X16) {
         const float f_ = X16 ? ils * is1_ : ils;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] *= f_;
       }
-      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
-        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
+      fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, d0);
+      fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, d1);
+      {
         bf16x8 a0[NCH], a1[NCH];
-        split2<NBL>(hin, a0, a1);
+        split2<NBL>(h, a0, a1);
         fuse_deposit4(exw, dep, a0);
         fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
         f32x4 zh[NBL];
 #pragma unroll
-        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * hin[b];
+        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * h[b];
         split2<NBL>(zh, a0, a1);
         fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
         fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
       }
+    };
+
+    // ---- hidden hyper-matrices, forward: the fourth item of a layer is the activation + the next layer's operands ... ------------
+    if (nh > 1) {
+      fwd_head(0, std::true_type());
+      prep_fwd(1);
+      S6_V_END()
+      for (int j = 1; j + 1 < nh; ++j) {
+        fwd_head(j, std::false_type());
+        prep_fwd(j + 1);
+        S6_V_END()
+      }
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // ---- first layer (the consumer waves take deposit 0 meanwhile) ------------------------------------------------------------
-    {
-      f32x4 ga[NBL];
-      tag_cos<NBL>(hin, dnext);
+    {   // ... or, behind the last matrix, the last layer (n -> so, linear), the loss and the start of the adjoint
+      if (nh > 1) fwd_head(nh - 1, std::false_type());
+      else fwd_head(0, std::true_type());
+      ZERO_T6(gh)
+      const float wsamp = (valid ? (A.sw ? wsp[0] : 1.0f) : 0.0f);
+      zt0 = zt_base[0];
+      float se = 0.f;
+      for (int o = 0; o < so; ++o) {
+        f32x4 wg[NBL];
+        ZERO_T6(wg)
+        float part = 0.f, bias = 0.f;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+        for (int k = 0; k <= r; ++k) {
+          const float zt = k < r ? zt0 : 1.0f;
+          const float* s0 = sm + k * nsm;
+          float sk = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
+            sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+            wg[b] += zt * w;
+          }
+          part = fmaf(zt, sk, part);
+          bias = fmaf(zt, s0[o_bl + o], bias);
+          if (k < r) sks[k * 64 + lane] = sk;
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float uo = part + bias;
+        const float e = uo - ys[o * 16];
+        NIF_LOSS_ACC(A.loss_kind, e, se, dfac)
+        const float du = dfac * wsamp * A.inv_bg / (float)so;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) gh[b] += du * wg[b];
+        {
+          float t = du * sks[lane];
+          if (g == 0) t = fmaf(du, sm[o_bl + o], t);
+          dzs[lane] += t;
+        }
+        if (g == 0 && o < 3) {     // du_o of the tile's 16 points as a bf16 (hi | lo) row: the last layer's weight-gradient vector
+          __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
+          const __bf16 v0 = (__bf16)du;
+          wv[o * 32 + p] = v0; wv[o * 32 + 16 + p] = (__bf16)(du - (float)v0);
+        }
+      }
+      if (g == 1) {     // zt of the tile (the hidden layers' plane-0 bias sums use it too)
+        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
+        const __bf16 z0 = (__bf16)zt0;
+        wv[3 * 32 + p] = z0; wv[3 * 32 + 16 + p] = (__bf16)(zt0 - (float)z0);
+      }
+      {   // deposit "nh": the last layer's input h_nh (and zt h_nh) as the A planes
+        bf16x8 a0[NCH], a1[NCH];
+        split2<NBL>(h, a0, a1);
+        fuse_deposit4(exw, dep, a0);
+        fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
+        f32x4 zh[NBL];
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * h[b];
+        split2<NBL>(zh, a0, a1);
+        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
+        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
+      }
+      if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+      prep_bwd(nh - 1);
+      S6_V_END()
+    }
+    // ---- adjoint through the hidden hyper-matrices: the fourth item ends with the layer below ... ---------------------------------
+    for (int j = nh - 1; j > 0; --j) {
+      bwd_head(j);
+      prep_bwd(j - 1);
+      S6_V_END()
+    }
+    {   // ... or with the first layer: dL/da_0, the tile's dL/dz, the weight-gradient vectors (its dL/da planes wait in e0 / e1 until
+        // the consumers have taken deposit 0: the next round's first V item, or the tail), and the next round's first layer
+      bwd_head(0);
+      f32x4 ga[NBL];
+      {
+        f32x4 dnext[NBL];
+        tag_cos<NBL>(h, dnext);
+#pragma unroll
+        for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
+      }
       {
         const float* s0 = sm + 4 * g;
         float s = 0.f;
@@ -752,15 +710,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         tot += __shfl_xor(tot, 32);
         if (active && g == 0) A.DZ[(tile32 * r) * 32 + poff] = tot;
       }
-      bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_s_barrier();          // deposit 0 has been consumed
-      asm volatile("" ::: "memory");
-      fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-      fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
-      {      // lane group g < si: x_g and zt x_g of the tile's 16 points as bf16 (hi | lo) rows; group 3: zt
+      split2<NBL>(ga, e0, e1);
+      {      // lane group g < si: x_g and zt x_g of the tile's 16 points as bf16 (hi | lo) rows; group 3: zt.  (The consumers read
+             // the previous round's vectors in intervals 2 .. 5 of a round: long done)
         __bf16* wv = reinterpret_cast<__bf16*>(WVF + wid * WVFT);
         const float x = g < si ? xs[g * 16] : 1.0f;
         const float zx = zt0 * x;
@@ -768,11 +720,28 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         if (g < si || g == 3) { wv[g * 32 + p] = z0; wv[g * 32 + 16 + p] = (__bf16)(zx - (float)z0); }
         if (g < si && g < 3) { wv[(4 + g) * 32 + p] = x0; wv[(4 + g) * 32 + 16 + p] = (__bf16)(x - (float)x0); }
       }
+      if (rd + 1 < nrounds) {      // the next round's first layer (its inputs arrived during this round)
+        setup_round(tg + gridDim.x, iset + 1);
+        dzs[lane] = 0.f;
+        first_layer(h);
+        prefetch_inputs(tg + 2 * (long)gridDim.x, iset & 1);
+        prep_fwd(0);
+      }
+      S6_V_END()
     }
   }
-#undef S6_CHUNK
-  __syncthreads();          // the last round's first-layer deposit is visible ...
-  __syncthreads();          // ... and consumed
+  if (nrounds > 0 && grp == 0) { S6_WAIT(0); S6_SYNC() }      // (group 1's last item)
+#undef S6_FWD
+#undef S6_BWD
+#undef S6_M_ITEM
+#undef S6_V_END
+#undef S6_SYNC
+#undef S6_WAIT
+  __syncthreads();          // every deposit of the last round is visible ...
+  __syncthreads();          // ... and deposit 0 consumed
+  fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, e0);
+  fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, e1);
+  __syncthreads();          // the last round's first-layer deposit is visible
   for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
   if (lane == 0) lsum[wid] = loss_lane;
   __syncthreads();
@@ -786,9 +755,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
-  const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
+  const size_t ni = (size_t)(((a.si + 3) & ~3) + 4 + ((a.so + 3) & ~3)) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 4 * (size_t)NBL * (a.prec == 0 ? 2 : 1) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {

@@ -22,13 +22,6 @@
 //   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
 // Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
 // Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
-#ifndef NIF_S6_GPRIO
-#define NIF_S6_GPRIO 0      // 1: the chunk step's operand reads + products of producer waves 0-3 at a higher priority than those of waves 4-7 (their
-#endif                      // SIMD partners): one wave's reads are served first and its products overlap the partner's reads -- measured: see DESIGN 5.5
-#if NIF_S6_GPRIO
-#define NIF_MFMA_PRIO_ON
-#define NIF_MFMA_PRIO_OFF
-#endif
 #include "k_fuse_dev.h"
 
 #define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
@@ -98,11 +91,6 @@ __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x
 #endif
 }
 
-#ifdef NIF_TIMELINE      // measurement builds: s_memtime stamps of producer wave 0 (entries 0 ..) and consumer wave 8 (entries 1024 ..) of block 0, third round
-#define S6_TL(id) do { if (A.tl && blockIdx.x == 0 && (tid == 0 || tid == 512) && tlr == 2 && tlc < 1000) { long long* q_ = A.tl + (tid ? 2048 : 0) + 2 * tlc; q_[0] = (id); q_[1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
-#else
-#define S6_TL(id) do { } while (0)
-#endif
 struct S6Args {
   SNetArgs s;
   float* partial; long pstride;     // partial-gradient rows [gridDim.x][pstride] (the ShapeNet = hypernetwork columns of them)
@@ -136,9 +124,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
   constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
-  // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
-  // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
-  constexpr int NBUF = 2;
+  constexpr int NBUF = 3;                               // LDS chunk buffers: group 0 multiplies chunk c, group 1 chunk c - 1, chunk c + 1 arrives
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
 #if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
   constexpr int NRING = 0;
@@ -198,7 +184,6 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     // the first layer, the bJ = 0 waves rows 32 bI .. of the last layer, wave (kk, 1, 1) the last layer's bias
     // =====================================================================================================================
     const int cw = wid - WAVES, kk = cw >> 2, bI = (cw >> 1) & 1, bJ = cw & 1;
-    int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
     __syncthreads();
     if (tid - NT < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
       const int t = (tid - NT) >> 4, q = (tid - NT) & 15;
@@ -222,11 +207,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CBAR()                                                             \
   {                                                                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): the transpose reads are back */ \
-    S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    S6_TL(500);                                                               \
   }
     // hidden matrix J_: this wave's block over the deposited tiles [T0_, T1_).  One tile's operands ahead of the MFMAs (the
     // transpose reads of tile t + 1 are in flight while tile t multiplies), never more: 64 accumulator + 2 x 16 operand registers
@@ -250,6 +233,24 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         bacc[J_] = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), bacc[J_]); \
       }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
+      ah_ = ah2_; al_ = al2_; bh_ = bh2_; bl_ = bl2_;                                                       \
+    }                                                                                                       \
+  }
+#define S6_HID_TILES_BAR(J_, T0_, T1_, TB_)                                                                          \
+  {                                                                                                         \
+    bf16x8 ah_, al_, bh_, bl_, ah2_, al2_, bh2_, bl2_;                                                      \
+    S6_HID_LOAD(T0_, ah_, al_, bh_, bl_)                                                                    \
+    _Pragma("unroll") for (int t_ = T0_; t_ < T1_; ++t_) {                                                  \
+      if (t_ + 1 < T1_ && t_ + 1 != TB_) S6_HID_LOAD(t_ + 1, ah2_, al2_, bh2_, bl2_)                        \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, acc[J_], 0, 0, 0);                        \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, acc[J_], 0, 0, 0);                        \
+      acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, acc[J_], 0, 0, 0);                        \
+      if (bI == 1) {                                                                                        \
+        const char* w_ = WVL + t_ * WVLT + (3 + kk) * 64 + wofs;                                            \
+        bacc[J_] = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), bacc[J_]); \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if (t_ + 1 == TB_) { S6_CBAR() S6_HID_LOAD(t_ + 1, ah2_, al2_, bh2_, bl2_) }   /* the tiles from TB_ on land an interval later */ \
       ah_ = ah2_; al_ = al2_; bh_ = bh2_; bl_ = bl2_;                                                       \
     }                                                                                                       \
   }
@@ -310,10 +311,13 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #else
 #define S6_DO(...) __VA_ARGS__
 #endif
-    // the barrier sequence of the producers' tile program, with this wave's share of the products between the barriers
-    for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
+    // the barrier sequence of the producers' tile program, with this wave's share of the products between the barriers (the rounds
+    // are cut behind group 0's first forward step, so that the two halves of deposit 0 -- group 0's tiles next to the first layer's
+    // adjoint, group 1's one interval later = next to the next round's first step -- are ONE piece of code)
+    S6_CBAR()
+    for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
       for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
-        S6_CBAR()
+        if (j > 0) S6_CBAR()
         if (j == 0) { S6_DO(consume_first(0, 4);) }
         S6_CBAR()
         if (j == 0) { S6_DO(consume_first(4, 8);) }
@@ -329,8 +333,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       S6_DO(consume_last(6, 8);)
       S6_CBAR()
       S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
-      S6_CBAR()                              // deposit 0 next to the first layer's adjoint
-      S6_DO(S6_HID_TILES(0, 0, 8))
+      S6_CBAR()                              // deposit 0: group 0's tiles next to the first layer's adjoint, group 1's behind them
+      S6_DO(S6_HID_TILES_BAR(0, 0, 8, 4))
+#ifdef NIF_S6_NOCONS
+      S6_CBAR()
+#endif
       S6_CBAR()
     }
     __syncthreads();
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #undef S6_DO
 #undef S6_HID_LAYER
 #undef S6_HID_TILES
+#undef S6_HID_TILES_BAR
 #undef S6_HID_LOAD
 #undef S6_CBAR
     // ---- this wave's entries of the workgroup's partial-gradient row (no reduction: every entry belongs to one wave) ---------------
@@ -446,8 +454,27 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   if (cs_left <= 0) cs_left = -1;
   cs_next(0);
   __syncthreads();
-  int cbuf = 0, nbuf = 1;
-  int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
+  // r5: the producers are two GROUPS of four (waves w and w + 4 share a SIMD: one of each group) that run the same program ONE
+  // BARRIER INTERVAL APART: in r4 all eight did their vector work (sine, splits, deposits) at the same time and their products at the
+  // same time, two waves per SIMD queueing for the same pipe while the other one idled.  One interval apart, a wave's big vector
+  // blocks (the start and the end of a layer) meet its partner's product-only steps.  The chunk DMA follows group 0's steps (every
+  // producer wave ticks once per interval, gt = the interval as group 0 counts it): group 0 multiplies chunk c while group 1
+  // multiplies chunk c - 1 and chunk c + 1 arrives -- three buffers.  Deposits of group 1 (tiles 4 .. 7) land one interval behind
+  // group 0's: the consumers' order (tiles 0-2, 3-5, 6-7 over the three intervals behind a deposit) already reads them late enough;
+  // only deposit 0 is split (tiles 0-3 next to the first layer's adjoint, 4-7 one interval later).
+  const int grp = wid >> 2;
+  int cbuf = 0, nbuf = 1, gt = 0;
+  auto dma_tick = [&]() {
+    if (gt < 8 * nh) { cs_next(nbuf); nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1; }
+    gt = gt == 8 * nh + 1 ? 0 : gt + 1;
+  };
+  if (grp == 1) {      // group 1's idle interval
+    dma_tick();
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   float loss_lane = 0.f;
   const long sstride = A.slot_stride, tstride = (long)stash_fp(n) * 32;
   float* IN0 = A.stash;
@@ -458,21 +485,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 
 #define S6_CHUNK(...)                                                         \
   {                                                                           \
-    S6_TL(100);                                                               \
-    cs_next(nbuf);                                                            \
-    S6_TL(200);                                                               \
+    dma_tick();                                                               \
     const bf16x8* cur = chunks + cbuf * CF;                                   \
-    if (NIF_S6_GPRIO) { if (wid < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); } \
     __VA_ARGS__                                                               \
-    if (NIF_S6_GPRIO) __builtin_amdgcn_s_setprio(0);                          \
-    S6_TL(300);                                                               \
     __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
-    S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    S6_TL(500);                                                               \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    cbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1;                                   \
   }
 // the chunk step that carries the layer's ring traffic: the NRING ring instructions are issued BEHIND the next chunk's DMA, so the
 // wait at the end of the step may leave exactly them in flight (vmcnt counts in issue order: "at most NRING outstanding" = every
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #if NIF_S6_VMRING
 #define S6_CHUNK_RING(PRE_, ...)                                              \
   {                                                                           \
-    cs_next(nbuf);                                                            \
+    dma_tick();                                                               \
     PRE_                                                                      \
     asm volatile("" ::: "memory");                                            \
     const bf16x8* cur = chunks + cbuf * CF;                                   \
@@ -489,15 +509,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    cbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1;                                   \
   }
 #else
 #define S6_CHUNK_RING(PRE_, ...) { PRE_ S6_CHUNK(__VA_ARGS__) }
 #endif
 
   int iset = 0;
-  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset, ++tlr) {
-    S6_TL(1);
+  for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++iset) {
     const long t16_raw = tg * WAVES + wid;
     const bool active = t16_raw < nt16;
     const long t16 = active ? t16_raw : nt16 - 1;
@@ -728,8 +747,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
       }
     }
+    dma_tick();                              // (no chunk step of group 0: group 1's tick of this interval may carry a chunk)
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
+    __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): the deposits (and a chunk issued here) have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // ---- first layer (the consumer waves take deposit 0 meanwhile) ------------------------------------------------------------
@@ -754,9 +774,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       }
       bf16x8 b0[NCH], b1[NCH];
       split2<NBL>(ga, b0, b1);
+      dma_tick();
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_s_barrier();          // deposit 0 has been consumed
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();          // deposit 0 has been consumed (this group's tiles)
       asm volatile("" ::: "memory");
       fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
       fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
@@ -771,6 +792,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     }
   }
 #undef S6_CHUNK
+  if (grp == 0) {           // group 1's last interval
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   __syncthreads();          // the last round's first-layer deposit is visible ...
   __syncthreads();          // ... and consumed
   for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
@@ -788,7 +815,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 3 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {
