@@ -61,10 +61,12 @@ def roofline_block(dims, B, snet_ms, fused, traffic_json, sha):
     if fused:     # k_snet6: forward + data adjoint + weight gradients; h_1 .. h_{nh-1} through the private ring (write + read; h_0 is
                   # recomputed in the adjoint), latent in, dL/dz out
         alg_flop = 6.0 * (r + 1) * n_w
-        exec_bf16 = (6.0 + 3.0 + 3.0) * 2.0 * (r + 1) * nh * n * n
+        # r5: three 16-bit products per fp32 product in all three sweeps (forward / data adjoint: half (hi, lo) pairs on
+        # v_mfma_f32_16x16x32_f16; weight gradients: bf16 (hi, lo) pairs on v_mfma_f32_32x32x16_bf16) -- r4: 6 + 3 + 3
+        exec_bf16 = (3.0 + 3.0 + 3.0) * 2.0 * (r + 1) * nh * n * n
         design_bytes = 4.0 * 32 * nblk * 2 * (nh - 1) + 4.0 * (si + so + 1) + 8.0 * r
-        kernel = ("k_snet6<4> (ShapeNet forward + MSE + data adjoint + every ShapeNet weight gradient; fp32 products as bf16 splits on "
-                  "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, 8 producer + 8 consumer waves per workgroup)")
+        kernel = ("k_snet6<4> (ShapeNet forward + MSE + data adjoint + every ShapeNet weight gradient; fp32 products as 3-product half / bf16 "
+                  "(hi, lo) pairs on v_mfma_f32_16x16x32_f16 / 32x32x16_bf16, 8 producer + 8 consumer waves per workgroup)")
     else:         # k_snet4: forward + data adjoint; h and dL/da stash rows written, h re-read
         alg_flop = 4.0 * (r + 1) * n_w
         exec_bf16 = (6.0 + 3.0) * 2.0 * (r + 1) * nh * n * n if (((n + 15) // 16) % 2) == 0 else 0.0
@@ -92,6 +94,11 @@ def roofline_block(dims, B, snet_ms, fused, traffic_json, sha):
             "achieved": hbm_gbs if hbm_bound else bf16_tf, "peak": HBM_PEAK_GBS if hbm_bound else BF16_PEAK_TFLOPS,
             "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_bf16,
             "frac_hbm": frac_hbm, "frac_bf16_pipe": frac_bf16, "frac_fp32_equiv": frac_f32,
+            "frac_bf16_pipe_algorithmic": f32_tf / BF16_PEAK_TFLOPS,
+            "frac_fp32_equiv_note": "algorithmic fp32 flops (SURVEY 8d-ii) over the 157.3 TF f32-input MFMA peak -- a pipe this kernel does not "
+                                    "run on: each fp32 product is THREE 16-bit products on the 16x faster bf16 / f16 matrix pipe (frac_bf16_pipe "
+                                    "counts those executed flops, frac_bf16_pipe_algorithmic the algorithmic ones against the same 2.5 PF), so "
+                                    "a value near or above 1 here is not a measurement error",
             "frac_hbm_of_measured_6290": hbm_gbs / HBM_MEASURED_GBS,
             "hbm_GBs": hbm_gbs, "hbm_bytes_source": "pmc" if traffic is not None else "design_bytes_per_point",
             "executed_bf16_TFLOPs": bf16_tf, "fp32_equiv_TFLOPs": f32_tf,
@@ -155,6 +162,27 @@ def cpu_baseline(sample_points=1 << 20, micro=4096, probe_points=65536):
             "sample": "%d whole train steps of %d points (the benchmark batch; micro-batches of %d) of the benchmark model; C/OpenMP fp32 "
                       "restatement of the reference formulation (materialised [b,po] + per-sample einsum), "
                       "OMP threads = %d; not TensorFlow" % (nrep, sample_points, micro, cores)}
+
+
+def gradient_error(m, model, x, y):
+    """(flat rel-L2, worst per-tensor rel-L2, note) of the engine's gradient on (x, y) against the NumPy fp64 oracle at the engine's
+    CURRENT weights.  The oracle is the checker here (extras leg, after the timed region), never the thing measured."""
+    from oracle import nif_oracle as O
+    ws = model.get_weights()
+    spec = O.Spec("NIFMultiScale", CFG_SHAPE, CFG_PARAM)
+    ws64 = [w.astype(np.float64) for w in ws]
+    _, g_ref = O.loss_and_grad(spec, ws64, x.astype(np.float64), y.astype(np.float64))
+    _, g = m._engine.loss_and_grad(x, y)
+    g = np.asarray(g, dtype=np.float64)
+    flat_ref = O.flatten(g_ref)
+    flat = float(np.linalg.norm(g - flat_ref) / np.linalg.norm(flat_ref))
+    worst, off = 0.0, 0
+    for t in g_ref:
+        nrm = float(np.linalg.norm(t))
+        if nrm > 0:
+            worst = max(worst, float(np.linalg.norm(g[off:off + t.size] - t.ravel()) / nrm))
+        off += t.size
+    return flat, worst, "%d points of the benchmark batch, the engine's weights after the timed steps, %d tensors; fp64 NumPy oracle" % (len(x), len(g_ref))
 
 
 def self_launch(args):
@@ -401,6 +429,14 @@ def main():
             e.sync()
             fp32_ms = (time.perf_counter() - t1) / 5 * 1e3
             e.set_option("fp32_mfma", 0)
+        # ---- the measured gradient error of the DEFAULT path: a 4 096-point sub-batch of the benchmark batch against the fp64 oracle
+        # (checker only, outside the timed region) -- flat rel-L2 and the worst tensor ----------------------------------------------
+        grad_err = None
+        if not args.no_extras:
+            try:
+                grad_err = gradient_error(m, model, x[:4096], y[:4096])
+            except Exception as ex:      # (the oracle is test infrastructure: a box without it still benches)
+                grad_err = (None, None, "not run: %r" % (ex,))
         # ---- the HBM-bound kernel north_star names: model_x_to_u_given_w ------------------------
         Bw = args.given_w_points
         rng = np.random.default_rng(7)
@@ -438,6 +474,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "clock_ramp_steps": max(args.ramp_steps, args.warmup + args.steps) if args.ramp_steps > 0 else 0,
             "cold_start_ms_per_step": cold_ms,
+            "value_cold_start": (Bg / (cold_ms * 1e-3)) if cold_ms else None,
             "clock_ramp_note": "untimed steps in front of the W warm-up steps: MI355X raises the shader clock over ~30 ms of load; a "
                                "timed region that starts 7 ms after idle measures the ramp instead of the step.  The first W + K of them "
                                "ARE the contract's measurement from a cold start: cold_start_ms_per_step",
@@ -447,8 +484,12 @@ def main():
                        "collective": "RCCL ncclAllReduce(sum, f32, P+1) on the library stream, one per step" if use_dist else "none (1 GPU)"},
             "median_ms_per_step_host_synced": med_ms,
             "value_from_median": (Bg / (med_ms * 1e-3)) if med_ms else None,
-            "grad_products": "forward: fp32-exact 6-product bf16 split; data adjoint: 3-product bf16 split; weight gradients: "
-                             "2-way hi/lo bf16 split (3 products); fp32 accumulation everywhere",
+            "grad_products": "forward and data adjoint: fp32 products as 3-product HALF (hi, lo) pairs (11 + 11 significand bits per operand, "
+                             "power-of-two scales; as accurate as the f32-input MFMA: tools/exp/f16_split_mfma.hip); weight gradients: "
+                             "2-way hi/lo bf16 split (3 products, 16 significand bits per operand); fp32 accumulation everywhere",
+            "grad_rel_l2_vs_oracle": grad_err[0] if grad_err else None,
+            "grad_max_tensor_rel_vs_oracle": grad_err[1] if grad_err else None,
+            "grad_check": grad_err[2] if grad_err else None,
             "fused_weight_gradients": fused,
             "ms_per_step_fp32_mfma": fp32_ms,
             "roofline": roofline,

@@ -48,7 +48,8 @@ typedef enum {
 /* activations (`keras.activations.get(name)` model.py:303, mlp.py:40; 'sine' = SIREN) */
 typedef enum {
   NIF_ACT_LINEAR = 0, NIF_ACT_SINE = 1, NIF_ACT_SWISH = 2, NIF_ACT_TANH = 3, NIF_ACT_RELU = 4,
-  NIF_ACT_SIGMOID = 5, NIF_ACT_ELU = 6, NIF_ACT_SOFTPLUS = 7, NIF_ACT_GELU = 8
+  NIF_ACT_SIGMOID = 5, NIF_ACT_ELU = 6, NIF_ACT_SOFTPLUS = 7, NIF_ACT_GELU = 8,
+  NIF_ACT_SELU = 9, NIF_ACT_SOFTSIGN = 10, NIF_ACT_EXPONENTIAL = 11, NIF_ACT_HARD_SIGMOID = 12   /* (r4; nif_create rejects ids beyond) */
 } nif_act;
 
 /* `mixed_policy` of the model constructors (tf.keras.mixed_precision.Policy, model.py:101-105).  Variables are fp32 under

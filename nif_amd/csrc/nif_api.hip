@@ -101,6 +101,8 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   if (cfg->mixed_policy != NIF_POLICY_FLOAT32 && cfg->mixed_policy != NIF_POLICY_MIXED_BF16 && cfg->mixed_policy != NIF_POLICY_MIXED_F16)
     return fail(NIF_ERR_INVALID, "unknown mixed_policy");
   for (int i = 0; i < 7; ++i) if (cfg->reserved[i] != 0) return fail(NIF_ERR_INVALID, "reserved fields must be zero");
+  if (cfg->p_act < 0 || cfg->p_act > NIF_ACT_HARD_SIGMOID || cfg->s_act < 0 || cfg->s_act > NIF_ACT_HARD_SIGMOID)
+    return fail(NIF_ERR_INVALID, "unknown activation id (nif_act)");
   if (cfg->kind == NIF_KIND_LASTLAYER && cfg->latent_dim * cfg->so_dim > 64)
     return fail(NIF_ERR_INVALID, "last-layer class: latent_dim * output_dim must be <= 64");
   if (cfg->pi_dim < 1 || cfg->si_dim < 1 || cfg->so_dim < 1 || cfg->latent_dim < 1)

@@ -226,6 +226,12 @@ class Model(object):
         if self._role != "full":
             raise ValueError("only the full model can be compiled for training")
         name = loss if isinstance(loss, str) else (getattr(loss, "name", None) or getattr(loss, "__name__", None))
+        if not isinstance(loss, str):      # a loss OBJECT: only its defaults are built (huber: delta = 1 in the kernels; Keras' default reduction)
+            if float(getattr(loss, "delta", 1.0)) != 1.0:
+                raise NotImplementedError("loss=%r: huber with delta != 1" % (loss,))
+            red = getattr(loss, "reduction", None)
+            if red is not None and str(red).lower().rsplit(".", 1)[-1] not in ("auto", "sum_over_batch_size"):
+                raise NotImplementedError("loss=%r: reduction %r (built: the default SUM_OVER_BATCH_SIZE)" % (loss, red))
         if name not in _lib.LOSS_IDS:
             raise NotImplementedError("loss=%r: built are 'mse' (README.md:33), 'mae', 'huber' (delta 1), 'log_cosh'" % (loss,))
         if kwargs:
@@ -425,6 +431,8 @@ class Model(object):
                          and max(sizes) <= self._GRAPH_MAX_BATCH and hasattr(e, "graph_begin") and epochs - initial_epoch >= 2)
             graph_id = None
             stream = [-1, 0]          # steps_per_epoch: (pass, next batch of the pass) of the one iterator over `epochs` passes
+            cur_perm = [None]         # the permutation of the pass the resident table holds (a pass may span epochs under steps_per_epoch:
+                                      # the metric forward of a batch reads the host rows through it -- ADVICE r4)
             if steps_per_epoch is not None:
                 if int(steps_per_epoch) < 1:
                     raise ValueError("steps_per_epoch must be a positive integer")
@@ -438,7 +446,7 @@ class Model(object):
                         cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
 
-                msum, mcnt, cur_perm = [0.0] * len(kinds), [0], [None]
+                msum, mcnt = [0.0] * len(kinds), [0]
 
                 def new_pass():      # one pass over the table = one permutation (Keras: the adapter's dataset of `epochs` passes)
                     cur_perm[0] = None
@@ -461,6 +469,7 @@ class Model(object):
                         if has_sw:
                             src_sw.upload(sw[perm])
                 adam = self.optimizer.as_struct()
+                self._push_losses(e, 1)           # (a callback of the previous epoch may have evaluated another model on the shared engine)
                 e.metric_read(reset=True)
 
                 def run_batches(lo=0, hi=None):
@@ -509,13 +518,21 @@ class Model(object):
                 if steps_per_epoch is not None:
                     pass
                 elif use_graph and graph_id is None:
+                    began = False
                     try:
-                        e.graph_begin()
-                        try:
-                            run_batches()
-                        finally:
-                            graph_id = e.graph_end()
+                        e.graph_begin()           # (raises before anything is recorded: nothing to end then -- ADVICE r4)
+                        began = True
+                        run_batches()
+                        graph_id = e.graph_end()
+                        began = False
                     except _lib.NifError:
+                        if began:                 # a call inside the capture failed: end the capture (restores the step counter), drop the graph
+                            try:
+                                gid = e.graph_end()
+                                if gid is not None:
+                                    e.graph_destroy(gid)
+                            except _lib.NifError:
+                                pass
                         use_graph, graph_id = False, None       # (a workspace that had to grow, a call that cannot be captured)
                 if steps_per_epoch is not None:
                     pass
@@ -534,6 +551,7 @@ class Model(object):
                         logs.update({"val_" + k: v for (k, _), v in zip(kinds, ev[1:])})
                     else:
                         logs["val_loss"] = ev
+                    self._push_losses(e, 1)       # evaluate() ends with _pop_losses: the next epoch trains with THIS model's loss / jac_reg again
                 for cb in callbacks:
                     if hasattr(cb, "on_epoch_end"):
                         cb.on_epoch_end(epoch, logs)

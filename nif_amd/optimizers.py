@@ -216,6 +216,12 @@ class TFPLBFGS(object):
         import numpy as np
         self._np = np
         name = loss_fun if isinstance(loss_fun, str) else getattr(loss_fun, "name", None) or getattr(loss_fun, "__name__", None)
+        if not isinstance(loss_fun, str) and loss_fun is not None:      # loss OBJECTS: only their defaults are built (as Model.compile)
+            if float(getattr(loss_fun, "delta", 1.0)) != 1.0:
+                raise NotImplementedError("TFPLBFGS: huber with delta != 1")
+            red = getattr(loss_fun, "reduction", None)
+            if red is not None and str(red).lower().rsplit(".", 1)[-1] not in ("auto", "sum_over_batch_size"):
+                raise NotImplementedError("TFPLBFGS: loss reduction %r (built: the default SUM_OVER_BATCH_SIZE)" % (red,))
         from . import _lib
         if name is not None and name not in _lib.LOSS_IDS:
             raise NotImplementedError("TFPLBFGS: built losses are 'mse', 'mae', 'huber', 'log_cosh', got %r" % (loss_fun,))
