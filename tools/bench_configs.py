@@ -57,30 +57,75 @@ WORK = {
 }
 
 
-def roofline(s, B, ns, policy, snet_ms):
-    """the bench line's roofline block for any config (bench.py): the fused ShapeNet kernel's own algorithmic HBM bytes (stash rows
-    written + re-read, x (1 + ns) streams for a Sobolev step), the bf16 flops it executes, fractions of 8 TB/s / 2.5 PFLOP/s, and
-    SURVEY 8d's fp32-equivalent figure against the 157.3 TF peak as a secondary key"""
+def csrc_sha():
+    import bench
+    return bench.csrc_sha()
+
+
+def load_config_traffic():
+    """profiles/configs_traffic.json (tools/pmc_configs.sh + tools/pmc_configs_md.py: FETCH_SIZE / WRITE_SIZE of every kernel of every
+    named config, stamped with the content hash of nif_amd/csrc/ the passes ran on) -- None when absent"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "configs_traffic.json")))
+    except (OSError, ValueError):
+        return None
+
+
+def roofline(name, s, B, nx, policy, kernel_ms, tj=None, sha=None):
+    """The roofline block of one config's DOMINANT kernel (the fused ShapeNet kernel: k_snet6 when the weight-gradient group is empty,
+    else k_snet4 / k_sobw / k_sob) -- r5: from MEASURED bytes.  `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of that kernel per launch from
+    the committed PMC passes of the same config, dropped (`traffic_stale`) when they ran on other sources than this build;
+    `traffic_ratio` against the step's algorithmic bytes 4 (pi + si + so [+ so nx]) per point; achieved HBM GB/s = traffic / the
+    kernel's time in THIS run; the 16-bit matrix work the kernel executes against 2.5 PF; SURVEY 8d's fp32-equivalent figure as a
+    secondary key.  Without usable counters the HBM side is null (no design formula stands in for a measurement any more)."""
+    snet_ms = kernel_ms.get("snet", 0.0)
     if snet_ms <= 0:
         return None
+    ns = len(nx) if nx else 0
     n, nh = s.n_sx, s.n_hidden_mats
-    planes = 1 if s.connectivity == "last_layer" else s.pi_hidden + 1
-    fp = 32 if n <= 32 else (64 if n <= 64 else 128)
-    stash = 4.0 * fp * (2 * (nh + 1) + nh) * (1 + ns) * B
-    so_eff = s.so_dim * (s.pi_hidden if s.connectivity == "last_layer" else 1)
+    ll = s.connectivity == "last_layer"
+    planes = 1 if ll else s.pi_hidden + 1
+    fused = kernel_ms.get("gw", 0.0) < 0.05 * snet_ms            # (k_snet6: no weight-gradient launches)
+    so_eff = s.so_dim * (s.pi_hidden if ll else 1)
     n_w = s.si_dim * n + nh * n * n + n * so_eff
-    flop32 = 4.0 * planes * n_w * (1 + ns) * B                     # forward + data adjoint, fp32-equivalent
-    prod = 2.0 if policy in ("mixed_bfloat16", "mixed_float16") else 9.0   # 16-bit products per fp32 product: 6 forward + 3 adjoint (1 + 1)
+    sweeps = 3.0 if fused else 2.0                               # forward + data adjoint (+ the weight gradients inside the kernel)
+    flop32 = sweeps * 2.0 * planes * n_w * (1 + ns) * B          # fp32-equivalent
+    pol = policy in ("mixed_bfloat16", "mixed_float16")
+    if fused:
+        prod = (1.0 + 1.0 + 3.0) if pol else 9.0                 # k_snet6: three half products forward and adjoint, three bf16 products per weight-gradient pair
+    else:
+        prod = 2.0 if pol else 9.0                               # k_snet4 / k_sobw: 6 bf16 products forward + 3 adjoint (policies: 1 + 1)
     nbl_even = (((n + 15) // 16) % 2) == 0 and n > 16
     exec16 = prod * 2.0 * planes * nh * n * n * (1 + ns) * B if nbl_even else 0.0
+    alg_bytes = 4.0 * (s.pi_dim + s.si_dim + s.so_dim + s.so_dim * ns) * B
     t = snet_ms * 1e-3
-    hbm, mf = stash / t / 1e9, exec16 / t / 1e12
-    bound = "hbm" if hbm / 8000.0 >= mf / 2500.0 else "mfma"
-    return {"kernel": "fused ShapeNet kernel (k_snet4 / k_sob)", "bound": bound, "achieved": round(hbm if bound == "hbm" else mf, 2),
+    traffic, stale, kname = None, None, ("k_snet6" if fused else ("k_sobw / k_sob" if ns else "k_snet4"))
+    if tj is not None:
+        if tj.get("csrc_sha") == sha and name in tj.get("configs", {}):
+            ks = tj["configs"][name]
+            cand = [k for k in ks if k.replace("void ", "").startswith(("k_snet6<", "k_snet4<", "k_sobw<", "k_sob<", "k_snet3<", "k_snet<"))]
+            if cand:
+                k = max(cand, key=lambda k: 2.0 * ks[k]["FETCH_SIZE_KB"] + ks[k]["WRITE_SIZE_KB"])
+                traffic = (2.0 * ks[k]["FETCH_SIZE_KB"] + ks[k]["WRITE_SIZE_KB"]) * 1024.0 * B / tj["configs_points"].get(name, B)
+                kname = k
+            stale = False
+        else:
+            stale = True
+    hbm = traffic / t / 1e9 if traffic is not None else None
+    mf = exec16 / t / 1e12
+    frac_hbm = hbm / 8000.0 if hbm is not None else None
+    bound = "hbm" if (frac_hbm is not None and frac_hbm >= mf / 2500.0) else "mfma"
+    return {"kernel": kname, "bound": bound, "achieved": round(hbm if bound == "hbm" else mf, 2),
             "peak": 8000.0 if bound == "hbm" else 2500.0, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "frac": round(max(hbm / 8000.0, mf / 2500.0), 4), "avg_ms": snet_ms, "stash_GBs": round(hbm, 1),
-            "executed_bf16_TFLOPs": round(mf, 1), "fp32_equiv_TFLOPs": round(flop32 / t / 1e12, 1),
-            "frac_of_fp32_mfma_peak_157": round(flop32 / t / 1e12 / 157.3, 4), "traffic": None}
+            "frac": round(frac_hbm if bound == "hbm" else mf / 2500.0, 4), "avg_ms": snet_ms,
+            "frac_hbm": None if frac_hbm is None else round(frac_hbm, 4), "frac_bf16_pipe": round(mf / 2500.0, 4),
+            "hbm_GBs": None if hbm is None else round(hbm, 1), "executed_bf16_TFLOPs": round(mf, 1),
+            "fp32_equiv_TFLOPs": round(flop32 / t / 1e12, 1), "frac_fp32_equiv": round(flop32 / t / 1e12 / 157.3, 4),
+            "frac_bf16_pipe_algorithmic": round(flop32 / t / 1e12 / 2500.0, 4),
+            "algorithmic_bytes_per_point": alg_bytes / B, "traffic": traffic, "traffic_stale": stale,
+            "traffic_ratio": None if traffic is None else round(traffic / alg_bytes, 1),
+            "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/configs_traffic.json)",
+            "fused_weight_gradients": bool(fused), "csrc_sha": sha}
 
 
 def main():
@@ -93,6 +138,7 @@ def main():
     import nif_amd
     from nif_amd.engine import DeviceArray
     out = {}
+    tj, sha = load_config_traffic(), csrc_sha()
     for name, work in WORK.items():
         cls, (cs, cp), B, xi = work[:4]
         policy = work[4] if len(work) > 4 else "float32"
@@ -146,7 +192,7 @@ def main():
         rec = {"points": B, "ms_per_step": round(msstep, 4), "Mpts_per_s": round(B / msstep / 1e3, 2),
                "params": int(e.n_params),
                "kernel_ms": {k: round(v[0] / a.steps, 4) for k, v in prof.items() if v[1] > 0}}
-        rec["roofline"] = roofline(m._spec, B, len(xi) if xi else 0, policy, rec["kernel_ms"].get("snet", 0.0))
+        rec["roofline"] = roofline(name, m._spec, B, xi, policy, rec["kernel_ms"], tj, sha)
         if name.startswith("cfg2"):
             # the same step when the boundary hands over HOST buffers (nif_train_step: H2D of x, y + step + loss readback)
             import time
@@ -189,8 +235,10 @@ def main():
         out["cfg0_tutorial1_fit_10k_b512"] = rec
         print("cfg0_tutorial1_fit_10k_b512", json.dumps(rec), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    # ONE JSON document (json.load works on it; r4's profiles/r04_configs.json was the per-line log): copy to profiles/rNN_configs.json
+    doc = {"csrc_sha": sha, "traffic_source": None if tj is None else tj.get("source"), "configs": out}
     with open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@
 R=$PWD
 export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmcc; mkdir -p $R/gpurun_out/pmcc
+(cd $R && python -c "import bench; print(bench.csrc_sha())") > $R/gpurun_out/pmcc/csrc_sha.txt
 cd /tmp
 for cfg in "$@"; do
   O=/tmp/pmcc_$cfg; rm -rf $O; mkdir -p $O

@@ -24,6 +24,30 @@ def parse(fn):
     return out
 
 
+def write_json(tag):
+    """profiles/configs_traffic.json: {csrc_sha, head, source, configs: {cfg: {kernel: {FETCH_SIZE_KB, WRITE_SIZE_KB, launches}}},
+    configs_points: {cfg: points}} -- what tools/bench_configs.py's roofline() reads (traffic_stale when the hash is not the build's)"""
+    import subprocess
+    doc = {"source": "profiles/%s_configs_traffic.md (tools/pmc_configs.sh: rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes around "
+                     "tools/bench_configs.py --only <cfg> --exact --steps 6 --warmup 3)" % tag,
+           "head": subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, universal_newlines=True).stdout.strip(),
+           "csrc_sha": None, "configs": {}, "configs_points": {}}
+    try:
+        doc["csrc_sha"] = open(os.path.join(ROOT, "gpurun_out", "pmcc", "csrc_sha.txt")).read().strip()
+    except OSError:
+        pass
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmcc", "*.md"))):
+        cfg = os.path.basename(f)[:-3]
+        doc["configs"][cfg] = {name: {"FETCH_SIZE_KB": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB": v.get("WRITE_SIZE", 0.0), "launches": v["n"]}
+                               for name, v in parse(f).items()}
+        try:
+            rec = json.loads(open(f[:-3] + ".out").read().strip().partition(" ")[2])
+            doc["configs_points"][cfg] = rec["points"]
+        except (OSError, ValueError, KeyError):
+            pass
+    json.dump(doc, open(os.path.join(ROOT, "profiles", "configs_traffic.json"), "w"), indent=1)
+
+
 def main(tag):
     print("# HBM traffic per launch of the other BASELINE configs' kernels, round %s (tools/pmc_configs.sh: rocprofv3 --pmc, FETCH_SIZE and "
           "WRITE_SIZE in separate passes)\n" % tag)
@@ -52,10 +76,12 @@ def main(tag):
             print("| `%s` | %d | %.4g | %.4g | %.3f |" % (name[:90], v["n"], v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0), gb))
         if rec and rec.get("roofline"):
             r = rec["roofline"]
-            print("\nfused ShapeNet kernel: %.3f ms per launch under the counter pass, design stash traffic %.0f GB/s (`stash_GBs`), executed 16-bit matrix work %.0f TFLOP/s."
-                  % (r["avg_ms"], r["stash_GBs"], r["executed_bf16_TFLOPs"]))
+            print("\nfused ShapeNet kernel (%s): %.3f ms per launch under the counter pass, executed 16-bit matrix work %.0f TFLOP/s."
+                  % (r.get("kernel", "?"), r["avg_ms"], r["executed_bf16_TFLOPs"]))
         print()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "json":
+    write_json(sys.argv[1])
+elif __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "r04")
