@@ -1,3 +1,9 @@
+// EXPERIMENT (r5, not in the build): fp32 deposits -- the producers deposit h / dL/da rows as fp32 (8 ds_write_b128 per layer and tile, no
+// splits: -34 % of their vector instructions, 32 KB of LDS less) and the CONSUMER waves form the bf16 (hi, lo) pairs and zt h.  Parity
+// green, but SLOWER: fused kernel 1.151 -> 1.444 ms.  Every h / dL/da block is converted by every consumer wave that uses it (8 waves x
+// 72 vector instructions per tile and layer against the 184 the producer saved): the total vector work per SIMD goes UP, and the consumers
+// (2 per SIMD) become the critical path of the chunk steps.  Needs nif_amd/csrc/k_fuse_dev.h of the same experiment (fuse32_* helpers).
+
 // k_snet6.hip -- the plain-SIREN training kernel (k_snet4<NBL, TRAIN, SINE, 0, SGN>) with EVERY ShapeNet weight gradient fused in:
 // no dL/da stash, no weight-gradient launches (k_gw_first_lds, 4 x k_gw_lds, k_gw_out_lds), one partial-gradient row per workgroup.
 //
@@ -98,14 +104,10 @@ __device__ __forceinline__ void ring_load16(const float* __restrict__ slot, f32x
 #endif
 }
 
-#ifdef NIF_TIMELINE      // measurement builds: s_memtime stamps of producer wave 0 and consumer wave 8 of block 0, third round -- kept in LDS
-                         // (a stamp in global memory is a vector-memory instruction of its own: it changes what the vmcnt waits wait for) and
-                         // copied out at the end: entries 0 .. of A.tl = wave 0, 1024 .. = wave 8
-#define S6_TL(id) do { if (blockIdx.x == 0 && (tid == 0 || tid == 512) && tlr == 2 && tlc < 380) { tlb[tlc] = ((long long)(id) << 48) | ((long long)__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFll); ++tlc; } } while (0)
-#define S6_TL_FLUSH() do { if (A.tl && blockIdx.x == 0 && (tid == 0 || tid == 512)) for (int q_ = 0; q_ < tlc; ++q_) { A.tl[(tid ? 2048 : 0) + 2 * q_] = tlb[q_] >> 48; A.tl[(tid ? 2048 : 0) + 2 * q_ + 1] = tlb[q_] & 0xFFFFFFFFFFFFll; } } while (0)
+#ifdef NIF_TIMELINE      // measurement builds: s_memtime stamps of producer wave 0 (entries 0 ..) and consumer wave 8 (entries 1024 ..) of block 0, third round
+#define S6_TL(id) do { if (A.tl && blockIdx.x == 0 && (tid == 0 || tid == 512) && tlr == 2 && tlc < 1000) { long long* q_ = A.tl + (tid ? 2048 : 0) + 2 * tlc; q_[0] = (id); q_[1] = (long long)__builtin_amdgcn_s_memtime(); ++tlc; } } while (0)
 #else
 #define S6_TL(id) do { } while (0)
-#define S6_TL_FLUSH() do { } while (0)
 #endif
 struct S6Args {
   SNetArgs s;
@@ -136,23 +138,22 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   // significand bits where r4's bf16 pairs carried 16).  The planes carry a power of two s_jk, the sines 2^12, dL/da a power of two per
   // point: all of it is scaled back exactly (biases pre-scaled in the LDS image, the combine factor zt s1 / s0, the sine's constants)
   constexpr bool X16 = PR == 0;
-  constexpr int CF = X16 ? NBL * 2 * 64 : NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
+  constexpr int CF = X16 ? NBL * 2 * 64 : NBL * 64, CB = CF;   // 16-byte units per chunk, forward and adjoint alike (the policies stream ONE plane per block)
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
   constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
   constexpr int QF = (CF + NT - 1) / NT;
   // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
   // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
   constexpr int NBUF = 2;
-  constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
+  constexpr int NPL = 2;                                // fp32 planes per tile (r5): h, dL/da -- the consumers form the bf16 (hi, lo) pairs and zt h
 #if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
   constexpr int NRING = 0;
 #else
   constexpr int NRING = NIF_S6_RING_V4 ? NBL : 4 * NBL; // vector-memory instructions of one ring_store16 / ring_load16
 #endif
-  constexpr int EXT = NPL * FUSE_PLANE_BYTES;
-  // per-tile weight vectors [hi 16 | lo 16] bf16 = 64 B.  Last layer (WVL): du_o (o < 3), zt, ones.  First layer (WVF), per plane k:
-  // k * 4 + c = (zt | 1) x_c, k * 4 + 3 = (zt | 1)
-  constexpr int NVL = 5, NVF = 8, WVLT = NVL * 64, WVFT = NVF * 64;
+  constexpr int EXT = NPL * FUSE32_PLANE;
+  // per-tile fp32 vectors [16 points] = 64 B.  Last layer (WVL): du_o (o < 3), zt.  First layer (WVF): x_c (c < 3)
+  constexpr int NVL = 4, NVF = 4, WVLT = NVL * 64, WVFT = NVF * 64;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
@@ -163,14 +164,13 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   char* WVL = EX + WAVES * EXT;
   char* WVF = WVL + WAVES * WVLT;
   bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);
-  float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
+  float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);      // (CF: the chunk buffers' stride)
   const int sm_tot = ((r + 1) * nsm + 3) & ~3;
   const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
   const int NI = (CX + CZ + CY + 4) * 16;
   const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   float* scl = lsum + 16;                               // X16: [matrix][plane][s | 1 / s] of the half planes
-  long long* tlb = reinterpret_cast<long long*>(scl + 16) + (tid ? 380 : 0); (void)tlb;      // (NIF_TIMELINE builds: 2 x 380 stamps)
   constexpr int NP = 16 * NBL;
   const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
@@ -205,57 +205,63 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     const int cw = wid - WAVES, kk = cw >> 2, bI = (cw >> 1) & 1, bJ = cw & 1;
     int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
     __syncthreads();
-    if (tid - NT < WAVES * 16) {     // the constant "ones" vectors (hi = 1, lo = 0) of every tile
-      const int t = (tid - NT) >> 4, q = (tid - NT) & 15;
-      reinterpret_cast<__bf16*>(WVL + t * WVLT)[4 * 32 + q] = (__bf16)1.0f;
-      reinterpret_cast<__bf16*>(WVF + t * WVFT)[7 * 32 + q] = (__bf16)1.0f;
-    }
     __builtin_amdgcn_s_setprio(NIF_S6_CONS_PRIO);
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    float bacc[4] = {0.f, 0.f, 0.f, 0.f};                         // hidden biases (kk, bJ) -- bI = 1 waves
-    float facc[3] = {0.f, 0.f, 0.f}, fbacc = 0.f;                  // first layer (kk, columns 32 bJ ..) -- bI = 0 waves
-    float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};   // last layer (kk, rows 32 bI ..) -- bJ = 0 waves; its bias -- wave (kk, 1, 1)
-    FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;
-    rdA.a0 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI; rdA.a1 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI;   // plane 0: zt h, plane 1 (= r): h
-    rdB.a0 += 4 * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += 4 * FUSE_PLANE_BYTES + 256 * bJ;                         // dL/da
-    const int wofs = 16 * (lane >> 5);                  // this lane's 8 points inside a weight vector (bytes)
+    // the skinny sums, by wave role (one register set per pair of roles that never meet in a wave):
+    //   sk[0..3]: bI = 1 waves: the hidden biases (kk, bJ) of matrix 0 .. 3;  bI = 0 waves: the first layer (kk, columns 32 bJ ..): sk[c] = W1 row c, sk[3] = b1
+    //   lk[0..2]: bJ = 0 waves: the last layer (kk, rows 32 bI ..);  wave (kk, 1, 1): the last layer's bias
+    float sk[4] = {0.f, 0.f, 0.f, 0.f}, lk[3] = {0.f, 0.f, 0.f};
+    const int aoff = fuse32_rd_off(lane, bI);                     // this lane's feature of the h plane ...
+    const int boff = FUSE32_PLANE + fuse32_rd_off(lane, bJ);       // ... and of the dL/da plane; its 8 points: + t * FUSE32_ROW
 
 #define S6_CBAR()                                                             \
   {                                                                           \
-    __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): the transpose reads are back */ \
+    __builtin_amdgcn_s_waitcnt(0xC07F);        /* lgkmcnt(0): the deposit reads are back */ \
     S6_TL(400);                                                               \
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
     S6_TL(500);                                                               \
   }
-    // hidden matrix J_: this wave's block over the deposited tiles [T0_, T1_).  One tile's operands ahead of the MFMAs (the
-    // transpose reads of tile t + 1 are in flight while tile t multiplies), never more: 64 accumulator + 2 x 16 operand registers
-#define S6_HID_LOAD(T_, AH_, AL_, BH_, BL_)                                                                 \
+    // hidden matrix J_: this wave's block over the deposited tiles [T0_, T1_): the lane's 8 points of its h feature (times zt: plane
+    // 0) and of its dL/da feature as fp32, their bf16 (hi, lo) pairs, three products (hi.lo + lo.hi + hi.hi, K = the tile's 16
+    // points).  The next tile's rows are read while this one is converted and multiplied
+#define S6_HID_LOAD(T_, A_, B_)                                                                             \
   {                                                                                                         \
     const char* img_ = EX + (T_) * EXT;                                                                     \
-    AH_ = fuse_read_op(img_, rdA, 0); AL_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdA, 0);                  \
-    BH_ = fuse_read_op(img_, rdB, 0); BL_ = fuse_read_op(img_ + FUSE_PLANE_BYTES, rdB, 0);                  \
+    fuse32_read8(img_, aoff, A_); fuse32_read8(img_, boff, B_);                                             \
   }
 #define S6_HID_TILES(J_, T0_, T1_)                                                                          \
   {                                                                                                         \
-    bf16x8 ah_, al_, bh_, bl_, ah2_, al2_, bh2_, bl2_;                                                      \
-    S6_HID_LOAD(T0_, ah_, al_, bh_, bl_)                                                                    \
+    float a_[8], b_[8];                                                                                     \
+    S6_HID_LOAD(T0_, a_, b_)                                                                                \
     _Pragma("unroll") for (int t_ = T0_; t_ < T1_; ++t_) {                                                  \
-      if (t_ + 1 < T1_) S6_HID_LOAD(t_ + 1, ah2_, al2_, bh2_, bl2_)                                         \
+      bf16x8 ah_, al_, bh_, bl_;                                                                            \
+      {                                                                                                     \
+        float z_[8];                                                                                        \
+        if (kk == 0) {                                                                                      \
+          fuse32_vec8(WVL + t_ * WVLT + 192, lane, z_);                                                     \
+          _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) a_[e_] *= z_[e_];                                \
+        }                                                                                                   \
+        fuse32_split8(a_, ah_, al_);                                                                        \
+        if (bI == 1) {                                                                                      \
+          float sb_ = 0.f;                                                                                  \
+          if (kk == 0) { _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) sb_ = fmaf(b_[e_], z_[e_], sb_); } \
+          else { _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) sb_ += b_[e_]; }                          \
+          sk[J_] += sb_;                                                                                  \
+        }                                                                                                   \
+        fuse32_split8(b_, bh_, bl_);                                                                        \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if (t_ + 1 < T1_) S6_HID_LOAD(t_ + 1, a_, b_)      /* (the raw rows are dead: the next tile's come in behind the products) */ \
       acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, acc[J_], 0, 0, 0);                        \
       acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, acc[J_], 0, 0, 0);                        \
       acc[J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, acc[J_], 0, 0, 0);                        \
-      if (bI == 1) {                                                                                        \
-        const char* w_ = WVL + t_ * WVLT + (3 + kk) * 64 + wofs;                                            \
-        bacc[J_] = fuse_dot8(bh_, bl_, *reinterpret_cast<const bf16x8*>(w_), *reinterpret_cast<const bf16x8*>(w_ + 32), bacc[J_]); \
-      }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
-      ah_ = ah2_; al_ = al2_; bh_ = bh2_; bl_ = bl2_;                                                       \
     }                                                                                                       \
   }
     // the four chunk steps of an adjoint layer with the consumption of hidden deposit DJ_ (a compile-time index: the accumulators
@@ -270,43 +276,75 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                          \
     S6_CBAR()                                                                                               \
   }
-    // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors).  The skinny sums run as ROLLED loops over the tiles:
-    // unrolled, hipcc fetched the weight vectors of all tiles first and spilled the accumulators to make room
+    // last layer (h_nh deposited as the h plane, du_o as vectors): plain fp32 sums over the lane's 8 points -- rolled loops over the tiles
     auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
       if (bJ == 0) {
 #pragma clang loop unroll(disable)
         for (int t = t0; t < t1; ++t) {
-          const char* img = EX + t * EXT;
-          const bf16x8 ah = fuse_read_op(img, rdA, 0), al = fuse_read_op(img + FUSE_PLANE_BYTES, rdA, 0);
-          const char* w = WVL + t * WVLT + wofs;
-          lacc[0] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), lacc[0]);
-          if (so > 1) lacc[1] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), lacc[1]);
-          if (so > 2) lacc[2] = fuse_dot8(ah, al, *reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), lacc[2]);
+          float a[8], z[8], d[8];
+          fuse32_read8(EX + t * EXT, aoff, a);
+          if (kk == 0) {
+            fuse32_vec8(WVL + t * WVLT + 192, lane, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] *= z[e];
+          }
+#pragma unroll
+          for (int o = 0; o < 3; ++o)
+            if (o < so) {
+              fuse32_vec8(WVL + t * WVLT + o * 64, lane, d);
+              float sv = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sv = fmaf(a[e], d[e], sv);
+              lk[o] += sv;
+            }
         }
       } else if (bI == 1) {
 #pragma clang loop unroll(disable)
         for (int t = t0; t < t1; ++t) {
-          const char* w = WVL + t * WVLT + wofs;
-          const char* z = w + (3 + kk) * 64;
-          const bf16x8 zhi = *reinterpret_cast<const bf16x8*>(z), zlo = *reinterpret_cast<const bf16x8*>(z + 32);
-          blacc[0] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), zhi, zlo, blacc[0]);
-          if (so > 1) blacc[1] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), zhi, zlo, blacc[1]);
-          if (so > 2) blacc[2] = fuse_dot8(*reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), zhi, zlo, blacc[2]);
+          float z[8], d[8];
+          if (kk == 0) fuse32_vec8(WVL + t * WVLT + 192, lane, z);
+#pragma unroll
+          for (int o = 0; o < 3; ++o)
+            if (o < so) {
+              fuse32_vec8(WVL + t * WVLT + o * 64, lane, d);
+              float sv = 0.f;
+              if (kk == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv = fmaf(d[e], z[e], sv);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv += d[e];
+              }
+              lk[o] += sv;       // (every lane of a half holds the same 8 points: lanes 0 and 32 are read at the end)
+            }
         }
       }
     };
-    // first layer (dL/da_0 deposited as the B planes, (zt | 1) x_c and (zt | 1) as vectors)
+    // first layer (dL/da_0 deposited as the dL/da plane, x_c as vectors)
     auto consume_first = [&](int t0, int t1) __attribute__((always_inline)) {
       if (bI == 0) {
 #pragma clang loop unroll(disable)
         for (int t = t0; t < t1; ++t) {
-          const char* img = EX + t * EXT;
-          const bf16x8 bh = fuse_read_op(img, rdB, 0), bl = fuse_read_op(img + FUSE_PLANE_BYTES, rdB, 0);
-          const char* w = WVF + t * WVFT + kk * 256 + wofs;
-          fbacc = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 192), *reinterpret_cast<const bf16x8*>(w + 224), fbacc);
-          facc[0] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w), *reinterpret_cast<const bf16x8*>(w + 32), facc[0]);
-          if (si > 1) facc[1] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 64), *reinterpret_cast<const bf16x8*>(w + 96), facc[1]);
-          if (si > 2) facc[2] = fuse_dot8(bh, bl, *reinterpret_cast<const bf16x8*>(w + 128), *reinterpret_cast<const bf16x8*>(w + 160), facc[2]);
+          float b[8], z[8], xc[8];
+          fuse32_read8(EX + t * EXT, boff, b);
+          if (kk == 0) {
+            fuse32_vec8(WVL + t * WVLT + 192, lane, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] *= z[e];
+          }
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sv += b[e];
+          sk[3] += sv;
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            if (c < si) {
+              fuse32_vec8(WVF + t * WVFT + c * 64, lane, xc);
+              float sc = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sc = fmaf(b[e], xc[e], sc);
+              sk[c] += sc;
+            }
         }
       }
     };
@@ -361,30 +399,29 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
           if (in < n && out < n) prow[gidx(ws + (long)in * n + out)] = om * acc[j][e];
           if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (hipcc would form all 64 addresses first: 128 registers next to the accumulators)
         }
-        float v = bacc[j];
+        float v = sk[j];
         v += __shfl_xor(v, 32);
         if (bI == 1 && hf == 0 && 32 * bJ + i < n) prow[gidx(slot_bh(A, j) + 32 * bJ + i)] = v;
       }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float v = facc[c];
+      float v = sk[c];
       v += __shfl_xor(v, 32);
       if (c < si && bI == 0 && hf == 0 && 32 * bJ + i < n) prow[gidx((long)c * n + 32 * bJ + i)] = om * v;
     }
     {
-      float v = fbacc;
+      float v = sk[3];
       v += __shfl_xor(v, 32);
       if (bI == 0 && hf == 0 && 32 * bJ + i < n) prow[gidx(slot_b1(A) + 32 * bJ + i)] = v;
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-      float v = lacc[o], w = blacc[o];
+      float v = lk[o], w = lk[o];
       v += __shfl_xor(v, 32);
       w += __shfl_xor(w, 32);
       if (o < so && bJ == 0 && hf == 0 && 32 * bI + i < n) prow[gidx(slot_wl(A) + (long)(32 * bI + i) * so + o)] = v;
       if (o < so && bJ == 1 && bI == 1 && lane == 0) prow[gidx(slot_bl(A) + o)] = w;
     }
-    S6_TL_FLUSH();
     __syncthreads();          // (the producers' loss reduction)
     return;
   }
@@ -459,7 +496,6 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   float* IN0 = A.stash;
   float* ring = A.stash + ((long)blockIdx.x * WAVES + wid) * (long)nh * (NP * 16);    // NIF_S6_RING: [matrix][NP features][16 points]
   (void)ring; (void)IN0; (void)sstride; (void)tstride;
-  const FuseDep dep = fuse_dep_addr(p, g);
   char* exw = EX + wid * EXT;                            // this wave's tile images
 
 #define S6_CHUNK(...)                                                         \
@@ -623,29 +659,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         if (g == 0) t = fmaf(du, sm[o_bl + o], t);
         dzs[lane] += t;
       }
-      if (g == 0 && o < 3) {     // du_o of the tile's 16 points as a bf16 (hi | lo) row: the last layer's weight-gradient vector
-        __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
-        const __bf16 d0 = (__bf16)du;
-        wv[o * 32 + p] = d0; wv[o * 32 + 16 + p] = (__bf16)(du - (float)d0);
-      }
+      if (g == 0 && o < 3) reinterpret_cast<float*>(WVL + wid * WVLT)[o * 16 + p] = du;     // du_o of the tile's 16 points: the last layer's weight-gradient vector
     }
-    if (g == 1) {     // zt of the tile (the hidden layers' plane-0 bias sums use it too)
-      __bf16* wv = reinterpret_cast<__bf16*>(WVL + wid * WVLT);
-      const __bf16 z0 = (__bf16)zt0;
-      wv[3 * 32 + p] = z0; wv[3 * 32 + 16 + p] = (__bf16)(zt0 - (float)z0);
-    }
-    {   // deposit "nh": the last layer's input h_nh (and zt h_nh) as the A planes
-      bf16x8 a0[NCH], a1[NCH];
-      split2<NBL>(h, a0, a1);
-      fuse_deposit4(exw, dep, a0);
-      fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
-      f32x4 zh[NBL];
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) zh[b] = zt0 * h[b];
-      split2<NBL>(zh, a0, a1);
-      fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
-      fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
-    }
+    if (g == 1) reinterpret_cast<float*>(WVL + wid * WVLT)[48 + p] = zt0;     // zt of the tile (the consumers' plane-0 operands and bias sums)
+    fuse32_deposit(exw, p, g, h);      // deposit "nh": the last layer's input h_nh
     if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
     // ---- adjoint through the hidden hyper-matrices ---------------------------------------------------------------------------
     f32x4 dnext[NBL], hin[NBL];
@@ -669,9 +686,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         }
         dzs[lane] += X16 ? sbv * (scl[j * 4 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s0 b^(0))
       }
-      bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);                // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
-      bf16x8 q0[NCH], q1[NCH];                // the products' operand: b0, or half(s dL/da), s per point (mixed_float16: hi alone; X16: (hi, lo))
+      bf16x8 q0[NCH], q1[NCH];                // the products' operand: half(s dL/da), s per point (X16: (hi, lo); mixed_float16: hi alone), or bf16(dL/da)
+                                              // (dL/da itself stays in ga until the deposit at the end of the layer: fp32, r5)
       const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
       float ils = 1.0f;
       if (PR == 2 || X16) {
@@ -685,13 +701,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         ils = __uint_as_float((254u - sf) << 23);
         if (X16) split2h<NBL>(ga, __uint_as_float(sf << 23), q0, q1);
         else cast_f16<NBL>(ga, q0, __uint_as_float(sf << 23));
-      } else {
+      } else split2<NBL>(ga, q0, q1);           // mixed_bfloat16: q0 = bf16(dL/da) is the operand
+      if (PR == 2) {
 #pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) q0[ks] = b0[ks];
-      }
-      if (!X16) {
-#pragma unroll
-        for (int ks = 0; ks < NCH; ++ks) q1[ks] = b1[ks];
+        for (int ks = 0; ks < NCH; ++ks) q1[ks] = q0[ks];      // (unused by the one-product forms)
       }
       constexpr int PB = X16 ? 3 : PR;
       {
@@ -719,20 +732,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] *= f_;
       }
-      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
-        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
-        bf16x8 a0[NCH], a1[NCH];
-        split2<NBL>(hin, a0, a1);
-        fuse_deposit4(exw, dep, a0);
-        fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
-        f32x4 zh[NBL];
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * hin[b];
-        split2<NBL>(zh, a0, a1);
-        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
-        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
-      }
+      // deposit j: (h_j ; dL/da_{j+1}) of this tile as fp32 rows -- the consumer waves take it during the chunk steps of layer j - 1
+      fuse32_deposit(exw + FUSE32_PLANE, p, g, ga);
+      fuse32_deposit(exw, p, g, hin);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
@@ -758,28 +760,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         tot += __shfl_xor(tot, 32);
         if (active && g == 0) A.DZ[(tile32 * r) * 32 + poff] = tot;
       }
-      bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_s_barrier();          // deposit 0 has been consumed
       asm volatile("" ::: "memory");
-      fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-      fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
-      {      // lane group g < si: x_g and zt x_g of the tile's 16 points as bf16 (hi | lo) rows; group 3: zt
-        __bf16* wv = reinterpret_cast<__bf16*>(WVF + wid * WVFT);
-        const float x = g < si ? xs[g * 16] : 1.0f;
-        const float zx = zt0 * x;
-        const __bf16 x0 = (__bf16)x, z0 = (__bf16)zx;
-        if (g < si || g == 3) { wv[g * 32 + p] = z0; wv[g * 32 + 16 + p] = (__bf16)(zx - (float)z0); }
-        if (g < si && g < 3) { wv[(4 + g) * 32 + p] = x0; wv[(4 + g) * 32 + 16 + p] = (__bf16)(x - (float)x0); }
-      }
+      fuse32_deposit(exw + FUSE32_PLANE, p, g, ga);      // the first layer's dL/da rows; lane group g < si: x_g of the tile's 16 points
+      if (g < si && g < 3) reinterpret_cast<float*>(WVF + wid * WVFT)[g * 16 + p] = xs[g * 16];
     }
   }
 #undef S6_CHUNK
   __syncthreads();          // the last round's first-layer deposit is visible ...
   __syncthreads();          // ... and consumed
-  S6_TL_FLUSH();
   for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
   if (lane == 0) lsum[wid] = loss_lane;
   __syncthreads();
@@ -795,11 +786,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
-#ifdef NIF_TIMELINE
-         + 2 * 380 * 8
-#endif
-      ;
+  return 8 * (2 * FUSE32_PLANE + (4 + 4) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 1) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float);
 }
 // the fused-gradient kernel takes this training step (plain NIFMultiScale, fp32 results)
 bool snet6_supported(const SNetArgs& a) {
