@@ -194,9 +194,15 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   dim3 grid(nblk), block(256);
   const size_t shm = snet4_shmem(a, NBL);
   SNetArgs h = a;
+  const int pr = snet4_pr(a);
   if (a.prec != 0) { h.WF4 = a.WF4h; h.WB4 = a.WB4h; }      // the policies' compact plane set (k_pack16b mode 1 / 2)
-  if (a.prec == 2) {      // mixed_float16: the PR = 2 instantiations (k_snet4_f16.hip)
+  if (pr == 2) {      // mixed_float16: the PR = 2 instantiations (k_snet4_f16.hip)
     launch_snet4_f16(h, train, nblk, shm, st);
+    return nblk;
+  }
+  if (pr == 3) {      // r5: fp32-exact products on half pairs -- every SIREN form (k_snet4_x16.hip); the bf16-split forms below are class NIF's
+    h.WF4 = a.WF4x; h.WB4 = a.WB4x;
+    launch_snet4_x16(h, train, nblk, shm, st);
     return nblk;
   }
 #define S4L(NBL_, TR_, ACT_, MODE_, SGN_, LL_, PR_)                                                                    \
@@ -216,11 +222,13 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
   if (a.res) { if (train) S4L(NBL_, true, ACT_SINE, 1, true, LL_, PR_) else S4L(NBL_, false, ACT_SINE, 1, false, LL_, PR_) } \
   else if (train) S4L(NBL_, true, ACT_SINE, 0, true, LL_, PR_)                                                      \
   else S4L(NBL_, false, ACT_SINE, 0, false, LL_, PR_)
+// (PR = 0, the exact bf16 splits: class NIF alone since r5 -- its activations are not bounded, the half pairs of the SIREN forms need |h| <= 1;
+//  a SIREN net reaches this point with PR = 0 only when the half planes are not packed, which nif_api never does: refused below)
 #define S4(NBL_)                                                            \
   if (a.ll && a.prec == 1) { S4N(NBL_, true, true) }                        \
-  else if (a.ll) { S4N(NBL_, true, false) }                                 \
   else if (a.prec == 1) { S4M(NBL_, false, true) }                          \
-  else { S4M(NBL_, false, false) }
+  else if (a.nif_skip) { if (train) S4L(NBL_, true, -1, 2, false, false, false) else S4L(NBL_, false, -1, 2, false, false, false) } \
+  else return -1;
 #ifdef NIF_S4_DEV      // ISA work (tools/isa_hist.py): only the benchmark shape's training / inference instantiations
   if (train) S4L(4, true, ACT_SINE, 0, true, false, false) else S4L(4, false, ACT_SINE, 0, false, false, false)
 #else

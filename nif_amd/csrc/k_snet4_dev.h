@@ -54,8 +54,15 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   constexpr int CF = NBS * 3 * 64, CB = NBS * 2 * 64;   // 16-byte units per forward / adjoint chunk
   // the policies' compact plane set (late r4): ONE 16-bit plane per block -- a third / half of the chunk DMA (LDS buffers keep the
   // stride CF: the phi layer's chunks of the last-layer class stay split groups)
-  constexpr bool CP = PR != 0;
-  constexpr int CFH = CP ? NBS * 64 : CF, CBH = CP ? NBS * 64 : CB;   // units per HIDDEN-matrix chunk
+  constexpr bool CP = PR == 1 || PR == 2;
+  // PR = 3 (r5): fp32-exact products on HALF pairs, as in k_snet6 -- planes (hi, lo) x operand (hi, lo), three v_mfma_f32_16x16x32_f16 per
+  // pair in BOTH directions (k_pack16b mode 3: forward chunks in the adjoint geometry; split2h; tools/exp/f16_split_mfma.hip: as
+  // accurate as the six bf16 products, better than the f32-input MFMA): half the forward matrix work, two thirds of its chunk bytes,
+  // 22 significand bits in the data adjoint where the bf16 pairs carried 16.  SIREN nets only (|h| <= 1: sines scaled by 2^12 stay in
+  // half's range; class NIF keeps the bf16 splits): the planes carry a power of two s_jk per (matrix, plane), dL/da one per point,
+  // scaled back exactly (biases pre-scaled in the LDS image, s_r / s_k in the latent combine, 1 / (4096 s_r) in the sine's constants)
+  constexpr bool X16 = PR == 3;
+  constexpr int CFH = CP ? NBS * 64 : (X16 ? CB : CF), CBH = CP ? NBS * 64 : CB;   // units per HIDDEN-matrix chunk
   constexpr int QF = (CF + NT - 1) / NT;
   // LDS ring of the chunk stream: NBUF buffers, the DMA runs DIST = NBUF - 1 chunk steps ahead of the MFMAs.  r2 had two buffers
   // and drained vmcnt(0) in front of every barrier: the L2 -> LDS latency of a chunk (~1.5-2 k cycles) had to hide behind ONE
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   float* dul = das + rl * 16;
   float* inp = dul + (LL ? sou * 16 : 0);
   float* lsum = sm + sm_tot + (long)WAVES * pw;
+  float* scl = lsum + 8;                              // X16: [matrix][plane][s | 1 / s] of the half planes
   const int o_llb = LL ? ((nsm - ((sou + 3) & ~3) - ((rl * rl + 3) & ~3))) : 0;   // LL extras sit at the end of sm
   const int o_lw = o_llb + ((sou + 3) & ~3);
   constexpr int NP = 16 * NBL;
@@ -195,12 +203,17 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
       else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
-      else if (e < o_bl) { const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP; if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f); }
+      else if (e < o_bl) {
+        const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP;
+        if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f);
+        if (X16) v *= 4096.0f * A.wscale[(j * (r + 1) + k) * 2];      // the hidden biases start the scaled MFMA chains
+      }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
       else if (LL && e >= o_llb && e < o_llb + sou) v = hyp3(A, k, s_bl + so + (e - o_llb));
       else if (LL && e >= o_lw && e < o_lw + rl * rl) v = hyp3(A, k, s_bl + so + sou + (e - o_lw));
       sm[idx] = v;
     }
+    if (X16) for (int idx = tid; idx < nh * (r + 1) * 2; idx += NT) scl[idx] = A.wscale[idx];
     if (cs_left <= 0) cs_left = -1;
 #pragma unroll
     for (int d = 0; d < DIST; ++d) cs_next(d);       // the first DIST chunks
@@ -246,19 +259,22 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   }
 
 // the SPL pieces of K-step ks_: forward (6-product) into T_, adjoint (3-product) into U_; ZI_: the chains start from zero
+#define NIF_FWD_MM(OB0_, KS_, T_)                                                                                      \
+  if (X16) mfma_x3<NBS, 3, false, NBL, OB0_, false>(cur, b0[KS_], b1[KS_], T_, lane);                                   \
+  else mfma_x6<NBS, PR, false, NBL, OB0_, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane);
 #define NIF_FWD_STEP(KS_, T_)                                                                                          \
   _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
-    if (sp_ == 0) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); })            \
-    else if (sp_ == 1) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 1 ? NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
-    else if (sp_ == 2) NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 2 ? 2 * NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
-    else NIF_CHUNK({ mfma_x6<NBS, PR, false, NBL, (SPL > 3 ? 3 * NBS : 0), CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }) \
+    if (sp_ == 0) NIF_CHUNK({ NIF_FWD_MM(0, KS_, T_) })                                                                 \
+    else if (sp_ == 1) NIF_CHUNK({ NIF_FWD_MM((SPL > 1 ? NBS : 0), KS_, T_) })                                          \
+    else if (sp_ == 2) NIF_CHUNK({ NIF_FWD_MM((SPL > 2 ? 2 * NBS : 0), KS_, T_) })                                      \
+    else NIF_CHUNK({ NIF_FWD_MM((SPL > 3 ? 3 * NBS : 0), KS_, T_) })                                                    \
   }
 #define NIF_BWD_STEP(B0_, B1_, U_, ZI_, PR_, ...)                                                                      \
   _Pragma("unroll") for (int sp_ = 0; sp_ < SPL; ++sp_) {                                                              \
-    if (sp_ == 0) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, 0, (PR_ != 0)>(cur, B0_, B1_, U_, lane); __VA_ARGS__ })                  \
-    else if (sp_ == 1) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 1 ? NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })       \
-    else if (sp_ == 2) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 2 ? 2 * NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })   \
-    else NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 3 ? 3 * NBS : 0), (PR_ != 0)>(cur, B0_, B1_, U_, lane); })                 \
+    if (sp_ == 0) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, 0, (PR_ == 1 || PR_ == 2)>(cur, B0_, B1_, U_, lane); __VA_ARGS__ })                  \
+    else if (sp_ == 1) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 1 ? NBS : 0), (PR_ == 1 || PR_ == 2)>(cur, B0_, B1_, U_, lane); })       \
+    else if (sp_ == 2) NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 2 ? 2 * NBS : 0), (PR_ == 1 || PR_ == 2)>(cur, B0_, B1_, U_, lane); })   \
+    else NIF_CHUNK({ mfma_x3<NBS, PR_, ZI_, NBL, (SPL > 3 ? 3 * NBS : 0), (PR_ == 1 || PR_ == 2)>(cur, B0_, B1_, U_, lane); })                 \
   }
 
   int iset = 0;
@@ -322,7 +338,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
     for (int j = 0; j < nh; ++j) {
       if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); vm_note(4 * NBL); }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
-      split3p<NBL, PR>(h, b0, b1, b2);
+      if (X16) split2h<NBL>(h, 4096.0f, b0, b1);
+      else split3p<NBL, PR>(h, b0, b1, b2);
       NIF_TL(10 + j);
       {
         const float* sb = sm + r * nsm + o_bh + j * NP + 4 * g;
@@ -336,15 +353,21 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #pragma unroll
         for (int ks = 0; ks < NCH; ++ks) NIF_FWD_STEP(ks, T)
-        const float zt = zt_base[k * 16];
+        const float zt = X16 ? zt_base[k * 16] * (scl[(j * (r + 1) + r) * 2] * scl[(j * (r + 1) + k) * 2 + 1]) : zt_base[k * 16];   // (plane k's chain carries s_k, the sum s_r)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
 #pragma unroll
       for (int ks = 0; ks < NCH; ++ks) NIF_FWD_STEP(ks, acc)
       NIF_TL(30 + j);
-      if (TRAIN && SGN) sine16_tag<NBL>(acc, acc);
+      if (TRAIN && SGN && X16) sine16_tag_sc<NBL>(acc, acc, scl[(j * (r + 1) + r) * 2 + 1] * (1.0f / 4096.0f));
+      else if (TRAIN && SGN) sine16_tag<NBL>(acc, acc);
       else {
+        if (X16) {
+          const float inv = scl[(j * (r + 1) + r) * 2 + 1] * (1.0f / 4096.0f);
+#pragma unroll
+          for (int b = 0; b < NBL; ++b) acc[b] *= inv;
+        }
         f32x4 d[NBL];
         act16<NBL, ACT>(A.act, acc, acc, d, n, g);
         if (TRAIN) {
@@ -545,7 +568,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
             const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
             sbv += (ga[b][0] * bb[0] + ga[b][1] * bb[1]) + (ga[b][2] * bb[2] + ga[b][3] * bb[3]);
           }
-          dzs[k * 64 + lane] += sbv;
+          dzs[k * 64 + lane] += X16 ? sbv * (scl[(j * (r + 1) + k) * 2 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s_k b^(k))
         }
         bf16x8 b0[NCH], b1[NCH];
         // mixed_float16: dL/da enters the products as half(s dL/da) with a loss scale s PER POINT -- the power of two that brings
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
         // a per-point power of two needs no history, cannot overflow and keeps the smallest adjoints half can represent
         // (exact scaling: only the rounding sees it).  A lane's point is lane & 15 in the B operand and in the C / D tile alike
         float ls = 1.0f, ils = 1.0f;
-        if (PR == 2) {
+        if (PR >= 2) {
           float mx = 0.f;
 #pragma unroll
           for (int b = 0; b < NBL; ++b) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ga[b][0]), fabsf(ga[b][1]))), fmaxf(fabsf(ga[b][2]), fabsf(ga[b][3])));
@@ -565,7 +588,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
           ls = __uint_as_float(sf << 23);
           ils = __uint_as_float((254u - sf) << 23);
         }
-        split2p<NBL, PR>(ga, b0, b1, ls);
+        if (X16) split2h<NBL>(ga, ls, b0, b1);
+        else split2p<NBL, PR>(ga, b0, b1, ls);
         NIF_TL(50 + j);
         for (int k = 0; k < r; ++k) {
           f32x4 U[NBL];
@@ -574,7 +598,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
             if (ks == 0) { NIF_BWD_STEP(b0[0], b1[0], U, true, PR, if (!SGN) st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);) }
             else { NIF_BWD_STEP(b0[ks], b1[ks], U, false, PR) }
           }
-          const float zt = zt_base[k * 16];
+          const float zt = X16 ? zt_base[k * 16] * (scl[(j * (r + 1) + r) * 2] * scl[(j * (r + 1) + k) * 2 + 1]) : zt_base[k * 16];
           float s = 0.f;
 #pragma unroll
           for (int b = 0; b < NBL; ++b)
@@ -587,16 +611,17 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
 #pragma unroll
             for (int b = 0; b < NBL; ++b) gh[b] += zt * U[b];
           }
-          dzs[k * 64 + lane] += PR == 2 ? ils * s : s;
+          dzs[k * 64 + lane] += X16 ? (ils * scl[(j * (r + 1) + k) * 2 + 1]) * s : (PR == 2 ? ils * s : s);
         }
 #pragma unroll
         for (int ks = 0; ks < NCH; ++ks) {
           if (LL && ks == 0) { NIF_BWD_STEP(b0[0], b1[0], gh, true, PR) }   // r = 0: the chain starts here
           else { NIF_BWD_STEP(b0[ks], b1[ks], gh, false, PR) }
         }
-        if (PR == 2) {
+        if (PR >= 2) {
+          const float f_ = X16 ? ils * scl[(j * (r + 1) + r) * 2 + 1] : ils;
 #pragma unroll
-          for (int b = 0; b < NBL; ++b) gh[b] *= ils;
+          for (int b = 0; b < NBL; ++b) gh[b] *= f_;
         }
         NIF_TL(70 + j);
         if (MODE == 2 || (MODE == 1 && !(j & 1))) {
@@ -636,6 +661,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   }
 #undef NIF_BWD_STEP
 #undef NIF_FWD_STEP
+#undef NIF_FWD_MM
 #undef NIF_CHUNK
   if (TRAIN) {
     for (int off = 32; off > 0; off >>= 1) loss_lane += __shfl_down(loss_lane, off);
@@ -646,10 +672,15 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
 }
 
 // ---- host side: LDS bytes of a launch ---------------------------------------------------------
+// the product form (template parameter PR) of a launch: the policies, else the half pairs for SIREN nets whose planes are packed
+static inline int snet4_pr(const SNetArgs& a) {
+  if (a.prec == 1 || a.prec == 2) return a.prec;
+  return (!a.nif_skip && a.WF4x && a.WB4x && a.wscale) ? 3 : 0;
+}
 static inline size_t snet4_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
   const int nz = a.ll ? a.rl : a.r, sou = a.ll ? a.so_u : a.so;
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((nz + 3) & ~3) + ((sou + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + (a.ll ? (size_t)(a.rl + a.so + a.so_u) * 16 : 0) + 2 * ni;
-  return (size_t)(NBL <= 4 ? NIF_S4_NBUF : ((NBL == 8 && a.ll) ? NIF_S4_NBUF_LL8 : 2)) * ((NBL == 8 && a.ll) ? NBL / NIF_S4_SPLIT8 : (NBL == 4 ? NBL / NIF_S4_SPLIT4 : NBL)) * 3 * 64 * 16 + (sm_tot + 4 * pw + 8) * sizeof(float);   // NBUF chunk buffers
+  return (size_t)(NBL <= 4 ? NIF_S4_NBUF : ((NBL == 8 && a.ll) ? NIF_S4_NBUF_LL8 : 2)) * ((NBL == 8 && a.ll) ? NBL / NIF_S4_SPLIT8 : (NBL == 4 ? NBL / NIF_S4_SPLIT4 : NBL)) * 3 * 64 * 16 + (sm_tot + 4 * pw + 8 + 2 * (size_t)(a.nh > 0 ? a.nh : 1) * (a.r + 1)) * sizeof(float);   // NBUF chunk buffers (+ the plane scales of the half form)
 }

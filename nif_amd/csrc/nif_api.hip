@@ -161,7 +161,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
     const int rr = c->kind == NIF_KIND_LASTLAYER ? 0 : c->r;   // last-layer class: shared dense weights, one plane
     if (e == hipSuccess) e = hipMalloc(&c->sWF4, (size_t)nh * snet4_fwd_elems(c->n, rr) * 2);
     if (e == hipSuccess) e = hipMalloc(&c->sWB4, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
-    if (c->kind != NIF_KIND_LASTLAYER && snet3_nbl(c->n) == 4 && c->r == 1) {   // k_snet6's shapes: the exact-product half planes
+    if (c->kind != NIF_KIND_NIF) {   // SIREN nets (r5): the exact-product half planes of k_snet4<.., PR = 3> / k_snet6 (class NIF keeps the bf16 splits)
       if (e == hipSuccess) e = hipMalloc(&c->sWF4x, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
       if (e == hipSuccess) e = hipMalloc(&c->sWB4x, (size_t)nh * snet4_bwd_elems(c->n, rr) * 2);
       if (e == hipSuccess) e = hipMalloc(&c->sWscale, sizeof(float) * (size_t)nh * (rr + 1) * 2);
@@ -490,6 +490,7 @@ static void fill_snet_ll(const nif_ctx* c, SNetArgs& a, const float* xin, int nc
   a.WPF = c->ll_wpf; a.WPB = c->ll_wpb;
   a.prec = c->opt_fp32_mfma ? 0 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_BF16 ? 1 : (c->cfg.mixed_policy == NIF_POLICY_MIXED_F16 ? 2 : 0));     // (k_snet4<LL> only; k_sob / k_jac stay exact)
   a.WF4h = c->sWF4h; a.WB4h = c->sWB4h;
+  a.WF4x = c->sWF4x; a.WB4x = c->sWB4x; a.wscale = c->sWscale;
   a.nsm = snet4_nsm_ll(c->si, sop, c->nh, c->n, c->so, c->r);
   a.tl = c->tl;
 }
@@ -581,6 +582,10 @@ static int ensure_packed(nif_ctx* c) {
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
                          (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2,
                          c->cfg.s_omega0, c->st);
+        if (c->use_ll4 && c->sWF4x)
+          launch_pack16b_batch(c->theta, dense_ref(w_off, n, n), 0, 1, snet3_nbl(n),
+                               (char*)c->sWF4x + (size_t)j * snet4_bwd_elems(n, 0) * 2, (char*)c->sWB4x + (size_t)j * snet4_bwd_elems(n, 0) * 2,
+                               0, 0, c->cfg.s_omega0, c->st, 3, c->sWscale + (size_t)j * 2);
         if (c->use_ll4 && c->sWF4h)
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
                          (char*)c->sWF4h + (size_t)j * (snet4_fwd_elems(n, 0) / 3) * 2, (char*)c->sWB4h + (size_t)j * (snet4_bwd_elems(n, 0) / 2) * 2,

@@ -194,6 +194,7 @@ long snet4_bwd_elems(int n, int r);
 // (scale = omega_0 of the layer: the bf16-split planes hold omega_0 M, see k_snet4.hip)
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode = 0);
 void launch_snet4_f16(const SNetArgs& a, bool train, int nblk, size_t shm, hipStream_t st);     // k_snet4_f16.hip
+void launch_snet4_x16(const SNetArgs& a, bool train, int nblk, size_t shm, hipStream_t st);     // k_snet4_x16.hip (r5: half-pair exact products)
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode = 0, float* pscale = nullptr);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
