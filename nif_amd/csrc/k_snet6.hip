@@ -22,13 +22,6 @@
 //   * what is left of the stash: the layer inputs h_0 .. h_{nh-1} of the wave's own tile (forward -> adjoint, re-read by the same wave).
 // Built for: NIFMultiScale without resblocks, fp32 results, 49..64 units (NBL = 4), latent_dim 1, 1..4 hidden matrices, si, so <= 3.
 // Everything else keeps k_snet4 + k_gw_*.  nif_set_option("fuse_gw", 0) / NIF_FUSE_GW=0 switches back (A/B, tests).
-#ifndef NIF_S6_GPRIO
-#define NIF_S6_GPRIO 0      // 1: the chunk step's operand reads + products of producer waves 0-3 at a higher priority than those of waves 4-7 (their
-#endif                      // SIMD partners): one wave's reads are served first and its products overlap the partner's reads -- measured: see DESIGN 5.5
-#if NIF_S6_GPRIO
-#define NIF_MFMA_PRIO_ON
-#define NIF_MFMA_PRIO_OFF
-#endif
 #include "k_fuse_dev.h"
 
 #define ZERO_T6(x) _Pragma("unroll") for (int b_ = 0; b_ < NBL; ++b_) { (x)[b_][0] = 0.f; (x)[b_][1] = 0.f; (x)[b_][2] = 0.f; (x)[b_][3] = 0.f; }
@@ -196,6 +189,38 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (int idx = tid; idx < (WAVES * (EXT + WVLT + WVFT)) / 16; idx += 1024) reinterpret_cast<f32x4*>(EX)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
+  const int NPC = (r + 1) * NCH;
+  const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
+  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
+  long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
+  auto cs_phase_step = [&]() {
+    ++cs_phase;
+    if (cs_phase < 1 + nh) {
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
+    }
+    if (cs_groups <= 0) { cs_left = -1; return; }
+    --cs_groups; cs_phase = 0;
+    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
+  };
+  // r5: BOTH roles walk the stream; the chunk of step c + 1 is issued during step c by the CONSUMER waves in the forward steps (they
+  // idle there: the s_memtime timeline shows ~250 ticks of every producer step going into the DMA issue) and by the producers in
+  // the adjoint steps (where the consumers carry the weight-gradient products)
+  const int ctid = tid & (NT - 1), cwid = wid & (WAVES - 1);
+  auto cs_next = [&](int buf, bool issue) {
+    if (cs_left < 0) return;
+    if (issue) {
+      bf16x8* dst = chunks + buf * CF;
+#pragma unroll
+      for (int q = 0; q < QF; ++q)
+        if (cwid * 64 + NT * q < cs_units)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + ctid + NT * q),
+                                           (__attribute__((address_space(3))) void*)(dst + cwid * 64 + NT * q), 16, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+    cs_src += cs_units;
+    if (--cs_left == 0) cs_phase_step();
+  };
   if (wid >= WAVES) {
     // =====================================================================================================================
     // consumer wave (plane kk, input block bI, output block bJ): the 32 x 32 block (kk, bI, bJ) of every hidden matrix; the
@@ -316,15 +341,29 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_DO(...) __VA_ARGS__
 #endif
     // the barrier sequence of the producers' tile program, with this wave's share of the products between the barriers
+    if (cs_left <= 0) cs_left = -1;
+    cs_next(0, false);                      // (chunk 0: issued by the producers in their prologue)
+    int nb_c = 1;
+    // a forward interval: this wave's slice of the NEXT step's chunk goes out first and has landed in front of the barrier
+#define S6_CFWD(...)                                                          \
+  {                                                                           \
+    cs_next(nb_c, true); nb_c ^= 1;                                           \
+    __VA_ARGS__                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0) */      \
+    S6_TL(400);                                                               \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    S6_TL(500);                                                               \
+  }
     for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
       for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
-        S6_CBAR()
-        if (j == 0) { S6_DO(consume_first(0, 4);) }
-        S6_CBAR()
-        if (j == 0) { S6_DO(consume_first(4, 8);) }
-        S6_CBAR()
-        S6_CBAR()
+        S6_CFWD()
+        S6_CFWD(if (j == 0) { S6_DO(consume_first(0, 4);) })
+        S6_CFWD(if (j == 0) { S6_DO(consume_first(4, 8);) })
+        S6_CFWD()
       }
+      for (int q = 0; q < 4 * nh; ++q) { cs_next(nb_c, false); nb_c ^= 1; }      // (the adjoint steps' chunks: the producers issue them)
       // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
       S6_CBAR()
       S6_DO(consume_last(0, 3);)
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     __syncthreads();
     S6_DO(consume_first(0, 8);)
     __syncthreads();
+#undef S6_CFWD
 #undef S6_DO
 #undef S6_HID_LAYER
 #undef S6_HID_TILES
@@ -395,32 +435,6 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   float* dzs = sm + sm_tot + (long)wid * pw;
   float* sks = dzs + r * 64;
   float* inp = sks + r * 64;
-  // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
-  const int NPC = (r + 1) * NCH;
-  const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
-  long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
-  auto cs_phase_step = [&]() {
-    ++cs_phase;
-    if (cs_phase < 1 + nh) {
-      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
-    }
-    if (cs_groups <= 0) { cs_left = -1; return; }
-    --cs_groups; cs_phase = 0;
-    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
-  };
-  auto cs_next = [&](int buf) {
-    if (cs_left < 0) return;
-    bf16x8* dst = chunks + buf * CF;
-#pragma unroll
-    for (int q = 0; q < QF; ++q)
-      if (wid * 64 + NT * q < cs_units)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cs_src + tid + NT * q),
-                                         (__attribute__((address_space(3))) void*)(dst + wid * 64 + NT * q), 16, 0, 0);
-    asm volatile("" ::: "memory");
-    cs_src += cs_units;
-    if (--cs_left == 0) cs_phase_step();
-  };
   auto prefetch_inputs = [&](long tgn, int set) {
     long t16n = tgn * WAVES + wid;
     if (t16n >= nt16) t16n = nt16 - 1;
@@ -450,8 +464,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   };
   prefetch_inputs(blockIdx.x, 0);
   if (cs_left <= 0) cs_left = -1;
-  cs_next(0);
+  cs_next(0, true);
   __syncthreads();
+  bool dma_mine = false;                                 // forward steps: the consumer waves issue the chunk DMA
   int cbuf = 0, nbuf = 1;
   int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
   float loss_lane = 0.f;
@@ -465,12 +480,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CHUNK(...)                                                         \
   {                                                                           \
     S6_TL(100);                                                               \
-    cs_next(nbuf);                                                            \
+    cs_next(nbuf, dma_mine);                                                  \
     S6_TL(200);                                                               \
     const bf16x8* cur = chunks + cbuf * CF;                                   \
-    if (NIF_S6_GPRIO) { if (wid < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); } \
     __VA_ARGS__                                                               \
-    if (NIF_S6_GPRIO) __builtin_amdgcn_s_setprio(0);                          \
     S6_TL(300);                                                               \
     __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
     S6_TL(400);                                                               \
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #if NIF_S6_VMRING
 #define S6_CHUNK_RING(PRE_, ...)                                              \
   {                                                                           \
-    cs_next(nbuf);                                                            \
+    cs_next(nbuf, dma_mine);                                                  \
     PRE_                                                                      \
     asm volatile("" ::: "memory");                                            \
     const bf16x8* cur = chunks + cbuf * CF;                                   \
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     first_layer(h);
     prefetch_inputs(tg + gridDim.x, (iset + 1) & 1);
     // ---- hidden hyper-matrices, forward ---------------------------------------------------------------------------------------
+    dma_mine = false;
     for (int j = 0; j < nh; ++j) {
 #if !NIF_S6_RING
       if (active) st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
@@ -651,6 +665,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     f32x4 dnext[NBL], hin[NBL];
 #pragma unroll
     for (int b = 0; b < NBL; ++b) hin[b] = h[b];
+    dma_mine = true;
     for (int j = nh - 1; j >= 0; --j) {
       f32x4 ga[NBL];
       tag_cos<NBL>(hin, dnext);

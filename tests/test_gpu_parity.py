@@ -1,6 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C-ABI / the drop-in Python surface) against
 the fp64 NumPy oracle on identical inputs and weights.  Tolerances: predictions and loss within
-1e-5 rel-L2 (BASELINE.json north_star, fp32); gradients within 2e-4 rel-L2 per tensor (fp32
+1e-5 rel-L2 (BASELINE.json north_star, fp32); gradients within 5e-5 rel-L2 per tensor since r5 (fp32
 accumulation over the batch vs fp64)."""
 import numpy as np
 import pytest
@@ -222,7 +222,9 @@ def test_loss_and_grad_match_oracle(name, weighted):
     loss, g = m._engine.loss_and_grad(x, y, s)
     lref, gref = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64),
                                  None if s is None else s.astype(np.float64))
-    assert abs(loss - lref) <= 1e-5 * abs(lref), (loss, lref)
+    # r5 bars (tools/exp/grad_survey.py over these 60 configs x 2: loss <= 5.0e-7, flat gradient <= 9.2e-6, worst tensor 1.9e-5 of
+    # (its norm + 5e-3 of the whole gradient's) -- since the data adjoint runs on half pairs; r1-r4: 1e-5 / 1e-4 / 2e-4)
+    assert abs(loss - lref) <= 2e-6 * abs(lref), (loss, lref)
     off = 0
     gnorm = np.linalg.norm(O.flatten(gref))
     for (nm, shp), gr in zip(spec.param_shapes(), gref):
@@ -230,8 +232,8 @@ def test_loss_and_grad_match_oracle(name, weighted):
         gg = g[off:off + k].reshape(shp)
         off += k
         err = np.linalg.norm(gg - gr)
-        assert err <= 2e-4 * np.linalg.norm(gr) + 1e-6 * gnorm, (nm, err, np.linalg.norm(gr))
-    assert _rel(g, O.flatten(gref)) < 1e-4
+        assert err <= 5e-5 * np.linalg.norm(gr) + 2.5e-7 * gnorm, (nm, err, np.linalg.norm(gr))
+    assert _rel(g, O.flatten(gref)) < 3e-5
 
 
 def test_adam_steps_follow_oracle():
@@ -1258,9 +1260,11 @@ def _oracle_grad_chunked(spec, ws, x, y, chunk=2048):
 
 
 def test_full_size_gradient_split_path_vs_fp32_mfma_vs_oracle():
-    """The training step's gradient products run as bf16 splits (data adjoint: 3 products, weight gradients: hi/lo).  At the
-    benchmark size (2^20 points, 4x64): every tensor of the flat gradient against the same step on the f32-input MFMAs
-    (`fp32_mfma` option: fmaf-exact products), and both against the fp64 oracle on a 65 536-point sub-batch."""
+    """The training step's products run as 16-bit pairs (r5: forward and data adjoint as HALF (hi, lo) pairs, three products, fp32-grade;
+    weight gradients as bf16 hi/lo pairs).  At the benchmark size (2^20 points, 4x64): every tensor of the flat gradient against the
+    same step on the f32-input MFMAs (`fp32_mfma` option: fmaf-exact products), and both against the fp64 oracle on a 65 536-point
+    sub-batch.  Bars re-tightened in r5 to ~3x what tools/exp/graderr.py measures (default path vs oracle: flat 1.3e-6, worst tensor
+    1.7e-5 -- the ParameterNet's first layer, k_pnet_bwg's bf16 pairs; fp32-MFMA path: 2.4e-7 / 2.9e-6; r4's bars: 1e-4 / 2e-4)."""
     m, model, x, y = _full_size_setup()
     e = m._engine
     spec = O.Spec("NIFMultiScale", m.cfg_shape_net, m.cfg_parameter_net)
@@ -1269,19 +1273,19 @@ def test_full_size_gradient_split_path_vs_fp32_mfma_vs_oracle():
     e.set_option("fp32_mfma", 1)
     lf, gf = e.loss_and_grad(x, y)
     e.set_option("fp32_mfma", 0)
-    assert abs(ls - lf) <= 2e-6 * abs(lf), (ls, lf)
+    assert abs(ls - lf) <= 5e-7 * abs(lf), (ls, lf)
     rel = _per_tensor_rel(spec, gs, gf)
-    assert max(rel.values()) < 2e-4, rel
-    assert _rel(gs, gf.astype(np.float64)) < 5e-5
+    assert max(rel.values()) < 5e-5, rel
+    assert _rel(gs, gf.astype(np.float64)) < 5e-6
     n_s = 1 << 16
     lo_, go_ = _oracle_grad_chunked(spec, ws, x[:n_s], y[:n_s])
     for fp32 in (0, 1):
         e.set_option("fp32_mfma", fp32)
         l_, g_ = e.loss_and_grad(x[:n_s], y[:n_s])
-        assert abs(l_ - lo_) <= 1e-5 * abs(lo_), (fp32, l_, lo_)
+        assert abs(l_ - lo_) <= 1e-6 * abs(lo_), (fp32, l_, lo_)
         rel = _per_tensor_rel(spec, g_, go_)
-        assert max(rel.values()) < 2e-4, (fp32, rel)
-        assert _rel(g_, go_) < (1e-4 if fp32 == 0 else 5e-5), (fp32, _rel(g_, go_))
+        assert max(rel.values()) < (5e-5 if fp32 == 0 else 1e-5), (fp32, rel)
+        assert _rel(g_, go_) < (5e-6 if fp32 == 0 else 1e-6), (fp32, _rel(g_, go_))
     e.set_option("fp32_mfma", 0)
 
 
