@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--only", default=None)
     ap.add_argument("--exact", action="store_true", help="--only names ONE config (default: every config whose name contains it)")
+    ap.add_argument("--out", default=None, help="where the JSON document goes (default: gpurun_out/bench_configs.json for a full run, "
+                    "nothing for an --only run: tools/pmc_configs.sh calls this per config under the profiler)")
     a = ap.parse_args()
     import nif_amd
     from nif_amd.engine import DeviceArray
@@ -237,8 +239,10 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     # ONE JSON document (json.load works on it; r4's profiles/r04_configs.json was the per-line log): copy to profiles/rNN_configs.json
     doc = {"csrc_sha": sha, "traffic_source": None if tj is None else tj.get("source"), "configs": out}
-    with open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w") as f:
-        json.dump(doc, f, indent=1)
+    path = a.out or (None if a.only else os.path.join(ROOT, "gpurun_out", "bench_configs.json"))
+    if path:
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,6 @@ if [ "${2:-}" != notests ]; then
   echo "gpu tests rc=$?"; tail -4 gpurun_out/${TAG}_gpu_tests.txt
 fi
 tools/profile_round.sh $TAG
-timeout 900 python tools/bench_configs.py > gpurun_out/${TAG}_configs.json 2> gpurun_out/${TAG}_configs.err
+timeout 900 python tools/bench_configs.py --out gpurun_out/${TAG}_configs_doc.json > gpurun_out/${TAG}_configs.json 2> gpurun_out/${TAG}_configs.err
 echo "configs rc=$?"
 cat gpurun_out/${TAG}_default/bench.json

@@ -17,7 +17,9 @@ open(ks, "w").write("\n".join(out) + "\n")
 pm = os.path.join(ROOT, "profiles", tag + "_pmc_default.md")
 hdrp = re.sub(r"csrc [0-9a-f]{16}", "csrc " + sha, open(pm).read().split("### `")[0])
 open(pm, "w").write(hdrp + open(os.path.join(d, "pmc.md")).read())
-cfg = os.path.join(ROOT, "gpurun_out", tag + "_configs.json")
+# the per-config table: tools/bench_configs.py's JSON DOCUMENT (gpu_round.sh copies it next to the per-line log)
+import json
+cfg = os.path.join(ROOT, "gpurun_out", tag + "_configs_doc.json")
 if os.path.exists(cfg):
-    open(os.path.join(ROOT, "profiles", tag + "_configs.json"), "w").write(open(cfg).read())
+    json.dump(json.load(open(cfg)), open(os.path.join(ROOT, "profiles", tag + "_configs.json"), "w"), indent=1)
 print(sha, rows[0]["Name"][:30], rows[0]["AverageNs"])
