@@ -504,9 +504,15 @@ bool gw_da_bf16_ok(int NBI, int NBO, int r) {
   if (NBI == 4) return use_gw8 && (r == 0 || r == 1);      // k_gw8<R, DAB>
   return gw_use_lds() && NBI <= 2;                         // k_gw_lds<.., DAB>
 }
+// ... and their hidden matrices' INPUT rows as 16-bit phases (r5)?  One reader: k_gw8<R, true, true>, next to bf16 dL/da rows
+bool gw_in_ph16_ok(int NBI, int NBO, int r) {
+  static const bool on = [] { const char* e = getenv("NIF_H_PH16"); return !(e && e[0] == '0'); }();
+  return on && NBI == 4 && gw_da_bf16_ok(NBI, NBO, r);
+}
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st);
 int launch_gw_mfma(const GwArgs& a_, int NBI, int NBO, int rows, hipStream_t st) {
   const GwArgs a = gw_fix(a_);
+  if (a.in_ph16 && !(a.da_bf16 && gw_in_ph16_ok(NBI, NBO, a.r))) return -1;
   // bf16 dL/da rows have readers of two forms only (k_gw8<R, true>, k_gw_lds<1|2, .., true>): anything else would read them as fp32
   if (a.da_bf16 && !gw_da_bf16_ok(NBI, NBO, a.r)) return -1;
   constexpr int WV = NIF_GW_WAVES;

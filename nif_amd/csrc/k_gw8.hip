@@ -24,6 +24,7 @@
 #endif
 typedef __bf16 g8_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 g8_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short g8_s16x4 __attribute__((ext_vector_type(4)));
 typedef float g8_f32x16 __attribute__((ext_vector_type(16)));
 
 // byte offset of points [p0, p0+4) of feature f inside a [128][32] bf16 plane (64-byte rows, 16-byte columns swizzled)
@@ -35,7 +36,10 @@ __device__ __forceinline__ int g8_off(int f, int p0) { return f * 64 + ((((p0 >>
 
 // DAB (mixed_bfloat16, r3): the dL/da stash holds bf16 rows (k_snet4<8, .., PR> writes them) and the sums are the policy's: one
 // product bf16(zt_k h_in) x dL/da per operand pair -- the dL/da pieces go to the operand plane as they are, no lo planes
-template <int R, bool DAB = false>   // R = 1: planes k = 0 (x zt), 1; R = 0: one plane
+// PH (r5, with DAB): the IN stash holds 16-bit PHASE rows (k_snet3_dev.h: q = rint(65536 f), f the reduced argument of the layer's
+// sine in revolutions) -- 8 bytes per piece instead of 16, h = v_sin_f32(q / 65536) rebuilt here (4 sines per piece: the kernel is
+// bound by its load stream, not by the VALU)
+template <int R, bool DAB = false, bool PH = false>   // R = 1: planes k = 0 (x zt), 1; R = 0: one plane
 __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   extern __shared__ __attribute__((aligned(16))) char g8sm[];
   constexpr int NPL = R + 1;
@@ -68,14 +72,21 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   // third set (registers: 1.12 -> 2.1 ms on cfg-3), the bf16-row forms do not move.  Also measured and not kept: the split of
   // tile t + 1 sharing the barrier interval with the products of tile t, the two waves of a SIMD in opposite order (+10 %)
   constexpr int NS = (R == 0 && !DAB) ? 3 : 2;
-  f32x4 rin[NS][2], rda[DAB ? 1 : NS][2], rz[NS];
+  f32x4 rin[PH ? 1 : NS][2], rda[DAB ? 1 : NS][2], rz[NS];
   g8_bf16x4 rdb[DAB ? NS : 1][2];
+  g8_s16x4 rph[PH ? NS : 1][2];
 #define G8_LOAD(SET_, T_)                                                                          \
   {                                                                                                \
     const float* in_ = A.IN + (T_) * (128 * 32);                                                   \
     const float* da_ = A.DA + (T_) * (128 * 32);                                                   \
-    rin[SET_][0] = *reinterpret_cast<const f32x4*>(in_ + f0 * 32 + p0);                            \
-    rin[SET_][1] = *reinterpret_cast<const f32x4*>(in_ + f1 * 32 + p0);                            \
+    if (PH) {                                                                                      \
+      const short* ph_ = reinterpret_cast<const short*>(A.IN) + (T_) * (128 * 32);                 \
+      rph[PH ? SET_ : 0][0] = *reinterpret_cast<const g8_s16x4*>(ph_ + f0 * 32 + p0);              \
+      rph[PH ? SET_ : 0][1] = *reinterpret_cast<const g8_s16x4*>(ph_ + f1 * 32 + p0);              \
+    } else {                                                                                       \
+      rin[PH ? 0 : SET_][0] = *reinterpret_cast<const f32x4*>(in_ + f0 * 32 + p0);                 \
+      rin[PH ? 0 : SET_][1] = *reinterpret_cast<const f32x4*>(in_ + f1 * 32 + p0);                 \
+    }                                                                                              \
     if (DAB) {                                                                                     \
       const __bf16* db_ = reinterpret_cast<const __bf16*>(A.DA) + (T_) * (128 * 32);               \
       rdb[DAB ? SET_ : 0][0] = *reinterpret_cast<const g8_bf16x4*>(db_ + f0 * 32 + p0);            \
@@ -107,16 +118,19 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
       f32x4 dav;                                                                                                       \
       if (DAB) { _Pragma("unroll") for (int e = 0; e < 4; ++e) dav[e] = (float)rdb[DAB ? RS : 0][j][e]; }              \
       else dav = rda[DAB ? 0 : RS][j];                                                                                 \
+      f32x4 hv;                                                                                                        \
+      if (PH) { _Pragma("unroll") for (int e = 0; e < 4; ++e) hv[e] = __builtin_amdgcn_sinf((float)(int)rph[PH ? RS : 0][j][e] * (1.0f / 65536.0f)); } \
+      else hv = rin[PH ? 0 : RS][j];                                                                                   \
       if (R) {                                                                                                         \
-        const f32x4 zin = {rin[RS][j][0] * rz[RS][0], rin[RS][j][1] * rz[RS][1], rin[RS][j][2] * rz[RS][2], rin[RS][j][3] * rz[RS][3]}; \
+        const f32x4 zin = {hv[0] * rz[RS][0], hv[1] * rz[RS][1], hv[2] * rz[RS][2], hv[3] * rz[RS][3]};                \
         split_store(S + 0 * PLANE, S + 1 * PLANE, f, zin);              /* plane 0: zt h */                            \
-        split_store(S + 2 * PLANE, S + 3 * PLANE, f, rin[RS][j]);       /* plane 1: h */                               \
+        split_store(S + 2 * PLANE, S + 3 * PLANE, f, hv);               /* plane 1: h */                               \
         if (wbias) {                                                                                                   \
           bsum[j][0] += (dav[0] * rz[RS][0] + dav[1] * rz[RS][1]) + (dav[2] * rz[RS][2] + dav[3] * rz[RS][3]);         \
           bsum[j][1] += (dav[0] + dav[1]) + (dav[2] + dav[3]);                                                         \
         }                                                                                                              \
       } else {                                                                                                         \
-        split_store(S + 0 * PLANE, S + 1 * PLANE, f, rin[RS][j]);                                                      \
+        split_store(S + 0 * PLANE, S + 1 * PLANE, f, hv);                                                              \
         if (wbias) bsum[j][0] += (dav[0] + dav[1]) + (dav[2] + dav[3]);                                                \
       }                                                                                                                \
       if (DAB) *reinterpret_cast<g8_bf16x4*>(S + 2 * NPL * PLANE + g8_off(f, p0)) = rdb[DAB ? RS : 0][j];              \
@@ -202,6 +216,16 @@ bool gw8_supported(const GwArgs& a, int NBI, int NBO) {
 void launch_gw8(const GwArgs& a, int rows, hipStream_t st) {
   if (a.da_bf16) {
     const size_t shm = (size_t)2 * (2 * (a.r + 1) + 2) * 128 * 64;
+    if (a.in_ph16) {
+      if (a.r == 1) {
+        (void)hipFuncSetAttribute((const void*)k_gw8<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL((k_gw8<1, true, true>), dim3(rows), dim3(512), shm, st, a);
+      } else {
+        (void)hipFuncSetAttribute((const void*)k_gw8<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL((k_gw8<0, true, true>), dim3(rows), dim3(512), shm, st, a);
+      }
+      return;
+    }
     if (a.r == 1) {
       (void)hipFuncSetAttribute((const void*)k_gw8<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_gw8<1, true>), dim3(rows), dim3(512), shm, st, a);

@@ -246,6 +246,89 @@ __device__ __forceinline__ void sine16_tag_sc(const f32x4 (&x_)[NBL], f32x4 (&h)
       }
     }
 }
+// ---- 16-bit PHASE stash (r5; mixed_bfloat16, 128-wide nets: k_snet4<8, .., PR = 1> -> k_gw8<R, true, true>) ---------------------------
+// Under the policy the stashed layer input h = sin(a) has two readers: the adjoint sweep (cos(a), and h itself for the dL/dz dot
+// products) and the weight-gradient kernel, whose operand is bf16(h).  Both can be rebuilt from the reduced argument: the stash row
+// holds q = rint(65536 f) as int16, f = a / 2 pi - rint(a / 2 pi) in [-1/2, 1/2] (q = +32768 wraps to -32768: the same angle), and a
+// reader takes sin / cos of q / 65536 revolutions on v_sin_f32 / v_cos_f32.  |delta a| <= 2 pi 2^-17 = 4.8e-5, i.e. the rebuilt
+// values are within 4.8e-5 of the exact ones where the policy's own operand rounding is 2^-9 relative -- for HALF the bytes of the
+// fp32 row on the store and on both reads (the stash traffic IS the 128-wide kernels' time: DESIGN 5.4).
+// sine16_tag with the phases on the side: ph[2 b + (v >> 1)] = q of element (b, v) in its low (v even) / high (v odd) half
+template <int NBL>
+__device__ __forceinline__ void sine16_tag_ph(const f32x4 (&a)[NBL], f32x4 (&h)[NBL], unsigned (&ph)[2 * NBL]) {
+  const f32x2 M = {12582912.0f, 12582912.0f}, Q = {65536.0f, 65536.0f};
+  if (sine16_big<NBL>(a)) {
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; v += 2) {
+        f32x2 f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          double t = (double)a[b][v + e] * 0.15915494309189535;
+          t -= __builtin_rint(t);
+          f[e] = (float)t;
+          const float sv = __builtin_amdgcn_sinf(f[e]);
+          h[b][v + e] = __uint_as_float((__float_as_uint(sv) & ~1u) | (fabsf(f[e]) > 0.25f ? 1u : 0u));
+        }
+        const f32x2 q = __builtin_elementwise_fma(f, Q, M);      // the mantissa's low 16 bits = rint(65536 f) mod 2^16
+        ph[2 * b + (v >> 1)] = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x05040100u);
+      }
+    return;
+  }
+  const f32x2 C = {0.15915493667125702f, 0.15915493667125702f}, CL = {6.420638326565253e-09f, 6.420638326565253e-09f};
+  const f32x2 IP = {0.318309886183790672f, 0.318309886183790672f};
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; v += 2) {
+      const f32x2 x = {a[b][v], a[b][v + 1]};
+      const f32x2 k = __builtin_elementwise_fma(x, C, M) - M;
+      f32x2 f = __builtin_elementwise_fma(x, C, -k);
+      f = __builtin_elementwise_fma(x, CL, f);
+      const f32x2 t = __builtin_elementwise_fma(x, IP, M);
+      const f32x2 q = __builtin_elementwise_fma(f, Q, M);
+      ph[2 * b + (v >> 1)] = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x05040100u);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sv = __builtin_amdgcn_sinf(f[e]);
+        unsigned o;
+        asm("s_nop 0\n\tv_bfi_b32 %0, 1, %1, %2" : "=v"(o) : "v"(__float_as_uint(t[e])), "v"(__float_as_uint(sv)));
+        h[b][v + e] = __uint_as_float(o);
+      }
+    }
+}
+// the tile's phases as int16 rows [tile32][feature][32 points] of 64 B (element index as st_store16)
+template <int NBL>
+__device__ __forceinline__ void st_store16_ph(float* __restrict__ slot, long row0, const unsigned (&ph)[2 * NBL], int g) {
+#pragma unroll
+  for (int b = 0; b < NBL; b += 2) {
+    unsigned short* q = reinterpret_cast<unsigned short*>(slot) + (row0 + (long)(16 * b + 4 * g) * 32);
+#pragma unroll
+    for (int bb = 0; bb < 2 && b + bb < NBL; ++bb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) q[(16 * bb + v) * 32] = (unsigned short)(ph[2 * (b + bb) + (v >> 1)] >> (16 * (v & 1)));
+  }
+}
+// ... read back as phases in REVOLUTIONS (f = q / 65536): ph_sin / ph_cos rebuild sin(a) / cos(a)
+template <int NBL>
+__device__ __forceinline__ void st_load16_ph(const float* __restrict__ slot, long row0, f32x4 (&f)[NBL], int g) {
+#pragma unroll
+  for (int b = 0; b < NBL; b += 2) {
+    const short* q = reinterpret_cast<const short*>(slot) + (row0 + (long)(16 * b + 4 * g) * 32);
+#pragma unroll
+    for (int bb = 0; bb < 2 && b + bb < NBL; ++bb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) f[b + bb][v] = (float)(int)q[(16 * bb + v) * 32] * (1.0f / 65536.0f);
+  }
+}
+template <int NBL>
+__device__ __forceinline__ void ph_cos(const f32x4 (&f)[NBL], f32x4 (&d)[NBL]) {
+#pragma unroll
+  for (int b = 0; b < NBL; ++b)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) d[b][v] = __builtin_amdgcn_cosf(f[b][v]);
+}
 // cos(a) from the tagged sine: sqrt(1 - s^2) with the sign from the tag bit
 template <int NBL>
 __device__ __forceinline__ void tag_cos(const f32x4 (&sn)[NBL], f32x4 (&d)[NBL]) {

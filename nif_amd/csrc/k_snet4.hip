@@ -182,6 +182,8 @@ bool snet4_sign_ring(const SNetArgs& a) { return !a.nif_skip; }
 // A.da_bf16` at the store), stated once next to it: the host derives the consumers' GwArgs.da_bf16 from THIS, not from a second copy
 // of the dispatch predicate
 bool snet4_writes_da_bf16(const SNetArgs& a) { return a.da_bf16 != 0 && a.prec == 1 && snet3_nbl(a.n) != 6; }
+// ... and the hidden matrices' INPUT rows as 16-bit phases: the kernel's PHC condition (plain tagged-sine training form, PR = 1, NBL = 8)
+bool snet4_writes_h_ph16(const SNetArgs& a) { return a.h_ph16 != 0 && a.prec == 1 && snet3_nbl(a.n) == 8 && !a.res && !a.nif_skip; }
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st) {
   const int NBL = snet3_nbl(a.n);
   const long nt16 = 2 * ((a.B + 31) / 32);

@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
   // half's range; class NIF keeps the bf16 splits): the planes carry a power of two s_jk per (matrix, plane), dL/da one per point,
   // scaled back exactly (biases pre-scaled in the LDS image, s_r / s_k in the latent combine, 1 / (4096 s_r) in the sine's constants)
   constexpr bool X16 = PR == 3;
+  // 16-bit phase stash of the layer inputs (r5, k_snet3_dev.h): plain SIREN training under mixed_bfloat16 on the 128-wide kernels,
+  // where the reader of the rows is k_gw8<R, true, true>; SNetArgs.h_ph16 switches it (nif_api: producer and readers agree)
+  constexpr bool PHC = TRAIN && SGN && MODE == 0 && PR == 1 && NBL == 8;
+  const bool ph16 = PHC && A.h_ph16 != 0; (void)ph16;
   constexpr int CFH = CP ? NBS * 64 : (X16 ? CB : CF), CBH = CP ? NBS * 64 : CB;   // units per HIDDEN-matrix chunk
   constexpr int QF = (CF + NT - 1) / NT;
   // LDS ring of the chunk stream: NBUF buffers, the DMA runs DIST = NBUF - 1 chunk steps ahead of the MFMAs.  r2 had two buffers
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
 
     NIF_TL(1);
     f32x4 h[NBL], acc[NBL];
+    unsigned phs[PHC ? 2 * NBL : 1]; (void)phs;      // 16-bit phase stash: the phases of h (k_snet3_dev.h, sine16_tag_ph)
     // ---- first layer: a = sum_k zt_k (x . (w0 W1^(k)) + b1^(k)) ---------------------------------------------------
     {
       const float* s0 = sm + r * nsm + 4 * g;           // the constant plane starts the sum
@@ -322,7 +327,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
         acc[b] += zt * s;
       }
     }
-    if (TRAIN && SGN) sine16_tag<NBL>(acc, h);          // h = sin(a), the cosine's sign in its last mantissa bit
+    if (TRAIN && SGN) {                                 // h = sin(a), the cosine's sign in its last mantissa bit
+      if constexpr (PHC) { if (ph16) sine16_tag_ph<NBL>(acc, h, phs); else sine16_tag<NBL>(acc, h); }
+      else sine16_tag<NBL>(acc, h);
+    }
     else {
       f32x4 d[NBL];
       act16<NBL, ACT>(A.act, acc, h, d, n, g);
@@ -336,7 +344,11 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
     // ---- hidden hyper-matrices: a = b^(r) + h (w0 M^(r)) + sum_{k<r} zt_k (b^(k) + h (w0 M^(k))) -------------------
     f32x4 ublk[MODE == 1 ? NBL : 1];
     for (int j = 0; j < nh; ++j) {
-      if (TRAIN && active) { st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); vm_note(4 * NBL); }
+      if (TRAIN && active) {
+        if constexpr (PHC) { if (ph16) st_store16_ph<NBL>(IN0 + (long)j * sstride, row0, phs, g); else st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g); }
+        else st_store16<NBL>(IN0 + (long)j * sstride, row0, h, g);
+        vm_note(4 * NBL);
+      }
       bf16x8 b0[NCH], b1[NCH], b2[NCH];
       if (X16) split2h<NBL>(h, 4096.0f, b0, b1);
       else split3p<NBL, PR>(h, b0, b1, b2);
@@ -361,7 +373,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       for (int ks = 0; ks < NCH; ++ks) NIF_FWD_STEP(ks, acc)
       NIF_TL(30 + j);
       if (TRAIN && SGN && X16) sine16_tag_sc<NBL>(acc, acc, scl[(j * (r + 1) + r) * 2 + 1] * (1.0f / 4096.0f));
-      else if (TRAIN && SGN) sine16_tag<NBL>(acc, acc);
+      else if (TRAIN && SGN) {
+        if constexpr (PHC) { if (ph16) sine16_tag_ph<NBL>(acc, acc, phs); else sine16_tag<NBL>(acc, acc); }
+        else sine16_tag<NBL>(acc, acc);
+      }
       else {
         if (X16) {
           const float inv = scl[(j * (r + 1) + r) * 2 + 1] * (1.0f / 4096.0f);
@@ -537,8 +552,10 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
                 ub[b][v] = __uint_as_float((__float_as_uint(t) & ~1u) | (__float_as_uint(hin[b][v]) & 1u));
               }
             tag_cos<NBL>(ub, dnext);
-          } else tag_cos<NBL>(hin, dnext);
-          st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
+          } else if (PHC && ph16 && j < nh - 1) ph_cos<NBL>(hin, dnext);      // (hin holds the PHASE of a_j since the load below)
+          else tag_cos<NBL>(hin, dnext);
+          if (PHC && ph16) st_load16_ph<NBL>(IN0 + (long)j * sstride, row0, hin, g);
+          else st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);   // h_j: dz dot product now, sin(a) of layer j-1 next
         } else {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[((j + 1) * NBL + b) * 64 + lane];
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
 #pragma unroll
           for (int b = 0; b < NBL; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) s = fmaf(hin[b][v], U[b][v], s);
+            for (int v = 0; v < 4; ++v) s = fmaf((PHC && ph16) ? __builtin_amdgcn_sinf(hin[b][v]) : hin[b][v], U[b][v], s);
           if (k == 0) {
 #pragma unroll
             for (int b = 0; b < NBL; ++b) gh[b] = zt * U[b];
@@ -634,7 +651,8 @@ __global__ __launch_bounds__(256, (NBL <= 4 ? NIF_S4_OCC : ((NBL == 8 && LL && T
       {
         f32x4 ga[NBL];
         if (SGN) {
-          tag_cos<NBL>(hin, dnext);
+          if (PHC && ph16) ph_cos<NBL>(hin, dnext);
+          else tag_cos<NBL>(hin, dnext);
         } else {
 #pragma unroll
           for (int b = 0; b < NBL; ++b) dnext[b] = reinterpret_cast<const f32x4*>(dring)[b * 64 + lane];

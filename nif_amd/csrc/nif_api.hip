@@ -1021,7 +1021,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
   if (!fused_p) { const int rcp = ensure_packed_p32(c); if (rcp) return rcp; }
   { ProfScope p_(c, NIF_PROF_PNET_FWD); launch_pnet(pa, c->NSTB, !fused_p, c->st); }
   int nloss = (int)((ntiles * 32 + 255) / 256);
-  bool ll_dab = false;
+  bool ll_dab = false, ll_ph = false;
   if (ns > 0) {   // Sobolev: primal + tangents + their adjoint on k_sob<.., LL>; stashes and DPHI hold (1 + ns) blocks of tiles
     SNetArgs sa; int rc = fill_snet_ll_sob(c, sa, xin, B); if (rc) return rc;
     sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
@@ -1054,6 +1054,10 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
       ll_dab = sa.prec == 1 && (nbl == 2 || nbl == 4 || nbl == 8) && gw_da_bf16_ok(c->NB, c->NB, 0);
       sa.da_bf16 = ll_dab ? 1 : 0;
       if (snet4_writes_da_bf16(sa) != ll_dab) return fail(NIF_ERR_STATE, "internal: dL/da stash format of producer and plan disagree");
+      // ... and, on the 128-wide kernel, the hidden matrices' input rows as 16-bit phases (k_gw8<0, true, true> reads them)
+      sa.h_ph16 = (ll_dab && nbl == 8 && !c->cfg.s_resblock && gw_in_ph16_ok(c->NB, c->NB, 0)) ? 1 : 0;
+      ll_ph = snet4_writes_h_ph16(sa);
+      if (ll_ph != (sa.h_ph16 != 0)) return fail(NIF_ERR_STATE, "internal: layer-input stash format of producer and plan disagree");
     }
     nloss = launch_snet4(sa, true, true, c->st);
     const long need = (long)nloss * 4 * snet3_ring_floats_per_wave(c->n, c->nh);
@@ -1110,6 +1114,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
       else { const int i = mi / 2; w_off = (mi & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (mi & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
       g.W = dense_ref(w_off, c->n, c->n); g.Bv = vec_ref(b_off, c->n);
       g.da_bf16 = ll_dab ? 1 : 0;
+      g.in_ph16 = ll_ph ? 1 : 0;
       if (launch_gw_mfma(g, c->NB, c->NB, rows, c->st) < 0) return fail(NIF_ERR_STATE, "internal: bf16 dL/da stash rows without a reader of that form");
     }
     sbase(g); g.IN = sST + (long)nms * c->slot_s; g.SM = c->DPHI; g.nc = c->r * c->so;
@@ -1283,11 +1288,15 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
     if (ns > 0) dab = dab && sobw_supported(sa, ns, sp && sp->any_par);
     else dab = dab && c->use_snet4 && !fused_gw;
     sa.da_bf16 = dab ? 1 : 0;
+    // ... and, on the 128-wide kernel, the hidden matrices' input rows as 16-bit phases (k_gw8<R, true, true> reads them)
+    sa.h_ph16 = (dab && ns == 0 && nbl == 8 && !c->cfg.s_resblock && !sa.nif_skip && gw_in_ph16_ok(c->NB, c->NB, c->r)) ? 1 : 0;
   }
   // what the producer of this step really writes (its own predicate, next to its kernels); the readers below follow THAT
   const bool wrote_da_bf16 = ns > 0 ? sob_writes_da_bf16(sa, ns, sp && sp->any_par)
                                     : (!fused_gw && c->use_snet4 && snet4_writes_da_bf16(sa));
   if (wrote_da_bf16 != (sa.da_bf16 != 0)) return fail(NIF_ERR_STATE, "internal: dL/da stash format of producer and plan disagree");
+  const bool wrote_h_ph16 = ns == 0 && !fused_gw && c->use_snet4 && snet4_writes_h_ph16(sa);
+  if (wrote_h_ph16 != (sa.h_ph16 != 0)) return fail(NIF_ERR_STATE, "internal: layer-input stash format of producer and plan disagree");
   {
     ProfScope p_(c, NIF_PROF_SNET, sa_st);
     if (ns > 0) {
@@ -1352,6 +1361,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   for (int j = 0; j < c->nh; ++j) {
     sbase(g); g.IN = sIN + (long)j * c->slot_s; g.DA = sDA + (long)(j + 1) * c->slot_s; g.Z = sa.Z; g.r = c->r; g.scale = om_s;
     g.da_bf16 = wrote_da_bf16 ? 1 : 0;
+    g.in_ph16 = wrote_h_ph16 ? 1 : 0;
     const long wslot = (long)c->si * c->n + (long)j * c->n * c->n;
     const long bslot = (long)c->si * c->n + (long)c->nh * c->n * c->n + (long)c->n * c->so + c->n + (long)j * c->n;
     g.W = hyper_ref(c, wslot, c->n, c->n, c->n);

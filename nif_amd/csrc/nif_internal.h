@@ -123,6 +123,8 @@ struct SNetArgs {
   int prec;                               // 0: fp32-exact products; 1: mixed_bfloat16 policy (operands of the n x n products rounded to bf16);
                                           // 2: mixed_float16 (k_snet4<.., PR = 2> alone; every other kernel family treats it as 0)
   int da_bf16;                            // prec == 1: the hidden layers' dL/da stash rows in bf16 (the consumer is k_gw_lds<.., DAB>; nif_api decides)
+  int h_ph16;                             // prec == 1, 128-wide plain SIREN training: the hidden matrices' INPUT stash rows as 16-bit phases (k_snet3_dev.h;
+                                          // the readers are k_snet4's own adjoint sweep and k_gw8<R, true, true>: snet4_writes_h_ph16)
   int wg_cap;                             // k_snet4: at most this many workgroups (0 = fill the device); the chunk pipeline leaves room for stream B
 };
 // slot-ordered copy of the dense ShapeNet parameters of the last-layer class: [W1 | (hidden: unused) | Wl | b1 | bh_j | bl |
@@ -169,6 +171,7 @@ struct GwArgs {
   // gradient and (first layer) use the one-hot input e_seed[t / zt_mod - 1].  0 = plain batch (launchers fix up).
   long zt_mod, bias_ntiles;
   int seed[3];
+  int in_ph16;          // IN holds 16-bit phase rows (k_snet4<8, .., PR = 1> wrote them: snet4_writes_h_ph16); k_gw8<R, true, true> alone reads that form
   int da_bf16;          // DA holds bf16 rows (mixed_bfloat16: k_snet4<PR> / k_sobw<PR> wrote them); k_gw_lds / k_gw8 (gw_da_bf16_ok)
 };
 bool gw_da_bf16_ok(int NBI, int NBO, int r);
@@ -198,6 +201,8 @@ void launch_snet4_x16(const SNetArgs& a, bool train, int nblk, size_t shm, hipSt
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode = 0, float* pscale = nullptr);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+bool snet4_writes_h_ph16(const SNetArgs& a);    // ... and its hidden-matrix input rows as 16-bit phases
+bool gw_in_ph16_ok(int NBI, int NBO, int r);    // a reader of that form exists for this shape (k_gw8<R, true, true>; NIF_H_PH16=0 switches it off)
 bool snet4_writes_da_bf16(const SNetArgs& a);   // stash format the training launch of `a` produces (k_snet4.hip)
 bool sob_writes_da_bf16(const SNetArgs& a, int ns, bool any_par);   // same for launch_sob (k_sob.hip)
 // k_snet4's plain-SIREN training step with every ShapeNet weight gradient fused in (k_snet6.hip): one partial-gradient row and one

@@ -586,12 +586,24 @@ def _grad_round(rnd):
     return (lambda a_: a_) if rnd is None else getattr(rnd, "grad", rnd)
 
 
-def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False):
+def phase16(a):
+    """the 16-bit phase stash of the build (nif_amd/csrc/k_snet3_dev.h, sine16_tag_ph): the argument a of a SIREN layer as the
+    readers of the stash row rebuild it -- q = rint(65536 f), f = a / 2 pi - rint(a / 2 pi), a' = 2 pi q / 65536 (|a' - a| <= 4.8e-5
+    modulo 2 pi).  Test infrastructure: restates the cast point of the policy step on the 128-wide kernels."""
+    t = np.asarray(a, dtype=np.float64) / (2.0 * np.pi)
+    f = t - np.rint(t)
+    return 2.0 * np.pi * np.rint(65536.0 * f) / 65536.0
+
+
+def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False, stash_ph16=False):
     """loss, grads (Keras order) and predictions of NIF / NIFMultiScale in the plane formulation.
     rnd=None: exact; rnd=bf16_round: the build's mixed_bfloat16 policy.  stash_bf16 (with rnd): the hidden layers' weight-gradient
     sums take dL/da as the bf16 rows the fused kernel stashed and bf16(zt_k h_in) as the other operand, one product each
-    (k_gw_lds<.., DAB>: nets of 17..32 / 49..64 units on the bf16 kernels); biases sum the same bf16 dL/da."""
+    (k_gw_lds<.., DAB>: nets of 17..32 / 49..64 units on the bf16 kernels); biases sum the same bf16 dL/da.  stash_ph16 (plain SIREN,
+    with stash_bf16: the 128-wide kernels, r5): the hidden matrices' inputs reach the adjoint sweep and the weight-gradient sums as
+    sin / cos of the 16-bit phase (phase16) -- every cosine but the top layer's, every h_in of a hidden matrix."""
     assert spec.kind in (KIND_NIF, KIND_MS)
+    assert not stash_ph16 or (spec.kind == KIND_MS and not spec.s_res and stash_bf16)
     R = (lambda a: a) if rnd is None else rnd
     Rg = _grad_round(rnd)
     B = inputs.shape[0]
@@ -699,10 +711,14 @@ def planes_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=N
     else:
         for i in reversed(range(nh)):
             hin, a = acts[i]
-            ga = gh * np.cos(a)
+            if stash_ph16:      # slot i holds the phase of the layer below, slot i + 1 (i < nh - 1) this layer's
+                hin = np.sin(phase16(a0 if i == 0 else acts[i - 1][1]))
+                ga = gh * (np.cos(a) if i == nh - 1 else np.cos(phase16(a)))
+            else:
+                ga = gh * np.cos(a)
             wgrad_h(sl["wh"][i], hin, ga, om); bgrad(sl["bh"][i], ga, True)
             gh = back(sl["wh"][i], (n, n), ga, hin, om, True)
-    ga0 = gh * df(a0)
+    ga0 = gh * (np.cos(phase16(a0)) if stash_ph16 else df(a0))
     wgrad(sl["w1"], x, ga0, om); bgrad(sl["b1"], ga0)
     back(sl["w1"], (si, n), ga0, x, om, False)
     grads = pnet_backward(spec, ws, ptape, None, g_z_extra=gzt[:, :spec.r], g_last=[gM[:spec.r], gM[spec.r]])
@@ -755,7 +771,7 @@ def snet_phi(spec, ws, x, keep=False, rnd=None):
     return phi
 
 
-def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
+def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False, stash_ph16=False):
     *_, rest = _pnet_split(spec, ws)
     first, hidden, bott, _ = _snet_split(spec, rest)
     R = (lambda a_: a_) if rnd is None else rnd      # policy: dL/da and the weights rounded in the data adjoint; weight gradients fp32
@@ -767,7 +783,7 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
     g_bott = [hL.T @ g, g.sum(0)]
     gh = g @ bott[0].T
     g_hidden = []
-    for lay, rec in zip(reversed(hidden), reversed(tape[1:])):
+    for li, lay, rec in zip(reversed(range(1, len(tape))), reversed(hidden), reversed(tape[1:])):
         if rec[0] == "sres":
             _, hin, a1, t, a2 = rec
             ga2 = 0.5 * gh * np.cos(a2)
@@ -779,11 +795,15 @@ def _snet_backward(spec, ws, tape_h, g_phi, rnd=None, stash_bf16=False):
             g_hidden.append([gw1, gb1, gw2, gb2])
         else:
             _, hin, a1 = rec
-            ga1 = gh * np.cos(a1)
+            if stash_ph16:      # (16-bit phase stash: planes_loss_and_grad)
+                hin = np.sin(phase16(tape[li - 1][2]))
+                ga1 = gh * (np.cos(a1) if li == len(tape) - 1 else np.cos(phase16(a1)))
+            else:
+                ga1 = gh * np.cos(a1)
             g_hidden.append([om * (S(hin).T @ S(ga1)), S(ga1).sum(0)])
             gh = Rg(ga1) @ R(om * lay[0]).T
     _, x, a = tape[0]
-    ga = gh * np.cos(a)
+    ga = gh * (np.cos(phase16(a)) if stash_ph16 else np.cos(a))
     grads = [om * (x.T @ ga), ga.sum(0)]
     for g_ in reversed(g_hidden):
         grads += g_
@@ -836,7 +856,7 @@ def mse_loss(u, y, sample_weight=None):
     return per.sum() / u.shape[0]
 
 
-def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False):
+def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_global=None, rnd=None, stash_bf16=False, stash_ph16=False):
     """last-layer class under the build's mixed_bfloat16 policy (rnd=bf16_round): -> (loss, grads, u), the counterpart of
     planes_loss_and_grad for the shared dense ShapeNet (hidden n x n products on rounded operands, everything else fp32)"""
     assert spec.kind == KIND_LL
@@ -852,7 +872,8 @@ def ll_policy_loss_and_grad(spec, ws, inputs, y, sample_weight=None, batch_globa
     loss = ((e ** 2).mean(axis=1) * w_a).sum() / Bg
     g_u = 2.0 * e * w_a[:, None] / (Bg * spec.so)
     g_pout = np.einsum("bsj,bs->bj", phi, g_u)
-    g_snet = _snet_backward(spec, ws, stape, g_u[:, :, None] * pout[:, None, :], rnd=rnd, stash_bf16=stash_bf16 and rnd is not None)
+    g_snet = _snet_backward(spec, ws, stape, g_u[:, :, None] * pout[:, None, :], rnd=rnd, stash_bf16=stash_bf16 and rnd is not None,
+                            stash_ph16=stash_ph16 and stash_bf16 and rnd is not None)
     return loss, pnet_backward(spec, ws, ptape, g_pout) + g_snet + [g_u.sum(0)], u
 
 

@@ -1188,7 +1188,7 @@ def test_full_size_shard_sum_other_configs(which):
     elif bf:      # the policy on the 128-wide nets: bf16 dL/da stash rows through k_gw8<R, DAB> (r3)
         fn = O.ll_policy_loss_and_grad if spec.kind == O.KIND_LL else O.planes_loss_and_grad
         lref, gref = fn(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64), rnd=O.bf16_round,
-                        stash_bf16=_stash_bf16(spec))[:2]
+                        stash_bf16=_stash_bf16(spec), stash_ph16=_stash_ph16(spec))[:2]
     else:
         lref, gref = O.loss_and_grad(spec, ws64, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64))
     sub = grad_of(0, n_s, n_s)
@@ -1206,7 +1206,7 @@ def test_full_size_shard_sum_other_configs(which):
             ws_n = [np.nextafter(w.astype(np.float32), np.float32(np.inf) * rng2.choice([-1.0, 1.0], size=w.shape).astype(np.float32))
                     .astype(np.float64) for w in ws64]
             gref_n = fn(spec, ws_n, x[:n_s].astype(np.float64), y[:n_s].astype(np.float64), rnd=O.bf16_round,
-                        stash_bf16=_stash_bf16(spec))[1]
+                        stash_bf16=_stash_bf16(spec), stash_ph16=_stash_ph16(spec))[1]
             sens = _per_tensor_rel(spec, O.flatten(gref_n), O.flatten(gref))
             for nm, v in rel.items():
                 assert v < max(bar, 3.0 * sens[nm]), (nm, v, sens[nm])
@@ -1371,6 +1371,14 @@ def _stash_bf16(spec, xi=None):
             and all(j >= spec.pi for j in xi) and spec.r >= 1)
 
 
+def _stash_ph16(spec):
+    """... and the hidden matrices' INPUT rows as 16-bit phases (r5: plain step of the 128-wide plain-SIREN nets, k_snet4<8, .., PR = 1>
+    -> k_gw8<R, true, true>; NIF_H_PH16=0 switches it off)"""
+    import os
+    return (os.environ.get("NIF_H_PH16", "1") != "0" and _stash_bf16(spec) and (spec.n + 15) // 16 == 8 and not spec.s_res
+            and spec.kind in (O.KIND_LL, O.KIND_MS))
+
+
 def _make_policy(name, policy, boost=1.0):
     import nif_amd
     (kind, cs, cp), B = CONFIGS[name] if isinstance(name, str) else name
@@ -1398,7 +1406,7 @@ def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
     m, model, spec, ws, x, y, sw = _make_policy(name, "mixed_bfloat16")
     assert m.compute_Dtype == "bfloat16" and m.variable_Dtype == "float32" and m.mixed_policy_name == "mixed_bfloat16"
     x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
-    rl, rg, ru = O.planes_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec))
+    rl, rg, ru = O.planes_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec), stash_ph16=_stash_ph16(spec))
     u = model.predict(x)
     assert _rel(u, ru) < 5e-4, _rel(u, ru)
     loss, g = m._engine.loss_and_grad(x, y, sw)
@@ -1433,7 +1441,7 @@ def test_mixed_bfloat16_policy_on_the_last_layer_class(name):
     ws = [w.astype(np.float32).astype(np.float64) for w in ws]
     assert m.compute_Dtype == "bfloat16"
     x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
-    rl, rg, ru = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec))
+    rl, rg, ru = O.ll_policy_loss_and_grad(spec, ws, x64, y64, s64, rnd=O.bf16_round, stash_bf16=_stash_bf16(spec), stash_ph16=_stash_ph16(spec))
     u = model.predict(x)
     assert _rel(u, ru) < 5e-4, _rel(u, ru)
     loss, g = m._engine.loss_and_grad(x, y, sw)

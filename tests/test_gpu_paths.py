@@ -134,6 +134,9 @@ KNOBS = [
     ({"NIF_S6_POLICY": "1"}, "ms_cfg2_64x4", "plain", "mixed_float16"),
     ({"NIF_S6_POLICY": "0"}, "ms_cfg2_64x4", "plain", "mixed_float16"),    # k_snet4<.., PR = 2> + the fp32-row reductions
     ({"NIF_DA_BF16": "0"}, "ms_cfg5_64x4_si2", "sobolev", "mixed_bfloat16"),
+    ({"NIF_H_PH16": "0"}, "ms_cfg3_128x3", "plain", "mixed_bfloat16"),     # r5: fp32 layer-input stash rows on the 128-wide policy step (default: 16-bit phases)
+    ({"NIF_H_PH16": "1"}, "ms_cfg3_128x3", "plain", "mixed_bfloat16"),
+    ({"NIF_H_PH16": "0"}, "ll_cfg4_128x2_r10_so3", "plain", "mixed_bfloat16"),
 ]
 
 
@@ -144,7 +147,7 @@ def test_every_runtime_knob_against_the_oracle(case, tmp_path):
     out = str(tmp_path / "knob.npz")
     env = dict(os.environ)
     for k in ("NIF_FUSE_GW", "NIF_SIDE_PNET", "NIF_PBW_TOUCH", "NIF_PNET_STASH", "NIF_PNET_BF2", "NIF_GW8", "NIF_GW_LDS", "NIF_SOBW", "NIF_LL_MLP",
-              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY"):
+              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY", "NIF_H_PH16"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", KNOB_CHILD, name, mode, policy, out], env=env, cwd=ROOT, stdout=subprocess.PIPE,

@@ -443,3 +443,27 @@ def test_other_keras_losses_match_torch_autograd(name, loss):
         lm = O.sobolev_loss_and_grad(spec, [w - h * q for w, q in zip(ws, d)], inputs, y, gt, xi, 0.3, sw, loss=loss)[0]
         dd = sum((a * b).sum() for a, b in zip(g0, d))
         assert abs((lp - lm) / (2 * h) - dd) <= 2e-5 * max(1.0, abs(dd)), ((lp - lm) / (2 * h), dd)
+
+
+def test_phase16_stash_emulation():
+    """the 16-bit phase stash of the 128-wide policy step (oracle.phase16, r5): the rebuilt argument is within 2 pi 2^-17 of the exact
+    one modulo 2 pi, and the gradient that takes every stashed sine / cosine from it is a small, non-zero perturbation of the
+    bf16-stash form (both classes that have it)"""
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=4000) * 40.0
+    a2 = O.phase16(a)
+    d = np.abs(np.exp(1j * a) - np.exp(1j * a2))
+    assert d.max() <= 2.0 * np.pi * 2.0 ** -17 * 1.0001 and d.max() > 1e-6
+    assert np.abs(a2).max() <= np.pi * 1.0001
+    from tests.test_gpu_parity import CONFIGS
+    for name in ("ms_cfg3_128x3", "ll_cfg4_128x2_r10_so3"):
+        (kind, cs, cp), B = CONFIGS[name]
+        spec = O.Spec(kind, cs, cp)
+        ws = O.init_weights(spec, np.random.default_rng(11))
+        x = rng.uniform(-1, 1, size=(37, spec.pi + spec.si)); y = rng.uniform(-1, 1, size=(37, spec.so))
+        fn = O.ll_policy_loss_and_grad if spec.kind == O.KIND_LL else O.planes_loss_and_grad
+        l0, g0, _ = fn(spec, ws, x, y, rnd=O.bf16_round, stash_bf16=True)
+        l1, g1, _ = fn(spec, ws, x, y, rnd=O.bf16_round, stash_bf16=True, stash_ph16=True)
+        assert l0 == l1                                       # the forward pass does not see the stash
+        e = np.linalg.norm(O.flatten(g1) - O.flatten(g0)) / np.linalg.norm(O.flatten(g0))
+        assert 1e-7 < e < 1e-3, (name, e)
