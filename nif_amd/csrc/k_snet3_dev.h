@@ -301,6 +301,9 @@ __device__ __forceinline__ void sine16_tag_ph(const f32x4 (&a)[NBL], f32x4 (&h)[
 // the tile's phases as int16 rows [tile32][feature][32 points] of 64 B (element index as st_store16)
 template <int NBL>
 __device__ __forceinline__ void st_store16_ph(float* __restrict__ slot, long row0, const unsigned (&ph)[2 * NBL], int g) {
+#ifdef NIF_ABL_NOSTORE
+  if (ph[0] != 0x12345678u) return;
+#endif
 #pragma unroll
   for (int b = 0; b < NBL; b += 2) {
     unsigned short* q = reinterpret_cast<unsigned short*>(slot) + (row0 + (long)(16 * b + 4 * g) * 32);
@@ -313,6 +316,13 @@ __device__ __forceinline__ void st_store16_ph(float* __restrict__ slot, long row
 // ... read back as phases in REVOLUTIONS (f = q / 65536): ph_sin / ph_cos rebuild sin(a) / cos(a)
 template <int NBL>
 __device__ __forceinline__ void st_load16_ph(const float* __restrict__ slot, long row0, f32x4 (&f)[NBL], int g) {
+#ifdef NIF_ABL_NOLOAD
+  if (row0 != -12345) {
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) { f[b][0] = 0.05f; f[b][1] = 0.25f; f[b][2] = 0.125f; f[b][3] = -0.075f; }
+    return;
+  }
+#endif
 #pragma unroll
   for (int b = 0; b < NBL; b += 2) {
     const short* q = reinterpret_cast<const short*>(slot) + (row0 + (long)(16 * b + 4 * g) * 32);
