@@ -109,6 +109,16 @@ struct S6Args {
 #define NIF_S6_RECOMP0 1     // the first layer's output (input of hidden matrix 0) is recomputed in the adjoint from the tile's inputs
                              // (si FMAs + a sine per element) instead of going through the ring: a quarter of the ring traffic less
 #endif
+#ifndef NIF_S6_EARLYDEP
+#define NIF_S6_EARLYDEP 0    // 1 (r5, measured and NOT kept): deposit j is written INSIDE the last chunk step of adjoint layer j (its operands
+                             // are complete after the first one) so that it is visible at that step's barrier and the consumer waves run 5
+                             // of its 8 tiles during the producers' long vector interval of the next layer -- where they idle -- and 3 in
+                             // the chunk step behind it (default: 3 + 3 + 2 in three chunk steps); one barrier per round less.  Parity
+                             // green, 1.268 vs 1.254 ms per step (three same-box pairs): the s_memtime timeline
+                             // (profiles/r05_timeline_earlydep.txt) shows the deposit's ~150 vector instructions costing 1.1 k ticks in
+                             // the chunk step and saving 0.25-0.4 k in the vector block -- both producer waves of a SIMD run them at the
+                             // same moment wherever they stand, and behind the step's matrix instructions they do not overlap its LDS wait
+#endif
 #ifndef NIF_S6_CONS_PRIO
 #define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
 #endif
@@ -285,6 +295,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   }
     // the four chunk steps of an adjoint layer with the consumption of hidden deposit DJ_ (a compile-time index: the accumulators
     // are never selected at run time -- a switch over them made hipcc copy and spill whole accumulators around every call)
+#if NIF_S6_EARLYDEP
+#define S6_HID_LAYER(DJ_)      /* entered behind the barrier of the step that deposited DJ_ */              \
+  if (DJ_ < nh) {                                                                                           \
+    S6_DO(S6_HID_TILES(DJ_, 0, 5))                                                                          \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, 5, 8))                                                                          \
+    S6_CBAR()                                                                                               \
+    S6_CBAR()                                                                                               \
+    S6_CBAR()                                                                                               \
+  }
+#else
 #define S6_HID_LAYER(DJ_)                                                                                   \
   if (DJ_ < nh) {                                                                                           \
     S6_CBAR()                                                                                               \
@@ -295,6 +316,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                          \
     S6_CBAR()                                                                                               \
   }
+#endif
     // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors).  The skinny sums run as ROLLED loops over the tiles:
     // unrolled, hipcc fetched the weight vectors of all tiles first and spilled the accumulators to make room
     auto consume_last = [&](int t0, int t1) __attribute__((always_inline)) {
@@ -365,6 +387,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       }
       for (int q = 0; q < 4 * nh; ++q) { cs_next(nb_c, false); nb_c ^= 1; }      // (the adjoint steps' chunks: the producers issue them)
       // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
+#if NIF_S6_EARLYDEP
+      S6_CBAR()
+      S6_DO(consume_last(0, 4);)
+      S6_CBAR()
+      S6_DO(consume_last(4, 8);)
+      S6_CBAR()                              // (the producers write deposit nh - 1 over the last layer's during this step)
+      S6_CBAR()
+      S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
+      S6_DO(S6_HID_TILES(0, 0, 8))           // deposit 0 (visible since the last chunk barrier) next to the first layer's adjoint
+      S6_CBAR()
+#else
       S6_CBAR()
       S6_DO(consume_last(0, 3);)
       S6_CBAR()
@@ -376,6 +409,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       S6_CBAR()                              // deposit 0 next to the first layer's adjoint
       S6_DO(S6_HID_TILES(0, 0, 8))
       S6_CBAR()
+#endif
     }
     __syncthreads();
     S6_DO(consume_first(0, 8);)
@@ -685,7 +719,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         dzs[lane] += X16 ? sbv * (scl[j * 4 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s0 b^(0))
       }
       bf16x8 b0[NCH], b1[NCH];
-      split2<NBL>(ga, b0, b1);                // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
+      constexpr bool LATE_SPLIT = X16 && NIF_S6_EARLYDEP;   // the deposit's pair is formed where it is deposited (dL/da stays live instead of it: same registers)
+      if (!LATE_SPLIT) split2<NBL>(ga, b0, b1);             // the deposit's (hi, lo) pair; b0 is also the bf16 policy's operand
       bf16x8 q0[NCH], q1[NCH];                // the products' operand: b0, or half(s dL/da), s per point (mixed_float16: hi alone; X16: (hi, lo))
       const float s1_ = X16 ? scl[j * 4 + 2] : 1.0f, is0_ = X16 ? scl[j * 4 + 1] : 1.0f, is1_ = X16 ? scl[j * 4 + 3] : 1.0f;
       float ils = 1.0f;
@@ -727,32 +762,45 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         for (int b = 0; b < NBL; ++b) gh[b] = ztc * U[b];
         dzs[lane] += X16 ? (ils * is0_) * s : (PR == 2 ? ils * s : s);
       }
+      // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the steps of layer j - 1
+#define S6_DEPOSIT()                                                          \
+      {                                                                       \
+        if (LATE_SPLIT) split2<NBL>(ga, b0, b1);                              \
+        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);                   \
+        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);                   \
+        bf16x8 a0[NCH], a1[NCH];                                              \
+        split2<NBL>(hin, a0, a1);                                             \
+        fuse_deposit4(exw, dep, a0);                                          \
+        fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);                       \
+        f32x4 zh[NBL];                                                        \
+        _Pragma("unroll") for (int b = 0; b < NBL; ++b) zh[b] = zt0 * hin[b]; \
+        split2<NBL>(zh, a0, a1);                                              \
+        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);                   \
+        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);                   \
+      }
       S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
+#if NIF_S6_EARLYDEP
+      // (the slot's previous deposit was consumed two barriers ago; the splits run behind this step's matrix instructions)
+      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); S6_DEPOSIT() })
+#else
       S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
+#endif
       if (PR == 2 || X16) {
         const float f_ = X16 ? ils * is1_ : ils;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) gh[b] *= f_;
       }
-      {   // deposit j: (h_j ; zt h_j ; dL/da) of this tile -- the consumer waves take it during the chunk steps of layer j - 1
-        fuse_deposit4(exw + 4 * FUSE_PLANE_BYTES, dep, b0);
-        fuse_deposit4(exw + 5 * FUSE_PLANE_BYTES, dep, b1);
-        bf16x8 a0[NCH], a1[NCH];
-        split2<NBL>(hin, a0, a1);
-        fuse_deposit4(exw, dep, a0);
-        fuse_deposit4(exw + FUSE_PLANE_BYTES, dep, a1);
-        f32x4 zh[NBL];
-#pragma unroll
-        for (int b = 0; b < NBL; ++b) zh[b] = zt0 * hin[b];
-        split2<NBL>(zh, a0, a1);
-        fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);
-        fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
-      }
+#if !NIF_S6_EARLYDEP
+      S6_DEPOSIT()
+#endif
+#undef S6_DEPOSIT
     }
+#if !NIF_S6_EARLYDEP
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the deposits have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#endif
     // ---- first layer (the consumer waves take deposit 0 meanwhile) ------------------------------------------------------------
     {
       f32x4 ga[NBL];
