@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void k_gw8(GwArgs A) {
   // r4: the one-plane fp32 form takes three sets (cfg-4 128 x 6: 0.49 -> 0.47 ms per matrix); the two-plane forms lose with a
   // third set (registers: 1.12 -> 2.1 ms on cfg-3), the bf16-row forms do not move.  Also measured and not kept: the split of
   // tile t + 1 sharing the barrier interval with the products of tile t, the two waves of a SIMD in opposite order (+10 %)
-  constexpr int NS = (R == 0 && !DAB) ? 3 : 2;
+  constexpr int NS = (R == 0 && (!DAB || PH)) ? 3 : 2;      // (r5: the one-plane phase-row form too: 1.735 -> 1.68 ms on configs[3] bf16; the two-plane one spills 42 registers with a third set: 0.755 -> 1.08 ms on cfg-3)
   f32x4 rin[PH ? 1 : NS][2], rda[DAB ? 1 : NS][2], rz[NS];
   g8_bf16x4 rdb[DAB ? NS : 1][2];
   g8_s16x4 rph[PH ? NS : 1][2];
