@@ -70,6 +70,9 @@ CONFIGS = {
     "nif_80x2_swish_r2": (_cfg("NIF", 80, 2, 32, 2, 2, 1, 1, 1, act="swish"), 100),
     # whole fp32 planes + the (r+1) copies of the small vectors exceed the LDS: the bf16-split kernel (chunked planes) still takes it
     "ms_res_128x4_r4_so2": (_cfg("NIFMultiScale", 128, 4, 32, 2, 4, 1, 2, 2, s_res=True), 97),
+    # r5: 113..127 units = eight 16-feature blocks with PADDED features (the half-pair forms, and under the policy the 16-bit phase stash)
+    "ms_pad_120x3": (_cfg("NIFMultiScale", 120, 3, 32, 2, 1, 2, 1, 1), 131),
+    "ll_pad_120x2_r6_so2": (_cfg("LL", 120, 2, 32, 2, 6, 2, 2, 1), 99),
 }
 
 
@@ -1342,7 +1345,8 @@ def test_adam_trajectory_200_steps_split_vs_fp32_mfma_vs_oracle():
 
 
 # ---- mixed_bfloat16 policy (BASELINE configs[4] names bf16; reference model.py:73,101-105) ----------------------------------
-BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_so2_b33", "nif_cfg1_32x2", "ms_64x8"]
+BF16 = ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_64x2_mlp_pnet_r3", "ms_64x3_r3_so2_b33", "nif_cfg1_32x2", "ms_64x8",
+        "ms_cfg3_128x3", "ms_pad_120x3"]      # (r5: the 128-wide policy step = k_snet4<8, .., PR = 1> with the 16-bit phase stash + k_gw8<1, true, true>)
 
 
 def _snet6_shape(spec):
@@ -1429,7 +1433,7 @@ def test_mixed_bfloat16_policy_matches_the_oracle_with_the_same_casts(name):
 
 
 @pytest.mark.parametrize("name", ["ll_plain_32x2_r3", "ll_cfg4_128x2_r10_so3", "ll_res_64x1_r4_so2", "ll_96x2_r5", "ll_64x3_r5_so2",
-                                  "ll_cfg4_128x6_r10_so3"])
+                                  "ll_cfg4_128x6_r10_so3", "ll_pad_120x2_r6_so2"])
 def test_mixed_bfloat16_policy_on_the_last_layer_class(name):
     """the policy on NIFMultiScaleLastLayerParameterized: operands of the SHARED hidden n x n products rounded to bf16 (one product,
     fp32 accumulation), the phi layer / Dot / loss / weight-gradient sums fp32 -- against the oracle with the same casts
