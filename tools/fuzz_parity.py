@@ -199,13 +199,14 @@ def run_case(cfg, B, seed, loss="mse"):
             mb = getattr(nif_amd, kind)(cs, cp, mixed_policy="mixed_bfloat16")
             modelb = mb.build(); modelb.set_weights(ws)
             if ll:
+                from tests.test_gpu_parity import _stash_ph16      # (r5: 16-bit phase rows on the 128-wide plain nets)
                 rlb, rgb, rub = O.ll_policy_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round,
-                                                          stash_bf16=(spec.n + 15) // 16 in (2, 4, 8))
+                                                          stash_bf16=(spec.n + 15) // 16 in (2, 4, 8), stash_ph16=_stash_ph16(spec))
             else:       # two / four 16-feature blocks: the dL/da stash rows are bf16 too (k_gw_lds<DAB>)
-                from tests.test_gpu_parity import _snet6_shape     # (k_snet6's policy forms keep no stash: exact weight-gradient rows)
-                rlb, rgb, rub = O.planes_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round,
-                                                       stash_bf16=(not _snet6_shape(spec))
-                                                       and ((spec.n + 15) // 16 in (2, 4) or ((spec.n + 15) // 16 == 8 and spec.r <= 1)))
+                from tests.test_gpu_parity import _snet6_shape, _stash_ph16     # (k_snet6's policy forms keep no stash: exact weight-gradient rows)
+                sb_ = (not _snet6_shape(spec)) and ((spec.n + 15) // 16 in (2, 4) or ((spec.n + 15) // 16 == 8 and spec.r <= 1))
+                rlb, rgb, rub = O.planes_loss_and_grad(spec, ws64, x64, y64, sw64, rnd=O.bf16_round, stash_bf16=sb_,
+                                                       stash_ph16=sb_ and spec.kind == O.KIND_MS and _stash_ph16(spec))
             lb, gb = mb._engine.loss_and_grad(x, y, sw)
             if abs(lb - rlb) > 1e-3 * abs(rlb) or _rel(gb, O.flatten(rgb)) > 5e-3:
                 bad.append(("bf16 policy", lb, rlb, _rel(gb, O.flatten(rgb))))
