@@ -104,6 +104,91 @@ __global__ void k_plane_scales(const float* __restrict__ theta, MatRef m, long m
     pscale[(blockIdx.y * (m.r + 1) + k) * 2 + 1] = ldexpf(1.0f, -sh);
   }
 }
+// r5: the split groups (mode 0) AND the half planes (mode 3) of a batch of matrices in ONE launch, the planes' powers of two found in
+// the kernel (every workgroup of a half plane takes the maximum over its plane itself -- <= 16 K cached words -- instead of waiting
+// for a k_plane_scales launch; all of them arrive at the same power of two, the workgroup holding the plane's first forward unit
+// writes it for the consumers): three launches of ~5 us per training step -> one.  Index space [mode-0 units | mode-3 units], both
+// multiples of the workgroup's 256 elements, so a workgroup's elements of one loop trip lie in ONE part and ONE plane.
+__global__ __launch_bounds__(256) void k_pack16b_dual(const float* __restrict__ theta, MatRef m, long mstride, int NBL,
+                                                     __bf16* __restrict__ WF, __bf16* __restrict__ WB, long fstride, long bstride,
+                                                     _Float16* __restrict__ WFx, _Float16* __restrict__ WBx, long fxstride, long bxstride,
+                                                     float scale, float* __restrict__ pscale) {
+  m.base_k += (long)blockIdx.y * mstride; m.base_last += (long)blockIdx.y * mstride;
+  WF += (long)blockIdx.y * fstride; WB += (long)blockIdx.y * bstride;
+  WFx += (long)blockIdx.y * fxstride; WBx += (long)blockIdx.y * bxstride;
+  const int NCH = NBL / 2;
+  const long fwd0 = (long)NCH * NBL * 3 * 64 * 8, bwd0 = (long)NCH * NBL * 2 * 64 * 8, px = bwd0;   // units per plane: mode 0 fwd / bwd, mode 3 (both directions)
+  const long tot0 = (fwd0 + bwd0) * (m.r + 1), totx = 2 * px * (m.r + 1);
+  __shared__ float red[256];
+  int k_have = -1;
+  float s_have = 1.0f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot0 + totx; idx += (long)gridDim.x * blockDim.x) {
+    const bool half = idx >= tot0;
+    const long i2 = half ? idx - tot0 : idx;
+    const long tf = half ? px * (m.r + 1) : fwd0 * (m.r + 1);
+    const bool fwd = i2 < tf;
+    const long e = fwd ? i2 : i2 - tf;
+    const int ns = half ? 2 : (fwd ? 3 : 2);
+    const long per_plane = half ? px : (fwd ? fwd0 : bwd0);
+    const int k = (int)(e / per_plane);
+    long rem = e - (long)k * per_plane;
+    const int t = rem & 7; rem >>= 3;
+    const int lane = rem & 63; rem >>= 6;
+    const int s = (int)(rem % ns); rem /= ns;
+    const int blk = (int)(rem % NBL);
+    const int ks = (int)(rem / NBL);
+    const int slot = 16 * (2 * ks + (t >> 2)) + 4 * (lane >> 4) + (t & 3);
+    const int row = 16 * blk + (lane & 15);
+    const int in = fwd ? slot : row, out = fwd ? row : slot;
+    float x = (in < m.nin && out < m.nout) ? scale * theta[matref_index(m, k, in, out)] : 0.f;
+    if (half) {
+      if (k != k_have) {        // (uniform over the workgroup: see above)
+        float mx = 0.f;
+        for (int q = threadIdx.x; q < m.nin * m.nout; q += 256) {
+          const int qi = q / m.nout, qo = q - qi * m.nout;
+          mx = fmaxf(mx, fabsf(scale * theta[matref_index(m, k, qi, qo)]));
+        }
+        __syncthreads();
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+          __syncthreads();
+        }
+        mx = red[0];
+        int ex = 0;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex); else ex = 14;     // (k_plane_scales' rule)
+        int sh = 14 - ex;
+        sh = sh > 60 ? 60 : (sh < -60 ? -60 : sh);
+        s_have = ldexpf(1.0f, sh); k_have = k;
+        if (fwd && e == (long)k * per_plane && pscale) {       // the thread holding the plane's first forward unit
+          pscale[(blockIdx.y * (m.r + 1) + k) * 2] = s_have;
+          pscale[(blockIdx.y * (m.r + 1) + k) * 2 + 1] = ldexpf(1.0f, -sh);
+        }
+      }
+      x *= s_have;
+      const _Float16 h0 = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+      const _Float16 h1 = (_Float16)(x - (float)h0);
+      (fwd ? WFx : WBx)[e] = s == 0 ? h0 : h1;
+      continue;
+    }
+    const __bf16 x0 = (__bf16)x;
+    const float r1 = x - (float)x0;
+    const __bf16 x1 = (__bf16)r1;
+    const __bf16 x2 = (__bf16)(r1 - (float)x1);
+    (fwd ? WF : WB)[e] = s == 0 ? x0 : (s == 1 ? x1 : x2);
+  }
+}
+// split groups into (WF, WB) and half planes into (WFx, WBx) + their scales into pscale[(matrix, plane)][s | 1 / s], one launch
+void launch_pack16b_dual(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB, long fstride_elems,
+                         long bstride_elems, void* WFx, void* WBx, long fxstride_elems, long bxstride_elems, float scale, float* pscale,
+                         hipStream_t st) {
+  const long total = (long)(NBL / 2) * NBL * (5 + 4) * 64 * 8 * (m0.r + 1);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pack16b_dual, dim3(grid, nmat), dim3(256), 0, st, theta, m0, mstride, NBL, (__bf16*)WF, (__bf16*)WB, fstride_elems,
+                     bstride_elems, (_Float16*)WFx, (_Float16*)WBx, fxstride_elems, bxstride_elems, scale, pscale);
+}
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode) {
   launch_pack16b_batch(theta, m, 0, 1, NBL, WF, WB, 0, 0, scale, st, mode);
 }

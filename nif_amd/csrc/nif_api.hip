@@ -578,14 +578,15 @@ static int ensure_packed(nif_ctx* c) {
         if (!c->cfg.s_resblock) { w_off = c->s_hid_w[j]; b_off = c->s_hid_b[j]; }
         else { const int i = j / 2; w_off = (j & 1) ? c->s_hid_w2[i] : c->s_hid_w[i]; b_off = (j & 1) ? c->s_hid_b2[i] : c->s_hid_b[i]; }
         seg(b_off, s_bh + (long)j * n, n);
-        if (c->use_ll4)
+        if (c->use_ll4 && c->sWF4x)       // (r5: split groups + half planes + their scales in one launch)
+          launch_pack16b_dual(c->theta, dense_ref(w_off, n, n), 0, 1, snet3_nbl(n),
+                              (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2, 0, 0,
+                              (char*)c->sWF4x + (size_t)j * snet4_bwd_elems(n, 0) * 2, (char*)c->sWB4x + (size_t)j * snet4_bwd_elems(n, 0) * 2,
+                              0, 0, c->cfg.s_omega0, c->sWscale + (size_t)j * 2, c->st);
+        else if (c->use_ll4)
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
                          (char*)c->sWF4 + (size_t)j * snet4_fwd_elems(n, 0) * 2, (char*)c->sWB4 + (size_t)j * snet4_bwd_elems(n, 0) * 2,
                          c->cfg.s_omega0, c->st);
-        if (c->use_ll4 && c->sWF4x)
-          launch_pack16b_batch(c->theta, dense_ref(w_off, n, n), 0, 1, snet3_nbl(n),
-                               (char*)c->sWF4x + (size_t)j * snet4_bwd_elems(n, 0) * 2, (char*)c->sWB4x + (size_t)j * snet4_bwd_elems(n, 0) * 2,
-                               0, 0, c->cfg.s_omega0, c->st, 3, c->sWscale + (size_t)j * 2);
         if (c->use_ll4 && c->sWF4h)
           launch_pack16b(c->theta, dense_ref(w_off, n, n), snet3_nbl(n),
                          (char*)c->sWF4h + (size_t)j * (snet4_fwd_elems(n, 0) / 3) * 2, (char*)c->sWB4h + (size_t)j * (snet4_bwd_elems(n, 0) / 2) * 2,
@@ -610,12 +611,13 @@ static int ensure_packed(nif_ctx* c) {
   // 128 units with latent_dim >= 3 and many matrices -- which k_snet3 / k_jac / k_sob at that width cannot)
   c->use_snet4 = c->sWF4 && !fp32_only && snet4_supported(probe);
   c->packed32 = false;
-  if (c->use_snet4 && c->nh > 0)   // all hidden hyper-matrices (n^2 slots apart) in one launch
+  if (c->use_snet4 && c->nh > 0 && c->sWF4x)   // all hidden hyper-matrices (n^2 slots apart): split groups, half planes and their scales in ONE launch (r5)
+    launch_pack16b_dual(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
+                        c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r),
+                        c->sWF4x, c->sWB4x, snet4_bwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->sWscale, c->st);
+  else if (c->use_snet4 && c->nh > 0)
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
                          c->sWF4, c->sWB4, snet4_fwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st);
-  if (c->use_snet4 && c->nh > 0 && c->sWF4x)
-    launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
-                         c->sWF4x, c->sWB4x, snet4_bwd_elems(c->n, c->r), snet4_bwd_elems(c->n, c->r), probe.omega, c->st, 3, c->sWscale);
   if (c->use_snet4 && c->nh > 0 && c->sWF4h)
     launch_pack16b_batch(c->theta, hyper_ref(c, (long)c->si * c->n, c->n, c->n, c->n), (long)c->n * c->n, c->nh, snet3_nbl(c->n),
                          c->sWF4h, c->sWB4h, snet4_fwd_elems(c->n, c->r) / 3, snet4_bwd_elems(c->n, c->r) / 2, probe.omega, c->st,

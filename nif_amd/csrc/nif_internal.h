@@ -196,6 +196,9 @@ long snet4_fwd_elems(int n, int r);
 long snet4_bwd_elems(int n, int r);
 // (scale = omega_0 of the layer: the bf16-split planes hold omega_0 M, see k_snet4.hip)
 void launch_pack16b(const float* theta, const MatRef& m, int NBL, void* WF, void* WB, float scale, hipStream_t st, int mode = 0);
+void launch_pack16b_dual(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB, long fstride_elems,
+                         long bstride_elems, void* WFx, void* WBx, long fxstride_elems, long bxstride_elems, float scale, float* pscale,
+                         hipStream_t st);     // mode 0 + mode 3 (scales found in the kernel) in one launch (k_snet4.hip)
 void launch_snet4_f16(const SNetArgs& a, bool train, int nblk, size_t shm, hipStream_t st);     // k_snet4_f16.hip
 void launch_snet4_x16(const SNetArgs& a, bool train, int nblk, size_t shm, hipStream_t st);     // k_snet4_x16.hip (r5: half-pair exact products)
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
