@@ -251,9 +251,15 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    float bacc[4] = {0.f, 0.f, 0.f, 0.f};                         // hidden biases (kk, bJ) -- bI = 1 waves
-    float facc[3] = {0.f, 0.f, 0.f}, fbacc = 0.f;                  // first layer (kk, columns 32 bJ ..) -- bI = 0 waves
-    float lacc[3] = {0.f, 0.f, 0.f}, blacc[3] = {0.f, 0.f, 0.f};   // last layer (kk, rows 32 bI ..) -- bJ = 0 waves; its bias -- wave (kk, 1, 1)
+    // the skinny sums by wave role, seven registers where the four roles' arrays would take fourteen (r5):
+    //   xacc[0 .. 3]: bI = 1 waves -- hidden biases (kk, bJ) of matrix j;  bI = 0 waves -- first layer (kk, columns 32 bJ ..): x_c (c < 3) | its bias
+    //   xacc[4 .. 6]: bJ = 0 waves -- last layer (kk, rows 32 bI ..), output o;  wave (kk, 1, 1) -- its bias
+    float xacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define bacc xacc
+#define facc xacc
+#define fbacc xacc[3]
+#define lacc (xacc + 4)
+#define blacc (xacc + 4)
     FuseRd rdA = fuse_rd_addr(lane), rdB = rdA;
     rdA.a0 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI; rdA.a1 += (2 - 2 * kk) * FUSE_PLANE_BYTES + 256 * bI;   // plane 0: zt h, plane 1 (= r): h
     rdB.a0 += 4 * FUSE_PLANE_BYTES + 256 * bJ; rdB.a1 += 4 * FUSE_PLANE_BYTES + 256 * bJ;                         // dL/da
@@ -462,6 +468,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     __syncthreads();          // (the producers' loss reduction)
     return;
   }
+#undef bacc
+#undef facc
+#undef fbacc
+#undef lacc
+#undef blacc
 
   // =======================================================================================================================
   // producer wave = one 16-point tile per round: k_snet4's tile program + the deposits
