@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr int NVL = 5, NVF = 8, WVLT = NVL * 64, WVFT = NVF * 64;
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const int n = A.n, nh = A.nh, si = A.si, so = A.so, nsm = A.nsm;
+  const int n = A.n, nh = A.nh, si = A.si, so = A.so;
   const long nt16 = 2 * ((A.B + 31) / 32);
   const long ngroups = (nt16 + WAVES - 1) / WAVES;
 
@@ -167,15 +167,19 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   char* WVF = WVL + WAVES * WVLT;
   bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);
   float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
-  const int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  const int CX = (si + 3) & ~3, CZ = (r + 3) & ~3, CY = (so + 3) & ~3;
-  const int NI = (CX + CZ + CY + 4) * 16;
-  const int pw = 2 * r * 64 + 2 * NI;                   // per-wave LDS floats (producers)
+  constexpr int NP = 16 * NBL;
+  // r5: the LDS image of the small hyper-vectors has a FIXED layout -- three first-layer rows, three last-layer rows, the first bias, four
+  // hidden biases, the last bias (the shape's unused rows are zeros): every offset into it is a compile-time constant that folds into the
+  // ds_read's immediate.  With offsets made of si / so / nh the tile program spent ~300 v_add_u32 per tile on LDS addresses (a tenth of
+  // the producers' vector instructions, all of them inside the vector blocks)
+  constexpr int o_w1 = 0, o_wl = 3 * NP, o_b1 = 6 * NP, o_bh = 7 * NP, o_bl = 11 * NP, nsm = 11 * NP + 4;
+  constexpr int sm_tot = ((r + 1) * nsm + 3) & ~3;
+  constexpr int CX = 4, CZ = 4, CY = 4;                 // input / latent / target rows of a tile's input set (si, so <= 3, r = 1: snet6_supported)
+  constexpr int NI = (CX + CZ + CY + 4) * 16;
+  constexpr int pw = 2 * r * 64 + 2 * NI;               // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   float* scl = lsum + 16;                               // X16: [matrix][plane][s | 1 / s] of the half planes
   long long* tlb = reinterpret_cast<long long*>(scl + 16) + (tid ? 380 : 0); (void)tlb;      // (NIF_TIMELINE builds: 2 x 380 stamps)
-  constexpr int NP = 16 * NBL;
-  const int o_w1 = 0, o_wl = si * NP, o_b1 = o_wl + so * NP, o_bh = o_b1 + NP, o_bl = o_bh + nh * NP;
 
   {   // prologue, all 12 waves: LDS image of the small hyper-vectors; the exchange images start as zeros (the first tile round
       // consumes a first-layer deposit that nobody made)
@@ -184,12 +188,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (int idx = tid; idx < (r + 1) * nsm; idx += 1024) {
       const int k = idx / nsm, e = idx - k * nsm;
       float v = 0.f;
-      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n) v = A.omega * hyp3(A, k, (long)dd * n + f); }
-      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n) v = hyp3(A, k, s_wl + (long)f * so + o); }
+      if (e < o_wl) { const int dd = e / NP, f = e - dd * NP; if (f < n && dd < si) v = A.omega * hyp3(A, k, (long)dd * n + f); }
+      else if (e < o_b1) { const int o = (e - o_wl) / NP, f = (e - o_wl) - o * NP; if (f < n && o < so) v = hyp3(A, k, s_wl + (long)f * so + o); }
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
       else if (e < o_bl) {
         const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP;
-        if (f < n) v = hyp3(A, k, s_bh + (long)j * n + f);
+        if (f < n && j < nh) v = hyp3(A, k, s_bh + (long)j * n + f);
         if (X16) v *= 4096.0f * A.wscale[(j * (r + 1) + k) * 2];      // the hidden biases start the scaled MFMA chains
       }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          _Pragma("unroll") for (int dd = 0; dd < 3; ++dd) if (dd < si) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
           a_[b] = s;
         }
       }
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           f32x4 s = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-          for (int dd = 0; dd < si; ++dd) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          _Pragma("unroll") for (int dd = 0; dd < 3; ++dd) if (dd < si) s += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
           a_[b] += zt * s;
         }
       }
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           f32x4 t = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
-          for (int dd = 0; dd < si; ++dd) t += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
+          _Pragma("unroll") for (int dd = 0; dd < 3; ++dd) if (dd < si) t += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
           s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
         }
         float tot = dzs[lane] + s;
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static size_t snet6_shmem(const SNetArgs& a, int NBL) {
-  const size_t sm_tot = (((size_t)(a.r + 1) * a.nsm) + 3) & ~(size_t)3;
+  const size_t sm_tot = (((size_t)(a.r + 1) * (11 * 16 * NBL + 4)) + 3) & ~(size_t)3;      // (the kernel's fixed small-vector layout)
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
   return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
