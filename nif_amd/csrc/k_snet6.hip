@@ -662,13 +662,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       for (int k = 0; k <= r; ++k) {
         const float zt = k < r ? zt0 : 1.0f;
         const float* s0 = sm + k * nsm;
-        float sk = 0.f;
+        float sk = 0.f, sk2 = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(s0 + o_wl + o * NP + 16 * b + 4 * g);
-          sk += (h[b][0] * w[0] + h[b][1] * w[1]) + (h[b][2] * w[2] + h[b][3] * w[3]);
+          sk = fmaf(h[b][0], w[0], sk); sk2 = fmaf(h[b][1], w[1], sk2); sk = fmaf(h[b][2], w[2], sk); sk2 = fmaf(h[b][3], w[3], sk2);      // (FMA chains, r5: 16 instructions per sum instead of 16 mul + 16 add)
           wg[b] += zt * w;
         }
+        sk += sk2;
         part = fmaf(zt, sk, part);
         bias = fmaf(zt, s0[o_bl + o], bias);
         if (k < r) sks[k * 64 + lane] = sk;
@@ -725,12 +726,13 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
       {
         const float* sb = sm + o_bh + j * NP + 4 * g;
-        float sbv = 0.f;
+        float sbv = 0.f, sbv2 = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(sb + 16 * b);
-          sbv += (ga[b][0] * bb[0] + ga[b][1] * bb[1]) + (ga[b][2] * bb[2] + ga[b][3] * bb[3]);
+          sbv = fmaf(ga[b][0], bb[0], sbv); sbv2 = fmaf(ga[b][1], bb[1], sbv2); sbv = fmaf(ga[b][2], bb[2], sbv); sbv2 = fmaf(ga[b][3], bb[3], sbv2);
         }
+        sbv += sbv2;
         dzs[lane] += X16 ? sbv * (scl[j * 4 + 1] * (1.0f / 4096.0f)) : sbv;     // (the LDS image holds 4096 s0 b^(0))
       }
       bf16x8 b0[NCH], b1[NCH];
@@ -824,14 +826,14 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       for (int b = 0; b < NBL; ++b) ga[b] = dnext[b] * gh[b];
       {
         const float* s0 = sm + 4 * g;
-        float s = 0.f;
+        float s = 0.f, s2 = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b) {
           f32x4 t = *reinterpret_cast<const f32x4*>(s0 + o_b1 + 16 * b);
           _Pragma("unroll") for (int dd = 0; dd < 3; ++dd) if (dd < si) t += xs[dd * 16] * *reinterpret_cast<const f32x4*>(s0 + o_w1 + dd * NP + 16 * b);
-          s += (ga[b][0] * t[0] + ga[b][1] * t[1]) + (ga[b][2] * t[2] + ga[b][3] * t[3]);
+          s = fmaf(ga[b][0], t[0], s); s2 = fmaf(ga[b][1], t[1], s2); s = fmaf(ga[b][2], t[2], s); s2 = fmaf(ga[b][3], t[3], s2);
         }
-        float tot = dzs[lane] + s;
+        float tot = dzs[lane] + (s + s2);
         tot += __shfl_xor(tot, 16);
         tot += __shfl_xor(tot, 32);
         if (active && g == 0) A.DZ[(tile32 * r) * 32 + poff] = tot;
