@@ -391,9 +391,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
       for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
         S6_CFWD()
-        S6_CFWD(if (j == 0) { S6_DO(consume_first(0, 4);) })
-        S6_CFWD(if (j == 0) { S6_DO(consume_first(4, 8);) })
-        S6_CFWD()
+        S6_CFWD(if (j == 0) { S6_DO(consume_first(0, 3);) })      // (three intervals: at four tiles the consumers were the last at these barriers, r5 timeline)
+        S6_CFWD(if (j == 0) { S6_DO(consume_first(3, 6);) })
+        S6_CFWD(if (j == 0) { S6_DO(consume_first(6, 8);) })
       }
       for (int q = 0; q < 4 * nh; ++q) { cs_next(nb_c, false); nb_c ^= 1; }      // (the adjoint steps' chunks: the producers issue them)
       // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
