@@ -193,8 +193,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       else if (e < o_bh) { const int f = e - o_b1; if (f < n) v = hyp3(A, k, s_b1 + f); }
       else if (e < o_bl) {
         const int j = (e - o_bh) / NP, f = (e - o_bh) - j * NP;
-        if (f < n && j < nh) v = hyp3(A, k, s_bh + (long)j * n + f);
-        if (X16) v *= 4096.0f * A.wscale[(j * (r + 1) + k) * 2];      // the hidden biases start the scaled MFMA chains
+        if (f < n && j < nh) {
+          v = hyp3(A, k, s_bh + (long)j * n + f);
+          if (X16) v *= 4096.0f * A.wscale[(j * (r + 1) + k) * 2];    // the hidden biases start the scaled MFMA chains (rows j >= nh stay zero: wscale holds nh matrices only)
+        }
       }
       else if (e < o_bl + so) v = hyp3(A, k, s_bl + (e - o_bl));
       sm[idx] = v;

@@ -640,7 +640,7 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
     if (c->use_ll4) {
       SNetArgs sa; fill_snet_ll(c, sa, xin, c->pi + c->si, c->pi, B);
       sa.u_out = u;
-      launch_snet4(sa, false, false, c->st);
+      if (launch_snet4(sa, false, false, c->st) < 0) return fail(NIF_ERR_STATE, "internal: no k_snet4 form for this net (SIREN planes not packed as half pairs)");
       HIPCHK(hipGetLastError());
       return NIF_OK;
     }
@@ -655,7 +655,7 @@ extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u
   sa.u_out = u;
   {
     ProfScope p_(c, NIF_PROF_SNET_FWD);
-    if (c->use_snet4) launch_snet4(sa, false, false, c->st);
+    if (c->use_snet4) { if (launch_snet4(sa, false, false, c->st) < 0) return fail(NIF_ERR_STATE, "internal: no k_snet4 form for this net (SIREN planes not packed as half pairs)"); }
     else if (c->use_snet3) launch_snet3(sa, false, false, nullptr, c->st);
     else launch_snet(sa, c->NB, false, c->st);
   }
@@ -1069,7 +1069,7 @@ static int loss_grad_ll(nif_ctx* c, const float* xin, const float* y, const floa
     }
     sa.dring = c->dring;
     ProfScope p_(c, NIF_PROF_SNET);
-    launch_snet4(sa, true, false, c->st);
+    if (launch_snet4(sa, true, false, c->st) < 0) return fail(NIF_ERR_STATE, "internal: no k_snet4 form for this net (SIREN planes not packed as half pairs)");
   } else {
     ProfScope p_(c, NIF_PROF_SNET);
     launch_pnet(ma, c->NB, true, c->st);
@@ -1314,7 +1314,7 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
       launch_sob(sa, true, ns, seeds, gt, wj, c->dring, nullptr, false, sa_st, sparp);
     }
     else if (fused_gw) launch_snet6(sa, partial, c->pstride, sa_st);
-    else if (c->use_snet4) launch_snet4(sa, true, false, sa_st);
+    else if (c->use_snet4) { if (launch_snet4(sa, true, false, sa_st) < 0) return fail(NIF_ERR_STATE, "internal: no k_snet4 form for this net (SIREN planes not packed as half pairs)"); }
     else if (c->use_snet3) launch_snet3(sa, true, false, nullptr, sa_st);
     else launch_snet(sa, c->NB, true, sa_st);
   }

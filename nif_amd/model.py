@@ -526,14 +526,15 @@ class Model(object):
                         graph_id = e.graph_end()
                         began = False
                     except _lib.NifError:
-                        if began:                 # a call inside the capture failed: end the capture (restores the step counter), drop the graph
-                            try:
-                                gid = e.graph_end()
-                                if gid is not None:
+                        use_graph, graph_id = False, None       # (a workspace that had to grow, a call that cannot be captured): plain launches
+                    finally:
+                        if began:                 # ANY exception inside the capture (a NifError, a KeyboardInterrupt, an error of the
+                            try:                  # communicator ...): end the capture (restores the step counter) and drop the graph, so
+                                gid = e.graph_end()     # that the stream is usable again and the outer `finally`'s sync cannot mask the
+                                if gid is not None:     # original error with "stream is capturing" 
                                     e.graph_destroy(gid)
                             except _lib.NifError:
                                 pass
-                        use_graph, graph_id = False, None       # (a workspace that had to grow, a call that cannot be captured)
                 if steps_per_epoch is not None:
                     pass
                 elif use_graph and graph_id is not None:

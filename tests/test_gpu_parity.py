@@ -1850,3 +1850,64 @@ def test_jac_reg_matches_oracle(name):
     assert abs((ev_b - ev_m) - lj_e) < 2e-4 * lj_e + 1e-6 * ev_m
     model.compile(nif_amd.Adam(1e-3), "mse")
     assert np.isfinite(model.fit(x, y, epochs=2, batch_size=32, verbose=0).history["loss"]).all()
+
+
+# ---- the HIP path against the FROZEN oracle vectors (tests/golden/oracle_v1.npz): forward, loss, per-tensor gradient, Jacobian and one
+# Adam step of 13 configurations at B in {7, 64, 257} against numbers on disk -- an edit that moved a kernel and the live oracle
+# together would still fail here -------------------------------------------------------------------------------------
+def _frozen_cases():
+    import importlib.util
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sp = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(gold, "make_oracle_goldens.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    return mod, os.path.join(gold, "oracle_v1.npz")
+
+
+@pytest.mark.parametrize("name", sorted(_frozen_cases()[0].CASES))
+def test_hip_path_matches_frozen_oracle_vectors(name):
+    import nif_amd
+    mod, path = _frozen_cases()
+    z = np.load(path)
+    kind, cs, cp = mod.CASES[name]
+    spec = O.Spec(kind, cs, cp)
+    ws = [w.astype(np.float32) for w in O.unflatten(spec, z["%s/theta" % name])]
+    for B in mod.BATCHES:
+        k = "%s/%d/" % (name, B)
+        x, y, sw = z[k + "x"], z[k + "y"], z[k + "sw"]
+        m = getattr(nif_amd, kind)(cs, cp)
+        model = m.build()
+        model.set_weights(ws)
+        assert _rel(model.predict(x), z[k + "u"]) < 1e-5, (name, B)
+        loss, g = m._engine.loss_and_grad(x, y, sw)
+        lref, gref = float(z[k + "loss"]), z[k + "grad"]
+        assert abs(loss - lref) <= 2e-6 * abs(lref) + 1e-12, (name, B, loss, lref)
+        gnorm, off = np.linalg.norm(gref), 0
+        for nm, shp in spec.param_shapes():
+            n_ = int(np.prod(shp))
+            gr = gref[off:off + n_]
+            err = np.linalg.norm(g[off:off + n_] - gr)
+            assert err <= 5e-5 * np.linalg.norm(gr) + 2.5e-7 * gnorm, (name, B, nm, err, np.linalg.norm(gr))
+            off += n_
+        yi, xi = list(range(spec.so)), list(range(spec.pi, spec.pi + spec.si))
+        _, J = nif_amd.JacobianLayer(model, yi, xi)(x)
+        assert _rel(J, z[k + "jac"]) < 2e-5, (name, B, _rel(J, z[k + "jac"]))
+        # one Adam step from zero moments (Keras 2.11, lr 1e-3): the step is +-lr per entry wherever the gradient is solid
+        model.compile(nif_amd.Adam(learning_rate=1e-3), loss="mse")
+        model.fit(x, y, epochs=1, batch_size=B, shuffle=False, verbose=0, sample_weight=sw)
+        got = O.flatten(model.get_weights()).astype(np.float64)
+        # Keras' first step is lr g / (|g| + eps / sqrt(1 - beta2)) = lr g / (|g| + 3.2e-6): insensitive to the fp32 gradient's relative
+        # error wherever |g| is well above that floor and not small against its tensor's scale
+        solid, off = np.abs(gref) > 1e-4, 0
+        for nm, shp in spec.param_shapes():
+            n_ = int(np.prod(shp))
+            rms = np.sqrt(np.mean(gref[off:off + n_] ** 2)) + 1e-300
+            solid[off:off + n_] &= np.abs(gref[off:off + n_]) > 0.02 * rms
+            off += n_
+        if not solid.any():
+            solid = np.abs(gref) >= np.abs(gref).max()
+        d = np.abs(got - z[k + "theta1"])
+        assert d[solid].max() < 0.01 * 1e-3, (name, B, d[solid].max())
+        assert d.max() <= 2.0 * 1e-3 * 1.001, (name, B)
+        m._engine.close()

@@ -467,3 +467,43 @@ def test_phase16_stash_emulation():
         assert l0 == l1                                       # the forward pass does not see the stash
         e = np.linalg.norm(O.flatten(g1) - O.flatten(g0)) / np.linalg.norm(O.flatten(g0))
         assert 1e-7 < e < 1e-3, (name, e)
+
+
+# ---- the frozen oracle (tests/golden/oracle_v1.npz, written by tests/golden/make_oracle_goldens.py): any later edit of the oracle's
+# arithmetic fails here (or shows up as a diff of the fixture) -- SURVEY 7 step 1, VERDICT r5 item 7 -----------------------------------
+def _frozen():
+    import importlib.util
+    sp = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(GOLD, "make_oracle_goldens.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    return mod, np.load(os.path.join(GOLD, "oracle_v1.npz"))
+
+
+def test_frozen_fixture_covers_its_case_list():
+    mod, z = _frozen()
+    assert sorted(z["names"].tolist()) == sorted(mod.CASES) and tuple(z["batches"].tolist()) == mod.BATCHES
+    assert len(mod.CASES) >= 12 and mod.BATCHES == (7, 64, 257)
+    kinds = {mod.CASES[n][0] for n in mod.CASES}
+    assert kinds == {"NIF", "NIFMultiScale", "NIFMultiScaleLastLayerParameterized"}
+
+
+def test_live_oracle_reproduces_frozen_vectors():
+    """forward, loss, flat gradient, Jacobian and one Adam step of 13 configurations x B in {7, 64, 257}: today's oracle against the
+    numbers it wrote when the fixture was made, from the STORED weights and inputs (nothing is redrawn), to 1e-13."""
+    mod, z = _frozen()
+    for name in sorted(mod.CASES):
+        kind, cs, cp = mod.CASES[name]
+        spec = O.Spec(kind, cs, cp)
+        ws = O.unflatten(spec, z["%s/theta" % name])
+        for B in mod.BATCHES:
+            k = "%s/%d/" % (name, B)
+            got = mod.evaluate(spec, ws, z[k + "x"], z[k + "y"], z[k + "sw"])
+            for q in ("u", "loss", "grad", "jac", "theta1"):
+                ref = z[k + q]
+                scale = max(float(np.abs(ref).max()), 1e-300)
+                assert np.asarray(got[q]).shape == ref.shape, (name, B, q)
+                assert float(np.abs(np.asarray(got[q]) - ref).max()) <= 1e-13 * scale, (name, B, q)
+            # ... and the stored inputs are what the generator would draw today (the fixture and its script belong together)
+            _, ws2, x2, y2, sw2 = mod.draw(name, B)
+            assert np.array_equal(O.flatten(ws2).astype(np.float32), z["%s/theta" % name]) and np.array_equal(x2, z[k + "x"])
+            assert np.array_equal(y2, z[k + "y"]) and np.array_equal(sw2, z[k + "sw"])

@@ -94,7 +94,10 @@ def roofline(name, s, B, nx, policy, kernel_ms, tj=None, sha=None):
     if fused:
         prod = (1.0 + 1.0 + 3.0) if pol else 9.0                 # k_snet6: three half products forward and adjoint, three bf16 products per weight-gradient pair
     else:
-        prod = 2.0 if pol else 9.0                               # k_snet4 / k_sobw: 6 bf16 products forward + 3 adjoint (policies: 1 + 1)
+        # k_snet4 on a SIREN class (NIFMultiScale, last-layer class) since r5: PR = 3, three half products forward + three in the data
+        # adjoint; class NIF and the Sobolev kernels (k_sobw / k_sob) still stream the bf16 split groups: 6 + 3; policies 1 + 1
+        siren_s4 = (not ns) and s.kind != "NIF"
+        prod = 2.0 if pol else (6.0 if siren_s4 else 9.0)
     nbl_even = (((n + 15) // 16) % 2) == 0 and n > 16
     exec16 = prod * 2.0 * planes * nh * n * n * (1 + ns) * B if nbl_even else 0.0
     alg_bytes = 4.0 * (s.pi_dim + s.si_dim + s.so_dim + s.so_dim * ns) * B
@@ -120,12 +123,138 @@ def roofline(name, s, B, nx, policy, kernel_ms, tj=None, sha=None):
             "frac": round(frac_hbm if bound == "hbm" else mf / 2500.0, 4), "avg_ms": snet_ms,
             "frac_hbm": None if frac_hbm is None else round(frac_hbm, 4), "frac_bf16_pipe": round(mf / 2500.0, 4),
             "hbm_GBs": None if hbm is None else round(hbm, 1), "executed_bf16_TFLOPs": round(mf, 1),
-            "fp32_equiv_TFLOPs": round(flop32 / t / 1e12, 1), "frac_fp32_equiv": round(flop32 / t / 1e12 / 157.3, 4),
+            "fp32_equiv_TFLOPs": round(flop32 / t / 1e12, 1), "speedup_vs_f32_input_mfma_peak": round(flop32 / t / 1e12 / 157.3, 4),
             "frac_bf16_pipe_algorithmic": round(flop32 / t / 1e12 / 2500.0, 4),
             "algorithmic_bytes_per_point": alg_bytes / B, "traffic": traffic, "traffic_stale": stale,
             "traffic_ratio": None if traffic is None else round(traffic / alg_bytes, 1),
             "traffic_unit": "HBM bytes per launch of the dominant kernel (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/configs_traffic.json)",
             "fused_weight_gradients": bool(fused), "csrc_sha": sha}
+
+
+def run_config(name, steps=10, warmup=3, tj=None, sha=None, host_buffers=False):
+    """One named config: build the engine, put synthetic inputs of the config's shape in HBM, ramp the clock, time `steps` train steps
+    (loss + gradient + Adam; HIP events on the library's stream), then an instrumented leg for the per-kernel-group breakdown.
+    -> the config's record (bench.py's `configs` block and this tool's JSON document use the same function)."""
+    import time as _t
+    import nif_amd
+    from nif_amd.engine import DeviceArray
+    work = WORK[name]
+    cls, (cs, cp), B, xi = work[:4]
+    policy = work[4] if len(work) > 4 else "float32"
+    nif_amd.set_seed(0)
+    m = getattr(nif_amd, cls)(cs, cp, mixed_policy=policy)
+    m.build()
+    e = m._engine
+    ncol = cp["input_dim"] + cs["input_dim"]
+    so = cs["output_dim"]
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(B, ncol)).astype(np.float32)
+    y = rng.uniform(-1, 1, size=(B, so)).astype(np.float32)
+    d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
+    d_x.upload(x); d_y.upload(y)
+    d_g = None
+    if xi:
+        g = rng.uniform(-1, 1, size=(B, so * len(xi))).astype(np.float32)
+        d_g = DeviceArray(e, g.size); d_g.upload(g)
+    adam = nif_amd.Adam(1e-3).as_struct()
+
+    def step():
+        if xi:
+            e.sobolev_loss_grad_dev(d_x.at(0), d_y.at(0), d_g.at(0), None, B, B, xi, 0.1)
+        else:
+            e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, B)
+        e.adam_step_dev(adam)
+
+    # clock ramp (DESIGN 5.4: the shader clock needs ~30 ms of load): steps for >= 80 ms, then the clean timing, then the
+    # instrumented leg (HIP events between the kernels: its per-kernel times add up to more than a clean step)
+    t0 = _t.perf_counter(); nr = 0
+    while nr < warmup or _t.perf_counter() - t0 < 0.08:
+        step(); nr += 1
+        if nr % 4 == 0:
+            e.sync()
+    e.sync()
+    e.timer_start()
+    for _ in range(steps):
+        step()
+    total = e.timer_stop()
+    e.profile_enable(True)
+    e.profile_read(reset=True)
+    for _ in range(steps):
+        step()
+    e.sync()
+    prof = e.profile_read(reset=True)
+    e.profile_enable(False)
+    msstep = total / steps
+    rec = {"points": B, "policy": policy, "ms_per_step": round(msstep, 4), "Mpts_per_s": round(B / msstep / 1e3, 2),
+           "steps": steps, "params": int(e.n_params),
+           "kernel_ms": {k: round(v[0] / steps, 4) for k, v in prof.items() if v[1] > 0}}
+    rec["roofline"] = roofline(name, m._spec, B, xi, policy, rec["kernel_ms"], tj, sha)
+    if host_buffers:
+        # the same step when the boundary hands over HOST buffers (nif_train_step: H2D of x, y + step + loss readback)
+        for _ in range(2):
+            e.train_step(x, y, None, adam)
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            e.train_step(x, y, None, adam)
+        dt = (_t.perf_counter() - t0) / steps
+        rec["host_buffers_ms_per_step"] = round(dt * 1e3, 4)
+        rec["host_buffers_Mpts_per_s"] = round(B / dt / 1e6, 2)
+    d_x.free(); d_y.free()
+    if d_g is not None:
+        d_g.free()
+    e.close()
+    return rec
+
+
+def run_cfg0(epochs=10):
+    """configs[0]: tutorial 1 -- NIF 2x32 + 2x32, the 10k-point lattice of SURVEY 8d, Model.fit with batch 512, 20 steps per epoch"""
+    import time
+    import nif_amd
+    nif_amd.set_seed(0)
+    cs = {"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+    cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
+    m = nif_amd.NIF(cs, cp)
+    model = m.build()
+    model.compile(nif_amd.Adam(1e-3), "mse")
+    t = np.repeat(np.linspace(0, 90, 50), 200); xx = np.tile(np.arange(200) * 0.005, 50)
+    raw = np.stack([t, xx, nif_amd.data.traveling_wave(t, xx, 4.0)], axis=1)
+    data, _, _ = nif_amd.data.PointWiseData.standard_normalize(raw)
+    x0, y0 = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
+    model.fit(x0, y0, epochs=2, batch_size=512, verbose=0)
+    t0 = time.perf_counter()
+    h = model.fit(x0, y0, epochs=epochs, batch_size=512, verbose=0)
+    dt = time.perf_counter() - t0
+    nsteps = epochs * ((x0.shape[0] + 511) // 512)
+    rec = {"points": int(x0.shape[0]), "batch": 512, "us_per_step": round(dt / nsteps * 1e6, 1), "ms_per_step": round(dt / nsteps * 1e3, 5),
+           "Mpts_per_s": round(epochs * x0.shape[0] / dt / 1e6, 2), "epochs": epochs, "final_loss": float(h.history["loss"][-1]),
+           "params": int(m._engine.n_params), "roofline": None,
+           "note": "Model.fit on the resident table (shuffle, gather, loss + gradient + Adam per 512-point step); launch-bound: no roofline applies at 512 points per step"}
+    m._engine.close()
+    return rec
+
+
+# the BASELINE.json configs other than the bench line's own (configs[1]) at their per-GPU shard sizes: what bench.py's `configs` block runs
+BASELINE_CONFIGS = [("configs[2] NIFMultiScale 6x128, 2-D, 2^19 points/GPU", "cfg3_ms_6x128_2d"),
+                    ("configs[3] last-layer class 128x6, r = 10, so = 3, 3-D, 2^21 points/GPU", "cfg4_linear_nif_3d_128x6"),
+                    ("configs[4] Sobolev 4x64, 2-D, du/dx + du/dy targets, fp32, 2^20 points/GPU", "cfg5_sobolev_2d_4x64"),
+                    ("configs[4] Sobolev 4x64 under mixed_bfloat16 (the config names bf16), 2^20 points/GPU", "cfg5_sobolev_2d_4x64_bf16")]
+
+
+def baseline_configs_block(steps=8, warmup=3):
+    """bench.py's `configs` object: every BASELINE config besides the headline one, driver-run -- ms_per_step,
+    the dominant kernel with its roofline fraction and traffic ratio, the per-kernel-group breakdown."""
+    tj, sha = load_config_traffic(), csrc_sha()
+    out = {"cfg0_tutorial1_fit_10k_b512": dict(run_cfg0(epochs=6), workload="configs[0] tutorial/1: NIF 2x32 + 2x32, 10k points, Model.fit batch 512")}
+    for label, name in BASELINE_CONFIGS:
+        rec = run_config(name, steps=steps, warmup=warmup, tj=tj, sha=sha)
+        rf = rec.get("roofline") or {}
+        out[name] = {"workload": label, "points": rec["points"], "policy": rec["policy"], "ms_per_step": rec["ms_per_step"],
+                     "Mpts_per_s": rec["Mpts_per_s"], "steps": steps, "warmup": warmup,
+                     "dominant_kernel": rf.get("kernel"), "dominant_kernel_ms": rf.get("avg_ms"), "bound": rf.get("bound"),
+                     "frac": rf.get("frac"), "frac_hbm": rf.get("frac_hbm"), "frac_bf16_pipe": rf.get("frac_bf16_pipe"),
+                     "traffic_ratio": rf.get("traffic_ratio"), "traffic_stale": rf.get("traffic_stale"),
+                     "kernel_ms": rec["kernel_ms"]}
+    return out
 
 
 def main():
@@ -137,103 +266,16 @@ def main():
     ap.add_argument("--out", default=None, help="where the JSON document goes (default: gpurun_out/bench_configs.json for a full run, "
                     "nothing for an --only run: tools/pmc_configs.sh calls this per config under the profiler)")
     a = ap.parse_args()
-    import nif_amd
-    from nif_amd.engine import DeviceArray
     out = {}
     tj, sha = load_config_traffic(), csrc_sha()
-    for name, work in WORK.items():
-        cls, (cs, cp), B, xi = work[:4]
-        policy = work[4] if len(work) > 4 else "float32"
+    for name in WORK:
         if a.only and (a.only != name if a.exact else a.only not in name):
             continue
-        nif_amd.set_seed(0)
-        m = getattr(nif_amd, cls)(cs, cp, mixed_policy=policy)
-        m.build()
-        e = m._engine
-        ncol = cp["input_dim"] + cs["input_dim"]
-        so = cs["output_dim"]
-        rng = np.random.default_rng(0)
-        x = rng.uniform(-1, 1, size=(B, ncol)).astype(np.float32)
-        y = rng.uniform(-1, 1, size=(B, so)).astype(np.float32)
-        d_x, d_y = DeviceArray(e, x.size), DeviceArray(e, y.size)
-        d_x.upload(x); d_y.upload(y)
-        d_g = None
-        if xi:
-            g = rng.uniform(-1, 1, size=(B, so * len(xi))).astype(np.float32)
-            d_g = DeviceArray(e, g.size); d_g.upload(g)
-        adam = nif_amd.Adam(1e-3).as_struct()
-
-        def step():
-            if xi:
-                e.sobolev_loss_grad_dev(d_x.at(0), d_y.at(0), d_g.at(0), None, B, B, xi, 0.1)
-            else:
-                e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, B)
-            e.adam_step_dev(adam)
-
-        # clock ramp (the shader clock needs ~30 ms of load): steps for >= 80 ms, then the clean timing, then the
-        # instrumented leg (HIP events between the kernels: its per-kernel times add up to more than a clean step)
-        import time as _t
-        t0 = _t.perf_counter(); nr = 0
-        while nr < a.warmup or _t.perf_counter() - t0 < 0.08:
-            step(); nr += 1
-            if nr % 4 == 0:
-                e.sync()
-        e.sync()
-        e.timer_start()
-        for _ in range(a.steps):
-            step()
-        total = e.timer_stop()
-        e.profile_enable(True)
-        e.profile_read(reset=True)
-        for _ in range(a.steps):
-            step()
-        e.sync()
-        prof = e.profile_read(reset=True)
-        e.profile_enable(False)
-        msstep = total / a.steps
-        rec = {"points": B, "ms_per_step": round(msstep, 4), "Mpts_per_s": round(B / msstep / 1e3, 2),
-               "params": int(e.n_params),
-               "kernel_ms": {k: round(v[0] / a.steps, 4) for k, v in prof.items() if v[1] > 0}}
-        rec["roofline"] = roofline(name, m._spec, B, xi, policy, rec["kernel_ms"], tj, sha)
-        if name.startswith("cfg2"):
-            # the same step when the boundary hands over HOST buffers (nif_train_step: H2D of x, y + step + loss readback)
-            import time
-            for _ in range(2):
-                e.train_step(x, y, None, adam)
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                e.train_step(x, y, None, adam)
-            dt = (time.perf_counter() - t0) / a.steps
-            rec["host_buffers_ms_per_step"] = round(dt * 1e3, 4)
-            rec["host_buffers_Mpts_per_s"] = round(B / dt / 1e6, 2)
+        rec = run_config(name, a.steps, a.warmup, tj, sha, host_buffers=name.startswith("cfg2"))
         out[name] = rec
         print(name, json.dumps(rec), flush=True)
-        d_x.free(); d_y.free()
-        if d_g is not None:
-            d_g.free()
-        e.close()
     if not a.only or ("cfg0" in a.only and not a.exact):
-        # configs[0]: tutorial 1 -- NIF 2x32 + 2x32, the 10k-point lattice of SURVEY 8d, Model.fit with batch 512, 20 steps per epoch
-        import time
-        nif_amd.set_seed(0)
-        cs = {"input_dim": 1, "output_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
-        cp = {"input_dim": 1, "latent_dim": 1, "units": 32, "nlayers": 2, "activation": "swish"}
-        m = nif_amd.NIF(cs, cp)
-        model = m.build()
-        model.compile(nif_amd.Adam(1e-3), "mse")
-        t = np.repeat(np.linspace(0, 90, 50), 200); xx = np.tile(np.arange(200) * 0.005, 50)
-        raw = np.stack([t, xx, nif_amd.data.traveling_wave(t, xx, 4.0)], axis=1)
-        data, _, _ = nif_amd.data.PointWiseData.standard_normalize(raw)
-        x0, y0 = data[:, :2].astype(np.float32), data[:, 2:3].astype(np.float32)
-        model.fit(x0, y0, epochs=2, batch_size=512, verbose=0)
-        t0 = time.perf_counter()
-        ep = 10
-        model.fit(x0, y0, epochs=ep, batch_size=512, verbose=0)
-        dt = time.perf_counter() - t0
-        nsteps = ep * ((x0.shape[0] + 511) // 512)
-        rec = {"points": int(x0.shape[0]), "batch": 512, "us_per_step": round(dt / nsteps * 1e6, 1), "Mpts_per_s": round(ep * x0.shape[0] / dt / 1e6, 2),
-               "params": int(m._engine.n_params), "roofline": None,
-               "note": "launch-bound (13 kernels x 4-8 us of launch-and-drain per step, DESIGN 5.2): no roofline applies at 512 points per step"}
+        rec = run_cfg0()
         out["cfg0_tutorial1_fit_10k_b512"] = rec
         print("cfg0_tutorial1_fit_10k_b512", json.dumps(rec), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -225,7 +225,10 @@ def run_case(cfg, B, seed, loss="mse"):
                                                      stash_ph16=sb_ and spec.kind == O.KIND_MS and _stash_ph16(spec))[1]
                     s_ = max(s_, _rel(O.flatten(gn_), O.flatten(rgb)))
                 eb_ = _rel(gb, O.flatten(rgb))
-                if abs(lb - rlb) <= 1e-3 * abs(rlb) + 3.0 * s_ * abs(rlb) and eb_ < max(5e-3, 3.0 * s_) and eb_ < 5e-2:
+                # the escape only counts when the SAME case passed every fp32-exact check above (no other entry in `bad`: a
+                # kernel regression shows there first) and stays within 3x the bar (1.5e-2, was 5e-2); cond cases are counted in the summary
+                fp32_clean = not [b for b in bad if "refused" not in b[0]]
+                if fp32_clean and abs(lb - rlb) <= 1e-3 * abs(rlb) + 3.0 * s_ * abs(rlb) and eb_ < max(5e-3, 3.0 * s_) and eb_ < 1.5e-2:
                     bad.append(("cond", eb_, s_, "bf16 policy: one-ulp sensitivity of the emulating oracle"))
                 else:
                     bad.append(("bf16 policy", lb, rlb, eb_, "one-ulp sensitivity of the emulating oracle", s_))
@@ -250,7 +253,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     only = set(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None      # re-run single cases of a sweep
     rng = np.random.default_rng(seed)
-    nbad = 0
+    nbad = ncond = 0
     for i in range(ncase):
         cfg, B, desc = draw(rng)
         if only is not None and i not in only:
@@ -263,8 +266,9 @@ def main():
         real = [b for b in bad if "refused" not in b[0] and b[0] != "cond"]
         tag = "FAIL" if real else ("cond" if any(b[0] == "cond" for b in bad) else ("refu" if bad else "ok  "))
         nbad += bool(real)
+        ncond += bool(not real and any(b[0] == "cond" for b in bad))
         print(tag, i, desc, bad if bad else "", flush=True)
-    print("cases %d, failing %d" % (ncase, nbad))
+    print("cases %d, failing %d, conditioning escapes (bf16 policy within 3x the emulating oracle's one-ulp sensitivity, fp32 checks clean) %d" % (ncase, nbad, ncond))
 
 
 if __name__ == "__main__":
