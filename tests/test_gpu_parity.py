@@ -1911,3 +1911,28 @@ def test_hip_path_matches_frozen_oracle_vectors(name):
         assert d[solid].max() < 0.01 * 1e-3, (name, B, d[solid].max())
         assert d.max() <= 2.0 * 1e-3 * 1.001, (name, B)
         m._engine.close()
+
+
+# ---- the 16-bit Keras policies against the EXACT fp64 oracle: the cast-for-cast tests above pin WHERE the kernels
+# round; this one bounds HOW FAR the rounded computation is from exact arithmetic.  Bars = 3x the worst value measured over these shapes
+# on MI355X (tools/exp/policy_distance.py, r6: bf16 predictions <= 1.1e-2, loss <= 5.7e-3, flat gradient <= 9.7e-3, worst tensor <= 2.3e-2;
+# half: 1.3e-3 / 5.5e-4 / 1.4e-3 / 5.6e-3); bf16 has 8 significand bits, half 11: the half policy must sit >= 3x closer on the flat gradient
+POLICY_BARS = {"mixed_bfloat16": (3e-2, 2e-2, 3e-2, 7e-2), "mixed_float16": (4e-3, 2e-3, 4.5e-3, 1.7e-2)}
+
+
+@pytest.mark.parametrize("name", ["ms_cfg2_64x4", "ms_cfg5_64x4_si2", "ms_cfg3_128x3", "nif_cfg1_32x2", "ll_plain_32x2_r3",
+                                  "ll_cfg4_128x6_r10_so3", "ms_64x8"])
+def test_policy_distance_from_exact_arithmetic(name):
+    got = {}
+    for pol, (bu, bl, bg, bt) in POLICY_BARS.items():
+        m, model, spec, ws, x, y, sw = _make_policy(name, pol)
+        x64, y64, s64 = x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64)
+        u = model.predict(x)
+        loss, g = m._engine.loss_and_grad(x, y, sw)
+        el, eg = O.loss_and_grad(spec, ws, x64, y64, s64)        # EXACT arithmetic: no rounding emulation
+        d_u, d_l, d_g = _rel(u, O.forward(spec, ws, x64)), abs(loss - el) / abs(el), _rel(g, O.flatten(eg))
+        d_t = max(_per_tensor_rel(spec, g, O.flatten(eg)).values())
+        assert d_u < bu and d_l < bl and d_g < bg and d_t < bt, (pol, name, d_u, d_l, d_g, d_t)
+        assert d_u > 1e-6, (pol, name, d_u)                       # (the policy really ran: fp32 sits at 1e-7)
+        got[pol] = d_g
+    assert got["mixed_float16"] * 3.0 < got["mixed_bfloat16"], got

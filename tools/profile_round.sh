@@ -6,7 +6,7 @@ set -u
 TAG=$1
 R=$PWD
 export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 3 --no-cpu-baseline"
+ARGS="--steps 6 --warmup 3 --no-cpu-baseline --no-configs"
 O=$R/gpurun_out/${TAG}_default
 rm -rf $O; mkdir -p $O
 python -c "import bench; print(bench.csrc_sha())" > $O/csrc_sha.txt
