@@ -255,76 +255,113 @@ __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w(const float* __restri
 // at every row: 67 KB) -- tools/exp/l2w_probe.hip.
 // R > 0: latent_dim known at compile time, the row's latent lives in registers (one load per unit, reloaded at a row
 // boundary); R = 0: any latent_dim, loaded per element
+// r6: (a) the LDS image is SWIZZLED -- column s of a plane sits at (s & 3) * Q + (s >> 2), Q = ceil(po / 4): lane i of a wave reads
+// column sc0 + 4 i + c, a stride of four dwords = a 4-way bank conflict in the plain image (PMC r5: 4.1e8 SQ_LDS_BANK_CONFLICT cycles,
+// 3.3x the kernel's busy cycles); swizzled, the 64 lanes of a read instruction touch 64 consecutive dwords.  (b) (row, column) of a
+// thread's unit by ONE 64-bit division at its first unit, then incrementally (a 64-bit division per unit was ~100 VALU instructions
+// of the ~128 a unit can afford at 5 TB/s).  (c) the latents of the block's rows (a contiguous span of the output = a few dozen rows)
+// are staged in LDS too: gfx9 counts loads and stores in ONE in-order vmcnt, so a per-unit global load of lr made every iteration
+// wait for the previous unit's STORE to be acknowledged -- 16 waves x 1 KB in flight per CU over ~2 k cycles of store latency is
+// exactly the 8 B / clk / CU (4.9 TB/s) r5 measured; now nothing in the loop waits for vector memory.
 template <int R>
 __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w_flat(const float* __restrict__ theta, long off_Wh, long off_bh, int r_,
                                                                int po, const float* __restrict__ lr, long B,
-                                                               float* __restrict__ w, long nunits, long span) {
-  extern __shared__ float l2w_sm[];            // [(r+1)][po]: planes k < r = Wh rows, plane r = bh
+                                                               float* __restrict__ w, long nunits, long span, int NR) {
+  extern __shared__ float l2w_sm[];            // [(r+1)][4 Q]: planes k < r = Wh rows, plane r = bh; column s at (s & 3) Q + (s >> 2); then [NR][r] latents
   const int r = R > 0 ? R : r_;
-  for (long idx = threadIdx.x; idx < (long)(r + 1) * po; idx += NIF_L2W_T) {
-    const int k = (int)(idx / po); const int e = (int)(idx - (long)k * po);
-    l2w_sm[idx] = k < r ? theta[off_Wh + (long)k * po + e] : theta[off_bh + e];
-  }
-  __syncthreads();
+  const int Q = (po + 3) >> 2, PS = 4 * Q;
   const int wmis = (int)((reinterpret_cast<size_t>(w) >> 2) & 3);       // misalignment of the buffer itself (floats)
-  const long n = B * (long)po;
-  const float* sB = l2w_sm + r * po;
   const long u0 = (long)blockIdx.x * span;
   const long u1 = u0 + span < nunits ? u0 + span : nunits;
-  for (long u = u0 + threadIdx.x; u < u1; u += NIF_L2W_T) {
-    const long e = 4 * u - wmis;               // flat index of the unit's first float (may be < 0 for u = 0)
-    long a = (e < 0 ? 0 : e) / po;
-    int sc = (int)(e - a * po);                // column of the first float (negative only for e < 0)
-    float zr[R > 0 ? R : 1];
-    if (R > 0) {
+  const long e0 = 4 * u0 - wmis;
+  const long a_first = (e0 < 0 ? 0 : e0) / po;                          // first row this block touches (block-uniform)
+  float* sL = l2w_sm + (r + 1) * PS;
+  for (int k = 0; k <= r; ++k) {
+    const float* src = k < r ? theta + off_Wh + (long)k * po : theta + off_bh;
+    float* dst = l2w_sm + k * PS;
+    for (int e = threadIdx.x; e < po; e += NIF_L2W_T) dst[(int)__umul24(e & 3, Q) + (e >> 2)] = src[e];
+  }
+  for (int i = threadIdx.x; i < NR * r; i += NIF_L2W_T) {
+    const long row = a_first + i / r;
+    sL[i] = row < B ? lr[a_first * r + i] : 0.f;
+  }
+  __syncthreads();
+  const long n = B * (long)po;
+  const float* sB = l2w_sm + r * PS;
+  long u = u0 + threadIdx.x;
+  if (u >= u1) return;
+  long e = 4 * u - wmis;                       // flat index of the unit's first float (may be < 0 for u = 0)
+  int a = (int)((e < 0 ? 0 : e) / po - a_first);       // row of the first float, relative to the block's first row
+  int sc = (int)(e - (a_first + a) * po);              // its column (negative only for e < 0)
+  const int da = (4 * NIF_L2W_T) / po, ds = (4 * NIF_L2W_T) - da * po;     // rows / columns a thread advances per iteration
+  for (; u < u1; u += NIF_L2W_T) {
+    if (sc >= 0 && sc + 4 <= po && e + 4 <= n) {
+      // the common unit: four columns of ONE row, inside the buffer -- straight-line code (the general form below is a chain of
+      // exec-masked blocks, one LDS round trip after the other: hipcc cannot hoist reads across its row-boundary tests)
+      int idx[4];
 #pragma unroll
-      for (int k = 0; k < R; ++k) zr[k] = a < B ? lr[a * R + k] : 0.f;
-    }
-    float v[4];
+      for (int c = 0; c < 4; ++c) idx[c] = (int)__umul24((sc + c) & 3, Q) + ((sc + c) >> 2);
+      f32x4 q;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float acc = 0.f;
-      if (sc >= 0) {
-        acc = sB[sc];
-        if (R > 0) {
+      for (int c = 0; c < 4; ++c) q[c] = sB[idx[c]];
+      if (R > 0) {
+        float zr[R > 0 ? R : 1];
 #pragma unroll
-          for (int k = 0; k < R; ++k) acc = fmaf(zr[k], l2w_sm[k * po + sc], acc);
-        } else if (a < B) {
-          for (int k = 0; k < r; ++k) acc = fmaf(lr[a * r + k], l2w_sm[k * po + sc], acc);
+        for (int k = 0; k < R; ++k) zr[k] = sL[a * R + k];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) q[c] = fmaf(zr[k], l2w_sm[k * PS + idx[c]], q[c]);
+      } else {
+        for (int k = 0; k < r; ++k) {
+          const float zk = sL[a * r + k];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) q[c] = fmaf(zk, l2w_sm[k * PS + idx[c]], q[c]);
         }
       }
-      v[c] = acc;
-      if (++sc == po) {
-        sc = 0; ++a;
-        if (R > 0) {
-#pragma unroll
-          for (int k = 0; k < R; ++k) zr[k] = a < B ? lr[a * R + k] : 0.f;
-        }
-      }
-    }
-    if (e >= 0 && e + 4 <= n) {
-      f32x4 q; q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
       *reinterpret_cast<f32x4*>(w + e) = q;
     } else {
+      // a unit that straddles a row boundary (or an end of the buffer): element by element
+      int ar = a, scc = sc;
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float acc = 0.f;
+        if (scc >= 0 && a_first + ar < B) {
+          const int idx = (int)__umul24(scc & 3, Q) + (scc >> 2);
+          acc = sB[idx];
+          for (int k = 0; k < r; ++k) acc = fmaf(sL[ar * r + k], l2w_sm[k * PS + idx], acc);
+        }
+        v[c] = acc;
+        if (++scc == po) { scc = 0; ++ar; }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (e + c >= 0 && e + c < n) w[e + c] = v[c];
     }
+    e += 4L * NIF_L2W_T;
+    sc += ds; a += da;                         // (a unit that starts in front of the buffer has a = 0, sc < 0: the same step)
+    if (sc >= po) { sc -= po; ++a; }
   }
 }
 void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, long po, const float* lr, long B, float* w,
                         hipStream_t st) {
-  if ((size_t)(r + 1) * po * sizeof(float) <= 144u * 1024u) {
+  if ((size_t)(r + 1) * (4 * ((po + 3) / 4)) * sizeof(float) <= 144u * 1024u) {
     const long nunits = (B * po + 3 + 3) / 4;
     const long nb = 4096;
-    const long span = ((nunits + nb - 1) / nb + NIF_L2W_T - 1) / NIF_L2W_T * NIF_L2W_T;
+    long span = ((nunits + nb - 1) / nb + NIF_L2W_T - 1) / NIF_L2W_T * NIF_L2W_T;
+    // the block's rows of lr sit in LDS: at most 8 KB of them (small po: more, shorter spans)
+    const long max_rows = (8 * 1024 / 4) / r;
+    const long span_cap = ((max_rows - 2) * po / 4) / NIF_L2W_T * NIF_L2W_T;
+    if (span > span_cap && span_cap >= NIF_L2W_T) span = span_cap;
+    const int NR = (int)((4 * span + po - 1) / po + 2);
     const long nblk = (nunits + span - 1) / span;
-    const size_t shm = sizeof(float) * (size_t)(r + 1) * po;
+    const size_t shm = sizeof(float) * ((size_t)(r + 1) * (4 * ((po + 3) / 4)) + (size_t)NR * r);
 #define NIF_L2WF(R_)                                                                                                       \
     {                                                                                                                       \
       (void)hipFuncSetAttribute((const void*)k_latent_to_w_flat<R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
       hipLaunchKernelGGL(k_latent_to_w_flat<R_>, dim3((unsigned)nblk), dim3(NIF_L2W_T), shm, st, theta, off_Wh, off_bh, r, (int)po, lr, \
-                         B, w, nunits, span);                                                                               \
+                         B, w, nunits, span, NR);                                                                           \
     }
     switch (r) {
       case 1: NIF_L2WF(1) break;
