@@ -263,6 +263,12 @@ __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w(const float* __restri
 // are staged in LDS too: gfx9 counts loads and stores in ONE in-order vmcnt, so a per-unit global load of lr made every iteration
 // wait for the previous unit's STORE to be acknowledged -- 16 waves x 1 KB in flight per CU over ~2 k cycles of store latency is
 // exactly the 8 B / clk / CU (4.9 TB/s) r5 measured; now nothing in the loop waits for vector memory.
+#ifndef NIF_L2W_NT
+#define NIF_L2W_NT 0      // 1: non-temporal stores of the output stream (measured r6: see DESIGN 5.6)
+#endif
+#ifndef NIF_L2W_NB
+#define NIF_L2W_NB 4096   // workgroups = contiguous spans of the output
+#endif
 template <int R>
 __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w_flat(const float* __restrict__ theta, long off_Wh, long off_bh, int r_,
                                                                int po, const float* __restrict__ lr, long B,
@@ -319,7 +325,11 @@ __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w_flat(const float* __r
           for (int c = 0; c < 4; ++c) q[c] = fmaf(zk, l2w_sm[k * PS + idx[c]], q[c]);
         }
       }
+#if NIF_L2W_NT
+      __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(w + e));
+#else
       *reinterpret_cast<f32x4*>(w + e) = q;
+#endif
     } else {
       // a unit that straddles a row boundary (or an end of the buffer): element by element
       int ar = a, scc = sc;
@@ -348,7 +358,7 @@ void launch_latent_to_w(const float* theta, long off_Wh, long off_bh, int r, lon
                         hipStream_t st) {
   if ((size_t)(r + 1) * (4 * ((po + 3) / 4)) * sizeof(float) <= 144u * 1024u) {
     const long nunits = (B * po + 3 + 3) / 4;
-    const long nb = 4096;
+    const long nb = NIF_L2W_NB;
     long span = ((nunits + nb - 1) / nb + NIF_L2W_T - 1) / NIF_L2W_T * NIF_L2W_T;
     // the block's rows of lr sit in LDS: at most 8 KB of them (small po: more, shorter spans)
     const long max_rows = (8 * 1024 / 4) / r;

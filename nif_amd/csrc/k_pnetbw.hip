@@ -30,6 +30,18 @@ struct PbwArgs {
 
 __device__ __forceinline__ f32x4 lds4(const float* q) { return *reinterpret_cast<const f32x4*>(q); }
 
+// r6: the wave-private LDS tiles [feature][32 points] are SWIZZLED -- the 16-byte column piece c of feature row f sits at piece
+// c ^ (f & 7).  The gradient GEMM reads lane (i, hf) <- 16 consecutive points of feature i with ds_read_b128 at a row stride of
+// 128 bytes: in the plain layout every second lane hits the same four banks (PMC r5: 1.45e7 SQ_LDS_BANK_CONFLICT cycles in this
+// kernel); swizzled, eight consecutive lanes cover all 64 banks.  The dword stores of a register tile (32 consecutive points of one
+// feature per half wave) stay conflict free: the swizzle permutes pieces inside a row.
+__device__ __forceinline__ int pswz(int f, int p) { return f * 32 + ((((p >> 2) ^ (f & 7))) << 2) + (p & 3); }
+__device__ __forceinline__ int pswz4(int f, int c) { return f * 32 + ((c ^ (f & 7)) << 2); }     // piece c (4 points) of row f
+__device__ __forceinline__ void tile_store(float* __restrict__ t, const f32x16& h, int p, int hf) {
+#pragma unroll
+  for (int v = 0; v < 16; ++v) t[pswz(fmap(v, hf), p)] = h[v];
+}
+
 // C[in][out] += sum_p IN[p][in] * DA[p][out] over the 32 points of the tile; IN, DA are LDS tiles [feature][32].
 // Gradient path: bf16 hi/lo splits, three v_mfma_f32_32x32x16_bf16 per 16 points (k_gw.hip) instead of 8 f32-input MFMAs
 typedef __bf16 pbw_bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,9 +53,9 @@ __device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x
   f32x4 a[4], b[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    a[q] = lds4(IN + (i < in_rows ? i : 0) * 32 + 16 * hf + 4 * q);
+    a[q] = lds4(IN + pswz4(i < in_rows ? i : 0, 4 * hf + q));
     if (i >= in_rows) { a[q][0] = 0.f; a[q][1] = 0.f; a[q][2] = 0.f; a[q][3] = 0.f; }
-    b[q] = lds4(DA + i * 32 + 16 * hf + 4 * q);
+    b[q] = lds4(DA + pswz4(i, 4 * hf + q));
   }
 #if NIF_PBW_BF16
 #pragma unroll
@@ -71,7 +83,7 @@ __device__ __forceinline__ void grad_mfma(const float* IN, const float* DA, f32x
 __device__ __forceinline__ float col_sum(const float* DA, int i, int hf) {
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const f32x4 b = lds4(DA + i * 32 + 16 * hf + 4 * q); s += (b[0] + b[1]) + (b[2] + b[3]); }
+  for (int q = 0; q < 4; ++q) { const f32x4 b = lds4(DA + pswz4(i, 4 * hf + q)); s += (b[0] + b[1]) + (b[2] + b[3]); }
   return s;
 }
 
@@ -169,13 +181,13 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       for (int v = 0; v < 16; ++v) park[v * 64 + lane] = d[0][0][v];
     }
     if (!SMALL && hf == 0) {
-      for (int dd = 0; dd < A.pi; ++dd) xT[dd * 32 + p] = prow[dd];
-      xT[A.pi * 32 + p] = 1.0f;
+      for (int dd = 0; dd < A.pi; ++dd) xT[pswz(dd, p)] = prow[dd];
+      xT[pswz(A.pi, p)] = 1.0f;
     }
     if (!RES) {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        stash_store<1>(hs + m * 1024, 0, h, p, hf);
+        tile_store(hs + m * 1024, h[0], p, hf);
         dense_f(m, h, T);
         T[0] = A.omega * T[0] + psmall_get(S.hb + m * 32, 0, hf);
         act_tile_sel<1, ACT>(A.act, T, T, d[m + 1], A.nst, hf);
@@ -183,11 +195,11 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       }
     } else {
       f32x16 t[1];
-      stash_store<1>(hs, 0, h, p, hf);
+      tile_store(hs, h[0], p, hf);
       dense_f(0, h, T);
       T[0] = A.omega * T[0] + psmall_get(S.hb, 0, hf);
       act_tile_sel<1, ACT>(A.act, T, t, d[1], A.nst, hf);
-      stash_store<1>(hs + 1024, 0, t, p, hf);
+      tile_store(hs + 1024, t[0], p, hf);
       dense_f(1, t, T);
       {
         const f32x16 lin = A.omega * T[0] + psmall_get(S.hb2, 0, hf);
@@ -196,20 +208,20 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       act_tile_sel<1, ACT>(A.act, T, T, d[NM], A.nst, hf);
       h[0] = A.siren ? 0.5f * (h[0] + T[0]) : T[0];
     }
-    if (!SMALL) stash_store<1>(hs + NM * 1024, 0, h, p, hf);
+    if (!SMALL) tile_store(hs + NM * 1024, h[0], p, hf);
     // ---- bottleneck: dL/dW_b[f][c] = sum_p h[p][f] dz_c[p]; gh[f] = sum_c dz_c W_b[f][c] -------------
     f32x16 gh[1], ga[1], U[1];
 #pragma unroll
     for (int v = 0; v < 16; ++v) gh[0][v] = 0.f;
     if (!SMALL) {
 #pragma unroll
-      for (int q = 0; q < NIF_PBW_DZR; ++q) gaT[lane + 64 * q] = dzr[q];       // rows >= r are zero
+      for (int q = 0; q < NIF_PBW_DZR; ++q) gaT[pswz(2 * q + hf, p)] = dzr[q];       // element lane + 64 q = (row 2 q + hf, point p); rows >= r are zero
 #pragma unroll
       for (int q = NIF_PBW_DZR; q < 16; ++q) {
         const int e = lane + 64 * q;
-        gaT[e] = e < A.r * 32 ? A.DZ[tile * A.r * 32 + e] : 0.f;
+        gaT[pswz(2 * q + hf, p)] = e < A.r * 32 ? A.DZ[tile * A.r * 32 + e] : 0.f;
       }
-      for (int c = 0; c < A.r; ++c) gh[0] += gaT[c * 32 + p] * psmall_get(S.bw + c * 32, 0, hf);
+      for (int c = 0; c < A.r; ++c) gh[0] += gaT[pswz(c, p)] * psmall_get(S.bw + c * 32, 0, hf);
     } else {
       gh[0] += A.DZ[tile * 32 + p] * psmall_get(S.bw, 0, hf);
     }
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
 #pragma unroll
       for (int m = NM - 1; m >= 0; --m) {
         ga[0] = gh[0] * d[m + 1][0];
-        stash_store<1>(gaT, 0, ga, p, hf);
+        tile_store(gaT, ga[0], p, hf);
         grad_mfma(hs + m * 1024, gaT, C[m], i, hf);
         gbh[m] += col_sum(gaT, i, hf);
         dense_b(m, ga, U);
@@ -247,14 +259,14 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
     } else {
       const float half = A.siren ? 0.5f : 1.0f;
       ga[0] = half * gh[0] * d[NM][0];
-      stash_store<1>(gaT, 0, ga, p, hf);
+      tile_store(gaT, ga[0], p, hf);
       grad_mfma(hs + 1024, gaT, C[NM - 1], i, hf);
       gbh[NM - 1] += col_sum(gaT, i, hf);
       dense_b(1, ga, U);
       f32x16 skip;
       skip = A.siren ? 0.5f * gh[0] : ga[0];
       ga[0] = A.omega * U[0] * d[1][0];
-      stash_store<1>(gaT, 0, ga, p, hf);
+      tile_store(gaT, ga[0], p, hf);
       grad_mfma(hs, gaT, C[0], i, hf);
       gbh[0] += col_sum(gaT, i, hf);
       dense_b(0, ga, U);
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(64 * NIF_PBW_WAVES) void k_pnet_bwg(PbwArgs G) {
       C1 += prow[0] * ga[0];
       CB1 += ga[0];
     } else {
-      stash_store<1>(gaT, 0, ga, p, hf);
+      tile_store(gaT, ga[0], p, hf);
       grad_mfma(xT, gaT, C1, i, hf, 8);     // rows of X^T: the pi <= 6 inputs, then ones (the bias row)
     }
     asm volatile("" ::"v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]));

@@ -517,6 +517,9 @@ __device__ __forceinline__ void mfma_x6(const bf16x8* cur, const bf16x8 b0, cons
   NIF_MFMA_PRIO_OFF
 }
 // one K-step chunk of an adjoint plane, 3-product form, two blocks' chains interleaved
+#ifndef NIF_X16_LOLO
+#define NIF_X16_LOLO 0
+#endif
 template <int NBL, int PR = 0, bool ZI = false, int NT = NBL, int OB0 = 0, bool CP = false>
 __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, const bf16x8 b1, f32x4 (&T_)[NT], int lane) {
   NIF_MFMA_PRIO_ON
@@ -539,8 +542,15 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
     const bf16x8 a0 = cur[(ib * 2 + 0) * 64 + lane], a1 = cur[(ib * 2 + 1) * 64 + lane];
     const bf16x8 c0 = cur[(ib * 2 + 2) * 64 + lane], c1 = cur[(ib * 2 + 3) * 64 + lane];
     if (PR == 3) {      // exact-product half planes (hi, lo) x half operand pair (b0 = hi, b1 = lo): three products, small terms first
+#if NIF_X16_LOLO      // measurement builds (r6): the lo.lo term as a fourth product (2^-24 of the product; DESIGN 7: what it buys the gradient)
+      T[ib] = mfma_f16(a1, b1, ZI ? z4 : T[ib]);
+      T[ib + 1] = mfma_f16(c1, b1, ZI ? z4 : T[ib + 1]);
+      T[ib] = mfma_f16(a0, b1, T[ib]);
+      T[ib + 1] = mfma_f16(c0, b1, T[ib + 1]);
+#else
       T[ib] = mfma_f16(a0, b1, ZI ? z4 : T[ib]);
       T[ib + 1] = mfma_f16(c0, b1, ZI ? z4 : T[ib + 1]);
+#endif
       T[ib] = mfma_f16(a1, b0, T[ib]);
       T[ib + 1] = mfma_f16(c1, b0, T[ib + 1]);
       T[ib] = mfma_f16(a0, b0, T[ib]);
@@ -554,6 +564,56 @@ __device__ __forceinline__ void mfma_x3(const bf16x8* cur, const bf16x8 b0, cons
     T[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, T[ib], 0, 0, 0);
     T[ib + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, b0, T[ib + 1], 0, 0, 0);
   }
+  NIF_MFMA_PRIO_OFF
+}
+
+// the PR = 3 form with the first block pair's A operands already in registers (k_snet6, r6: read in front of the step's DMA issue)
+template <int NBL, bool ZI>
+__device__ __forceinline__ void mfma_x3_pre(const bf16x8* cur, const bf16x8 (&pa)[4], const bf16x8 b0, const bf16x8 b1, f32x4 (&T)[NBL], int lane) {
+  NIF_MFMA_PRIO_ON
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ib = 0; ib < NBL; ib += 2) {
+    const bf16x8 a0 = ib == 0 ? pa[0] : cur[(ib * 2 + 0) * 64 + lane], a1 = ib == 0 ? pa[1] : cur[(ib * 2 + 1) * 64 + lane];
+    const bf16x8 c0 = ib == 0 ? pa[2] : cur[(ib * 2 + 2) * 64 + lane], c1 = ib == 0 ? pa[3] : cur[(ib * 2 + 3) * 64 + lane];
+    T[ib] = mfma_f16(a0, b1, ZI ? z4 : T[ib]);
+    T[ib + 1] = mfma_f16(c0, b1, ZI ? z4 : T[ib + 1]);
+    T[ib] = mfma_f16(a1, b0, T[ib]);
+    T[ib + 1] = mfma_f16(c1, b0, T[ib + 1]);
+    T[ib] = mfma_f16(a0, b0, T[ib]);
+    T[ib + 1] = mfma_f16(c0, b0, T[ib + 1]);
+  }
+  NIF_MFMA_PRIO_OFF
+}
+
+// ... and the software-pipelined form (k_snet6, NIF_S6_PF): the first block pair's operands of THIS chunk come from registers when the
+// previous step prefetched them (USEPF), and the first pair of the NEXT chunk (already landed: three chunk buffers, DMA two steps
+// ahead) is read behind this chunk's first six products (MAKEPF) -- the LDS latency of a step's first reads leaves the critical path
+template <int NBL, bool ZI, bool USEPF, bool MAKEPF>
+__device__ __forceinline__ void mfma_x3_pf(const bf16x8* cur, const bf16x8* nxt, bf16x8 (&pf)[4], const bf16x8 b0, const bf16x8 b1,
+                                           f32x4 (&T)[NBL], int lane) {
+  static_assert(NBL == 4, "two block pairs per chunk");
+  NIF_MFMA_PRIO_ON
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const bf16x8 a0 = USEPF ? pf[0] : cur[0 * 64 + lane], a1 = USEPF ? pf[1] : cur[1 * 64 + lane];
+  const bf16x8 c0 = USEPF ? pf[2] : cur[2 * 64 + lane], c1 = USEPF ? pf[3] : cur[3 * 64 + lane];
+  const bf16x8 d0 = cur[4 * 64 + lane], d1 = cur[5 * 64 + lane], e0 = cur[6 * 64 + lane], e1 = cur[7 * 64 + lane];
+  T[0] = mfma_f16(a0, b1, ZI ? z4 : T[0]);
+  T[1] = mfma_f16(c0, b1, ZI ? z4 : T[1]);
+  T[0] = mfma_f16(a1, b0, T[0]);
+  T[1] = mfma_f16(c1, b0, T[1]);
+  T[0] = mfma_f16(a0, b0, T[0]);
+  T[1] = mfma_f16(c0, b0, T[1]);
+  if (MAKEPF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = nxt[i * 64 + lane];
+  }
+  T[2] = mfma_f16(d0, b1, ZI ? z4 : T[2]);
+  T[3] = mfma_f16(e0, b1, ZI ? z4 : T[3]);
+  T[2] = mfma_f16(d1, b0, T[2]);
+  T[3] = mfma_f16(e1, b0, T[3]);
+  T[2] = mfma_f16(d0, b0, T[2]);
+  T[3] = mfma_f16(e0, b0, T[3]);
   NIF_MFMA_PRIO_OFF
 }
 

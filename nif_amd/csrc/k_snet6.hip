@@ -119,6 +119,18 @@ struct S6Args {
                              // the chunk step and saving 0.25-0.4 k in the vector block -- both producer waves of a SIMD run them at the
                              // same moment wherever they stand, and behind the step's matrix instructions they do not overlap its LDS wait
 #endif
+#ifndef NIF_S6_PF
+#define NIF_S6_PF 0
+#endif
+#ifndef NIF_S6_DBAR_T0
+#define NIF_S6_DBAR_T0 8     // tiles of the deposit taken under the vector block + the first chunk step (timeline r6: 240 ticks per tile there,
+                             // 650 once the producers' matrix instructions compete)
+#endif
+#ifndef NIF_S6_DBAR
+#define NIF_S6_DBAR 0        // 1 (r6): a barrier right BEHIND every hidden deposit (not only deposit 0's): the consumer waves take deposit j
+                             // during the producers' vector block of layer j - 1 (the matrix pipe idles there) and its first chunk step
+                             // (5 + 3 tiles) instead of in chunk steps 1-3 (3 + 3 + 2), where they were the last at every barrier
+#endif
 #ifndef NIF_S6_CONS_PRIO
 #define NIF_S6_CONS_PRIO 0     // s_setprio of the consumer waves
 #endif
@@ -145,7 +157,10 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr int QF = (CF + NT - 1) / NT;
   // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
   // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
-  constexpr int NBUF = 2;
+  // r6 (NIF_S6_PF = 1, exact-product form): THREE buffers, the DMA two steps ahead, so that a step can read the first operands of the next
+  // chunk behind its own first products (mfma_x3_pf)
+  constexpr bool PF = X16 && NIF_S6_PF;
+  constexpr int NBUF = PF ? 3 : 2;
   constexpr int NPL = 6;                                // planes per tile: h (hi, lo), zt h (hi, lo), dL/da (hi, lo)
 #if defined(NIF_ABL_NOSTORE) || defined(NIF_ABL_NOLOAD) || !NIF_S6_RING
   constexpr int NRING = 0;
@@ -317,6 +332,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_CBAR()                                                                                               \
     S6_CBAR()                                                                                               \
   }
+#elif NIF_S6_DBAR
+#define S6_HID_LAYER(DJ_)      /* entered in front of the barrier behind deposit DJ_ */                     \
+  if (DJ_ < nh) {                                                                                           \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, 0, NIF_S6_DBAR_T0))                                                             \
+    S6_CBAR()                                                                                               \
+    S6_DO(S6_HID_TILES(DJ_, NIF_S6_DBAR_T0, 8))                                                             \
+    S6_CBAR()                                                                                               \
+    S6_CBAR()                                                                                               \
+    S6_CBAR()                                                                                               \
+  }
 #else
 #define S6_HID_LAYER(DJ_)                                                                                   \
   if (DJ_ < nh) {                                                                                           \
@@ -378,10 +404,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     if (cs_left <= 0) cs_left = -1;
     cs_next(0, false);                      // (chunk 0: issued by the producers in their prologue)
     int nb_c = 1;
+    if (PF) { cs_next(1, false); nb_c = 2; }     // (PF: chunk 1 too; a step issues the chunk two steps ahead)
+#define S6_ROTC() { if (PF) nb_c = nb_c == 2 ? 0 : nb_c + 1; else nb_c ^= 1; }
     // a forward interval: this wave's slice of the NEXT step's chunk goes out first and has landed in front of the barrier
 #define S6_CFWD(...)                                                          \
   {                                                                           \
-    cs_next(nb_c, true); nb_c ^= 1;                                           \
+    cs_next(nb_c, true); S6_ROTC()                                            \
     __VA_ARGS__                                                               \
     __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0) */      \
     S6_TL(400);                                                               \
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         S6_CFWD(if (j == 0) { S6_DO(consume_first(3, 6);) })
         S6_CFWD(if (j == 0) { S6_DO(consume_first(6, 8);) })
       }
-      for (int q = 0; q < 4 * nh; ++q) { cs_next(nb_c, false); nb_c ^= 1; }      // (the adjoint steps' chunks: the producers issue them)
+      for (int q = 0; q < 4 * nh; ++q) { cs_next(nb_c, false); S6_ROTC() }      // (the adjoint steps' chunks: the producers issue them)
       // adjoint: the last layer's deposit next to the steps of layer nh - 1, then deposit j + 1 next to layer j
 #if NIF_S6_EARLYDEP
       S6_CBAR()
@@ -516,9 +544,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   prefetch_inputs(blockIdx.x, 0);
   if (cs_left <= 0) cs_left = -1;
   cs_next(0, true);
+  if (PF) cs_next(1, true);
   __syncthreads();
   bool dma_mine = false;                                 // forward steps: the consumer waves issue the chunk DMA
-  int cbuf = 0, nbuf = 1;
+  int cbuf = 0, nbuf = PF ? 2 : 1;
+  bf16x8 pf[4]; (void)pf;                                // PF: the next chunk's first block pair (live inside a layer's four steps only)
+#define S6_ROT() { if (PF) { cbuf = cbuf == 2 ? 0 : cbuf + 1; nbuf = nbuf == 2 ? 0 : nbuf + 1; } else { cbuf ^= 1; nbuf ^= 1; } }
   int tlc = 0, tlr = 0; (void)tlc; (void)tlr;
   float loss_lane = 0.f;
   const long sstride = A.slot_stride, tstride = (long)stash_fp(n) * 32;
@@ -542,7 +573,48 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
     S6_TL(500);                                                               \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    S6_ROT()                                                                  \
+  }
+// r6 (NIF_S6_PRE): the exact-product steps read the first block pair's A operands IN FRONT of the next chunk's DMA issue -- the issue
+// (60-180 cycles per piece, MI355X_MICROARCH.md) then overlaps the LDS latency of the reads the step's first MFMAs wait for
+#ifndef NIF_S6_PRE
+#define NIF_S6_PRE 0
+#endif
+#define S6_CHUNKP(ZI_, B0_, B1_, T_)                                          \
+  {                                                                           \
+    S6_TL(100);                                                               \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8 pa_[4] = {cur[lane], cur[64 + lane], cur[128 + lane], cur[192 + lane]};   \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    cs_next(nbuf, dma_mine);                                                  \
+    S6_TL(200);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    mfma_x3_pre<NBL, ZI_>(cur, pa_, B0_, B1_, T_, lane);                      \
+    S6_TL(300);                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0070);                                       \
+    S6_TL(400);                                                               \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    S6_TL(500);                                                               \
+    S6_ROT()                                                                  \
+  }
+#define S6_CHUNKF(USE_, MAKE_, ZI_, B0_, B1_, T_)                             \
+  {                                                                           \
+    S6_TL(100);                                                               \
+    cs_next(nbuf, dma_mine);                                                  \
+    S6_TL(200);                                                               \
+    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8* nxt = chunks + (cbuf == 2 ? 0 : cbuf + 1) * CF;             \
+    mfma_x3_pf<NBL, ZI_, USE_, MAKE_>(cur, nxt, pf, B0_, B1_, T_, lane);      \
+    S6_TL(300);                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0070);                                       \
+    S6_TL(400);                                                               \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                             \
+    asm volatile("" ::: "memory");                                            \
+    S6_TL(500);                                                               \
+    S6_ROT()                                                                  \
   }
 // the chunk step that carries the layer's ring traffic: the NRING ring instructions are issued BEHIND the next chunk's DMA, so the
 // wait at the end of the step may leave exactly them in flight (vmcnt counts in issue order: "at most NRING outstanding" = every
@@ -559,7 +631,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     asm volatile("" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                             \
     asm volatile("" ::: "memory");                                            \
-    cbuf ^= 1; nbuf ^= 1;                                                     \
+    S6_ROT()                                                                  \
   }
 #else
 #define S6_CHUNK_RING(PRE_, ...) { PRE_ S6_CHUNK(__VA_ARGS__) }
@@ -633,17 +705,23 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
 #define S6_FWD(KS_, T_) { if (X16) mfma_x3<NBL, 3, false, NBL, 0, false>(cur, b0[KS_], b1[KS_], T_, lane); else mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }
-        S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, S6_FWD(0, T))
+        if (PF) {
+          if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
+          S6_CHUNKF(false, true, false, b0[0], b1[0], T)
+        } else S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, S6_FWD(0, T))
 #else
         S6_CHUNK(S6_FWD(0, T))
 #endif
-        S6_CHUNK(S6_FWD(1, T))
+        if (PF) S6_CHUNKF(true, true, false, b0[1], b1[1], T)
+        else S6_CHUNK(S6_FWD(1, T))
         const float zt = X16 ? zt_base[0] * (s1_ * is0_) : zt_base[0];      // (plane 0's chain carries s0, the sum s1)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      S6_CHUNK(S6_FWD(0, acc))
-      S6_CHUNK(S6_FWD(1, acc))
+      if (PF) S6_CHUNKF(true, true, false, b0[0], b1[0], acc)
+      else S6_CHUNK(S6_FWD(0, acc))
+      if (PF) S6_CHUNKF(true, false, false, b0[1], b1[1], acc)
+      else S6_CHUNK(S6_FWD(1, acc))
 #undef S6_FWD
       if (X16) sine16_tag_sc<NBL>(acc, acc, is1_ * (1.0f / 4096.0f));
       else sine16_tag<NBL>(acc, acc);
@@ -766,11 +844,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
+        if (PF) {
+          if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p);
+          S6_CHUNKF(false, true, true, q0[0], q1[0], U)
+        } else S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #else
         S6_CHUNK({ mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #endif
-        S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], U, lane); })
+        if (PF) S6_CHUNKF(true, true, false, q0[1], q1[1], U)
+        else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[1], q1[1], U)
+        else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], U, lane); })
         float s = 0.f;
 #pragma unroll
         for (int b = 0; b < NBL; ++b)
@@ -797,12 +880,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);                   \
         fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);                   \
       }
-      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
+      if (PF) S6_CHUNKF(true, true, false, q0[0], q1[0], gh)
+      else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[0], q1[0], gh)
+      else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
 #if NIF_S6_EARLYDEP
       // (the slot's previous deposit was consumed two barriers ago; the splits run behind this step's matrix instructions)
       S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); S6_DEPOSIT() })
 #else
-      S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
+      if (PF) S6_CHUNKF(true, false, false, q0[1], q1[1], gh)
+      else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[1], q1[1], gh)
+      else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
 #endif
       if (PR == 2 || X16) {
         const float f_ = X16 ? ils * is1_ : ils;
@@ -813,6 +900,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       S6_DEPOSIT()
 #endif
 #undef S6_DEPOSIT
+#if NIF_S6_DBAR && !NIF_S6_EARLYDEP
+      if (j > 0) {      // deposit j is visible NOW: the consumers start on it under this wave's next vector block
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        S6_TL(600);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        S6_TL(700);
+      }
+#endif
     }
 #if !NIF_S6_EARLYDEP
     asm volatile("" ::: "memory");
@@ -877,7 +974,7 @@ static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * (11 * 16 * NBL + 4)) + 3) & ~(size_t)3;      // (the kernel's fixed small-vector layout)
   const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + 2 * (size_t)NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + (size_t)((a.prec == 0 && NIF_S6_PF) ? 3 : 2) * NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
 #ifdef NIF_TIMELINE
          + 2 * 380 * 8
 #endif
