@@ -283,7 +283,8 @@ void launch_pnet(const PNetArgs& a_, int NSTB, bool train, hipStream_t st) {
   PNetArgs a = a_;
   const long ntiles = (a.B + 31) / 32;
   long nblk = (ntiles + 3) / 4;
-  if (nblk > 2048) nblk = 2048;          // persistent: the small vectors are staged in LDS once per workgroup
+  static const long cap = [] { const char* e = getenv("NIF_PNET_BLOCKS"); return e ? atol(e) : 2048L; }();
+  if (nblk > cap) nblk = cap;            // persistent: the small vectors are staged in LDS once per workgroup
   const int nmat = a.lst * (a.res ? 2 : 1);
   const size_t shm0 = ((a.ll_kind ? (size_t)4 * a.r * 32 : 0) + (size_t)((psmall_floats(a, NSTB) + 3) & ~3)) * sizeof(float);
   static const bool bf2_on = [] { const char* e = getenv("NIF_PNET_BF2"); return !(e && e[0] == '0'); }();

@@ -124,6 +124,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   c->cfg = *cfg;
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
   { const char* e = getenv("NIF_FUSE_GW"); c->opt_fuse_gw = !(e && e[0] == '0'); }
+  { const char* e = getenv("NIF_SMALL_STEP"); c->opt_small_step = !(e && e[0] == '0'); }
   { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
   { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
@@ -406,7 +407,8 @@ static int ensure_capacity(nif_ctx* c, long B, bool train) {
   if (train) {
     // one loss partial per workgroup of the fused kernel: the 16-point-tile kernels launch up to ceil(2*ntiles/4)
     // workgroups (k_snet3/4, k_sob), k_ll_out ntiles/8, k_snet ntiles/4
-    const long nblk = (2 * ntiles + 3) / 4 + 1;
+    // (r6: k_small one per 16 points = 2 ntiles)
+    const long nblk = 2 * ntiles + 1;
     if (nblk > c->nloss_cap) {
       HIPCHK(hipStreamSynchronize(c->st));
       if (c->loss_partial) HIPCHK(hipFree(c->loss_partial));
@@ -1406,6 +1408,25 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
                           const int* seeds, const float* gt, float wj, const SobPlan* sp = nullptr) {
   HIPCHK(hipSetDevice(c->dev));
+  // r6: a small batch of a small net -- ONE launch for the loss and every gradient (k_small: fp32 FMAs straight from theta, no plane
+  // packing), then the usual row reduction.  configs[0]'s 512-point steps spent 82 us in eleven tile-kernel launches
+  if (ns == 0 && c->opt_small_step && B <= NIF_SMALL_MAX_B && c->kind != NIF_KIND_LASTLAYER && !act_on(c) && !c->opt_fp32_mfma) {
+    if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
+    PNetArgs pa; fill_pnet(c, pa, xin, B);
+    SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
+    if (small_supported(pa, sa) && small_rows(B) <= c->rows_cap) {
+      int rc = ensure_capacity(c, ((B + 31) / 32) * 32, true); if (rc) return rc;
+      const int rows = small_rows(B);
+      if (rows > c->nloss_cap) return fail(NIF_ERR_STATE, "internal: loss partial buffer too small for the small-batch step");
+      c->reg_applied = false;
+      sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
+      { ProfScope p_(c, NIF_PROF_SNET); launch_small(pa, sa, c->partial, c->pstride, c->P, c->st); }
+      { ProfScope pr_(c, NIF_PROF_REDUCE); launch_reduce(c->partial, c->pstride, rows, c->loss_partial, rows, c->grad, c->P, c->st); }
+      if (c->jac_l1 != 0.f) { rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
+      HIPCHK(hipGetLastError());
+      return NIF_OK;
+    }
+  }
   int rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B + 31) / 32;
   if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
@@ -1968,6 +1989,7 @@ extern "C" int nif_device_pci_bus_id(int32_t dev, char* out, int32_t cap) {
 extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
   if (!c || !key) return fail(NIF_ERR_INVALID, "null");
   if (strcmp(key, "fuse_gw") == 0) { c->opt_fuse_gw = value != 0; return NIF_OK; }   // 0: k_snet4 + k_gw_* instead of the fused-gradient kernel
+  if (strcmp(key, "small_step") == 0) { c->opt_small_step = value != 0; return NIF_OK; }   // 0: small batches on the tile kernels too (A/B, tests)
   if (strcmp(key, "fp32_mfma") == 0) {      // 1: every product on the f32-input MFMAs (k_snet3) instead of the bf16 splits
     c->opt_fp32_mfma = value != 0;
     c->packed = false; c->packed32 = false; c->packed_p32 = false;

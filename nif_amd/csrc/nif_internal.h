@@ -204,6 +204,11 @@ void launch_snet4_x16(const SNetArgs& a, bool train, int nblk, size_t shm, hipSt
 void launch_pack16b_batch(const float* theta, const MatRef& m0, long mstride, int nmat, int NBL, void* WF, void* WB,
                           long fstride_elems, long bstride_elems, float scale, hipStream_t st, int mode = 0, float* pscale = nullptr);
 int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st);
+// k_small.hip (r6): loss + every gradient of a small batch in one launch (one partial row per 16 points)
+#define NIF_SMALL_MAX_B 2048
+bool small_supported(const PNetArgs& p, const SNetArgs& s);
+int small_rows(long B);
+void launch_small(const PNetArgs& p, const SNetArgs& s, float* partial, long pstride, long P, hipStream_t st);
 bool snet4_writes_h_ph16(const SNetArgs& a);    // ... and its hidden-matrix input rows as 16-bit phases
 bool gw_in_ph16_ok(int NBI, int NBO, int r);    // a reader of that form exists for this shape (k_gw8<R, true, true>; NIF_H_PH16=0 switches it off)
 bool snet4_writes_da_bf16(const SNetArgs& a);   // stash format the training launch of `a` produces (k_snet4.hip)

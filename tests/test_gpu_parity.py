@@ -1936,3 +1936,66 @@ def test_policy_distance_from_exact_arithmetic(name):
         assert d_u > 1e-6, (pol, name, d_u)                       # (the policy really ran: fp32 sits at 1e-7)
         got[pol] = d_g
     assert got["mixed_float16"] * 3.0 < got["mixed_bfloat16"], got
+
+
+# ---- r6: the small-batch step (k_small: loss + every gradient of <= 2048 points in one launch) and the tile kernels it replaces for those
+# batches: both against the oracle, and against each other ---------------------------------------------------------------------------------
+SMALL_CASES = {
+    "nif_cfg1_32x2": CONFIGS["nif_cfg1_32x2"],
+    "nif_pad_n30_tanh_r2_so2": CONFIGS["nif_pad_n30_tanh_r2_so2"],
+    "ms_tiny_b1": CONFIGS["ms_tiny_b1"],
+    "cfg0_nif_2x32_b512": (_cfg("NIF", 32, 2, 32, 2, 1, 1, 1, 1), 512),            # configs[0]'s own step
+    "nif_32x3_r2_si3_so3_b2047": (_cfg("NIF", 32, 3, 32, 3, 2, 3, 3, 2, act="tanh"), 2047),
+    "ms_plain_32x3_r2_b17": (_cfg("NIFMultiScale", 32, 3, 24, 2, 2, 2, 2, 1), 17),
+    "ms_plain_24x2_mlp_pnet_b333": (_cfg("NIFMultiScale", 24, 2, 32, 1, 3, 1, 1, 3, p_act="swish"), 333),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SMALL_CASES))
+@pytest.mark.parametrize("weighted", [False, True])
+def test_small_batch_step_matches_oracle_and_tile_kernels(name, weighted):
+    m, model, spec, ws, x, y, sw = _make(SMALL_CASES[name])
+    s = sw if weighted else None
+    e = m._engine
+    lref, gref = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), None if s is None else s.astype(np.float64))
+    gref = O.flatten(gref)
+    res = {}
+    for small in (1, 0):
+        e.set_option("small_step", small)
+        loss, g = e.loss_and_grad(x, y, s)
+        res[small] = (loss, np.asarray(g, dtype=np.float64))
+        assert abs(loss - lref) <= 2e-6 * abs(lref), (small, loss, lref)
+        rel = _per_tensor_rel(spec, g, gref)
+        # k_small runs plain fp32 FMAs (no split products): 1e-5 per tensor; the tile kernels keep their r5 bar
+        assert max(rel.values()) < (1e-5 if small else 5e-5), (small, rel)
+    e.set_option("small_step", 1)
+    assert _rel(res[1][1], res[0][1]) < 3e-5
+    # the step really went through k_small: its launch is booked on the ShapeNet group and NOTHING on the ParameterNet / weight-gradient groups
+    e.profile_enable(True); e.profile_read(reset=True)
+    e.loss_and_grad(x, y, s)
+    prof = e.profile_read(reset=True); e.profile_enable(False)
+    assert prof["snet"][1] == 1 and prof["pnet_fwd"][1] == 0 and prof["pnet_bwd"][1] == 0 and prof["gw"][1] == 0, prof
+
+
+def test_small_batch_fit_follows_the_oracle_adam_steps():
+    """Model.fit at configs[0]'s shape (batch 512 of a 2 000-point table, no shuffle): four Adam steps through k_small + k_reduce + k_adam
+    against the oracle's Keras-2.11 updates, teacher-forced per step as in test_adam_steps_follow_oracle"""
+    import nif_amd
+    m, model, spec, ws, x, y, sw = _make((_cfg("NIF", 32, 2, 32, 2, 1, 1, 1, 1), 2000))
+    model.compile(nif_amd.Adam(learning_rate=1e-3), loss="mse")
+    e = m._engine
+    f32 = lambda a: float(np.float32(a))      # noqa: E731
+    th = O.flatten(model.get_weights()).astype(np.float64)
+    h = model.fit(x, y, epochs=1, batch_size=512, shuffle=False, verbose=0)
+    mm = np.zeros_like(th); vv = np.zeros_like(th)
+    tot, cnt = 0.0, 0
+    for t, b0 in enumerate(range(0, 2000, 512), start=1):
+        xb, yb = x[b0:b0 + 512].astype(np.float64), y[b0:b0 + 512].astype(np.float64)
+        l_, g_ = O.loss_and_grad(spec, O.unflatten(spec, th), xb, yb)
+        tot += l_ * len(xb); cnt += len(xb)
+        th, mm, vv = O.adam_step(th, O.flatten(g_), mm, vv, t, lr=f32(1e-3), b1=f32(0.9), b2=f32(0.999), eps=f32(1e-7))
+    assert abs(h.history["loss"][0] - tot / cnt) <= 1e-4 * abs(tot / cnt), (h.history["loss"][0], tot / cnt)
+    got = O.flatten(model.get_weights()).astype(np.float64)
+    assert np.abs(got - th).max() <= 4 * 2.0 * 1e-3 * 1.001        # four steps of at most 2 lr each
+    assert np.median(np.abs(got - th)) < 0.05 * 1e-3               # ... and almost everywhere on the oracle's trajectory
+    assert e.get_opt_state()[2] == 4

@@ -137,6 +137,9 @@ KNOBS = [
     ({"NIF_H_PH16": "0"}, "ms_cfg3_128x3", "plain", "mixed_bfloat16"),     # r5: fp32 layer-input stash rows on the 128-wide policy step (default: 16-bit phases)
     ({"NIF_H_PH16": "1"}, "ms_cfg3_128x3", "plain", "mixed_bfloat16"),
     ({"NIF_H_PH16": "0"}, "ll_cfg4_128x2_r10_so3", "plain", "mixed_bfloat16"),
+    ({"NIF_SMALL_STEP": "0"}, "nif_cfg1_32x2", "plain", "float32"),        # r6: a small batch on the tile kernels (default: k_small, one launch)
+    ({"NIF_SMALL_STEP": "1"}, "nif_cfg1_32x2", "plain", "float32"),
+    ({"NIF_SMALL_STEP": "0"}, "nif_pad_n30_tanh_r2_so2", "plain", "float32"),
 ]
 
 
@@ -147,7 +150,7 @@ def test_every_runtime_knob_against_the_oracle(case, tmp_path):
     out = str(tmp_path / "knob.npz")
     env = dict(os.environ)
     for k in ("NIF_FUSE_GW", "NIF_SIDE_PNET", "NIF_PBW_TOUCH", "NIF_PNET_STASH", "NIF_PNET_BF2", "NIF_GW8", "NIF_GW_LDS", "NIF_SOBW", "NIF_LL_MLP",
-              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY", "NIF_H_PH16"):
+              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY", "NIF_H_PH16", "NIF_SMALL_STEP"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", KNOB_CHILD, name, mode, policy, out], env=env, cwd=ROOT, stdout=subprocess.PIPE,
