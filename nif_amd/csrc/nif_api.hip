@@ -194,6 +194,8 @@ extern "C" int nif_destroy(nif_ctx* c) {
   if (!c) return NIF_OK;
   hipSetDevice(c->dev);
   if (c->st) hipStreamSynchronize(c->st);
+  if (c->small_idx) hipFree(c->small_idx);
+  if (c->small_desc) hipFree(c->small_desc);
   if (c->comm) (void)nif_comm_destroy(c);
   if (c->st2) { hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }
   if (c->st_copy) { hipStreamSynchronize(c->st_copy); hipStreamDestroy(c->st_copy); }
@@ -1405,9 +1407,31 @@ static int step_chunk(nif_ctx* c, const float* xin0, const float* y0, const floa
   return NIF_OK;
 }
 
+// k_small's tables of this context (the index map of its LDS images and the tensor descriptors: offsets only), built once
+static int ensure_small_tables(nif_ctx* c, const PNetArgs& pa, const SNetArgs& sa) {
+  if (c->small_idx) return NIF_OK;
+  if (c->capturing) return fail(NIF_ERR_STATE, "small-batch step tables inside a graph capture (nif_graph_begin builds them)");
+  std::vector<int> idx, desc;
+  small_tables(pa, sa, idx, desc);
+  HIPCHK(hipMalloc(&c->small_idx, idx.size() * sizeof(int)));
+  HIPCHK(hipMalloc(&c->small_desc, desc.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(c->small_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->small_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice));
+  return NIF_OK;
+}
+// a Keras loss-metric accumulation that nif_metric_accumulate left for the next k_small launch (r6: one launch less per small step):
+// everything that would change grad[P] or read the metric without such a launch runs it now
+static int metric_flush(nif_ctx* c) {
+  if (!c->metric_pending) return NIF_OK;
+  c->metric_pending = false;
+  launch_metric(c->grad, c->P, c->metric_pending_w, c->metric, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
                           const int* seeds, const float* gt, float wj, const SobPlan* sp = nullptr) {
   HIPCHK(hipSetDevice(c->dev));
+  c->last_step_small = false;
   // r6: a small batch of a small net -- ONE launch for the loss and every gradient (k_small: fp32 FMAs straight from theta, no plane
   // packing), then the usual row reduction.  configs[0]'s 512-point steps spent 82 us in eleven tile-kernel launches
   if (ns == 0 && c->opt_small_step && B <= NIF_SMALL_MAX_B && c->kind != NIF_KIND_LASTLAYER && !act_on(c) && !c->opt_fp32_mfma) {
@@ -1420,14 +1444,21 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
       if (rows > c->nloss_cap) return fail(NIF_ERR_STATE, "internal: loss partial buffer too small for the small-batch step");
       c->reg_applied = false;
       sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;
-      { ProfScope p_(c, NIF_PROF_SNET); launch_small(pa, sa, c->partial, c->pstride, c->P, c->st); }
+      rc = ensure_small_tables(c, pa, sa); if (rc) return rc;
+      const bool mp = c->metric_pending && c->metric != nullptr;
+      { ProfScope p_(c, NIF_PROF_SNET);
+        launch_small(pa, sa, c->partial, c->pstride, c->P, c->small_idx, c->small_desc, mp ? c->metric : nullptr, c->metric_pending_w,
+                     c->grad + c->P, c->st); }
+      if (mp) c->metric_pending = false;
+      c->last_step_small = true;
       { ProfScope pr_(c, NIF_PROF_REDUCE); launch_reduce(c->partial, c->pstride, rows, c->loss_partial, rows, c->grad, c->P, c->st); }
       if (c->jac_l1 != 0.f) { rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
       HIPCHK(hipGetLastError());
       return NIF_OK;
     }
   }
-  int rc = ensure_packed(c); if (rc) return rc;
+  int rc = metric_flush(c); if (rc) return rc;
+  rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B + 31) / 32;
   if (ns > 0) { rc = ensure_packed32(c); if (rc) return rc; }
   if (ns > 0) {
@@ -1866,6 +1897,11 @@ extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
   if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
+  int rc = metric_flush(c); if (rc) return rc;
+  if (c->last_step_small && c->opt_small_step && !c->capturing) {     // behind a small step: rides in the next k_small launch (grad[P] is not
+    c->metric_pending = true; c->metric_pending_w = weight;          // touched before that launch's row reduction; every other path flushes)
+    return NIF_OK;
+  }
   launch_metric(c->grad, c->P, weight, c->metric, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
@@ -1874,6 +1910,7 @@ extern "C" int nif_metric_read(nif_ctx* c, double* sum, double* cnt, int reset) 
   if (!c || !sum || !cnt) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
   double h[2] = {0.0, 0.0};
+  { const int rcf = metric_flush(c); if (rcf) return rcf; }
   if (c->metric) {
     HIPCHK(hipMemcpyAsync(h, c->metric, 2 * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
@@ -1920,7 +1957,14 @@ extern "C" int nif_graph_begin(nif_ctx* c) {
   if (c->capturing) return fail(NIF_ERR_STATE, "nif_graph_begin: already capturing");
   if (c->comm) return fail(NIF_ERR_STATE, "nif_graph_begin: not with a communicator attached (the all-reduce is not captured)");
   HIPCHK(hipSetDevice(c->dev));
-  int rc = ensure_packed(c); if (rc) return rc;
+  int rc = metric_flush(c); if (rc) return rc;
+  c->last_step_small = false;
+  rc = ensure_packed(c); if (rc) return rc;
+  if (c->kind != NIF_KIND_LASTLAYER) {      // (a captured small step must find its tables)
+    PNetArgs pa; fill_pnet(c, pa, nullptr, 32);
+    SNetArgs sa; fill_snet(c, sa, nullptr, c->pi + c->si, c->pi, 32);
+    if (small_supported(pa, sa)) { rc = ensure_small_tables(c, pa, sa); if (rc) return rc; }
+  }
   if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
   if (!c->adam_dev) HIPCHK(hipMalloc(&c->adam_dev, sizeof(AdamDev)));
   if (!c->adam_host) HIPCHK(hipHostMalloc(&c->adam_host, sizeof(AdamDev)));
@@ -1972,6 +2016,8 @@ extern "C" int nif_graph_destroy(nif_ctx* c, int32_t graph_id) {
 extern "C" int nif_zero_grad(nif_ctx* c) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  { const int rcf = metric_flush(c); if (rcf) return rcf; }      // (a deferred loss-metric accumulation reads grad[P]: before it is cleared)
+  c->last_step_small = false;
   HIPCHK(hipMemsetAsync(c->grad, 0, sizeof(float) * (size_t)(c->P + 1), c->st));
   c->reg_applied = false;
   return NIF_OK;

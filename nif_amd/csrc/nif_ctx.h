@@ -92,6 +92,9 @@ struct nif_ctx {
   // shard streaming (nif_h2d_async): a copy stream and, per staging slot, 'copy landed' / 'slot consumed' events
   hipStream_t st_copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   bool opt_fp32_mfma = false;      // nif_set_option("fp32_mfma"): A/B switch, default from NIF_FP32_MFMA
+  int* small_idx = nullptr; int* small_desc = nullptr;     // k_small's tables (offsets only), built at the first small step
+  bool metric_pending = false; float metric_pending_w = 0.f;   // a nif_metric_accumulate deferred into the next k_small launch
+  bool last_step_small = false;
   bool opt_small_step = true;      // nif_set_option("small_step"): batches <= NIF_SMALL_MAX_B points of a net k_small takes run on it (one launch for loss + gradient); default from NIF_SMALL_STEP
   bool opt_fuse_gw = true;         // nif_set_option("fuse_gw"): ShapeNet weight gradients inside the training kernel (k_snet6) where it has the shape; default from NIF_FUSE_GW
 };

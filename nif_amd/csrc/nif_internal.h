@@ -12,6 +12,7 @@
 //     [tile][feature][32 points] fp32: every wave store/load is two full 128-B lines.
 //   * small per-point vectors (latent z, dL/dz, dL/du) use the same [tile][c][32] layout.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -208,7 +209,9 @@ int launch_snet4(const SNetArgs& a, bool train, bool query_only, hipStream_t st)
 #define NIF_SMALL_MAX_B 2048
 bool small_supported(const PNetArgs& p, const SNetArgs& s);
 int small_rows(long B);
-void launch_small(const PNetArgs& p, const SNetArgs& s, float* partial, long pstride, long P, hipStream_t st);
+void small_tables(const PNetArgs& p, const SNetArgs& s, std::vector<int>& idx, std::vector<int>& desc);
+void launch_small(const PNetArgs& p, const SNetArgs& s, float* partial, long pstride, long P, const int* idx_dev, const int* desc_dev,
+                  double* metric, float metric_w, const float* g_loss, hipStream_t st);
 bool snet4_writes_h_ph16(const SNetArgs& a);    // ... and its hidden-matrix input rows as 16-bit phases
 bool gw_in_ph16_ok(int NBI, int NBO, int r);    // a reader of that form exists for this shape (k_gw8<R, true, true>; NIF_H_PH16=0 switches it off)
 bool snet4_writes_da_bf16(const SNetArgs& a);   // stash format the training launch of `a` produces (k_snet4.hip)

@@ -1945,7 +1945,7 @@ SMALL_CASES = {
     "nif_pad_n30_tanh_r2_so2": CONFIGS["nif_pad_n30_tanh_r2_so2"],
     "ms_tiny_b1": CONFIGS["ms_tiny_b1"],
     "cfg0_nif_2x32_b512": (_cfg("NIF", 32, 2, 32, 2, 1, 1, 1, 1), 512),            # configs[0]'s own step
-    "nif_32x3_r2_si3_so3_b2047": (_cfg("NIF", 32, 3, 32, 3, 2, 3, 3, 2, act="tanh"), 2047),
+    "nif_32x2_r2_si3_so3_b2047": (_cfg("NIF", 32, 2, 32, 3, 2, 3, 3, 2, act="tanh"), 2047),
     "ms_plain_32x3_r2_b17": (_cfg("NIFMultiScale", 32, 3, 24, 2, 2, 2, 2, 1), 17),
     "ms_plain_24x2_mlp_pnet_b333": (_cfg("NIFMultiScale", 24, 2, 32, 1, 3, 1, 1, 3, p_act="swish"), 333),
 }
