@@ -204,14 +204,18 @@ void launch_given_w(const float* x, const float* w, float* u, long B, int si, in
 __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w(const float* __restrict__ theta, long off_Wh, long off_bh, int r,
                                                           long po, const float* __restrict__ lr, long B,
                                                           float* __restrict__ w, int CU, int LW, long rows_per_block) {
-  extern __shared__ float l2w_sm[];            // [(r+1)][LW]: planes k < r = Wh rows, plane r = bh; slot s at [s - c0 + 3]
+  extern __shared__ float l2w_sm[];            // [(r+1)][LW]: planes k < r = Wh rows, plane r = bh; slot s = window element e = s - c0 + 3
+  // r6: element e of a plane sits at (e & 3) * Q + (e >> 2), Q = LW / 4 (as in k_latent_to_w_flat): lane i reads element e0 + 4 i + c --
+  // a stride of four dwords was a 4-way bank conflict on every read
+  const int Q = LW >> 2;
   const long c0 = 4L * blockIdx.x * CU;        // first slot of this column window's units (row-relative, before the -m shift)
-  for (int idx = threadIdx.x; idx < (r + 1) * LW; idx += NIF_L2W_T) {
-    const int k = idx / LW, e = idx - k * LW;
-    const long sc = c0 - 3 + e;
-    float v = 0.f;
-    if (sc >= 0 && sc < po) v = k < r ? theta[off_Wh + (long)k * po + sc] : theta[off_bh + sc];
-    l2w_sm[idx] = v;
+  for (int k = 0; k <= r; ++k) {
+    const float* src = k < r ? theta + off_Wh + (long)k * po : theta + off_bh;
+    float* dst = l2w_sm + (long)k * LW;
+    for (int e = threadIdx.x; e < LW; e += NIF_L2W_T) {
+      const long sc = c0 - 3 + e;
+      dst[(int)__umul24(e & 3, Q) + (e >> 2)] = (sc >= 0 && sc < po) ? src[sc] : 0.f;
+    }
   }
   __syncthreads();
   const int wmis = (int)((reinterpret_cast<size_t>(w) >> 2) & 3);       // misalignment of the buffer itself (floats)
@@ -226,15 +230,18 @@ __global__ __launch_bounds__(NIF_L2W_T) void k_latent_to_w(const float* __restri
     for (int ul = threadIdx.x; ul < CU; ul += NIF_L2W_T) {
       const long U = (long)blockIdx.x * CU + ul;
       if (U >= nun) break;
-      const int e0 = 4 * ul - m + 3;                       // LDS index of the unit's first slot
+      const int e0 = 4 * ul - m + 3;                       // window element of the unit's first slot
+      int ix[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ix[c] = (int)__umul24((e0 + c) & 3, Q) + ((e0 + c) >> 2);
       float acc[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = sB[e0 + c];
+      for (int c = 0; c < 4; ++c) acc[c] = sB[ix[c]];
       for (int k = 0; k < r; ++k) {
         const float zk = lrow[k];
-        const float* sW = l2w_sm + (long)k * LW + e0;
+        const float* sW = l2w_sm + (long)k * LW;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = fmaf(zk, sW[c], acc[c]);
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(zk, sW[ix[c]], acc[c]);
       }
       const long s0 = 4 * U - m;
       float* dst = wrow + s0;                              // (a * po + s0) * 4 bytes is a multiple of 16 by construction

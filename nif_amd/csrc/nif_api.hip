@@ -396,10 +396,20 @@ static int ensure_capacity(nif_ctx* c, long B, bool train) {
       c->stash_s = c->stash_p = nullptr;
       c->slot_s = (long)c->NB * 32 * newcap;
       c->slot_p = (long)c->NSTB * 32 * newcap;
-      HIPCHK(hipMalloc(&c->stash_s, sizeof(float) * (size_t)(c->slot_s * 2 * (c->nh + 1))));
+      // r6 (fuzz case 606/16): k_snet6 keeps its private h ring in this buffer -- [workgroups][8 waves][nh][64 features][16 points],
+      // EVERY wave of a workgroup writes its slice, active or not -- and for batches of <= 32 points of a net with nh >= 2 that is more
+      // than the 2 (nh + 1) stash slots of one 32-point tile: the ring ran 32 KB past the allocation into the ParameterNet's stash
+      // (wrong ParameterNet gradients on the stash path: ParameterNets with > 2 hidden matrices or > 32 units)
+      long s_floats = c->slot_s * 2 * (c->nh + 1);
+      {
+        long nblk6 = (2 * (newcap / 32) + 7) / 8; if (nblk6 > 256) nblk6 = 256; if (nblk6 < 1) nblk6 = 1;
+        const long ring6 = nblk6 * 8 * (long)c->nh * 64 * 16;
+        if (ring6 > s_floats) s_floats = ring6;
+      }
+      HIPCHK(hipMalloc(&c->stash_s, sizeof(float) * (size_t)s_floats));
       HIPCHK(hipMalloc(&c->stash_p, sizeof(float) * (size_t)(c->slot_p * (2 * c->nm + 2))));
       if (c->NB * 32 > ((c->n + 15) / 16) * 16)    // 65..96 (and 33..48) units: the rows the fused kernels never write must read as zero
-        HIPCHK(hipMemsetAsync(c->stash_s, 0, sizeof(float) * (size_t)(c->slot_s * 2 * (c->nh + 1)), c->st));
+        HIPCHK(hipMemsetAsync(c->stash_s, 0, sizeof(float) * (size_t)s_floats, c->st));
     } else if (newcap > c->cap && c->stash_s) {
       HIPCHK(hipFree(c->stash_s)); HIPCHK(hipFree(c->stash_p));
       c->stash_s = c->stash_p = nullptr;

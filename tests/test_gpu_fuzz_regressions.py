@@ -182,3 +182,22 @@ def test_sobolev_step_takes_fewer_columns_per_pass_when_three_do_not_fit():
     assert max(rel.values()) < 4e-4, rel
     u, J = m._engine.sobolev_forward(x, xi)
     assert _rel(u, ru) < 1e-5 and _rel(J.reshape(rJ.shape), rJ) < 3e-5
+
+
+@pytest.mark.parametrize("B", [1, 2, 17, 32])
+def test_r6_sweep_case_16_snet6_ring_inside_its_allocation(B):
+    """`tools/fuzz_parity.py 200 606`, case 16 (r6): NIFMultiScale 56 x 3 (the fused-gradient kernel k_snet6) with a ParameterNet of three
+    hidden matrices (the HBM-stash adjoint) at a batch of <= 32 points: k_snet6's private `h` ring (every wave of a workgroup writes its
+    slice) was larger than the ShapeNet stash of one 32-point tile and ran 32 KB into the ParameterNet's stash -- loss right, every
+    ParameterNet gradient wrong by factors (1.4 ... 9.9 rel).  The workspace now covers the ring; all gradients within the plain bars."""
+    from tests.test_gpu_parity import _cfg, _make, _per_tensor_rel
+    m, model, spec, ws, x, y, sw = _make((_cfg("NIFMultiScale", 56, 3, 20, 3, 1, 1, 3, 3, p_act="swish"), B))
+    loss, g = m._engine.loss_and_grad(x, y, sw)
+    lref, gref = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))
+    assert abs(loss - lref) <= 2e-6 * abs(lref)
+    rel = _per_tensor_rel(spec, g, O.flatten(gref))
+    assert max(rel.values()) < 1e-4, rel
+    # ... and the same net through the k_snet4 + k_gw_* path agrees
+    m._engine.set_option("fuse_gw", 0)
+    _, g0 = m._engine.loss_and_grad(x, y, sw)
+    assert float(np.linalg.norm(np.asarray(g) - np.asarray(g0)) / np.linalg.norm(g0)) < 5e-5

@@ -6,8 +6,10 @@ import bench, nif_amd
 from nif_amd.engine import DeviceArray
 from nif_amd._lib import check
 nif_amd.set_seed(1)
-m = nif_amd.NIFMultiScale(bench.CFG_SHAPE, bench.CFG_PARAM); m.build(); e = m._engine; s = m._spec
-Bw = 1 << 17
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"      # configs[2]'s 6 x 128 net: the column-window form (the hyper layer does not fit the LDS)
+cs = dict(bench.CFG_SHAPE, units=128, nlayers=6, input_dim=2) if WIDE else bench.CFG_SHAPE
+m = nif_amd.NIFMultiScale(cs, bench.CFG_PARAM); m.build(); e = m._engine; s = m._spec
+Bw = 1 << (14 if WIDE else 17)
 d_lr = DeviceArray(e, Bw * s.pi_hidden); d_lr.upload(np.random.default_rng(7).standard_normal(Bw * s.pi_hidden).astype(np.float32))
 d_w = DeviceArray(e, Bw * s.po_dim)
 for _ in range(3):
@@ -20,4 +22,4 @@ for rep in range(3):
         check(e.lib.nif_latent_to_w_dev(e.ctx, d_lr.at(0), Bw, d_w.at(0)))
     e.sync()
     best = min(best, (time.perf_counter() - t0) / 10)
-print("%s latent_to_w %.1f GB/s (%.3f ms)" % (os.environ.get("NIF_LIB", "product"), 4.0 * s.po_dim * Bw / best / 1e9, best * 1e3))
+print("%s latent_to_w%s po=%d %.1f GB/s (%.3f ms)" % (os.environ.get("NIF_LIB", "product"), " [window form]" if WIDE else "", s.po_dim, 4.0 * s.po_dim * Bw / best / 1e9, best * 1e3))
