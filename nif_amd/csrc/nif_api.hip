@@ -1448,9 +1448,10 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
     if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set (call nif_set_params first)");
     PNetArgs pa; fill_pnet(c, pa, xin, B);
     SNetArgs sa; fill_snet(c, sa, xin, c->pi + c->si, c->pi, B);
-    if (small_supported(pa, sa) && small_rows(B) <= c->rows_cap) {
-      int rc = ensure_capacity(c, ((B + 31) / 32) * 32, true); if (rc) return rc;
+    if (small_supported(pa, sa) && small_rows(B) <= 256) {
+      int rc = ensure_capacity(c, ((B + 31) / 32) * 32, true); if (rc) return rc;      // (first call: allocates the partial rows, rows_cap = 256)
       const int rows = small_rows(B);
+      if (rows > c->rows_cap) return fail(NIF_ERR_STATE, "internal: partial-row buffer too small for the small-batch step");
       if (rows > c->nloss_cap) return fail(NIF_ERR_STATE, "internal: loss partial buffer too small for the small-batch step");
       c->reg_applied = false;
       sa.y = y; sa.sw = sw; sa.loss_partial = c->loss_partial; sa.inv_bg = 1.0f / (float)Bg;

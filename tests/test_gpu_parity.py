@@ -1957,6 +1957,11 @@ def test_small_batch_step_matches_oracle_and_tile_kernels(name, weighted):
     m, model, spec, ws, x, y, sw = _make(SMALL_CASES[name])
     s = sw if weighted else None
     e = m._engine
+    # the FIRST training call of a fresh context already takes k_small (r6 sweep: it fell back to the tile kernels once, silently)
+    e.profile_enable(True); e.profile_read(reset=True)
+    e.loss_and_grad(x, y, s)
+    prof0 = e.profile_read(reset=True); e.profile_enable(False)
+    assert prof0["snet"][1] == 1 and prof0["pnet_fwd"][1] == 0 and prof0["pnet_bwd"][1] == 0 and prof0["gw"][1] == 0, prof0
     lref, gref = O.loss_and_grad(spec, ws, x.astype(np.float64), y.astype(np.float64), None if s is None else s.astype(np.float64))
     gref = O.flatten(gref)
     res = {}
