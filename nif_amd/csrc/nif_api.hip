@@ -1909,7 +1909,7 @@ extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {
   HIPCHK(hipSetDevice(c->dev));
   if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
   int rc = metric_flush(c); if (rc) return rc;
-  if (c->last_step_small && c->opt_small_step && !c->capturing) {     // behind a small step: rides in the next k_small launch (grad[P] is not
+  if (c->last_step_small && c->opt_small_step && !c->capturing && !c->comm) {     // behind a small step: rides in the next k_small launch (grad[P] is not
     c->metric_pending = true; c->metric_pending_w = weight;          // touched before that launch's row reduction; every other path flushes)
     return NIF_OK;
   }
