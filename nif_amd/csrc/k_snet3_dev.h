@@ -617,6 +617,52 @@ __device__ __forceinline__ void mfma_x3_pf(const bf16x8* cur, const bf16x8* nxt,
   NIF_MFMA_PRIO_OFF
 }
 
+// ... and a whole PLANE of the exact-product form in one step (k_snet6, NIF_S6_BIGCHUNK: the 16 KB chunk = K-step halves at cur and cur + CFU
+// units): four operand groups (K step, block pair); the reads of group g + 2 are issued BEHIND the products of group g, so that the
+// step exposes ONE LDS round trip instead of one per group (r6 timeline: ~1 200 ticks of `mfma` phase for 384 matrix cycles)
+template <int NBL, bool ZI, int CFU>
+__device__ __forceinline__ void mfma_x3_plane(const bf16x8* cur, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2], f32x4 (&T)[NBL], int lane) {
+  static_assert(NBL == 4, "two block pairs per K step");
+  NIF_MFMA_PRIO_ON
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const bf16x8* c0_ = cur + lane;
+  bf16x8 p0 = c0_[0 * 64], p1 = c0_[1 * 64], p2 = c0_[2 * 64], p3 = c0_[3 * 64];                   // (K step 0, blocks 0 1)
+  bf16x8 q0 = c0_[4 * 64], q1 = c0_[5 * 64], q2 = c0_[6 * 64], q3 = c0_[7 * 64];                   // (K step 0, blocks 2 3)
+  __builtin_amdgcn_sched_barrier(0);
+  T[0] = mfma_f16(p0, b1[0], ZI ? z4 : T[0]);
+  T[1] = mfma_f16(p2, b1[0], ZI ? z4 : T[1]);
+  T[0] = mfma_f16(p1, b0[0], T[0]);
+  T[1] = mfma_f16(p3, b0[0], T[1]);
+  T[0] = mfma_f16(p0, b0[0], T[0]);
+  T[1] = mfma_f16(p2, b0[0], T[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  const bf16x8* c1_ = cur + CFU + lane;
+  p0 = c1_[0 * 64]; p1 = c1_[1 * 64]; p2 = c1_[2 * 64]; p3 = c1_[3 * 64];                          // (K step 1, blocks 0 1)
+  __builtin_amdgcn_sched_barrier(0);
+  T[2] = mfma_f16(q0, b1[0], ZI ? z4 : T[2]);
+  T[3] = mfma_f16(q2, b1[0], ZI ? z4 : T[3]);
+  T[2] = mfma_f16(q1, b0[0], T[2]);
+  T[3] = mfma_f16(q3, b0[0], T[3]);
+  T[2] = mfma_f16(q0, b0[0], T[2]);
+  T[3] = mfma_f16(q2, b0[0], T[3]);
+  __builtin_amdgcn_sched_barrier(0);
+  q0 = c1_[4 * 64]; q1 = c1_[5 * 64]; q2 = c1_[6 * 64]; q3 = c1_[7 * 64];                          // (K step 1, blocks 2 3)
+  __builtin_amdgcn_sched_barrier(0);
+  T[0] = mfma_f16(p0, b1[1], T[0]);
+  T[1] = mfma_f16(p2, b1[1], T[1]);
+  T[0] = mfma_f16(p1, b0[1], T[0]);
+  T[1] = mfma_f16(p3, b0[1], T[1]);
+  T[0] = mfma_f16(p0, b0[1], T[0]);
+  T[1] = mfma_f16(p2, b0[1], T[1]);
+  T[2] = mfma_f16(q0, b1[1], T[2]);
+  T[3] = mfma_f16(q2, b1[1], T[3]);
+  T[2] = mfma_f16(q1, b0[1], T[2]);
+  T[3] = mfma_f16(q3, b0[1], T[3]);
+  T[2] = mfma_f16(q0, b0[1], T[2]);
+  T[3] = mfma_f16(q2, b0[1], T[3]);
+  NIF_MFMA_PRIO_OFF
+}
+
 // ---- sign-of-cosine shift register (plain SIREN: cos(a) = +-sqrt(1 - sin^2(a)), sin(a) is the next layer's stashed
 // input; see k_snet4.hip) ------------------------------------------------------------------------------------
 __device__ __forceinline__ void sgn_push(unsigned long long& lo, unsigned long long& hi, unsigned bits, int w) {

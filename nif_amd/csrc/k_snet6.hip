@@ -122,8 +122,13 @@ struct S6Args {
 #ifndef NIF_S6_PF
 #define NIF_S6_PF 0
 #endif
+#ifndef NIF_S6_BIGCHUNK
+#define NIF_S6_BIGCHUNK 1    // 1 (r6, exact-product form; brings the NIF_S6_DBAR schedule with it; 0: the r5 form, 2: + the pipelined plane step, measured slower): chunks of 16 KB = a whole plane of a hidden matrix (both K steps), TWO chunk
+                             // steps per layer and direction instead of four: half the per-step fixed costs (DMA issue 170-380 ticks, s_waitcnt
+                             // 140, barrier >= 140, loop glue 120 of a ~1 250-tick forward step: r6 timeline)
+#endif
 #ifndef NIF_S6_DBAR_T0
-#define NIF_S6_DBAR_T0 8     // tiles of the deposit taken under the vector block + the first chunk step (timeline r6: 240 ticks per tile there,
+#define NIF_S6_DBAR_T0 5     // tiles of the deposit taken under the vector block + the first chunk step (timeline r6: 240 ticks per tile there,
                              // 650 once the producers' matrix instructions compete)
 #endif
 #ifndef NIF_S6_DBAR
@@ -154,7 +159,12 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   constexpr int CF = X16 ? NBL * 2 * 64 : NBL * 3 * 64, CB = NBL * 2 * 64;   // 16-byte units per forward / adjoint chunk
   constexpr bool CP = PR != 0;                           // the policies' compact plane set (k_snet4_dev.h): one plane per block
   constexpr int CFH = CP ? NBL * 64 : CF, CBH = CP ? NBL * 64 : CB;
-  constexpr int QF = (CF + NT - 1) / NT;
+  constexpr bool BIG = X16 && NIF_S6_BIGCHUNK;
+  static_assert(!NIF_S6_BIGCHUNK || (!NIF_S6_PF && !NIF_S6_EARLYDEP), "NIF_S6_BIGCHUNK: without NIF_S6_PF / NIF_S6_EARLYDEP");
+  constexpr bool DBAR = BIG || (NIF_S6_DBAR != 0);      // a barrier behind every hidden deposit: always with the big chunks (the consumers' only
+                                                        // other window would be ONE chunk step per layer), optional on the 8 KB forms (the policies)
+  constexpr int CFB = BIG ? 2 * CF : CF;                 // units of one chunk BUFFER
+  constexpr int QF = (CFB + NT - 1) / NT;
   // (r5: three buffers with the DMA two chunk steps ahead measured no gain -- 1.185 vs 1.15-1.19 ms -- although the s_memtime timeline
   // shows ~300 ticks of every step in front of the barrier's s_waitcnt: tools/exp/k_snet6_3buf.hip, profiles/r05_timeline_*.txt)
   // r6 (NIF_S6_PF = 1, exact-product form): THREE buffers, the DMA two steps ahead, so that a step can read the first operands of the next
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   char* WVL = EX + WAVES * EXT;
   char* WVF = WVL + WAVES * WVLT;
   bf16x8* chunks = reinterpret_cast<bf16x8*>(WVF + WAVES * WVFT);
-  float* sm = reinterpret_cast<float*>(chunks + NBUF * CF);
+  float* sm = reinterpret_cast<float*>(chunks + NBUF * CFB);
   constexpr int NP = 16 * NBL;
   // r5: the LDS image of the small hyper-vectors has a FIXED layout -- three first-layer rows, three last-layer rows, the first bias, four
   // hidden biases, the last bias (the shape's unused rows are zeros): every offset into it is a compile-time constant that folds into the
@@ -189,8 +199,11 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   // the producers' vector instructions, all of them inside the vector blocks)
   constexpr int o_w1 = 0, o_wl = 3 * NP, o_b1 = 6 * NP, o_bh = 7 * NP, o_bl = 11 * NP, nsm = 11 * NP + 4;
   constexpr int sm_tot = ((r + 1) * nsm + 3) & ~3;
-  constexpr int CX = 4, CZ = 4, CY = 4;                 // input / latent / target rows of a tile's input set (si, so <= 3, r = 1: snet6_supported)
-  constexpr int NI = (CX + CZ + CY + 4) * 16;
+  // r6: the input set of a tile is EIGHT rows of 16 points -- x_0..x_2 | z | y_0..y_2 | sample weight (si, so <= 3, r = 1: snet6_supported) --
+  // fetched by TWO LDS-DMA instructions whose lane groups point at different arrays (r5: sixteen rows, four instructions, most of them
+  // duplicates): 8 KB of LDS back per workgroup -- what the 16 KB chunk buffers of NIF_S6_BIGCHUNK need
+  constexpr int CX = 3, CZ = 1, CY = 3;
+  constexpr int NI = (CX + CZ + CY + 1) * 16;
   constexpr int pw = 2 * r * 64 + 2 * NI;               // per-wave LDS floats (producers)
   float* lsum = sm + sm_tot + (long)WAVES * pw;
   float* scl = lsum + 16;                               // X16: [matrix][plane][s | 1 / s] of the half planes
@@ -223,16 +236,17 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   // ---- the chunk stream (k_snet4): forward planes of all hidden matrices, then the adjoint planes of matrix nh-1 .. 0 -----------
   const int NPC = (r + 1) * NCH;
   const bf16x8* cs_src = reinterpret_cast<const bf16x8*>(A.WF4);
-  int cs_units = CFH, cs_left = nh * NPC, cs_phase = 0;
+  const int NPCS = BIG ? (r + 1) : NPC;                  // chunks per matrix as the stream hands them out (BIG: one per plane)
+  int cs_units = BIG ? 2 * CFH : CFH, cs_left = nh * NPCS, cs_phase = 0;
   long cs_groups = (ngroups - 1 - (long)blockIdx.x) / gridDim.x;
   auto cs_phase_step = [&]() {
     ++cs_phase;
     if (cs_phase < 1 + nh) {
-      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = CBH; cs_left = NPC; return;
+      cs_src = reinterpret_cast<const bf16x8*>(A.WB4) + (long)(nh - 1 - (cs_phase - 1)) * NPC * CBH; cs_units = BIG ? 2 * CBH : CBH; cs_left = NPCS; return;
     }
     if (cs_groups <= 0) { cs_left = -1; return; }
     --cs_groups; cs_phase = 0;
-    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = CFH; cs_left = nh * NPC;
+    cs_src = reinterpret_cast<const bf16x8*>(A.WF4); cs_units = BIG ? 2 * CFH : CFH; cs_left = nh * NPCS;
   };
   // r5: BOTH roles walk the stream; the chunk of step c + 1 is issued during step c by the CONSUMER waves in the forward steps (they
   // idle there: the s_memtime timeline shows ~250 ticks of every producer step going into the DMA issue) and by the producers in
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   auto cs_next = [&](int buf, bool issue) {
     if (cs_left < 0) return;
     if (issue) {
-      bf16x8* dst = chunks + buf * CF;
+      bf16x8* dst = chunks + buf * CFB;
 #pragma unroll
       for (int q = 0; q < QF; ++q)
         if (cwid * 64 + NT * q < cs_units)
@@ -332,27 +346,28 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_CBAR()                                                                                               \
     S6_CBAR()                                                                                               \
   }
-#elif NIF_S6_DBAR
-#define S6_HID_LAYER(DJ_)      /* entered in front of the barrier behind deposit DJ_ */                     \
-  if (DJ_ < nh) {                                                                                           \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 0, NIF_S6_DBAR_T0))                                                             \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, NIF_S6_DBAR_T0, 8))                                                             \
-    S6_CBAR()                                                                                               \
-    S6_CBAR()                                                                                               \
-    S6_CBAR()                                                                                               \
-  }
 #else
-#define S6_HID_LAYER(DJ_)                                                                                   \
+#define S6_HID_LAYER(DJ_)      /* DBAR: entered in front of the barrier behind deposit DJ_; else in front of the first chunk barrier of layer DJ_ - 1 */ \
   if (DJ_ < nh) {                                                                                           \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 0, 3))                                                                          \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 3, 6))                                                                          \
-    S6_CBAR()                                                                                               \
-    S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                          \
-    S6_CBAR()                                                                                               \
+    if (DBAR) {                                                                                             \
+      S6_CBAR()                                                                                             \
+      S6_DO(S6_HID_TILES(DJ_, 0, NIF_S6_DBAR_T0))                                                           \
+      S6_CBAR()                                                                                             \
+      S6_DO(S6_HID_TILES(DJ_, NIF_S6_DBAR_T0, 8))                                                           \
+      S6_CBAR()                                                                                             \
+      if (!BIG) {                                                                                           \
+        S6_CBAR()                                                                                           \
+        S6_CBAR()                                                                                           \
+      }                                                                                                     \
+    } else {                                                                                                \
+      S6_CBAR()                                                                                             \
+      S6_DO(S6_HID_TILES(DJ_, 0, 3))                                                                        \
+      S6_CBAR()                                                                                             \
+      S6_DO(S6_HID_TILES(DJ_, 3, 6))                                                                        \
+      S6_CBAR()                                                                                             \
+      S6_DO(S6_HID_TILES(DJ_, 6, 8))                                                                        \
+      S6_CBAR()                                                                                             \
+    }                                                                                                       \
   }
 #endif
     // last layer (h_nh, zt h_nh deposited as the A planes, du_o as vectors).  The skinny sums run as ROLLED loops over the tiles:
@@ -419,6 +434,22 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_TL(500);                                                               \
   }
     for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
+      if (BIG) {
+        // two intervals per layer; the previous round's first-layer deposit (visible behind the first barrier) over the next three
+        for (int j = 0; j < nh; ++j) {
+          S6_CFWD(if (j == 1) { S6_DO(consume_first(3, 6);) })
+          S6_CFWD(if (j == 0) { S6_DO(consume_first(0, nh > 1 ? 3 : 8);) } else if (j == 1) { S6_DO(consume_first(6, 8);) })
+        }
+        for (int q = 0; q < (r + 1) * nh; ++q) { cs_next(nb_c, false); S6_ROTC() }
+        S6_CBAR()                              // first step of adjoint layer nh - 1: the last layer's deposit is visible behind it
+        S6_DO(consume_last(0, 8);)
+        S6_CBAR()
+        S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
+        S6_CBAR()                              // deposit 0 next to the first layer's adjoint
+        S6_DO(S6_HID_TILES(0, 0, 8))
+        S6_CBAR()
+        continue;
+      }
       for (int j = 0; j < nh; ++j) {        // forward: the previous round's first-layer deposit next to hidden matrix 0
         S6_CFWD()
         S6_CFWD(if (j == 0) { S6_DO(consume_first(0, 3);) })      // (three intervals: at four tiles the consumers were the last at these barriers, r5 timeline)
@@ -522,24 +553,18 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     long ptn = t16n * 16 + p;
     if (ptn >= A.B) ptn = A.B - 1;
     float* dst = inp + set * NI;
-    for (int i0 = 0; i0 < CX; i0 += 4) {
-      const int c = i0 + g < si ? i0 + g : si - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.xin + ptn * A.ncol + A.col0 + c),
-                                       (__attribute__((address_space(3))) void*)(dst + i0 * 16), 4, 0, 0);
+    {     // rows 0..3: x_g (g < 3, clamped to the net's coordinates) | z
+      const int c = g < si ? g : si - 1;
+      const float* src = g < 3 ? A.xin + ptn * A.ncol + A.col0 + c : A.Z + (tile32n * r) * 32 + poffn;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
     }
-    for (int i0 = 0; i0 < CZ; i0 += 4) {
-      const int c = i0 + g < r ? i0 + g : r - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.Z + (tile32n * r + c) * 32 + poffn),
-                                       (__attribute__((address_space(3))) void*)(dst + (CX + i0) * 16), 4, 0, 0);
+    {     // rows 4..7: y_g (g < 3, clamped) | sample weight (or a target where there is none: never read then)
+      const int c = g < so ? g : so - 1;
+      const float* src = (g < 3 || !A.sw) ? A.y + ptn * so + c : A.sw + ptn;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + 4 * 16), 4, 0, 0);
     }
-    for (int i0 = 0; i0 < CY; i0 += 4) {
-      const int c = i0 + g < so ? i0 + g : so - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.y + ptn * so + c),
-                                       (__attribute__((address_space(3))) void*)(dst + (CX + CZ + i0) * 16), 4, 0, 0);
-    }
-    const float* swp = A.sw ? A.sw + ptn : A.y + ptn * so;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)swp,
-                                     (__attribute__((address_space(3))) void*)(dst + (CX + CZ + CY) * 16), 4, 0, 0);
   };
   prefetch_inputs(blockIdx.x, 0);
   if (cs_left <= 0) cs_left = -1;
@@ -564,7 +589,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_TL(100);                                                               \
     cs_next(nbuf, dma_mine);                                                  \
     S6_TL(200);                                                               \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8* cur = chunks + cbuf * CFB;                                  \
     __VA_ARGS__                                                               \
     S6_TL(300);                                                               \
     __builtin_amdgcn_s_waitcnt(0x0070);        /* vmcnt(0) lgkmcnt(0): the chunk DMA has landed, the deposits are visible */ \
@@ -583,7 +608,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CHUNKP(ZI_, B0_, B1_, T_)                                          \
   {                                                                           \
     S6_TL(100);                                                               \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8* cur = chunks + cbuf * CFB;                                  \
     const bf16x8 pa_[4] = {cur[lane], cur[64 + lane], cur[128 + lane], cur[192 + lane]};   \
     __builtin_amdgcn_sched_barrier(0);                                        \
     cs_next(nbuf, dma_mine);                                                  \
@@ -599,12 +624,15 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     S6_TL(500);                                                               \
     S6_ROT()                                                                  \
   }
+// BIG: one step = a whole plane (two K-step halves of the 16 KB chunk)
+#define S6_CHUNK2(ZI_, Q0_, Q1_, T_)                                          \
+  S6_CHUNK({ if (NIF_S6_BIGCHUNK == 2) mfma_x3_plane<NBL, ZI_, CF>(cur, Q0_, Q1_, T_, lane); else { mfma_x3<NBL, 3, ZI_, NBL, 0, false>(cur, Q0_[0], Q1_[0], T_, lane); mfma_x3<NBL, 3, false, NBL, 0, false>(cur + CF, Q0_[1], Q1_[1], T_, lane); } })
 #define S6_CHUNKF(USE_, MAKE_, ZI_, B0_, B1_, T_)                             \
   {                                                                           \
     S6_TL(100);                                                               \
     cs_next(nbuf, dma_mine);                                                  \
     S6_TL(200);                                                               \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8* cur = chunks + cbuf * CFB;                                  \
     const bf16x8* nxt = chunks + (cbuf == 2 ? 0 : cbuf + 1) * CF;             \
     mfma_x3_pf<NBL, ZI_, USE_, MAKE_>(cur, nxt, pf, B0_, B1_, T_, lane);      \
     S6_TL(300);                                                               \
@@ -625,7 +653,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     cs_next(nbuf, dma_mine);                                                  \
     PRE_                                                                      \
     asm volatile("" ::: "memory");                                            \
-    const bf16x8* cur = chunks + cbuf * CF;                                   \
+    const bf16x8* cur = chunks + cbuf * CFB;                                  \
     __VA_ARGS__                                                               \
     __builtin_amdgcn_s_waitcnt(0x0070 | (NRING & 15) | ((NRING >> 4) << 14));   /* vmcnt(NRING) lgkmcnt(0) */ \
     asm volatile("" ::: "memory");                                            \
@@ -705,22 +733,28 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         for (int b = 0; b < NBL; ++b) T[b] = *reinterpret_cast<const f32x4*>(sb + 16 * b);
 #if NIF_S6_RING
 #define S6_FWD(KS_, T_) { if (X16) mfma_x3<NBL, 3, false, NBL, 0, false>(cur, b0[KS_], b1[KS_], T_, lane); else mfma_x6<NBL, PR, false, NBL, 0, CP>(cur, b0[KS_], b1[KS_], b2[KS_], T_, lane); }
-        if (PF) {
+        if (BIG) {
+          if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
+          S6_CHUNK2(false, b0, b1, T)
+        } else if (PF) {
           if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p);
           S6_CHUNKF(false, true, false, b0[0], b1[0], T)
         } else S6_CHUNK_RING({ if (!NIF_S6_RECOMP0 || j > 0) ring_store16<NBL>(ring + j * (NP * 16), h, g, p); }, S6_FWD(0, T))
 #else
         S6_CHUNK(S6_FWD(0, T))
 #endif
-        if (PF) S6_CHUNKF(true, true, false, b0[1], b1[1], T)
+        if (BIG) { }
+        else if (PF) S6_CHUNKF(true, true, false, b0[1], b1[1], T)
         else S6_CHUNK(S6_FWD(1, T))
         const float zt = X16 ? zt_base[0] * (s1_ * is0_) : zt_base[0];      // (plane 0's chain carries s0, the sum s1)
 #pragma unroll
         for (int b = 0; b < NBL; ++b) acc[b] += zt * T[b];
       }
-      if (PF) S6_CHUNKF(true, true, false, b0[0], b1[0], acc)
+      if (BIG) S6_CHUNK2(false, b0, b1, acc)
+      else if (PF) S6_CHUNKF(true, true, false, b0[0], b1[0], acc)
       else S6_CHUNK(S6_FWD(0, acc))
-      if (PF) S6_CHUNKF(true, false, false, b0[1], b1[1], acc)
+      if (BIG) { }
+      else if (PF) S6_CHUNKF(true, false, false, b0[1], b1[1], acc)
       else S6_CHUNK(S6_FWD(1, acc))
 #undef S6_FWD
       if (X16) sine16_tag_sc<NBL>(acc, acc, is1_ * (1.0f / 4096.0f));
@@ -844,14 +878,18 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       {
         f32x4 U[NBL];
 #if NIF_S6_RING     // h_j (dz dot product, this layer's A planes, the cosine of the layer below) -- dnext was taken from hin above
-        if (PF) {
+        if (BIG) {
+          if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p);
+          S6_CHUNK2(true, q0, q1, U)
+        } else if (PF) {
           if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p);
           S6_CHUNKF(false, true, true, q0[0], q1[0], U)
         } else S6_CHUNK_RING({ if (NIF_S6_RECOMP0 && j == 0) first_layer(hin); else ring_load16<NBL>(ring + j * (NP * 16), hin, g, p); }, { mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #else
         S6_CHUNK({ mfma_x3<NBL, PB, true, NBL, 0, CP>(cur, q0[0], q1[0], U, lane); })
 #endif
-        if (PF) S6_CHUNKF(true, true, false, q0[1], q1[1], U)
+        if (BIG) { }
+        else if (PF) S6_CHUNKF(true, true, false, q0[1], q1[1], U)
         else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[1], q1[1], U)
         else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], U, lane); })
         float s = 0.f;
@@ -880,14 +918,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
         fuse_deposit4(exw + 2 * FUSE_PLANE_BYTES, dep, a0);                   \
         fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);                   \
       }
-      if (PF) S6_CHUNKF(true, true, false, q0[0], q1[0], gh)
+      if (BIG) S6_CHUNK2(false, q0, q1, gh)
+      else if (PF) S6_CHUNKF(true, true, false, q0[0], q1[0], gh)
       else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[0], q1[0], gh)
       else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[0], q1[0], gh, lane); })
 #if NIF_S6_EARLYDEP
       // (the slot's previous deposit was consumed two barriers ago; the splits run behind this step's matrix instructions)
       S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); S6_DEPOSIT() })
 #else
-      if (PF) S6_CHUNKF(true, false, false, q0[1], q1[1], gh)
+      if (BIG) { }
+      else if (PF) S6_CHUNKF(true, false, false, q0[1], q1[1], gh)
       else if (X16 && NIF_S6_PRE) S6_CHUNKP(false, q0[1], q1[1], gh)
       else S6_CHUNK({ mfma_x3<NBL, PB, false, NBL, 0, CP>(cur, q0[1], q1[1], gh, lane); })
 #endif
@@ -900,8 +940,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       S6_DEPOSIT()
 #endif
 #undef S6_DEPOSIT
-#if NIF_S6_DBAR && !NIF_S6_EARLYDEP
-      if (j > 0) {      // deposit j is visible NOW: the consumers start on it under this wave's next vector block
+#if !NIF_S6_EARLYDEP
+      if (DBAR && j > 0) {      // deposit j is visible NOW: the consumers start on it under this wave's next vector block
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
         S6_TL(600);
@@ -972,9 +1012,9 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static size_t snet6_shmem(const SNetArgs& a, int NBL) {
   const size_t sm_tot = (((size_t)(a.r + 1) * (11 * 16 * NBL + 4)) + 3) & ~(size_t)3;      // (the kernel's fixed small-vector layout)
-  const size_t ni = (size_t)(((a.si + 3) & ~3) + ((a.r + 3) & ~3) + ((a.so + 3) & ~3) + 4) * 16;
+  const size_t ni = 8 * 16;      // (the kernel's input set: x_0..x_2 | z | y_0..y_2 | sample weight, 16 points each)
   const size_t pw = 2 * a.r * 64 + 2 * ni;
-  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + (size_t)((a.prec == 0 && NIF_S6_PF) ? 3 : 2) * NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
+  return 8 * (6 * FUSE_PLANE_BYTES + (5 + 8) * 64) + (size_t)((a.prec == 0 && NIF_S6_PF) ? 3 : 2) * ((a.prec == 0 && NIF_S6_BIGCHUNK) ? 2 : 1) * NBL * (a.prec == 0 ? 2 : 3) * 64 * 16 + (sm_tot + 8 * pw + 16 + 16) * sizeof(float)
 #ifdef NIF_TIMELINE
          + 2 * 380 * 8
 #endif
