@@ -127,6 +127,11 @@ struct S6Args {
                              // steps per layer and direction instead of four: half the per-step fixed costs (DMA issue 170-380 ticks, s_waitcnt
                              // 140, barrier >= 140, loop glue 120 of a ~1 250-tick forward step: r6 timeline)
 #endif
+#ifndef NIF_S6_EARLYDMA
+#define NIF_S6_EARLYDMA 1    // 1 (r6, with NIF_S6_BIGCHUNK; the product form: 1.154-1.166 vs 1.169-1.185 ms on same-box triples): the chunk DMA of an adjoint layer's second step is issued at the TOP of the
+                             // layer's vector block instead of inside its first chunk step (an LDS-DMA piece costs 25-60 cycles to issue in a
+                             // VALU-only stretch, 100-185 inside a phase with matrix and LDS traffic: MI355X_MICROARCH.md)
+#endif
 #ifndef NIF_S6_DBAR_T0
 #define NIF_S6_DBAR_T0 5     // tiles of the deposit taken under the vector block + the first chunk step (timeline r6: 240 ticks per tile there,
                              // 650 once the producers' matrix instructions compete)
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
   if (PF) cs_next(1, true);
   __syncthreads();
   bool dma_mine = false;                                 // forward steps: the consumer waves issue the chunk DMA
+  bool dma_early = false;                                // NIF_S6_EARLYDMA: the next S6_CHUNK's DMA went out already
   int cbuf = 0, nbuf = PF ? 2 : 1;
   bf16x8 pf[4]; (void)pf;                                // PF: the next chunk's first block pair (live inside a layer's four steps only)
 #define S6_ROT() { if (PF) { cbuf = cbuf == 2 ? 0 : cbuf + 1; nbuf = nbuf == 2 ? 0 : nbuf + 1; } else { cbuf ^= 1; nbuf ^= 1; } }
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
 #define S6_CHUNK(...)                                                         \
   {                                                                           \
     S6_TL(100);                                                               \
-    cs_next(nbuf, dma_mine);                                                  \
+    if (!dma_early) cs_next(nbuf, dma_mine);                                  \
+    dma_early = false;                                                        \
     S6_TL(200);                                                               \
     const bf16x8* cur = chunks + cbuf * CFB;                                  \
     __VA_ARGS__                                                               \
@@ -832,6 +839,7 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     dma_mine = true;
     for (int j = nh - 1; j >= 0; --j) {
       f32x4 ga[NBL];
+      if (BIG && NIF_S6_EARLYDMA) { cs_next(nbuf, true); dma_early = true; }
       tag_cos<NBL>(hin, dnext);
 #if !NIF_S6_RING
       st_load16<NBL>(IN0 + (long)j * sstride, row0, hin, g);
