@@ -441,14 +441,19 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
     for (long tg = blockIdx.x; tg < ngroups; tg += gridDim.x, ++tlr) {
       if (BIG) {
         // two intervals per layer; the previous round's first-layer deposit (visible behind the first barrier) over the next three
+        // (r6 timeline: at 3 + 3 + 2 tiles over three intervals the consumers were the LAST at those barriers by 0.5-1.1 k ticks -- the
+        // skinny sums are rolled, latency-bound loops; spread over all 2 nh - 1 intervals behind the first they hide under the producers' steps)
+        const int nq = 2 * nh - 1;
         for (int j = 0; j < nh; ++j) {
-          S6_CFWD(if (j == 1) { S6_DO(consume_first(3, 6);) })
-          S6_CFWD(if (j == 0) { S6_DO(consume_first(0, nh > 1 ? 3 : 8);) } else if (j == 1) { S6_DO(consume_first(6, 8);) })
+          S6_CFWD(if (j > 0) { const int q_ = 2 * j - 1; S6_DO(consume_first(q_ * 8 / nq, (q_ + 1) * 8 / nq);) })
+          S6_CFWD({ const int q_ = 2 * j; S6_DO(consume_first(q_ * 8 / nq, (q_ + 1) * 8 / nq);) })
         }
         for (int q = 0; q < (r + 1) * nh; ++q) { cs_next(nb_c, false); S6_ROTC() }
-        S6_CBAR()                              // first step of adjoint layer nh - 1: the last layer's deposit is visible behind it
-        S6_DO(consume_last(0, 8);)
-        S6_CBAR()
+        S6_CBAR()                              // behind the last layer's deposit
+        S6_DO(consume_last(0, 5);)
+        S6_CBAR()                              // first chunk step of adjoint layer nh - 1
+        S6_DO(consume_last(5, 8);)
+        S6_CBAR()                              // second
         S6_HID_LAYER(3) S6_HID_LAYER(2) S6_HID_LAYER(1)
         S6_CBAR()                              // deposit 0 next to the first layer's adjoint
         S6_DO(S6_HID_TILES(0, 0, 8))
@@ -832,6 +837,16 @@ __global__ __launch_bounds__(1024, 4) void k_snet6(S6Args F) {
       fuse_deposit4(exw + 3 * FUSE_PLANE_BYTES, dep, a1);
     }
     if (g == 0) loss_lane += wsamp * se / (float)so * A.inv_bg;
+    if (BIG) {      // the last layer's deposit is visible NOW: its eight tiles of skinny sums (3.1 k ticks of rolled, latency-bound loops) spread over
+                    // this wave's vector block and the first chunk step instead of filling the one step behind the first barrier (r6 timeline: the
+                    // producers waited 1.9 k ticks for them there)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+      S6_TL(600);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      S6_TL(700);
+    }
     // ---- adjoint through the hidden hyper-matrices ---------------------------------------------------------------------------
     f32x4 dnext[NBL], hin[NBL];
 #pragma unroll
