@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_snet4" in r["Kernel_Name"] or "k_snet3" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if any(s in r["Kernel_Name"] for s in ("k_snet4", "k_snet3", "k_snet6"))]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 i0, i1 = idx[k], idx[k + 1]
 prev = int(rows[i0 - 1]["End_Timestamp"])
