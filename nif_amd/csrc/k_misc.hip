@@ -449,6 +449,54 @@ void launch_reduce(const float* partial, long pstride, int rows, const float* lo
   hipLaunchKernelGGL(k_reduce, grid, block, 0, st, partial, pstride, rows, loss_partial, nloss, g, P);
 }
 
+// k_reduce with the Adam update of column i behind its sum (r6: the deferred row reduction of a plain single-GPU step; the same
+// summation order and the same update expressions as k_reduce + k_adam: bit-identical results, g is still written)
+__global__ __launch_bounds__(512) void k_reduce_adam(const float* __restrict__ partial, long pstride, int rows,
+                                                     const float* __restrict__ lossp, int nloss, float* __restrict__ g, long P,
+                                                     float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
+                                                     float lr_t, float b1, float b2, float eps) {
+  __shared__ float red[8][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < P) {
+    const float* p = partial + i;
+    int rrow = rg;
+    for (; rrow + 24 < rows; rrow += 32) {
+      s0 += p[(long)rrow * pstride]; s1 += p[(long)(rrow + 8) * pstride];
+      s2 += p[(long)(rrow + 16) * pstride]; s3 += p[(long)(rrow + 24) * pstride];
+    }
+    for (; rrow < rows; rrow += 8) s0 += p[(long)rrow * pstride];
+  }
+  red[rg][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < P) {
+    const float gi = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    g[i] = gi;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    __syncthreads();
+    float ls = 0.f;
+    for (int b = threadIdx.x; b < nloss; b += 512) ls += lossp[b];
+    red[rg][col] = ls;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float vv = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+      for (int off = 32; off > 0; off >>= 1) vv += __shfl_down(vv, off);
+      if (threadIdx.x == 0) g[P] = vv;
+    }
+  }
+}
+void launch_reduce_adam(const float* partial, long pstride, int rows, const float* loss_partial, int nloss, float* g, long P,
+                        float* theta, float* m, float* v, float lr_t, float b1, float b2, float eps, hipStream_t st) {
+  dim3 grid((unsigned)((P + 63) / 64)), block(512);
+  hipLaunchKernelGGL(k_reduce_adam, grid, block, 0, st, partial, pstride, rows, loss_partial, nloss, g, P, theta, m, v, lr_t, b1, b2, eps);
+}
+
 // Keras-2.11 Adam (SURVEY a-11): lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host
 __global__ void k_adam(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, long P, float lr_t, float b1, float b2, float eps) {

@@ -125,6 +125,7 @@ extern "C" int nif_create(const nif_cfg* cfg, int device_id, nif_ctx** out) {
   { const char* e = getenv("NIF_FP32_MFMA"); c->opt_fp32_mfma = e && e[0] == '1'; }
   { const char* e = getenv("NIF_FUSE_GW"); c->opt_fuse_gw = !(e && e[0] == '0'); }
   { const char* e = getenv("NIF_SMALL_STEP"); c->opt_small_step = !(e && e[0] == '0'); }
+  { const char* e = getenv("NIF_FUSE_TAIL"); c->opt_fuse_tail = !(e && e[0] == '0'); }
   { const char* e = getenv("NIF_PIPE_CHUNK"); if (e && e[0]) c->opt_pipe_chunk = atol(e); }
   { const char* e = getenv("NIF_SIDE_PNET"); if (e && e[0]) c->opt_side_pnet = e[0] != '0'; }
   { const char* e = getenv("NIF_PIPE_WGS"); if (e && e[0]) c->opt_pipe_wgs = atoi(e); }
@@ -228,6 +229,7 @@ extern "C" int nif_set_params(nif_ctx* c, const float* host, int64_t n) {
   if (!c || !host) return fail(NIF_ERR_INVALID, "null");
   if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(c->theta, host, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   c->have_params = true; c->packed = false; c->packed32 = false; c->packed_p32 = false;
@@ -237,6 +239,7 @@ extern "C" int nif_get_params(nif_ctx* c, float* host, int64_t n) {
   if (!c || !host) return fail(NIF_ERR_INVALID, "null");
   if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(host, c->theta, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
@@ -245,6 +248,7 @@ extern "C" int nif_get_opt_state(nif_ctx* c, float* mh, float* vh, int64_t n, in
   if (!c || !mh || !vh || !step) return fail(NIF_ERR_INVALID, "null");
   if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(mh, c->m, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(vh, c->v, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
@@ -255,6 +259,7 @@ extern "C" int nif_set_opt_state(nif_ctx* c, const float* mh, const float* vh, i
   if (!c || !mh || !vh) return fail(NIF_ERR_INVALID, "null");
   if (n != c->P) return fail(NIF_ERR_INVALID, "parameter count mismatch");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(c->m, mh, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipMemcpyAsync(c->v, vh, sizeof(float) * n, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
@@ -265,12 +270,14 @@ extern "C" int nif_set_opt_state(nif_ctx* c, const float* mh, const float* vh, i
 extern "C" int nif_dev_alloc(nif_ctx* c, int64_t bytes, void** dptr) {
   if (!c || !dptr || bytes < 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMalloc(dptr, bytes > 0 ? (size_t)bytes : 4));
   return NIF_OK;
 }
 extern "C" int nif_dev_free(nif_ctx* c, void* dptr) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   if (dptr) HIPCHK(hipFree(dptr));
   return NIF_OK;
@@ -278,6 +285,7 @@ extern "C" int nif_dev_free(nif_ctx* c, void* dptr) {
 extern "C" int nif_h2d(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
   if (!c || !dst || !src) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
@@ -285,6 +293,7 @@ extern "C" int nif_h2d(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
 extern "C" int nif_d2h(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
   if (!c || !dst || !src) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
@@ -292,6 +301,7 @@ extern "C" int nif_d2h(nif_ctx* c, void* dst, const void* src, int64_t bytes) {
 extern "C" int nif_sync(nif_ctx* c) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
 }
@@ -299,12 +309,14 @@ extern "C" int nif_sync(nif_ctx* c) {
 extern "C" int nif_host_alloc(nif_ctx* c, int64_t bytes, void** hptr) {
   if (!c || !hptr || bytes < 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipHostMalloc(hptr, bytes > 0 ? (size_t)bytes : 4, hipHostMallocDefault));
   return NIF_OK;
 }
 extern "C" int nif_host_free(nif_ctx* c, void* hptr) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   if (c->st_copy) HIPCHK(hipStreamSynchronize(c->st_copy));
   if (hptr) HIPCHK(hipHostFree(hptr));
   return NIF_OK;
@@ -323,6 +335,7 @@ static int ensure_copy_stream(nif_ctx* c) {
 extern "C" int nif_h2d_async(nif_ctx* c, void* dst_dev, const void* src_pinned, int64_t bytes, int32_t slot) {
   if (!c || !dst_dev || !src_pinned || bytes < 0 || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_copy_stream(c); if (rc) return rc;
   HIPCHK(hipStreamWaitEvent(c->st_copy, c->ev_consumed[slot], 0));   // the steps that read this slot's device buffer are done
   HIPCHK(hipMemcpyAsync(dst_dev, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, c->st_copy));
@@ -332,6 +345,7 @@ extern "C" int nif_h2d_async(nif_ctx* c, void* dst_dev, const void* src_pinned, 
 extern "C" int nif_copy_acquire(nif_ctx* c, int32_t slot) {       // compute stream: wait until the slot's copies have landed
   if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_copy_stream(c); if (rc) return rc;
   HIPCHK(hipStreamWaitEvent(c->st, c->ev_copied[slot], 0));
   return NIF_OK;
@@ -339,6 +353,7 @@ extern "C" int nif_copy_acquire(nif_ctx* c, int32_t slot) {       // compute str
 extern "C" int nif_copy_release(nif_ctx* c, int32_t slot) {       // compute stream: everything enqueued so far has consumed the slot
   if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_copy_stream(c); if (rc) return rc;
   HIPCHK(hipEventRecord(c->ev_consumed[slot], c->st));
   return NIF_OK;
@@ -346,6 +361,7 @@ extern "C" int nif_copy_release(nif_ctx* c, int32_t slot) {       // compute str
 extern "C" int nif_copy_wait_host(nif_ctx* c, int32_t slot) {     // host: the slot's pinned staging buffer may be overwritten
   if (!c || slot < 0 || slot > 1) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_copy_stream(c); if (rc) return rc;
   HIPCHK(hipEventSynchronize(c->ev_copied[slot]));
   return NIF_OK;
@@ -353,13 +369,14 @@ extern "C" int nif_copy_wait_host(nif_ctx* c, int32_t slot) {     // host: the s
 extern "C" int nif_gather_rows_dev(nif_ctx* c, const float* src_dev, const int32_t* perm_dev, int64_t n, int32_t ncol, float* dst_dev) {
   if (!c || !src_dev || !perm_dev || !dst_dev || n < 0 || ncol < 1) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   if (n > 0) launch_gather_rows(src_dev, perm_dev, n, ncol, dst_dev, c->st);
   HIPCHK(hipGetLastError());
   return NIF_OK;
 }
 
 extern "C" void* nif_stream(nif_ctx* c) { return c ? (void*)c->st : nullptr; }
-extern "C" void* nif_grad_dev(nif_ctx* c) { return c ? (void*)c->grad : nullptr; }
+extern "C" void* nif_grad_dev(nif_ctx* c) { if (c) (void)nif_tail_flush(c); return c ? (void*)c->grad : nullptr; }
 extern "C" void* nif_params_dev(nif_ctx* c) { return c ? (void*)c->theta : nullptr; }
 
 // ------------------------------------------------------------------------------------------
@@ -645,6 +662,7 @@ static int ensure_packed(nif_ctx* c) {
 extern "C" int nif_forward_dev(nif_ctx* c, const float* xin, int64_t B, float* u) {
   if (!c || !xin || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, false); if (rc) return rc;
   PNetArgs pa; fill_pnet(c, pa, xin, B);
@@ -686,6 +704,7 @@ static int stage(nif_ctx* c, float** buf, long* cap, const float* host, long n) 
 extern "C" int nif_forward(nif_ctx* c, const float* xin, int64_t B, float* u) {
   if (!c || !xin || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
   rc = stage(c, &c->d_d, &c->cap_d, nullptr, B * c->so); if (rc) return rc;
@@ -704,6 +723,7 @@ extern "C" int nif_jacobian(nif_ctx* c, const float* xin, int64_t B, const int32
   for (int j = 0; j < nx; ++j)
     if (x_idx[j] < 0 || x_idx[j] >= c->pi + c->si) return fail(NIF_ERR_INVALID, "x_index out of range");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_packed32(c); if (rc) return rc;
@@ -882,12 +902,14 @@ extern "C" int nif_hessian_dev(nif_ctx* c, const float* xin_dev, int64_t B, cons
                                int32_t nx, float* y_dev, float* dydx_dev, float* d2_dev) {
   int rc = hessian_check(c, xin_dev, B, y_idx, ny, x_idx, nx, y_dev, dydx_dev, d2_dev); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   return hessian_core(c, xin_dev, B, y_idx, ny, x_idx, nx, y_dev, dydx_dev, d2_dev);
 }
 extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_t* y_idx, int32_t ny, const int32_t* x_idx,
                            int32_t nx, float* y_out, float* dydx_out, float* d2_out) {
   int rc = hessian_check(c, xin, B, y_idx, ny, x_idx, nx, y_out, dydx_out, d2_out); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   rc = stage(c, &c->d_a, &c->cap_a, xin, B * (c->pi + c->si)); if (rc) return rc;
   const size_t n_y = (size_t)B * c->so, n_d = (size_t)B * ny * nx, n_h = n_d * nx;
@@ -908,6 +930,7 @@ extern "C" int nif_hessian(nif_ctx* c, const float* xin, int64_t B, const int32_
 extern "C" int nif_pnet_latent(nif_ctx* c, const float* p, int64_t B, float* lr) {
   if (!c || !p || !lr || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -927,6 +950,7 @@ extern "C" int nif_x_to_phi(nif_ctx* c, const float* x, int64_t B, float* phi) {
   if (!c || !x || !phi || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   if (c->kind != NIF_KIND_LASTLAYER) return fail(NIF_ERR_INVALID, "model_x_to_phi exists only for the last-layer class");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = ensure_packed(c); if (rc) return rc;
   rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -947,6 +971,7 @@ extern "C" int nif_latent_to_w_dev(nif_ctx* c, const float* lr, int64_t B, float
   if (c->kind == NIF_KIND_LASTLAYER)
     return fail(NIF_ERR_INVALID, "In this class: NIFMultiScaleLastLayerParameterization, `w` is the same as `lr`");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   { ProfScope p_(c, NIF_PROF_LATENT_TO_W); launch_latent_to_w(c->theta, c->last_w, c->last_b, c->r, c->po, lr, B, w, c->st); }
   HIPCHK(hipGetLastError());
   return NIF_OK;
@@ -954,6 +979,7 @@ extern "C" int nif_latent_to_w_dev(nif_ctx* c, const float* lr, int64_t B, float
 extern "C" int nif_latent_to_w(nif_ctx* c, const float* lr, int64_t B, float* w) {
   if (!c || !lr || !w || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = stage(c, &c->d_a, &c->cap_a, lr, B * c->r); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, nullptr, B * c->po); if (rc) return rc;
@@ -966,6 +992,7 @@ extern "C" int nif_latent_to_w(nif_ctx* c, const float* lr, int64_t B, float* w)
 extern "C" int nif_shapenet_given_w_dev(nif_ctx* c, const float* x, const float* w, int64_t B, float* u) {
   if (!c || !x || !w || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   if (c->kind == NIF_KIND_LASTLAYER) {   // u = Dot(phi(x), w) + bias with caller-supplied w [B, r]
     int rc = ensure_packed(c); if (rc) return rc;
     rc = ensure_capacity(c, B, false); if (rc) return rc;
@@ -987,6 +1014,7 @@ extern "C" int nif_shapenet_given_w_dev(nif_ctx* c, const float* x, const float*
 extern "C" int nif_shapenet_given_w(nif_ctx* c, const float* x, const float* w, int64_t B, float* u) {
   if (!c || !x || !w || !u || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   int rc = stage(c, &c->d_a, &c->cap_a, x, B * c->si); if (rc) return rc;
   rc = stage(c, &c->d_b, &c->cap_b, w, B * c->po); if (rc) return rc;   // po == r for the last-layer class
@@ -1429,10 +1457,29 @@ static int ensure_small_tables(nif_ctx* c, const PNetArgs& pa, const SNetArgs& s
   HIPCHK(hipMemcpy(c->small_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice));
   return NIF_OK;
 }
+// r6: the row reduction of a plain step waits for its consumer when nothing else needs [grad | loss] first: nif_adam_step_dev runs it fused
+// with the update (k_reduce_adam: one launch less per step -- 5 of the 31 us of a 512-point step, 0.5 % of the 2^20-point one).  Every
+// other entry point of the library starts with nif_tail_flush; the reduction is NOT deferred with a communicator attached, inside a graph
+// capture, under the profiler (its per-group events would lose the REDUCE group) or when a regulariser adds to the gradient behind it.
+int nif_tail_flush(nif_ctx* c) {
+  if (!c || !c->tail_pending) return NIF_OK;
+  c->tail_pending = false;
+  HIPCHK(hipSetDevice(c->dev));
+  launch_reduce(c->partial, c->pstride, c->tail_rows, c->loss_partial, c->tail_nloss, c->grad, c->P, c->st);
+  HIPCHK(hipGetLastError());
+  return NIF_OK;
+}
+static bool tail_can_defer(const nif_ctx* c) {
+  if (!c->opt_fuse_tail || c->comm || c->capturing || c->prof_on) return false;
+  if ((c->reg_l1 != 0.f || c->reg_l2 != 0.f) && c->reg_hi > c->reg_lo) return false;
+  if (c->sreg_l1 != 0.f || c->sreg_l2 != 0.f) return false;
+  return true;
+}
 // a Keras loss-metric accumulation that nif_metric_accumulate left for the next k_small launch (r6: one launch less per small step):
 // everything that would change grad[P] or read the metric without such a launch runs it now
 static int metric_flush(nif_ctx* c) {
   if (!c->metric_pending) return NIF_OK;
+  TAIL_FLUSH(c)
   c->metric_pending = false;
   launch_metric(c->grad, c->P, c->metric_pending_w, c->metric, c->st);
   HIPCHK(hipGetLastError());
@@ -1441,6 +1488,7 @@ static int metric_flush(nif_ctx* c) {
 static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, int64_t Bg, int ns,
                           const int* seeds, const float* gt, float wj, const SobPlan* sp = nullptr) {
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)      // (a step whose gradient was never consumed: its rows are about to be overwritten)
   c->last_step_small = false;
   // r6: a small batch of a small net -- ONE launch for the loss and every gradient (k_small: fp32 FMAs straight from theta, no plane
   // packing), then the usual row reduction.  configs[0]'s 512-point steps spent 82 us in eleven tile-kernel launches
@@ -1462,7 +1510,8 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
                      c->grad + c->P, c->st); }
       if (mp) c->metric_pending = false;
       c->last_step_small = true;
-      { ProfScope pr_(c, NIF_PROF_REDUCE); launch_reduce(c->partial, c->pstride, rows, c->loss_partial, rows, c->grad, c->P, c->st); }
+      if (c->jac_l1 == 0.f && tail_can_defer(c)) { c->tail_pending = true; c->tail_rows = rows; c->tail_nloss = rows; }
+      else { ProfScope pr_(c, NIF_PROF_REDUCE); launch_reduce(c->partial, c->pstride, rows, c->loss_partial, rows, c->grad, c->P, c->st); }
       if (c->jac_l1 != 0.f) { rc = jac_reg_pass(c, xin, B, Bg); if (rc) return rc; }
       HIPCHK(hipGetLastError());
       return NIF_OK;
@@ -1508,6 +1557,11 @@ static int loss_grad_core(nif_ctx* c, const float* xin, const float* y, const fl
       HIPCHK(hipStreamWaitEvent(c->st, c->ev_done, 0));
     }
     const int rows = rows_for(c, ntiles);
+    if (ns == 0 && !act_on(c) && c->jac_l1 == 0.f && !(sp && sp->any_par) && tail_can_defer(c)) {
+      c->tail_pending = true; c->tail_rows = rows; c->tail_nloss = nloss;
+      HIPCHK(hipGetLastError());
+      return NIF_OK;
+    }
     ProfScope pr_(c, NIF_PROF_REDUCE);
     launch_reduce(c->partial, c->pstride, rows, c->loss_partial, nloss, c->grad, c->P, c->st);
     if (act_on(c)) {   // the plane side of the activity regulariser and its loss, on top of the reduced gradient
@@ -1562,6 +1616,7 @@ extern "C" int nif_reserve(nif_ctx* c, int64_t B_max, int32_t n_tangents) {
   if (!c || B_max <= 0 || n_tangents < 0 || n_tangents > 16) return fail(NIF_ERR_INVALID, "bad argument");
   if (n_tangents > 3) n_tangents = 3;      // (more x_index columns run as passes over groups of three)
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = ensure_packed(c); if (rc) return rc;
   const long ntiles = (B_max + 31) / 32;
   rc = ensure_capacity(c, ntiles * 32 * (1 + n_tangents), true); if (rc) return rc;
@@ -1654,6 +1709,7 @@ extern "C" int nif_sobolev_loss_grad_dev_y(nif_ctx* c, const float* xin, const f
   unsigned ymask; int nys;
   int rc = sobolev_check(c, x_idx, nx, y_idx, ny, &ymask, &nys); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   const int gs = sob_cols_per_pass(c, x_idx, nx);
   const int ngroups = (nx + gs - 1) / gs;
   if (ngroups > 1 && !c->sob_acc) HIPCHK(hipMalloc(&c->sob_acc, sizeof(float) * (size_t)(c->P + 1)));
@@ -1690,6 +1746,7 @@ extern "C" int nif_sobolev_forward_dev(nif_ctx* c, const float* xin, int64_t B, 
   unsigned ymask; int nys;
   int rc = sobolev_check(c, x_idx, nx, nullptr, 0, &ymask, &nys); if (rc) return rc;
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   const int gs = sob_cols_per_pass(c, x_idx, nx);
   for (int g0 = 0; g0 < nx; g0 += gs) {      // groups of <= 3 columns, each filling its columns of the [B][so][nx] rows
     const int ng = nx - g0 < gs ? nx - g0 : gs;
@@ -1907,6 +1964,7 @@ extern "C" int nif_set_activity_regularizer(nif_ctx* c, float l1, float l2) {
 extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   if (!c->metric) { HIPCHK(hipMalloc(&c->metric, 2 * sizeof(double))); HIPCHK(hipMemsetAsync(c->metric, 0, 2 * sizeof(double), c->st)); }
   int rc = metric_flush(c); if (rc) return rc;
   if (c->last_step_small && c->opt_small_step && !c->capturing && !c->comm) {     // behind a small step: rides in the next k_small launch (grad[P] is not
@@ -1920,6 +1978,7 @@ extern "C" int nif_metric_accumulate(nif_ctx* c, float weight) {
 extern "C" int nif_metric_read(nif_ctx* c, double* sum, double* cnt, int reset) {
   if (!c || !sum || !cnt) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   double h[2] = {0.0, 0.0};
   { const int rcf = metric_flush(c); if (rcf) return rcf; }
   if (c->metric) {
@@ -1934,6 +1993,19 @@ extern "C" int nif_adam_step_dev(nif_ctx* c, const nif_adam* opt) {
   if (!c || !opt) return fail(NIF_ERR_INVALID, "null");
   if (!c->have_params) return fail(NIF_ERR_STATE, "parameters not set");
   HIPCHK(hipSetDevice(c->dev));
+  if (c->tail_pending && !c->capturing && tail_can_defer(c)) {      // the step's row reduction and the update in ONE launch
+    c->tail_pending = false;
+    c->step += 1;
+    const double t = (double)c->step;
+    const double lr_t = (double)opt->lr * std::sqrt(1.0 - std::pow((double)opt->beta2, t)) / (1.0 - std::pow((double)opt->beta1, t));
+    launch_reduce_adam(c->partial, c->pstride, c->tail_rows, c->loss_partial, c->tail_nloss, c->grad, c->P, c->theta, c->m, c->v,
+                       (float)lr_t, opt->beta1, opt->beta2, opt->eps, c->st);
+    HIPCHK(hipGetLastError());
+    c->packed = false; c->packed32 = false; c->packed_p32 = false;
+    c->reg_applied = false;
+    return NIF_OK;
+  }
+  TAIL_FLUSH(c)
   apply_reg(c);
   if (c->capturing) {      // inside nif_graph_begin / _end: hyper-parameters and iteration count come from device memory at replay time
     launch_adam_dev(c->theta, c->grad, c->m, c->v, c->P, c->adam_dev, c->st);
@@ -1968,6 +2040,7 @@ extern "C" int nif_graph_begin(nif_ctx* c) {
   if (c->capturing) return fail(NIF_ERR_STATE, "nif_graph_begin: already capturing");
   if (c->comm) return fail(NIF_ERR_STATE, "nif_graph_begin: not with a communicator attached (the all-reduce is not captured)");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = metric_flush(c); if (rc) return rc;
   c->last_step_small = false;
   rc = ensure_packed(c); if (rc) return rc;
@@ -2008,6 +2081,7 @@ extern "C" int nif_graph_launch(nif_ctx* c, int32_t graph_id, const nif_adam* op
   if (!c || !opt || graph_id < 0 || graph_id >= (int32_t)c->graphs.size() || !c->graphs[graph_id]) return fail(NIF_ERR_INVALID, "bad argument");
   if (c->capturing) return fail(NIF_ERR_STATE, "nif_graph_launch while capturing");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));      // (the pinned staging struct is reused: the previous launch's copy must be through)
   c->adam_host->lr = opt->lr; c->adam_host->beta1 = opt->beta1; c->adam_host->beta2 = opt->beta2; c->adam_host->eps = opt->eps;
   c->adam_host->step = c->step;
@@ -2027,6 +2101,7 @@ extern "C" int nif_graph_destroy(nif_ctx* c, int32_t graph_id) {
 extern "C" int nif_zero_grad(nif_ctx* c) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   { const int rcf = metric_flush(c); if (rcf) return rcf; }      // (a deferred loss-metric accumulation reads grad[P]: before it is cleared)
   c->last_step_small = false;
   HIPCHK(hipMemsetAsync(c->grad, 0, sizeof(float) * (size_t)(c->P + 1), c->st));
@@ -2046,6 +2121,7 @@ extern "C" int nif_device_pci_bus_id(int32_t dev, char* out, int32_t cap) {
 extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
   if (!c || !key) return fail(NIF_ERR_INVALID, "null");
   if (strcmp(key, "fuse_gw") == 0) { c->opt_fuse_gw = value != 0; return NIF_OK; }   // 0: k_snet4 + k_gw_* instead of the fused-gradient kernel
+  if (strcmp(key, "fuse_tail") == 0) { c->opt_fuse_tail = value != 0; return NIF_OK; }     // 0: the row reduction runs inside nif_loss_grad_dev (A/B, tests)
   if (strcmp(key, "small_step") == 0) { c->opt_small_step = value != 0; return NIF_OK; }   // 0: small batches on the tile kernels too (A/B, tests)
   if (strcmp(key, "fp32_mfma") == 0) {      // 1: every product on the f32-input MFMAs (k_snet3) instead of the bf16 splits
     c->opt_fp32_mfma = value != 0;
@@ -2063,6 +2139,7 @@ extern "C" int nif_set_option(nif_ctx* c, const char* key, int32_t value) {
 extern "C" int nif_grad_read(nif_ctx* c, float* loss, float* grad) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   apply_reg(c);
   if (grad) HIPCHK(hipMemcpyAsync(grad, c->grad, sizeof(float) * (size_t)c->P, hipMemcpyDeviceToHost, c->st));
   if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
@@ -2073,6 +2150,7 @@ extern "C" int nif_grad_read(nif_ctx* c, float* loss, float* grad) {
 extern "C" int nif_last_loss(nif_ctx* c, float* loss) {
   if (!c || !loss) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   return NIF_OK;
@@ -2096,8 +2174,10 @@ extern "C" int nif_loss_and_grad(nif_ctx* c, const float* xin, const float* y, c
                                  float* grad) {
   if (!c || !xin || !y || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
   rc = nif_loss_grad_dev(c, c->d_a, c->d_b, sw ? c->d_c : nullptr, B, B); if (rc) return rc;
+  TAIL_FLUSH(c)
   apply_reg(c);
   if (grad) HIPCHK(hipMemcpyAsync(grad, c->grad, sizeof(float) * (size_t)c->P, hipMemcpyDeviceToHost, c->st));
   if (loss) HIPCHK(hipMemcpyAsync(loss, c->grad + c->P, sizeof(float), hipMemcpyDeviceToHost, c->st));
@@ -2109,6 +2189,7 @@ extern "C" int nif_train_step(nif_ctx* c, const float* xin, const float* y, cons
                               const nif_adam* opt, float* loss) {
   if (!c || !xin || !y || !opt || B <= 0) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = stage_batch(c, xin, y, sw, B); if (rc) return rc;
   rc = nif_loss_grad_dev(c, c->d_a, c->d_b, sw ? c->d_c : nullptr, B, B); if (rc) return rc;
   rc = nif_adam_step_dev(c, opt); if (rc) return rc;
@@ -2134,6 +2215,7 @@ static int drain_profile(nif_ctx* c) {
 extern "C" int nif_profile_enable(nif_ctx* c, int on) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = drain_profile(c); if (rc) return rc;
   c->prof_on = on != 0;
   return NIF_OK;
@@ -2141,6 +2223,7 @@ extern "C" int nif_profile_enable(nif_ctx* c, int on) {
 extern "C" int nif_profile_read(nif_ctx* c, float* ms, int64_t* cnt, int n, int reset) {
   if (!c || !ms || !cnt || n < NIF_PROF_N) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   int rc = drain_profile(c); if (rc) return rc;
   for (int i = 0; i < NIF_PROF_N; ++i) { ms[i] = (float)c->prof_ms[i]; cnt[i] = c->prof_cnt[i]; }
   if (reset) for (int i = 0; i < NIF_PROF_N; ++i) { c->prof_ms[i] = 0; c->prof_cnt[i] = 0; }
@@ -2149,6 +2232,7 @@ extern "C" int nif_profile_read(nif_ctx* c, float* ms, int64_t* cnt, int n, int 
 extern "C" int nif_debug_timeline(nif_ctx* c, int64_t* out, int32_t n_pairs) {
   if (!c || n_pairs < 0 || n_pairs > 2048) return fail(NIF_ERR_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipStreamSynchronize(c->st));
   if (!c->tl) {
     HIPCHK(hipMalloc(&c->tl, 4096 * sizeof(long long)));
@@ -2162,6 +2246,7 @@ extern "C" int nif_debug_timeline(nif_ctx* c, int64_t* out, int32_t n_pairs) {
 extern "C" int nif_timer_start(nif_ctx* c) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   if (!c->t0) { HIPCHK(hipEventCreate(&c->t0)); HIPCHK(hipEventCreate(&c->t1)); }
   HIPCHK(hipEventRecord(c->t0, c->st));
   return NIF_OK;
@@ -2169,6 +2254,7 @@ extern "C" int nif_timer_start(nif_ctx* c) {
 extern "C" int nif_timer_stop(nif_ctx* c, float* ms) {
   if (!c || !ms || !c->t0) return fail(NIF_ERR_INVALID, "timer not started");
   HIPCHK(hipSetDevice(c->dev));
+  TAIL_FLUSH(c)
   HIPCHK(hipEventRecord(c->t1, c->st));
   HIPCHK(hipEventSynchronize(c->t1));
   HIPCHK(hipEventElapsedTime(ms, c->t0, c->t1));

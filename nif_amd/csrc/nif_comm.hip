@@ -49,6 +49,7 @@ extern "C" int nif_comm_init_rank(nif_ctx* c, const void* id, int32_t rank, int3
   if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(NIF_ERR_INVALID, "bad argument");
   if (c->comm) return fail(NIF_ERR_STATE, "context already has a communicator");
   HIPCHK(hipSetDevice(c->dev));
+  { const int rct = nif_tail_flush(c); if (rct) return rct; }      // (a deferred row reduction: the all-reduce reads [grad | loss])
   ncclUniqueId uid;
   memcpy(&uid, id, NIF_COMM_ID_BYTES);
   ncclComm_t comm = nullptr;
@@ -63,6 +64,7 @@ extern "C" int nif_comm_init_all(nif_ctx** ctxs, int32_t n) {
   for (int i = 0; i < n; ++i) {
     if (!ctxs[i]) return fail(NIF_ERR_INVALID, "null context");
     if (ctxs[i]->comm) return fail(NIF_ERR_STATE, "context already has a communicator");
+    { const int rct = nif_tail_flush(ctxs[i]); if (rct) return rct; }
     devs[i] = ctxs[i]->dev;
     for (int j = 0; j < i; ++j)
       if (devs[j] == devs[i]) return fail(NIF_ERR_INVALID, "two contexts of one communicator on the same device");
@@ -117,6 +119,7 @@ extern "C" int nif_allreduce_grad(nif_ctx* c) {
   if (!c) return fail(NIF_ERR_INVALID, "null");
   if (!c->comm) return c->comm_world == 1 ? NIF_OK : fail(NIF_ERR_STATE, "no communicator");
   HIPCHK(hipSetDevice(c->dev));
+  { const int rct = nif_tail_flush(c); if (rct) return rct; }
   NCCLCHK(ncclAllReduce(c->grad, c->grad, (size_t)(c->P + 1), ncclFloat32, ncclSum, comm_of(c), c->st));
   return NIF_OK;
 }
@@ -132,6 +135,7 @@ extern "C" int nif_comm_selftest(nif_ctx* c, int32_t* ranks_seen) {
   if (!c || !ranks_seen) return fail(NIF_ERR_INVALID, "null");
   if (!c->grad) return fail(NIF_ERR_STATE, "no gradient buffer");
   HIPCHK(hipSetDevice(c->dev));
+  { const int rct = nif_tail_flush(c); if (rct) return rct; }
   const long n = c->P + 1;
   hipLaunchKernelGGL(k_fill_f32, dim3(64), dim3(256), 0, c->st, c->grad, n, (float)(c->comm_rank + 1));
   int rc = nif_allreduce_grad(c); if (rc) return rc;
@@ -156,6 +160,7 @@ extern "C" int nif_allreduce_grad_multi(nif_ctx** ctxs, int32_t n) {
   if (n == 1 && !ctxs[0]->comm) return NIF_OK;
   for (int i = 0; i < n; ++i)
     if (!ctxs[i] || !ctxs[i]->comm || ctxs[i]->comm_world != n) return fail(NIF_ERR_STATE, "contexts are not one nif_comm_init_all group");
+  for (int i = 0; i < n; ++i) { const int rct = nif_tail_flush(ctxs[i]); if (rct) return rct; }
   NCCLCHK(ncclGroupStart());
   for (int i = 0; i < n; ++i) {
     nif_ctx* c = ctxs[i];

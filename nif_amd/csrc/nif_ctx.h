@@ -95,6 +95,9 @@ struct nif_ctx {
   int* small_idx = nullptr; int* small_desc = nullptr;     // k_small's tables (offsets only), built at the first small step
   bool metric_pending = false; float metric_pending_w = 0.f;   // a nif_metric_accumulate deferred into the next k_small launch
   bool last_step_small = false;
+  // r6: the row reduction of a plain step may wait for its consumer -- nif_adam_step_dev then runs it fused with the update (one launch
+  // less per step); every other entry point of the library runs it first (tail_flush).  nif_set_option("fuse_tail") / NIF_FUSE_TAIL
+  bool tail_pending = false; int tail_rows = 0, tail_nloss = 0; bool opt_fuse_tail = true;
   bool opt_small_step = true;      // nif_set_option("small_step"): batches <= NIF_SMALL_MAX_B points of a net k_small takes run on it (one launch for loss + gradient); default from NIF_SMALL_STEP
   bool opt_fuse_gw = true;         // nif_set_option("fuse_gw"): ShapeNet weight gradients inside the training kernel (k_snet6) where it has the shape; default from NIF_FUSE_GW
 };
@@ -118,3 +121,7 @@ struct ProfScope {
 
 // host batch -> this context's staging buffers (asynchronous H2D on c->st); used by the host-pointer entry points
 int nif_stage_batch(nif_ctx* c, const float* xin, const float* y, const float* sw, int64_t B, float** dx, float** dy, float** dsw);
+// the deferred row reduction of the last plain step (nif_ctx::tail_pending), run before anything but nif_adam_step_dev touches
+// [grad | loss], the partial rows or the weights (nif_api.hip)
+int nif_tail_flush(nif_ctx* c);
+#define TAIL_FLUSH(c_) { const int rct_ = nif_tail_flush(c_); if (rct_) return rct_; }

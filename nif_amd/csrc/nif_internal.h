@@ -260,6 +260,8 @@ void launch_reduce(const float* partial, long pstride, int rows, const float* lo
                    float* g, long P, hipStream_t st);
 void launch_reg(const float* theta, float* g, long lo, long hi, long P, float l1, float l2, hipStream_t st);
 void launch_metric(const float* g, long P, float weight, double* acc, hipStream_t st);
+void launch_reduce_adam(const float* partial, long pstride, int rows, const float* loss_partial, int nloss, float* g, long P,
+                        float* theta, float* m, float* v, float lr_t, float b1, float b2, float eps, hipStream_t st);
 struct AdamDev { float lr, beta1, beta2, eps; long step; };      // device-resident Adam state of a captured graph of steps (k_adam_dev)
 void launch_adam_dev(float* theta, const float* g, float* m, float* v, long P, AdamDev* ad, hipStream_t st);
 void launch_adam(float* theta, const float* g, float* m, float* v, long P, float lr_t, float b1, float b2,

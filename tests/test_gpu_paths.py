@@ -140,6 +140,8 @@ KNOBS = [
     ({"NIF_SMALL_STEP": "0"}, "nif_cfg1_32x2", "plain", "float32"),        # r6: a small batch on the tile kernels (default: k_small, one launch)
     ({"NIF_SMALL_STEP": "1"}, "nif_cfg1_32x2", "plain", "float32"),
     ({"NIF_SMALL_STEP": "0"}, "nif_pad_n30_tanh_r2_so2", "plain", "float32"),
+    ({"NIF_FUSE_TAIL": "0"}, "ms_cfg2_64x4", "plain", "float32"),          # r6: the row reduction inside nif_loss_grad_dev (default: deferred to its consumer)
+    ({"NIF_FUSE_TAIL": "0"}, "nif_cfg1_32x2", "plain", "float32"),
 ]
 
 
@@ -150,7 +152,7 @@ def test_every_runtime_knob_against_the_oracle(case, tmp_path):
     out = str(tmp_path / "knob.npz")
     env = dict(os.environ)
     for k in ("NIF_FUSE_GW", "NIF_SIDE_PNET", "NIF_PBW_TOUCH", "NIF_PNET_STASH", "NIF_PNET_BF2", "NIF_GW8", "NIF_GW_LDS", "NIF_SOBW", "NIF_LL_MLP",
-              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY", "NIF_H_PH16", "NIF_SMALL_STEP"):
+              "NIF_FP32_MFMA", "NIF_PIPE_CHUNK", "NIF_DA_BF16", "NIF_S6_POLICY", "NIF_H_PH16", "NIF_SMALL_STEP", "NIF_FUSE_TAIL"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", KNOB_CHILD, name, mode, policy, out], env=env, cwd=ROOT, stdout=subprocess.PIPE,
