@@ -420,6 +420,10 @@ def main():
         # ---- per-kernel durations, live, with HIP events on the library's stream -------------
         e.profile_enable(True)
         nprof = max(3, min(args.steps, 10))
+        for _ in range(3):      # (the leg's own warm-up: the event pool is created on first use)
+            e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
+            e.adam_step_dev(adam)
+        e.profile_read(reset=True)
         for _ in range(nprof):
             e.loss_grad_dev(d_x.at(0), d_y.at(0), None, B, Bg)
             e.adam_step_dev(adam)
