@@ -275,7 +275,11 @@ int nif_last_loss(nif_ctx* ctx, float* loss_out);
  * once, copies loss and/or the flat gradient to the host, synchronises.  Either pointer may be NULL. */
 int nif_grad_read(nif_ctx* ctx, float* loss_out_or_null, float* grad_host_or_null);
 /* A/B switches for measurement and tests (no reference counterpart).  "fp32_mfma" = 1: every product of the
- * ShapeNet on the f32-input MFMAs instead of the exact bf16 splits (default 0, or NIF_FP32_MFMA=1 in the environment) */
+ * ShapeNet on the f32-input MFMAs instead of the exact bf16 splits (default 0, or NIF_FP32_MFMA=1 in the environment);
+ * "fuse_gw", "small_step", "fuse_tail" (default 1; NIF_FUSE_GW / NIF_SMALL_STEP / NIF_FUSE_TAIL = 0): the fused-gradient kernel, the
+ * one-launch small-batch step, the row reduction deferred to nif_adam_step_dev (which then runs it fused with the update: the
+ * [grad | loss] buffer is complete after ANY other call of this library on the context -- nif_grad_dev included -- and after the
+ * update; a caller that reads the buffer through a pointer it cached earlier, without such a call, sets "fuse_tail" to 0) */
 int nif_set_option(nif_ctx* ctx, const char* key, int32_t value);
 
 /* ---- multi-GPU: RCCL over xGMI, called directly (replaces `tf.distribute.MirroredStrategy().scope()`, reference
